@@ -1,0 +1,198 @@
+"""oracle -- TEST INFRASTRUCTURE ONLY (CPU restatement of the reference's PMVO path).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package; the product (monohair_amd) never does.  See oracle/pmvo_oracle.c for the
+per-function reference citations and the parity status (PINNED against golden vectors
+generated from the imported reference by tools/gen_golden.py).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+CAM_STRIDE = 48
+
+c_f = ctypes.POINTER(ctypes.c_float)
+c_i = ctypes.POINTER(ctypes.c_int32)
+c_u8 = ctypes.POINTER(ctypes.c_uint8)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = ctypes.CDLL(so)
+        _LIB.orc_num_threads.restype = ctypes.c_int
+    return _LIB
+
+
+def _p(a, t=c_f):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+class _Views(ctypes.Structure):
+    _fields_ = [
+        ("V", ctypes.c_int),
+        ("H", ctypes.c_int),
+        ("W", ctypes.c_int),
+        ("cams", c_f),
+        ("depth", ctypes.POINTER(c_f)),
+        ("ori", ctypes.POINTER(c_f)),
+        ("conf", ctypes.POINTER(c_f)),
+        ("mask", ctypes.POINTER(c_f)),
+    ]
+
+
+class Views:
+    """Compact per-view planes + camera records, as the C oracle wants them.
+
+    depth/conf/mask: [V,H,W] float32, ori: [V,H,W,2] float32 (channel 0 of the reference's
+    3-channel depth/mask arrays), cams: [V,48] float32 records (monohair_amd.camera.Camera.record)."""
+
+    def __init__(self, cams, depth, ori, conf, mask):
+        self.cams = np.ascontiguousarray(cams, dtype=np.float32)
+        self.depth = np.ascontiguousarray(depth, dtype=np.float32)
+        self.ori = np.ascontiguousarray(ori, dtype=np.float32)
+        self.conf = np.ascontiguousarray(conf, dtype=np.float32)
+        self.mask = np.ascontiguousarray(mask, dtype=np.float32)
+        self.V, self.H, self.W = self.depth.shape
+        assert self.cams.shape == (self.V, CAM_STRIDE)
+        arr = c_f * self.V
+        self._pd = arr(*[_p(self.depth[v]) for v in range(self.V)])
+        self._po = arr(*[_p(self.ori[v]) for v in range(self.V)])
+        self._pc = arr(*[_p(self.conf[v]) for v in range(self.V)])
+        self._pm = arr(*[_p(self.mask[v]) for v in range(self.V)])
+        self.c = _Views(self.V, self.H, self.W, _p(self.cams), self._pd, self._po, self._pc, self._pm)
+
+    @classmethod
+    def from_reference_dicts(cls, cameras, depths, Ori, Conf, masks):
+        """Same argument shapes as the reference's PMVO.__init__ (PMVO.py:14-28)."""
+        from monohair_amd.camera import camera_records
+
+        keys = list(cameras.keys())
+        d = np.stack([np.asarray(depths[k], dtype=np.float32)[..., 0] for k in keys])
+        o = np.stack([np.asarray(Ori[k]).astype(np.float32) for k in keys])
+        c = np.stack([np.asarray(Conf[k]).astype(np.float32) for k in keys])
+        m = np.stack([np.asarray(masks[k]).astype(np.float32)[..., 0] for k in keys])
+        return cls(camera_records(cameras), d, o, c, m)
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+def project_points(cam_rec, pts, H, W):
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    N = pts.shape[0]
+    rc = np.empty((N, 2), np.int32)
+    zp = np.empty(N, np.float32)
+    oob = np.empty(N, np.uint8)
+    pixf = np.empty((N, 2), np.float32)
+    rec = np.ascontiguousarray(cam_rec, dtype=np.float32)
+    lib().orc_project_points(_p(rec), _p(pts), N, H, W, _p(rc, c_i), _p(zp), _p(oob, c_u8), _p(pixf))
+    return rc, zp, oob.astype(bool), pixf
+
+
+def visible_and_ori(views, pts, patch):
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    N, V, P = pts.shape[0], views.V, patch * patch
+    out = dict(
+        visible=np.empty((V, N), np.float32),
+        Ori=np.empty((V, N, 2), np.float32),
+        Conf=np.empty((V, N), np.float32),
+        mask=np.empty((V, N), np.float32),
+        Ori_patch=np.empty((V, N, P, 2), np.float32),
+        Conf_patch=np.empty((V, N, P), np.float32),
+        pixf=np.empty((V, N, 2), np.float32),
+    )
+    lib().orc_visible_and_ori(
+        ctypes.byref(views.c), _p(pts), N, patch, _p(out["visible"]), _p(out["Ori"]), _p(out["Conf"]),
+        _p(out["mask"]), _p(out["Ori_patch"]), _p(out["Conf_patch"]), _p(out["pixf"]))
+    return out
+
+
+def topk_views(vis, conf, k=20):
+    vis = np.ascontiguousarray(vis, np.float32)
+    conf = np.ascontiguousarray(conf, np.float32)
+    V, N = vis.shape
+    idx = np.empty((k, N), np.int32)
+    val = np.empty((k, N), np.float32)
+    lib().orc_topk_views(_p(vis), _p(conf), V, N, k, _p(idx, c_i), _p(val))
+    return idx, val
+
+
+def sample_next(views, pts, base_view, ori_c, offsets):
+    pts = np.ascontiguousarray(pts, np.float32)
+    base_view = np.ascontiguousarray(base_view, np.int32)
+    ori_c = np.ascontiguousarray(ori_c, np.float32)
+    offsets = np.ascontiguousarray(offsets, np.float32)
+    N, S = pts.shape[0], offsets.shape[0]
+    out = np.empty((N, S, 3), np.float32)
+    lib().orc_sample_next(ctypes.byref(views.c), _p(pts), N, _p(base_view, c_i), _p(ori_c), _p(offsets), S, _p(out))
+    return out
+
+
+def reproject_ori(views, pts, samples):
+    pts = np.ascontiguousarray(pts, np.float32)
+    samples = np.ascontiguousarray(samples, np.float32)
+    N, S = samples.shape[0], samples.shape[1]
+    D = np.empty((views.V, N, S, 2), np.float32)
+    lib().orc_reproject_ori(ctypes.byref(views.c), _p(pts), _p(samples), N, S, _p(D))
+    return D
+
+
+def prj_loss(D, ori_patch, conf_patch, vis, thr, want_all=False):
+    D = np.ascontiguousarray(D, np.float32)
+    ori_patch = np.ascontiguousarray(ori_patch, np.float32)
+    conf_patch = np.ascontiguousarray(conf_patch, np.float32)
+    vis = np.ascontiguousarray(vis, np.float32)
+    V, N, S, _ = D.shape
+    P = conf_patch.shape[-1]
+    loss = np.empty(N, np.float32)
+    idx = np.empty(N, np.int32)
+    hc = np.empty(N, np.uint8)
+    all_ = np.empty((N, S), np.float32) if want_all else None
+    lib().orc_prj_loss(V, N, S, P, ctypes.c_float(thr), _p(D), _p(ori_patch), _p(conf_patch), _p(vis), _p(loss),
+                       _p(idx, c_i), _p(hc, c_u8), _p(all_))
+    if want_all:
+        return loss, idx, hc.astype(bool), all_
+    return loss, idx, hc.astype(bool)
+
+
+def forward(views, pts, patch, thr, offsets, base_idx=None, base_val=None, nrank=10, rank_step=2, extra=False):
+    """PMVO.forward (PMVO.py:39-78): returns (points, line_ori, min_loss, high_conf[, extras])."""
+    pts = np.ascontiguousarray(pts, np.float32)
+    offsets = np.ascontiguousarray(offsets, np.float32)
+    N, S = pts.shape[0], offsets.shape[0]
+    if base_idx is not None:
+        base_idx = np.ascontiguousarray(base_idx, np.int32)
+        base_val = np.ascontiguousarray(base_val, np.float32)
+    lo = np.empty((N, 3), np.float32)
+    ml = np.empty(N, np.float32)
+    hc = np.empty(N, np.uint8)
+    bs = np.empty((N, 3), np.float32)
+    br = np.empty(N, np.int32)
+    bi = np.empty(N, np.int32)
+    lib().orc_forward(ctypes.byref(views.c), _p(pts), N, patch, ctypes.c_float(thr), _p(offsets), S, nrank,
+                      rank_step, _p(base_idx, c_i), _p(base_val), _p(lo), _p(ml), _p(hc, c_u8), _p(bs),
+                      _p(br, c_i), _p(bi, c_i))
+    if extra:
+        return pts, lo, ml, hc.astype(bool), dict(best_sample=bs, best_rank=br, best_s=bi)
+    return pts, lo, ml, hc.astype(bool)

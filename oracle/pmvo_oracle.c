@@ -1,0 +1,506 @@
+/*
+ * oracle/pmvo_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A CPU restatement, in plain C, of MonoHair's patch-based multi-view optimisation
+ * (PMVO) hot path.  It exists to CHECK the HIP kernels in monohair_amd/csrc and to
+ * give bench.py its `cpu_baseline` leg; nothing in the product path may call it.
+ *
+ * Every function cites the reference lines it restates (/root/reference/...).
+ * Floating point is written operation by operation in the order the reference's
+ * PyTorch-CPU ops evaluate them (probed in the survey container, torch 2.10 + MKL):
+ *   - torch.matmul of a 4x4 / 3x3 matrix with a [K,N] matrix  = k-ordered fmaf chain from 0;
+ *   - torch.linalg.(vector_)norm over a short last dim          = sqrt of a k-ordered fmaf chain;
+ *   - torch.cosine_similarity(x,y)  = sum_k (x_k/max(|x|,eps)) * (y_k/max(|y|,eps)),
+ *     products rounded separately, then added left to right (NO fma);
+ *   - torch.sum(t, dim=0) on a contiguous [V,...] float tensor   = ATen "cascade sum":
+ *     16-row blocks accumulated sequentially, block sums accumulated sequentially,
+ *     remainder rows added, then the two levels added (valid for V < 256);
+ *   - torch.round = round-half-even; torch.min propagates NaN (first NaN index wins).
+ * Compile with -ffp-contract=off so that the compiler adds no fma of its own.
+ *
+ * Parity status: PINNED -- checked against golden vectors produced by the imported
+ * reference itself (tools/gen_golden.py -> tests/golden/, tests/test_oracle_golden.py).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_CAM_STRIDE 48 /* floats per camera record */
+/* camera record: [0..15] pose (world->camera, row-major), [16..31] proj (row-major),
+ * [32..40] inverse of pose[:3,:3] (row-major), rest padding. */
+
+typedef struct {
+    int V, H, W;
+    const float *cams;           /* V * ORC_CAM_STRIDE */
+    const float *const *depth;   /* V pointers, [H,W]   (channel 0 of the reference's [H,W,3]) */
+    const float *const *ori;     /* V pointers, [H,W,2] */
+    const float *const *conf;    /* V pointers, [H,W]   */
+    const float *const *mask;    /* V pointers, [H,W]   (channel 0) */
+} orc_views;
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+/* ---- Camera.projection (Utils/Camera_utils.py:38-58): camera_v = pose@[X;1]; uv = proj@camera_v; uv[:2]/=z */
+static inline void cam_project(const float *cam, const float *X, float *u, float *v, float *z) {
+    const float *P = cam, *Q = cam + 16;
+    float c[4];
+    for (int r = 0; r < 4; ++r) {
+        float a = P[r * 4 + 0] * X[0];
+        a = fmaf(P[r * 4 + 1], X[1], a);
+        a = fmaf(P[r * 4 + 2], X[2], a);
+        a = fmaf(P[r * 4 + 3], 1.0f, a);
+        c[r] = a;
+    }
+    float q[2];
+    for (int r = 0; r < 2; ++r) {
+        float a = Q[r * 4 + 0] * c[0];
+        a = fmaf(Q[r * 4 + 1], c[1], a);
+        a = fmaf(Q[r * 4 + 2], c[2], a);
+        a = fmaf(Q[r * 4 + 3], c[3], a);
+        q[r] = a;
+    }
+    *z = c[2];
+    *u = q[0] / c[2];
+    *v = q[1] / c[2];
+}
+
+/* ndc -> unrounded pixel, x (column) then y (row): PMVO.py:380-382 == Camera_utils.py:67-69 */
+static inline void ndc_to_pixel(float u, float v, int H, int W, float *col, float *row) {
+    *col = ((-u + 1.0f) / 2.0f) * (float)W;
+    *row = ((v + 1.0f) / 2.0f) * (float)H;
+}
+
+/* PMVO.project_points (PMVO.py:378-397) for one point: rounded+clamped (row,col), z'=-z/2, oob flag */
+static inline void project_point(const float *cam, const float *X, int H, int W, int *row, int *col, float *zp,
+                                 int *oob, float *rowf, float *colf) {
+    float u, v, z, cf, rf;
+    cam_project(cam, X, &u, &v, &z);
+    ndc_to_pixel(u, v, H, W, &cf, &rf);
+    float cr = nearbyintf(cf), rr = nearbyintf(rf);
+    /* torch: round -> long; compare on the integers. NaN/inf never occur for points in front of a camera. */
+    long long ci = (long long)cr, ri = (long long)rr;
+    *oob = (ci > W - 1) || (ci < 0) || (ri > H - 1) || (ri < 0);
+    if (ci < 0) ci = 0;
+    if (ci > W - 1) ci = W - 1;
+    if (ri < 0) ri = 0;
+    if (ri > H - 1) ri = H - 1;
+    *row = (int)ri;
+    *col = (int)ci;
+    *zp = -z / 2.0f;
+    if (rowf) *rowf = rf;
+    if (colf) *colf = cf;
+}
+
+void orc_project_points(const float *cam, const float *pts, int N, int H, int W, int32_t *rc, float *zp,
+                        uint8_t *oob, float *pixf) {
+    for (int n = 0; n < N; ++n) {
+        int r, c, o;
+        float z, rf, cf;
+        project_point(cam, pts + 3 * n, H, W, &r, &c, &z, &o, &rf, &cf);
+        rc[2 * n] = r;
+        rc[2 * n + 1] = c;
+        zp[n] = z;
+        oob[n] = (uint8_t)o;
+        if (pixf) {
+            pixf[2 * n] = rf;
+            pixf[2 * n + 1] = cf;
+        }
+    }
+}
+
+static inline int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+static inline float clampf(float x, float lo, float hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* PMVO.compute_visible (PMVO.py:525-529): d = z'*255 - depth */
+static inline float soft_visible(float depth, float z255) {
+    float d = z255 - depth;
+    float vis = (d < 0.1f) ? (1.0f - d / 0.1f) : -1.0f;
+    return clampf(vis, -1.0f, 1.0f);
+}
+
+/*
+ * PMVO.Compute_Visible_and_Ori (PMVO.py:346-376) with the gathers of PMVO.py:482-523.
+ * Outputs (any may be NULL): vis[V,N], ori[V,N,2], conf[V,N] (clamped 1e-6..1), mask[V,N],
+ * ori_patch[V,N,P,2], conf_patch[V,N,P] (clamped), pixf[V,N,2] (unrounded row,col; extra).
+ * Patch taps: row offset outer, column offset inner, each tap clamped to the image.
+ */
+void orc_visible_and_ori(const orc_views *vw, const float *pts, int N, int patch, float *vis, float *ori,
+                         float *conf, float *mask, float *ori_patch, float *conf_patch, float *pixf) {
+    const int V = vw->V, H = vw->H, W = vw->W, P = patch * patch, hp = patch / 2;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int v = 0; v < V; ++v) {
+        for (int n = 0; n < N; ++n) {
+            const float *cam = vw->cams + (size_t)v * ORC_CAM_STRIDE;
+            int r, c, oob;
+            float zp, rf, cf;
+            project_point(cam, pts + 3 * n, H, W, &r, &c, &zp, &oob, &rf, &cf);
+            size_t vn = (size_t)v * N + n;
+            size_t pix = (size_t)r * W + c;
+            if (vis) {
+                float vb = soft_visible(vw->depth[v][pix], zp * 255.0f);
+                if (oob) vb = -1.0f;
+                vis[vn] = vb;
+            }
+            if (ori) {
+                ori[2 * vn] = vw->ori[v][2 * pix];
+                ori[2 * vn + 1] = vw->ori[v][2 * pix + 1];
+            }
+            if (conf) conf[vn] = clampf(vw->conf[v][pix], 1e-6f, 1.0f);
+            if (mask) mask[vn] = vw->mask[v][pix];
+            if (pixf) {
+                pixf[2 * vn] = rf;
+                pixf[2 * vn + 1] = cf;
+            }
+            if (ori_patch || conf_patch) {
+                int t = 0;
+                for (int i = -hp; i <= hp; ++i)
+                    for (int j = -hp; j <= hp; ++j, ++t) {
+                        size_t q = (size_t)clampi(r + i, 0, H - 1) * W + clampi(c + j, 0, W - 1);
+                        if (ori_patch) {
+                            ori_patch[(vn * P + t) * 2] = vw->ori[v][2 * q];
+                            ori_patch[(vn * P + t) * 2 + 1] = vw->ori[v][2 * q + 1];
+                        }
+                        if (conf_patch) conf_patch[vn * P + t] = clampf(vw->conf[v][q], 1e-6f, 1.0f);
+                    }
+            }
+        }
+    }
+}
+
+/*
+ * PMVO.Find_max_conf_from_visible_view (PMVO.py:339-343): C' = vis<1 ? conf*max(vis,0) : conf; top-k over views.
+ * torch.topk's order among equal values is unspecified; this restatement (and the HIP kernel) use
+ * (value descending, view index ascending).  out_idx/out_val are [k,N].
+ */
+void orc_topk_views(const float *vis, const float *conf, int V, int N, int k, int32_t *out_idx, float *out_val) {
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+        float cv[1024];
+        for (int v = 0; v < V; ++v) {
+            float vb = vis[(size_t)v * N + n], c = conf[(size_t)v * N + n];
+            cv[v] = (vb < 1.0f) ? c * fmaxf(vb, 0.0f) : c;
+        }
+        for (int v = 0; v < V; ++v) {
+            int rank = 0;
+            for (int u = 0; u < V; ++u) rank += (cv[u] > cv[v]) || (cv[u] == cv[v] && u < v);
+            if (rank < k) {
+                out_idx[(size_t)rank * N + n] = v;
+                out_val[(size_t)rank * N + n] = cv[v];
+            }
+        }
+    }
+}
+
+/* the 90 depth offsets of PMVO.sample_next_3d_pos (PMVO.py:274-278) are torch.arange values that are
+ * not start+i*step in fp32; they are passed in (fixture tests/golden/depth_offsets.npy). */
+
+/* Camera.reprojection(..., to_world=True) (Camera_utils.py:81-106) */
+static inline void cam_unproject(const float *cam, float u, float v, float z, float *X) {
+    const float *P = cam, *Q = cam + 16, *Ri = cam + 32;
+    float c0 = (u - Q[2]) / Q[0] * z;
+    float c1 = (v - Q[6]) / Q[5] * z;
+    float c2 = z;
+    float d0 = c0 - P[3], d1 = c1 - P[7], d2 = c2 - P[11];
+    /* torch.matmul(inv(R) [column-major LAPACK output], (c - t) [transposed view]) lands in an MKL sgemm
+     * kernel that, for fewer than ~28k columns (<= 316 points per base view -- the production regime and
+     * every golden case), evaluates (a0*b0 + a2*b2) + a1*b1 with separately rounded products; above that
+     * size MKL switches to a k-ordered fma chain.  The oracle (and the HIP kernel) pin the small-size form. */
+    for (int r = 0; r < 3; ++r) {
+        float p0 = Ri[r * 3 + 0] * d0;
+        float p1 = Ri[r * 3 + 1] * d1;
+        float p2 = Ri[r * 3 + 2] * d2;
+        X[r] = (p0 + p2) + p1;
+    }
+}
+
+/*
+ * PMVO.sample_next_3d_pos (PMVO.py:263-335) for one point whose base view is `cam`:
+ * pixel (unrounded) + 2*(Ori_col, Ori_row) -> ndc -> unproject at z + offset[s].
+ * ori_c = centre orientation sample (row comp, col comp) of the base view at the point.
+ * (The surface_points assignments at PMVO.py:333-334 write into temporaries: surface_points == points.)
+ */
+static inline void sample_next_point(const float *cam, const float *X, const float *ori_c, int H, int W,
+                                     const float *offs, int S, float *out /* S*3 */) {
+    float u, v, z, col, row;
+    cam_project(cam, X, &u, &v, &z);
+    ndc_to_pixel(u, v, H, W, &col, &row);
+    float nx = col + ori_c[1] * 2.0f;
+    float ny = row + ori_c[0] * 2.0f;
+    nx = nx / (float)W;
+    ny = ny / (float)H;
+    nx = nx * 2.0f - 1.0f;
+    ny = ny * 2.0f - 1.0f;
+    nx = -nx;
+    for (int s = 0; s < S; ++s) cam_unproject(cam, nx, ny, z + offs[s], out + 3 * s);
+}
+
+void orc_sample_next(const orc_views *vw, const float *pts, int N, const int32_t *base_view /*N*/,
+                     const float *ori /*V,N,2*/, const float *offs, int S, float *out /*N,S,3*/) {
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+        int b = base_view[n];
+        sample_next_point(vw->cams + (size_t)b * ORC_CAM_STRIDE, pts + 3 * n, ori + ((size_t)b * N + n) * 2, vw->H,
+                          vw->W, offs, S, out + (size_t)n * S * 3);
+    }
+}
+
+/* unrounded pixel (row, col) of a world point: Camera.projection + Camera.uv2pixel (Camera_utils.py:60-71) */
+static inline void pixel_of(const float *cam, const float *X, int H, int W, float *row, float *col) {
+    float u, v, z;
+    cam_project(cam, X, &u, &v, &z);
+    ndc_to_pixel(u, v, H, W, col, row);
+}
+
+/* PMVO.compute_reproject_ori (PMVO.py:219-241): D[v,n,s] = pix(sample) - pix(point), as (row, col) */
+void orc_reproject_ori(const orc_views *vw, const float *pts, const float *samples, int N, int S, float *D) {
+    const int V = vw->V;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int v = 0; v < V; ++v)
+        for (int n = 0; n < N; ++n) {
+            const float *cam = vw->cams + (size_t)v * ORC_CAM_STRIDE;
+            float r0, c0;
+            pixel_of(cam, pts + 3 * n, vw->H, vw->W, &r0, &c0);
+            for (int s = 0; s < S; ++s) {
+                float r1, c1;
+                pixel_of(cam, samples + ((size_t)n * S + s) * 3, vw->H, vw->W, &r1, &c1);
+                float *d = D + (((size_t)v * N + n) * S + s) * 2;
+                d[0] = r1 - r0;
+                d[1] = c1 - c0;
+            }
+        }
+}
+
+/* x / max(|x|, 1e-8) for a 2-vector, as torch.cosine_similarity normalises (norm = sqrt of an fmaf chain) */
+static inline void unit2(const float *x, float *o) {
+    float s = x[0] * x[0];
+    s = fmaf(x[1], x[1], s);
+    float nrm = fmaxf(sqrtf(s), 1e-8f);
+    /* fmaxf drops a NaN operand; torch.clamp_min keeps it.  Make NaN norms stay NaN. */
+    if (s != s) nrm = s;
+    o[0] = x[0] / nrm;
+    o[1] = x[1] / nrm;
+}
+
+/* 1 - max(cos(O,D), cos(-O,D)) on pre-normalised vectors: products rounded, added, no fma */
+static inline float tap_loss(const float *oh, const float *dh) {
+    float p0 = oh[0] * dh[0];
+    float p1 = oh[1] * dh[1];
+    float cs = p0 + p1;
+    return 1.0f - fabsf(cs);
+}
+
+/* ATen cascade sum over the leading (view) dimension, one column: see file header. */
+typedef struct {
+    float a0, a1;
+} casc;
+static inline void casc_step(casc *c, int v, float x) {
+    if (v > 0 && (v & 15) == 0) {
+        c->a1 = c->a1 + c->a0;
+        c->a0 = 0.0f;
+    }
+    c->a0 = c->a0 + x;
+}
+static inline float casc_done(const casc *c) { return c->a0 + c->a1; }
+
+/*
+ * PMVO.compute_prj_loss (PMVO.py:151-209) for ONE point.
+ *   D        [V,S,2] view-strided by dstride floats (projected 2D segment directions)
+ *   opatch   [V,P,2], cpatch [V,P] view-strided (clamped confidences), vis [V] view-strided
+ * Returns min loss, argmin sample and the high-confidence flag of that sample.
+ * scratch: S*(2 casc + 1 int) -- caller provides.
+ */
+static void prj_loss_point(int V, int S, int P, float thr, const float *D, size_t dstride, const float *opatch,
+                           size_t ostride, const float *cpatch, size_t cstride, const float *vis, size_t vstride,
+                           float *out_loss, int *out_idx, int *out_hc, float *loss_s /*S or NULL*/) {
+    casc *num = (casc *)calloc((size_t)S, sizeof(casc));
+    casc *den = (casc *)calloc((size_t)S, sizeof(casc));
+    int *cnt = (int *)calloc((size_t)S, sizeof(int));
+    float *oh = (float *)malloc(sizeof(float) * 2 * (size_t)P);
+    for (int v = 0; v < V; ++v) {
+        const float *op = opatch + (size_t)v * ostride, *cp = cpatch + (size_t)v * cstride;
+        float cmax = cp[0];
+        for (int p = 1; p < P; ++p) cmax = (cp[p] > cmax) ? cp[p] : cmax;
+        const int hc = cmax > thr;
+        for (int p = 0; p < P; ++p) unit2(op + 2 * p, oh + 2 * p);
+        const float visible = vis[(size_t)v * vstride];
+        for (int s = 0; s < S; ++s) {
+            float dh[2];
+            unit2(D + (size_t)v * dstride + 2 * s, dh);
+            float ml = tap_loss(oh, dh), bc = cp[0];
+            for (int p = 1; p < P; ++p) {
+                float l = tap_loss(oh + 2 * p, dh);
+                int idx = l < ml;
+                int upd = hc ? (idx && (cp[p] > thr)) : idx;
+                if (upd) {
+                    ml = l;
+                    bc = cp[p];
+                }
+            }
+            float w = (visible == -1.0f ? 0.0f : 1.0f) * bc;
+            casc_step(&num[s], v, ml * w);
+            casc_step(&den[s], v, w);
+            cnt[s] += (w > 0.0f);
+        }
+    }
+    int npos = 0;
+    float best = 0.f;
+    int besti = 0, seen_nan = 0;
+    unsigned char *pos = (unsigned char *)malloc((size_t)S);
+    float *ls = (float *)malloc(sizeof(float) * (size_t)S);
+    for (int s = 0; s < S; ++s) {
+        float dn = casc_done(&den[s]);
+        float ratio = dn / (float)cnt[s];
+        pos[s] = ratio > thr;
+        npos += pos[s];
+        ls[s] = casc_done(&num[s]) / dn;
+    }
+    const int low = npos < 5;
+    for (int s = 0; s < S; ++s) {
+        float l = ls[s];
+        if (!low && !pos[s]) l = 1.0f;
+        if (loss_s) loss_s[s] = l;
+        if (s == 0) {
+            best = l;
+            besti = 0;
+            seen_nan = (l != l);
+        } else if (!seen_nan) {
+            if (l != l) {
+                best = l;
+                besti = s;
+                seen_nan = 1;
+            } else if (l < best) {
+                best = l;
+                besti = s;
+            }
+        }
+    }
+    *out_loss = best;
+    *out_idx = besti;
+    *out_hc = pos[besti];
+    free(num);
+    free(den);
+    free(cnt);
+    free(oh);
+    free(pos);
+    free(ls);
+}
+
+/* compute_prj_loss over N points from materialised tensors: D[V,N,S,2], ori_patch[V,N,P,2], conf_patch[V,N,P], vis[V,N] */
+void orc_prj_loss(int V, int N, int S, int P, float thr, const float *D, const float *ori_patch,
+                  const float *conf_patch, const float *vis, float *loss, int32_t *idx, uint8_t *hc,
+                  float *loss_ns /* [N,S] or NULL */) {
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int n = 0; n < N; ++n) {
+        float l;
+        int i, h;
+        prj_loss_point(V, S, P, thr, D + (size_t)n * S * 2, (size_t)N * S * 2, ori_patch + (size_t)n * P * 2,
+                       (size_t)N * P * 2, conf_patch + (size_t)n * P, (size_t)N * P, vis + n, (size_t)N, &l, &i, &h,
+                       loss_ns ? loss_ns + (size_t)n * S : NULL);
+        loss[n] = l;
+        idx[n] = i;
+        hc[n] = (uint8_t)h;
+    }
+}
+
+/*
+ * PMVO.forward (PMVO.py:39-78) for N points.
+ *   base_idx/base_val: [K,N] ranking of base views (K >= 2*nrank-1); if NULL it is computed with orc_topk_views.
+ * Outputs: line_ori[N,3], min_loss[N], high_conf[N]; optional best_sample[N,3], best_rank[N], best_s[N].
+ */
+void orc_forward(const orc_views *vw, const float *pts, int N, int patch, float thr, const float *offs, int S,
+                 int nrank, int rank_step, const int32_t *base_idx_in, const float *base_val_in, float *line_ori,
+                 float *min_loss, uint8_t *high_conf, float *best_sample, int32_t *best_rank, int32_t *best_s) {
+    const int V = vw->V, P = patch * patch, K = 20;
+    float *vis = (float *)malloc(sizeof(float) * (size_t)V * N);
+    float *ori = (float *)malloc(sizeof(float) * (size_t)V * N * 2);
+    float *conf = (float *)malloc(sizeof(float) * (size_t)V * N);
+    float *opatch = (float *)malloc(sizeof(float) * (size_t)V * N * P * 2);
+    float *cpatch = (float *)malloc(sizeof(float) * (size_t)V * N * P);
+    orc_visible_and_ori(vw, pts, N, patch, vis, ori, conf, NULL, opatch, cpatch, NULL);
+    int32_t *bidx = NULL;
+    float *bval = NULL;
+    if (!base_idx_in) {
+        bidx = (int32_t *)malloc(sizeof(int32_t) * (size_t)K * N);
+        bval = (float *)malloc(sizeof(float) * (size_t)K * N);
+        orc_topk_views(vis, conf, V, N, K, bidx, bval);
+        base_idx_in = bidx;
+        base_val_in = bval;
+    }
+#pragma omp parallel for schedule(dynamic, 2)
+    for (int n = 0; n < N; ++n) {
+        float *samples = (float *)malloc(sizeof(float) * (size_t)S * 3);
+        float *D = (float *)malloc(sizeof(float) * (size_t)V * S * 2);
+        const float *X = pts + 3 * n;
+        float ml = 0.f, bs[3] = {0, 0, 0};
+        int hcb = 0, br = 0, bsi = 0;
+        for (int r = 0; r < nrank; ++r) {
+            const int i = r * rank_step;
+            const int b = base_idx_in[(size_t)i * N + n];
+            sample_next_point(vw->cams + (size_t)b * ORC_CAM_STRIDE, X, ori + ((size_t)b * N + n) * 2, vw->H, vw->W,
+                              offs, S, samples);
+            for (int v = 0; v < V; ++v) {
+                const float *cam = vw->cams + (size_t)v * ORC_CAM_STRIDE;
+                float r0, c0;
+                pixel_of(cam, X, vw->H, vw->W, &r0, &c0);
+                for (int s = 0; s < S; ++s) {
+                    float r1, c1;
+                    pixel_of(cam, samples + 3 * s, vw->H, vw->W, &r1, &c1);
+                    D[((size_t)v * S + s) * 2] = r1 - r0;
+                    D[((size_t)v * S + s) * 2 + 1] = c1 - c0;
+                }
+            }
+            float l;
+            int idx, h;
+            prj_loss_point(V, S, P, thr, D, (size_t)S * 2, opatch + (size_t)n * P * 2, (size_t)N * P * 2,
+                           cpatch + (size_t)n * P, (size_t)N * P, vis + n, (size_t)N, &l, &idx, &h, NULL);
+            int take = (r == 0) || ((l < ml) && (base_val_in[(size_t)i * N + n] > 0.0f));
+            if (take) {
+                ml = l;
+                hcb = h;
+                br = r;
+                bsi = idx;
+                memcpy(bs, samples + 3 * idx, sizeof(bs));
+            }
+        }
+        float d0 = bs[0] - X[0], d1 = bs[1] - X[1], d2 = bs[2] - X[2];
+        float s2 = d0 * d0;
+        s2 = fmaf(d1, d1, s2);
+        s2 = fmaf(d2, d2, s2);
+        float nrm = sqrtf(s2);
+        line_ori[3 * n] = d0 / nrm;
+        line_ori[3 * n + 1] = d1 / nrm;
+        line_ori[3 * n + 2] = d2 / nrm;
+        min_loss[n] = ml;
+        high_conf[n] = (uint8_t)hcb;
+        if (best_sample) memcpy(best_sample + 3 * n, bs, sizeof(bs));
+        if (best_rank) best_rank[n] = br;
+        if (best_s) best_s[n] = bsi;
+        free(samples);
+        free(D);
+    }
+    free(vis);
+    free(ori);
+    free(conf);
+    free(opatch);
+    free(cpatch);
+    free(bidx);
+    free(bval);
+}

@@ -1,0 +1,51 @@
+import ast
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    meta = ast.literal_eval(str(z["meta"]))
+    return meta, z
+
+
+_scene_cache = {}
+
+
+def golden_scene(meta):
+    """Regenerate the synthetic scene of a golden case (bit-identical; checked by checksum in the tests)."""
+    from monohair_amd import synth
+
+    key = (meta["V"], meta["H"], meta["W"], meta["seed"], meta["scale"], meta["rings"], meta["quantize"])
+    if key not in _scene_cache:
+        _scene_cache[key] = synth.make_scene(meta["V"], meta["H"], meta["W"], seed=meta["seed"], scale=meta["scale"],
+                                             rings=meta["rings"], quantize=meta["quantize"])
+    return _scene_cache[key]
+
+
+def scene_views(scene):
+    """oracle.Views of a synth scene (host planes + camera records)."""
+    import oracle
+    from monohair_amd.camera import camera_records, cameras_from_list
+
+    cams = cameras_from_list(scene["cams"])
+    return oracle.Views(camera_records(cams), scene["depth"].cpu().numpy(), scene["ori"].cpu().numpy(),
+                        scene["conf"].cpu().numpy(), scene["mask"].cpu().numpy())
+
+
+@pytest.fixture(scope="session")
+def depth_offsets():
+    return np.load(os.path.join(GOLDEN, "depth_offsets.npy"))

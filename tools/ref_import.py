@@ -1,0 +1,53 @@
+"""Import the MonoHair reference (read-only, /root/reference) in THIS container only.
+
+Used by tools/gen_golden.py to produce the golden vectors under tests/golden/.
+Nothing here travels in any form that contains reference code: the reference is
+imported from where it lies, with empty stand-in modules for the third-party
+packages that are not installed (they are never *called* on the paths we run --
+only imported at module top level).  SURVEY.md Appendix B is the recipe.
+"""
+import sys
+import types
+
+REF = "/root/reference"
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules.setdefault(name, m)
+    return sys.modules[name]
+
+
+def import_reference(gabor=False):
+    import torch
+
+    sys.dont_write_bytecode = True
+    for name in ("cv2", "trimesh", "open3d", "termcolor"):
+        _stub(name)
+    _stub("easydict", EasyDict=dict)
+    if gabor:
+        _stub("imageio")
+        sk = _stub("skimage")
+        skf = _stub("skimage.filters", difference_of_gaussians=lambda *a, **k: None)
+        sk.filters = skf
+        tv = _stub("torchvision")
+        tvt = _stub("torchvision.transforms")
+        tvu = _stub("torchvision.utils", save_image=lambda *a, **k: None)
+        tv.transforms, tv.utils = tvt, tvu
+        ident = lambda self, *a, **k: self
+        torch.Tensor.cuda = ident
+        torch.nn.Module.cuda = ident
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import PMVO as ref_pmvo  # noqa
+    import Utils.Camera_utils as ref_cam  # noqa
+    import Utils.PMVO_utils as ref_utils  # noqa
+
+    out = dict(PMVO=ref_pmvo, Camera_utils=ref_cam, PMVO_utils=ref_utils)
+    if gabor:
+        import preprocess_capture_data.GaborFilter as ref_gabor  # noqa
+
+        out["GaborFilter"] = ref_gabor
+    return out
