@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py -- PMVO iterations/sec on the synthetic 60-view 1080p / 256^3 workload (BASELINE.json).
+
+One step = one PMVO iteration = one `PMVO.forward()` over a chunk of 5000 candidate points against all
+V views (one step of the trange at /root/reference/PMVO.py:572-574): project-and-gather, base-view
+ranking, tap preparation and the fused loss search, maps resident in HBM, no file IO.
+
+    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+
+Points shard across ranks (every GPU holds all views; no collective inside an iteration -- SURVEY.md §8e),
+so per-GPU work is fixed as N grows: "scaling": "weak".  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from monohair_amd import synth  # noqa: E402
+from monohair_amd.camera import camera_records, cameras_from_list  # noqa: E402
+from monohair_amd.pmvo import PMVO, depth_offsets  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+CHUNK = 5000                 # PMVO.py:566
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--views", type=int, default=60)
+    ap.add_argument("--height", type=int, default=1920)
+    ap.add_argument("--width", type=int, default=1080)
+    ap.add_argument("--volume", type=int, default=256)
+    ap.add_argument("--patch", type=int, default=7)          # big_wavy1.yaml:18
+    ap.add_argument("--conf-threshold", type=float, default=0.15)
+    ap.add_argument("--quantize", action="store_true", help="8-bit orientation/confidence maps (file hand-off)")
+    ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--variant", type=int, default=0)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    n_gpus = max(a.gpus, world) if world > 1 else 1
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    V, H, W, P = a.views, a.height, a.width, a.patch * a.patch
+    scene = synth.make_scene(V, H, W, device=dev, seed=0, quantize=a.quantize)
+    cams = cameras_from_list(scene["cams"])
+    recs = camera_records(cams)
+    pm = PMVO.from_planes(recs, scene["depth"], scene["ori"], scene["conf"], scene["mask"], device=dev,
+                          patch_size=a.patch, visible_threshold=1, conf_threshold=a.conf_threshold, camera=cams)
+    if a.variant:
+        pm.set_option("search_variant", a.variant)
+
+    # candidate points of the 256^3 volume; keep the ones the reference would send to optimize()
+    # (filter_negative_points, PMVO.py:535-557), then chunk by 5000 and deal the chunks to the ranks
+    cand = synth.candidate_points(res=a.volume, seed=0)
+    surf = []
+    for i in range(0, len(cand), 200000):
+        s, _, _ = pm.filter_points(cand[i:i + 200000])
+        surf.append(s.cpu().numpy())
+    surf = np.concatenate(surf)
+    pts = cand[surf]
+    nchunk = max(1, len(pts) // CHUNK)
+    chunks = [pts[i * CHUNK:(i + 1) * CHUNK] for i in range(nchunk)]
+    my = [chunks[i] for i in range(rank, nchunk, world)] or chunks[:1]
+    dev_chunks = [torch.from_numpy(c).to(dev).float() for c in my]
+
+    def step(i):
+        return pm.forward(dev_chunks[i % len(dev_chunks)])
+
+    for i in range(a.warmup):
+        step(i)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # --- timed region: exactly K steps
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # --- per-kernel durations of the same steps (HIP events on the launch stream), outside the timed region
+    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
+    t_pg = t_tk = t_sr = 0.0
+    nvis = 0.0
+    reps = max(3, min(a.steps, 10))
+    for i in range(reps):
+        c = dev_chunks[i % len(dev_chunks)]
+        e = [ev() for _ in range(4)]
+        e[0].record()
+        pm.Compute_Visible_and_Ori(c)
+        e[1].record()
+        bidx, bval = pm.Find_max_conf_from_visible_view()
+        e[2].record()
+        torch.cuda.synchronize()
+        nvis += float((pm.visible != -1).float().mean().item())
+        e2 = [ev(), ev()]
+        e2[0].record()
+        pm.forward(c)
+        e2[1].record()
+        torch.cuda.synchronize()
+        t_pg += e[0].elapsed_time(e[1])
+        t_tk += e[1].elapsed_time(e[2])
+        t_sr += e2[0].elapsed_time(e2[1])
+    t_pg, t_tk, t_sr, nvis = t_pg / reps, t_tk / reps, t_sr / reps, nvis / reps
+    t_search = max(t_sr - t_pg - t_tk, 1e-6)
+
+    if rank != 0:
+        return
+    ms = dt / a.steps * 1e3
+    value = a.steps * world / dt
+    # algorithmic bytes of project-and-gather per iteration: V*N*(12P+20) gathered + the same
+    # written + 12N of points, fp32 reference layout
+    pg_bytes = 2 * V * CHUNK * (12 * P + 20) + 12 * CHUNK
+    achieved = pg_bytes / (t_pg * 1e-3) / 1e9
+    pairs_nominal = 10 * V * CHUNK * 90 * P
+    out = {
+        "metric": "PMVO iterations/sec (60x1080p views, 256^3 volume)",
+        "value": round(value, 3),
+        "unit": "iterations/s",
+        "n_gpus": n_gpus,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": round(ms, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "synthetic sphere, %d views @ %dx%d, %d^3 volume, %d points/iteration, patch %d, S=90, "
+                        "10 base views (BASELINE.json configs[2])" % (V, H, W, a.volume, CHUNK, a.patch),
+            "views": V, "image": [H, W], "volume": a.volume, "points_per_iteration": CHUNK, "patch": a.patch,
+            "conf_threshold": a.conf_threshold, "surface_points": int(len(pts)), "iterations_full_pass": nchunk,
+            "parallelism": "points sharded over %d GPU(s), views replicated" % world,
+            "maps": "quantized-8bit" if a.quantize else "continuous",
+        },
+        "roofline": {
+            "kernel": "mh_project_gather_kernel<%d>" % a.patch,
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_launch": pg_bytes,
+            "launch_ms": round(t_pg, 4),
+        },
+        "kernels_ms": {"project_gather": round(t_pg, 4), "topk": round(t_tk, 4),
+                       "prep_taps+search": round(t_search, 4)},
+        "search": {
+            "pair_evals_nominal": pairs_nominal,
+            "visible_view_fraction": round(nvis, 4),
+            "gpair_per_s_nominal": round(pairs_nominal / (t_search * 1e-3) / 1e9, 1),
+        },
+    }
+    if not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(a, scene, recs, my[0], ms)
+    print(json.dumps(out))
+
+
+def cpu_baseline(a, scene, recs, chunk, gpu_ms):
+    """The CPU oracle (oracle/pmvo_oracle.c, OpenMP over points) timed on this host on a bounded sample of the
+    same iteration: the first n points of the chunk against all views."""
+    import oracle
+
+    views = oracle.Views(recs, scene["depth"].cpu().numpy(), scene["ori"].cpu().numpy(),
+                         scene["conf"].cpu().numpy(), scene["mask"].cpu().numpy())
+    cores = oracle.num_threads()
+    offs = depth_offsets(90)
+    n = a.cpu_points
+    if n <= 0:
+        # calibrate on a few points, then size the sample for ~15 s
+        t0 = time.perf_counter()
+        oracle.forward(views, chunk[:2 * cores], a.patch, a.conf_threshold, offs)
+        per_pt = (time.perf_counter() - t0) / (2 * cores)
+        n = int(min(len(chunk), max(4 * cores, 15.0 / max(per_pt, 1e-6))))
+    t0 = time.perf_counter()
+    oracle.forward(views, chunk[:n], a.patch, a.conf_threshold, offs)
+    t = time.perf_counter() - t0
+    its = (n / float(CHUNK)) / t
+    return {
+        "value": round(its, 5),
+        "unit": "iterations/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d of the %d points of one iteration, all %d views, C oracle with OpenMP (%.1f s)" %
+                  (n, CHUNK, a.views, t),
+    }
+
+
+if __name__ == "__main__":
+    main()

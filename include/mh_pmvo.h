@@ -1,0 +1,124 @@
+/*
+ * mh_pmvo.h -- C ABI of libmhpmvo.so: MonoHair's PMVO hot path as hand-written HIP kernels for
+ * MI355X (gfx950).  This is the drop-in boundary: the reference has no FFI of its own (the path is
+ * plain PyTorch, /root/reference/PMVO.py), so each entry point below names the reference function(s)
+ * whose tensor-op sequence it replaces; the Python mirror of the reference classes
+ * (monohair_amd/pmvo.py, gabor.py, pmvo_utils.py) binds them with ctypes -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer that is not marked "host" is a DEVICE pointer owned by the caller (e.g. a torch
+ *     tensor's data_ptr()); nothing is retained after the call returns except inside mh_ctx;
+ *   - all calls are asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return value: 0 on success, negative mh_status on failure; mh_last_error() returns a
+ *     thread-local description.  No exceptions cross the ABI.  No global state.
+ *   - layouts are the reference's (row-major, fp32): vis[V,N], ori[V,N,2], conf[V,N], mask[V,N],
+ *     ori_patch[V,N,P,2], conf_patch[V,N,P], with P = patch*patch taps in row-offset-major order.
+ */
+#ifndef MH_PMVO_H
+#define MH_PMVO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mh_ctx mh_ctx;
+
+enum mh_status {
+    MH_OK = 0,
+    MH_ERR_ARG = -1,     /* bad argument */
+    MH_ERR_HIP = -2,     /* a HIP runtime call failed */
+    MH_ERR_STATE = -3,   /* call order violated (e.g. views not set) */
+    MH_ERR_NOMEM = -4
+};
+
+#define MH_CAM_STRIDE 48 /* floats per camera record: pose[16] | proj[16] | inv(pose[:3,:3])[9] | pad */
+#define MH_TOPK 20       /* PMVO.py:341 */
+
+const char *mh_last_error(void);
+int mh_version(void);
+
+/* ---- context: owns the packed per-view maps, the camera table and the depth-offset table -------- */
+int mh_ctx_create(int device_id, mh_ctx **out);
+void mh_ctx_destroy(mh_ctx *ctx);
+
+/* Allocate packed storage for V views of H x W pixels (20 B / pixel: {ori_row, ori_col, conf, depth}
+ * + mask).  Replaces the per-view H2D copies of PMVO.__init__ (PMVO.py:21-28). */
+int mh_ctx_alloc_views(mh_ctx *ctx, int V, int H, int W);
+
+/* Pack one view.  depth/mask are the reference's [H,W,C] arrays of which channel 0 is used
+ * (PMVO.py:485,523): pass the channel count as the pixel stride.  cam_host: MH_CAM_STRIDE floats (host). */
+int mh_ctx_set_view(mh_ctx *ctx, int view, const float *cam_host, const float *depth, int depth_stride,
+                    const float *ori /*[H,W,2]*/, const float *conf /*[H,W]*/, const float *mask,
+                    int mask_stride, void *stream);
+
+/* The S depth offsets of PMVO.sample_next_3d_pos (PMVO.py:274-278), host pointer, S <= 256. */
+int mh_ctx_set_depth_offsets(mh_ctx *ctx, const float *offsets_host, int S);
+
+/* ---- K3+K4+K5: PMVO.Compute_Visible_and_Ori (PMVO.py:346-376) with project_points (:378-397),
+ * the gathers (:482-523) and compute_visible (:525-529).  Any output may be NULL.
+ * pixf[V,N,2] = unrounded (row, col) of each point in each view (what Camera.uv2pixel returns,
+ * Camera_utils.py:60-71); the search kernel reuses it. */
+int mh_project_gather(mh_ctx *ctx, const float *points /*[N,3]*/, int N, int patch, float *vis, float *ori,
+                      float *conf, float *mask, float *ori_patch, float *conf_patch, float *pixf, void *stream);
+
+/* ---- K6: PMVO.Find_max_conf_from_visible_view (PMVO.py:339-343).  out_idx/out_val are [MH_TOPK,N].
+ * Tie order (unspecified in torch.topk): value descending, then view index ascending. */
+int mh_topk_views(mh_ctx *ctx, const float *vis, const float *conf, int N, int32_t *out_idx, float *out_val,
+                  void *stream);
+
+/* bytes of scratch mh_search_forward / mh_refine_loss need for N points and this patch size */
+size_t mh_search_scratch_bytes(mh_ctx *ctx, int N, int patch);
+
+/* ---- K7-K10 fused: the body of PMVO.forward (PMVO.py:50-78): for base-view ranks 0,rank_step,...
+ * sample_next_3d_pos (:263-335), compute_reproject_ori (:219-241), compute_prj_loss (:151-209) and the
+ * best-so-far update (:57-70); line_ori = normalize(best_sample - point).
+ * Inputs are the tensors mh_project_gather produced for the same points.  Optional outputs may be NULL. */
+int mh_search_forward(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank,
+                      int rank_step, const float *vis, const float *ori, const float *pixf,
+                      const float *ori_patch, const float *conf_patch, const int32_t *base_idx,
+                      const float *base_val, void *scratch, size_t scratch_bytes, float *line_ori,
+                      float *min_loss, uint8_t *high_conf, float *best_sample, int32_t *best_rank,
+                      int32_t *best_s, void *stream);
+
+/* ---- compute_reproject_ori + compute_prj_loss with ONE given candidate per point: the core of
+ * PMVO.refine (PMVO.py:86-90), next = point + ori*step_mul/step_div
+ * (0.005 and 4 in the reference, applied in that order).  loss[N] (raw num/den, PMVO.py:199-204). */
+int mh_refine_loss(mh_ctx *ctx, const float *points, const float *dir /*[N,3]*/, float step_mul, float step_div,
+                   int N, int patch, float conf_threshold, const float *vis, const float *ori_patch,
+                   const float *conf_patch, float *loss, uint8_t *high_conf, void *stream);
+
+/* ---- K13: per-view visibility / mask / confidence votes of PMVO.filter_points (PMVO.py:402-459),
+ * PMVO.compute_unvisible_points (:461-480) and PMVO.filter_head_points (:110-137).
+ * surface_index/filter_index/unvisible_index/head_filter: uint8 [N]; any may be NULL. */
+int mh_filter_points(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold,
+                     float visible_threshold, uint8_t *surface_index, uint8_t *filter_index,
+                     uint8_t *unvisible_index, uint8_t *head_filter, void *stream);
+
+/* ---- K11: compute_points_similarity (Utils/PMVO_utils.py:366-382): medoid orientation of each group.
+ * Dense form: ori[G,K,3] -> out[G,3], out_index[G].  Segmented form (voxel fit, PMVO.py:717-726):
+ * ori[M,3] sorted by group, seg_start[G+1] (device), max_group = largest group size (<= 4096). */
+int mh_medoid_dense(mh_ctx *ctx, const float *ori, int G, int K, float *out, int32_t *out_index, void *stream);
+int mh_medoid_segmented(mh_ctx *ctx, const float *ori, const int32_t *seg_start, int G, int max_group,
+                        float *out, int32_t *out_index, void *stream);
+
+/* ---- K1+K2: calOrientationGabor.forward with iter=1 (preprocess_capture_data/GaborFilter.py:29-145):
+ * 180 real Gabor kernels 17x17 (sigma 1.8/2.4, lambda 4), |response| argmax -> orientation index,
+ * response-curve variance -> confidence normalised by the image maximum.
+ * image[H,W] (DoG-filtered gray) -> orient_index[H,W] (int32, degrees), conf[H,W], variance[H,W] (un-normalised). */
+int mh_gabor_bank(mh_ctx *ctx, const float *image, int H, int W, int32_t *orient_index, float *conf,
+                  float *variance, void *stream);
+/* Optional: install the 180 x 17 x 17 kernels (host pointer, kernel-major like gabor_fn's output) instead of
+ * the bank the library builds on the device; lets the host reproduce the reference's CPU transcendental
+ * functions bit for bit. */
+int mh_gabor_set_bank(mh_ctx *ctx, const float *bank_host);
+
+/* Tuning knobs (e.g. "search_variant": threads per point in the search kernel; 0 = default). */
+int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MH_PMVO_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of libmhpmvo.so (include/mh_pmvo.h).  There is NO fallback: if the HIP library is
+missing or a call fails, the product path raises -- it never routes through a CPU implementation."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmhpmvo.so")
+_lib = None
+
+vp = ctypes.c_void_p
+ci = ctypes.c_int
+cf = ctypes.c_float
+csz = ctypes.c_size_t
+
+_SIGS = {
+    "mh_last_error": (ctypes.c_char_p, []),
+    "mh_version": (ci, []),
+    "mh_ctx_create": (ci, [ci, ctypes.POINTER(vp)]),
+    "mh_ctx_destroy": (None, [vp]),
+    "mh_ctx_alloc_views": (ci, [vp, ci, ci, ci]),
+    "mh_ctx_set_view": (ci, [vp, ci, vp, vp, ci, vp, vp, vp, ci, vp]),
+    "mh_ctx_set_depth_offsets": (ci, [vp, vp, ci]),
+    "mh_ctx_set_option": (ci, [vp, ctypes.c_char_p, ci]),
+    "mh_project_gather": (ci, [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "mh_topk_views": (ci, [vp, vp, vp, ci, vp, vp, vp]),
+    "mh_search_scratch_bytes": (csz, [vp, ci, ci]),
+    "mh_search_forward": (ci, [vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, csz, vp, vp, vp, vp, vp,
+                               vp, vp]),
+    "mh_refine_loss": (ci, [vp, vp, vp, cf, cf, ci, ci, cf, vp, vp, vp, vp, vp, vp]),
+    "mh_filter_points": (ci, [vp, vp, ci, ci, cf, cf, vp, vp, vp, vp, vp]),
+    "mh_medoid_dense": (ci, [vp, vp, ci, ci, vp, vp, vp]),
+    "mh_medoid_segmented": (ci, [vp, vp, vp, ci, ci, vp, vp, vp]),
+    "mh_gabor_bank": (ci, [vp, vp, ci, ci, vp, vp, vp, vp]),
+    "mh_gabor_set_bank": (ci, [vp, vp]),
+}
+
+EXPORTS = sorted(_SIGS)
+
+
+class MhError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 in-tree (monohair_amd/lib/libmhpmvo.so)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-C", csrc, "-j8"] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MhError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().mh_last_error()
+        raise MhError("%s failed (%d): %s" % (what or "libmhpmvo", rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """data pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,300 @@
+// capi.cpp -- the C ABI of libmhpmvo.so (include/mh_pmvo.h): argument checking, the context that
+// owns the packed maps, and the launch sequences.  All arithmetic lives in the .hip kernels.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/mh_pmvo.h"
+
+struct MhViews {
+    int V, H, W;
+    const float4 *rec;
+    const float *mask;
+    const float *cams;
+};
+
+struct mh_ctx {
+    int device = 0;
+    int V = 0, H = 0, W = 0;
+    float4 *rec = nullptr;    // [V][H][W]
+    float *mask = nullptr;    // [V][H][W]
+    float *cams = nullptr;    // [V][MH_CAM_STRIDE]
+    float *offs = nullptr;    // [S]
+    float *gabor = nullptr;   // tap-major Gabor bank [289][192]
+    unsigned int *gabor_max = nullptr;
+    int S = 0;
+    int search_variant = 0;
+    MhViews views() const { return MhViews{V, H, W, rec, mask, cams}; }
+};
+
+// launchers implemented in the .hip files
+extern "C" {
+int mh_launch_pack_view(float4 *, float *, const float *, int, const float *, const float *, const float *, int,
+                        size_t, hipStream_t);
+int mh_launch_project_gather(MhViews, const float *, int, int, float *, float *, float *, float *, float *, float *,
+                             float *, hipStream_t);
+int mh_launch_topk(const float *, const float *, int, int, int32_t *, float *, hipStream_t);
+int mh_launch_prep_taps(const float *, const float *, const float *, const float *, int, int, float, float4 *,
+                        hipStream_t);
+int mh_launch_search(MhViews, const float *, int, int, int, const float *, int, int, float, const float *,
+                     const int32_t *, const float *, const float4 *, float *, float *, uint8_t *, float *, int32_t *,
+                     int32_t *, int, hipStream_t);
+int mh_launch_refine_loss(MhViews, const float *, const float *, float, float, int, int, float, const float *,
+                          const float *, const float *, float *, uint8_t *, hipStream_t);
+int mh_launch_filter_points(MhViews, const float *, int, int, float, float, uint8_t *, uint8_t *, uint8_t *,
+                            uint8_t *, hipStream_t);
+int mh_launch_medoid_dense(const float *, int, int, float *, int32_t *, hipStream_t);
+int mh_launch_medoid_segmented(const float *, const int32_t *, int, int, float *, int32_t *, hipStream_t);
+int mh_launch_gabor_bank(const float *, const float *, int, int, int32_t *, float *, float *, unsigned int *,
+                         hipStream_t);
+int mh_launch_gabor_build(float *, hipStream_t);
+}
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define MH_HIP(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) return fail(MH_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+static int launched(int rc, const char *what) {
+    if (rc == -1) return fail(MH_ERR_ARG, "%s: unsupported size/shape", what);
+    if (rc != 0) return fail(MH_ERR_HIP, "%s: launch failed: %s", what, hipGetErrorString((hipError_t)rc));
+    return MH_OK;
+}
+
+extern "C" const char *mh_last_error(void) { return g_err; }
+extern "C" int mh_version(void) { return 100; }
+
+extern "C" int mh_ctx_create(int device_id, mh_ctx **out) {
+    if (!out) return fail(MH_ERR_ARG, "mh_ctx_create: out is NULL");
+    int ndev = 0;
+    MH_HIP(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(MH_ERR_ARG, "mh_ctx_create: no device %d", device_id);
+    mh_ctx *c = new (std::nothrow) mh_ctx();
+    if (!c) return fail(MH_ERR_NOMEM, "mh_ctx_create: out of host memory");
+    c->device = device_id;
+    *out = c;
+    return MH_OK;
+}
+
+static void free_views(mh_ctx *c) {
+    if (c->rec) (void)hipFree(c->rec);
+    if (c->mask) (void)hipFree(c->mask);
+    if (c->cams) (void)hipFree(c->cams);
+    c->rec = nullptr;
+    c->mask = nullptr;
+    c->cams = nullptr;
+    c->V = c->H = c->W = 0;
+}
+
+extern "C" void mh_ctx_destroy(mh_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    free_views(ctx);
+    if (ctx->offs) (void)hipFree(ctx->offs);
+    if (ctx->gabor) (void)hipFree(ctx->gabor);
+    if (ctx->gabor_max) (void)hipFree(ctx->gabor_max);
+    delete ctx;
+}
+
+extern "C" int mh_ctx_alloc_views(mh_ctx *ctx, int V, int H, int W) {
+    if (!ctx || V < 1 || H < 1 || W < 1) return fail(MH_ERR_ARG, "mh_ctx_alloc_views: bad arguments");
+    MH_HIP(hipSetDevice(ctx->device));
+    free_views(ctx);
+    const size_t npix = (size_t)V * H * W;
+    if (hipMalloc(&ctx->rec, npix * sizeof(float4)) != hipSuccess ||
+        hipMalloc(&ctx->mask, npix * sizeof(float)) != hipSuccess ||
+        hipMalloc(&ctx->cams, (size_t)V * MH_CAM_STRIDE * sizeof(float)) != hipSuccess) {
+        free_views(ctx);
+        return fail(MH_ERR_NOMEM, "mh_ctx_alloc_views: hipMalloc of %zu bytes failed", npix * 20);
+    }
+    ctx->V = V;
+    ctx->H = H;
+    ctx->W = W;
+    return MH_OK;
+}
+
+extern "C" int mh_ctx_set_view(mh_ctx *ctx, int view, const float *cam_host, const float *depth, int depth_stride,
+                               const float *ori, const float *conf, const float *mask, int mask_stride,
+                               void *stream) {
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_ctx_set_view: views not allocated");
+    if (view < 0 || view >= ctx->V || !cam_host || !depth || !ori || !conf || !mask || depth_stride < 1 ||
+        mask_stride < 1)
+        return fail(MH_ERR_ARG, "mh_ctx_set_view: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)ctx->H * ctx->W;
+    // pageable host -> device copy of 192 bytes: synchronous w.r.t. the host buffer, ordered on `st`
+    MH_HIP(hipMemcpyAsync(ctx->cams + (size_t)view * MH_CAM_STRIDE, cam_host, MH_CAM_STRIDE * sizeof(float),
+                          hipMemcpyHostToDevice, st));
+    return launched(mh_launch_pack_view(ctx->rec + (size_t)view * npix, ctx->mask + (size_t)view * npix, depth,
+                                        depth_stride, ori, conf, mask, mask_stride, npix, st),
+                    "mh_ctx_set_view");
+}
+
+extern "C" int mh_ctx_set_depth_offsets(mh_ctx *ctx, const float *offsets_host, int S) {
+    if (!ctx || !offsets_host || S < 1 || S > 256) return fail(MH_ERR_ARG, "mh_ctx_set_depth_offsets: bad arguments");
+    MH_HIP(hipSetDevice(ctx->device));
+    if (ctx->offs) (void)hipFree(ctx->offs);
+    ctx->offs = nullptr;
+    MH_HIP(hipMalloc(&ctx->offs, S * sizeof(float)));
+    MH_HIP(hipMemcpy(ctx->offs, offsets_host, S * sizeof(float), hipMemcpyHostToDevice));
+    ctx->S = S;
+    return MH_OK;
+}
+
+extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
+    if (!ctx || !key) return fail(MH_ERR_ARG, "mh_ctx_set_option: bad arguments");
+    if (!strcmp(key, "search_variant")) {
+        ctx->search_variant = value;
+        return MH_OK;
+    }
+    return fail(MH_ERR_ARG, "mh_ctx_set_option: unknown key %s", key);
+}
+
+extern "C" int mh_project_gather(mh_ctx *ctx, const float *points, int N, int patch, float *vis, float *ori,
+                                 float *conf, float *mask, float *ori_patch, float *conf_patch, float *pixf,
+                                 void *stream) {
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_project_gather: views not set");
+    if (!points || N < 0 || patch < 1 || !(patch & 1)) return fail(MH_ERR_ARG, "mh_project_gather: bad arguments");
+    if (N == 0) return MH_OK;
+    return launched(mh_launch_project_gather(ctx->views(), points, N, patch, vis, ori, conf, mask, ori_patch,
+                                             conf_patch, pixf, (hipStream_t)stream),
+                    "mh_project_gather");
+}
+
+extern "C" int mh_topk_views(mh_ctx *ctx, const float *vis, const float *conf, int N, int32_t *out_idx,
+                             float *out_val, void *stream) {
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_topk_views: views not set");
+    if (!vis || !conf || !out_idx || !out_val || N < 0) return fail(MH_ERR_ARG, "mh_topk_views: bad arguments");
+    if (ctx->V < MH_TOPK)
+        return fail(MH_ERR_ARG, "mh_topk_views: %d views < %d (the reference's torch.topk raises too, PMVO.py:341)",
+                    ctx->V, MH_TOPK);
+    if (N == 0) return MH_OK;
+    return launched(mh_launch_topk(vis, conf, ctx->V, N, out_idx, out_val, (hipStream_t)stream), "mh_topk_views");
+}
+
+extern "C" size_t mh_search_scratch_bytes(mh_ctx *ctx, int N, int patch) {
+    if (!ctx || N < 0 || patch < 1) return 0;
+    return (size_t)ctx->V * (size_t)N * (size_t)(patch * patch + 1) * sizeof(float4);
+}
+
+extern "C" int mh_search_forward(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank,
+                                 int rank_step, const float *vis, const float *ori, const float *pixf,
+                                 const float *ori_patch, const float *conf_patch, const int32_t *base_idx,
+                                 const float *base_val, void *scratch, size_t scratch_bytes, float *line_ori,
+                                 float *min_loss, uint8_t *high_conf, float *best_sample, int32_t *best_rank,
+                                 int32_t *best_s, void *stream) {
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_search_forward: views not set");
+    if (!ctx->offs) return fail(MH_ERR_STATE, "mh_search_forward: depth offsets not set");
+    if (!points || !vis || !ori || !pixf || !ori_patch || !conf_patch || !base_idx || !base_val || !scratch ||
+        !line_ori || !min_loss || !high_conf || N < 0 || nrank < 1 || rank_step < 1 ||
+        (nrank - 1) * rank_step >= MH_TOPK)
+        return fail(MH_ERR_ARG, "mh_search_forward: bad arguments");
+    if (scratch_bytes < mh_search_scratch_bytes(ctx, N, patch))
+        return fail(MH_ERR_ARG, "mh_search_forward: scratch too small (%zu < %zu)", scratch_bytes,
+                    mh_search_scratch_bytes(ctx, N, patch));
+    if (ctx->V >= 256) return fail(MH_ERR_ARG, "mh_search_forward: V >= 256 needs a third cascade level");
+    if (N == 0) return MH_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int P = patch * patch;
+    int rc = launched(mh_launch_prep_taps(ori_patch, conf_patch, vis, pixf, ctx->V * N, P, conf_threshold,
+                                          (float4 *)scratch, st),
+                      "mh_search_forward(prep)");
+    if (rc) return rc;
+    return launched(mh_launch_search(ctx->views(), ctx->offs, ctx->S, nrank, rank_step, points, N, P + 1,
+                                     conf_threshold, ori, base_idx, base_val, (const float4 *)scratch, line_ori,
+                                     min_loss, high_conf, best_sample, best_rank, best_s, ctx->search_variant, st),
+                    "mh_search_forward");
+}
+
+extern "C" int mh_refine_loss(mh_ctx *ctx, const float *points, const float *dir, float step_mul, float step_div,
+                              int N, int patch, float conf_threshold, const float *vis, const float *ori_patch,
+                              const float *conf_patch, float *loss, uint8_t *high_conf, void *stream) {
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_refine_loss: views not set");
+    if (!points || !dir || !vis || !ori_patch || !conf_patch || !loss || N < 0)
+        return fail(MH_ERR_ARG, "mh_refine_loss: bad arguments");
+    if (N == 0) return MH_OK;
+    return launched(mh_launch_refine_loss(ctx->views(), points, dir, step_mul, step_div, N, patch * patch,
+                                          conf_threshold, vis, ori_patch, conf_patch, loss, high_conf,
+                                          (hipStream_t)stream),
+                    "mh_refine_loss");
+}
+
+extern "C" int mh_filter_points(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold,
+                                float visible_threshold, uint8_t *surface_index, uint8_t *filter_index,
+                                uint8_t *unvisible_index, uint8_t *head_filter, void *stream) {
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_filter_points: views not set");
+    if (!points || N < 0 || patch < 1 || !(patch & 1)) return fail(MH_ERR_ARG, "mh_filter_points: bad arguments");
+    if (N == 0) return MH_OK;
+    return launched(mh_launch_filter_points(ctx->views(), points, N, patch, conf_threshold, visible_threshold,
+                                            surface_index, filter_index, unvisible_index, head_filter,
+                                            (hipStream_t)stream),
+                    "mh_filter_points");
+}
+
+extern "C" int mh_medoid_dense(mh_ctx *ctx, const float *ori, int G, int K, float *out, int32_t *out_index,
+                               void *stream) {
+    if (!ctx || !ori || !out || G < 0 || K < 1) return fail(MH_ERR_ARG, "mh_medoid_dense: bad arguments");
+    if (G == 0) return MH_OK;
+    return launched(mh_launch_medoid_dense(ori, G, K, out, out_index, (hipStream_t)stream), "mh_medoid_dense");
+}
+
+extern "C" int mh_medoid_segmented(mh_ctx *ctx, const float *ori, const int32_t *seg_start, int G, int max_group,
+                                   float *out, int32_t *out_index, void *stream) {
+    if (!ctx || !ori || !seg_start || !out || G < 0 || max_group < 1)
+        return fail(MH_ERR_ARG, "mh_medoid_segmented: bad arguments");
+    if (G == 0) return MH_OK;
+    return launched(mh_launch_medoid_segmented(ori, seg_start, G, max_group, out, out_index, (hipStream_t)stream),
+                    "mh_medoid_segmented");
+}
+
+static int gabor_alloc(mh_ctx *ctx) {
+    if (ctx->gabor) return MH_OK;
+    MH_HIP(hipSetDevice(ctx->device));
+    MH_HIP(hipMalloc(&ctx->gabor, 289 * 192 * sizeof(float)));
+    MH_HIP(hipMalloc(&ctx->gabor_max, sizeof(unsigned int)));
+    return MH_OK;
+}
+
+extern "C" int mh_gabor_set_bank(mh_ctx *ctx, const float *bank_host) {
+    if (!ctx || !bank_host) return fail(MH_ERR_ARG, "mh_gabor_set_bank: bad arguments");
+    int rc = gabor_alloc(ctx);
+    if (rc) return rc;
+    // kernel-major [180][289] -> tap-major [289][192], zero padded
+    float *tmp = new (std::nothrow) float[289 * 192]();
+    if (!tmp) return fail(MH_ERR_NOMEM, "mh_gabor_set_bank: out of host memory");
+    for (int k = 0; k < 180; ++k)
+        for (int t = 0; t < 289; ++t) tmp[t * 192 + k] = bank_host[k * 289 + t];
+    hipError_t e = hipMemcpy(ctx->gabor, tmp, 289 * 192 * sizeof(float), hipMemcpyHostToDevice);
+    delete[] tmp;
+    if (e != hipSuccess) return fail(MH_ERR_HIP, "mh_gabor_set_bank: %s", hipGetErrorString(e));
+    return MH_OK;
+}
+
+extern "C" int mh_gabor_bank(mh_ctx *ctx, const float *image, int H, int W, int32_t *orient_index, float *conf,
+                             float *variance, void *stream) {
+    if (!ctx || !image || !orient_index || !conf || !variance || H < 1 || W < 1)
+        return fail(MH_ERR_ARG, "mh_gabor_bank: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (!ctx->gabor) {
+        int rc = gabor_alloc(ctx);
+        if (rc) return rc;
+        rc = launched(mh_launch_gabor_build(ctx->gabor, st), "mh_gabor_bank(build)");
+        if (rc) return rc;
+    }
+    return launched(mh_launch_gabor_bank(ctx->gabor, image, H, W, orient_index, conf, variance, ctx->gabor_max, st),
+                    "mh_gabor_bank");
+}

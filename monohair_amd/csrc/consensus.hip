@@ -1,0 +1,99 @@
+// consensus.hip -- orientation consensus (K11/K12): compute_points_similarity
+// (Utils/PMVO_utils.py:366-382), the medoid of a group of 3D directions under |cos| similarity:
+//     argmax_k mean_j max(cos(o_k,o_j), cos(-o_k,o_j))      (self term included, first max wins)
+// used on the 100 nearest neighbours of every point (PMVO.py:626,678) and on the points of every voxel
+// (PMVO.py:717-726).  One workgroup per group; unit vectors are staged once in LDS, each lane owns a
+// candidate k and walks all j (LDS broadcast reads), then a wave-shuffle + LDS argmax picks the winner.
+// cos = (x0*y0 + x1*y1) + x2*y2 on vectors normalised as torch.cosine_similarity does; cos(-o_k,o_j) is
+// the exact negation, so the max is |cos|.  The mean adds the K terms left to right and divides by K.
+#include "mh_device.h"
+
+#define MH_MEDOID_MAXK 4096
+
+__device__ __forceinline__ bool mh_arg_better(float av, int ai, float bv, int bi) {
+    // torch.argmax: NaN is the maximum; first index among equals
+    const bool an = av != av, bn = bv != bv;
+    if (an || bn) return (an && bn) ? (ai < bi) : an;
+    return (av > bv) || (av == bv && ai < bi);
+}
+
+__global__ __launch_bounds__(256) void mh_medoid_kernel(const float *__restrict__ ori,
+                                                        const int32_t *__restrict__ seg_start, int K_dense,
+                                                        float *__restrict__ out, int32_t *__restrict__ out_index) {
+    extern __shared__ __attribute__((aligned(16))) float s_u[];   // [K][3] unit vectors (+ reduction scratch)
+    __shared__ float s_bv[4];
+    __shared__ int s_bi[4];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int begin = seg_start ? seg_start[g] : g * K_dense;
+    const int K = seg_start ? (seg_start[g + 1] - begin) : K_dense;
+    if (K <= 0) return;
+    const float *__restrict__ o = ori + (size_t)begin * 3;
+    for (int k = tid; k < K; k += 256) {
+        const float x0 = o[3 * k], x1 = o[3 * k + 1], x2 = o[3 * k + 2];
+        float s = x0 * x0;
+        s = mh_fma(x1, x1, s);
+        s = mh_fma(x2, x2, s);
+        float nrm = __builtin_sqrtf(s);
+        nrm = (nrm < 1e-8f) ? 1e-8f : nrm;
+        s_u[3 * k] = x0 / nrm;
+        s_u[3 * k + 1] = x1 / nrm;
+        s_u[3 * k + 2] = x2 / nrm;
+    }
+    __syncthreads();
+    float bv = 0.0f;
+    int bi = 0x7fffffff;
+    for (int k = tid; k < K; k += 256) {
+        const float a0 = s_u[3 * k], a1 = s_u[3 * k + 1], a2 = s_u[3 * k + 2];
+        float acc = 0.0f;
+        for (int j = 0; j < K; ++j) {
+            const float cs = (a0 * s_u[3 * j] + a1 * s_u[3 * j + 1]) + a2 * s_u[3 * j + 2];
+            acc = acc + __builtin_fabsf(cs);
+        }
+        const float mean = acc / (float)K;
+        if (bi == 0x7fffffff || mh_arg_better(mean, k, bv, bi)) {
+            bv = mean;
+            bi = k;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(bv, off);
+        const int oi = __shfl_xor(bi, off);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || mh_arg_better(ov, oi, bv, bi))) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if ((tid & 63) == 0) {
+        s_bv[tid >> 6] = bv;
+        s_bi[tid >> 6] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (s_bi[w] != 0x7fffffff && (bi == 0x7fffffff || mh_arg_better(s_bv[w], s_bi[w], bv, bi))) {
+                bv = s_bv[w];
+                bi = s_bi[w];
+            }
+        out[3 * g] = o[3 * bi];
+        out[3 * g + 1] = o[3 * bi + 1];
+        out[3 * g + 2] = o[3 * bi + 2];
+        if (out_index) out_index[g] = bi;
+    }
+}
+
+extern "C" int mh_launch_medoid_dense(const float *ori, int G, int K, float *out, int32_t *out_index,
+                                      hipStream_t st) {
+    if (K > MH_MEDOID_MAXK) return -1;
+    hipLaunchKernelGGL(mh_medoid_kernel, dim3(G), dim3(256), (size_t)K * 3 * sizeof(float), st, ori, nullptr, K, out,
+                       out_index);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mh_launch_medoid_segmented(const float *ori, const int32_t *seg_start, int G, int max_group,
+                                          float *out, int32_t *out_index, hipStream_t st) {
+    if (max_group > MH_MEDOID_MAXK) return -1;
+    hipLaunchKernelGGL(mh_medoid_kernel, dim3(G), dim3(256), (size_t)max_group * 3 * sizeof(float), st, ori,
+                       seg_start, 0, out, out_index);
+    return (int)hipGetLastError();
+}

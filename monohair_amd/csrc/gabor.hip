@@ -1,0 +1,133 @@
+// gabor.hip -- the per-view Gabor orientation/confidence bank (K1+K2), gfx950 only.
+// Reference: preprocess_capture_data/GaborFilter.py -- gabor_fn :115-145, filter :29-94, forward :98-113.
+//
+//   R_k = | sum_{i,j} img[y+i-8, x+j-8] * g_k[i,j] |      180 kernels, 17x17, zero padding
+//   M = max_k R_k, b = first argmax;  d_k = circular distance between theta_b and theta_k
+//   var = sqrt( sum_k d_k * (R_k-M)^2 );  conf = clamp( (var / max_image(var)) / 0.2, 0, 1 )
+//
+// Direct form, compute bound (2*180*289 FLOP per pixel against 12 B): every lane owns one pixel and keeps
+// ALL 180 accumulators in registers (gfx950: 512 VGPR+AGPR per lane at one wave per SIMD); the image tile
+// sits in LDS (one ds_read per tap), the bank is stored tap-major ([289][192]) so the 180 weights of a tap
+// are one uniform, contiguous run that the scalar unit streams into SGPRs -- the inner loop is 180
+// v_fma_f32 with an SGPR operand per LDS read.  The [1,180,H,W] response stack of the reference (1.49 GB
+// at 1080p) never exists; argmax, variance and the image-wide maximum are fused behind the accumulators.
+#include "mh_device.h"
+
+#define MH_GB_NK 180
+#define MH_GB_KS 17
+#define MH_GB_NT (MH_GB_KS * MH_GB_KS)
+#define MH_GB_KPAD 192
+#define MH_GB_TILE 16
+#define MH_GB_LDW (MH_GB_TILE + MH_GB_KS - 1)   // 32
+
+// theta_k exactly as the reference builds it in fp32: ones * pi * k / 180  (GaborFilter.py:44,52)
+__host__ __device__ __forceinline__ float mh_theta(float k) { return (3.14159265358979323846f * k) / 180.0f; }
+
+// gabor_fn (GaborFilter.py:115-145), fp32 tensor ops in the reference's order; stored tap-major.
+__global__ void mh_gabor_build_kernel(float *__restrict__ bankT) {
+    const int k = blockIdx.x, t = threadIdx.x;
+    if (t >= MH_GB_NT) return;
+    const int i = t / MH_GB_KS, j = t - i * MH_GB_KS;
+    const float theta = (float)(3.14159265358979323846 * (double)k / 180.0);   // math.pi*k/180 in double, then fp32
+    const float x = (float)(i - 8) - 0.5f, y = (float)(j - 8) - 0.5f;
+    const float ct = cosf(theta), st = sinf(theta);
+    const float xt = x * ct + y * st;
+    const float yt = -x * st + y * ct;
+    const float sx = 1.8f, sy = 2.4f, lam = 4.0f;
+    const float e = -0.5f * ((xt * xt) / (sx * sx) + (yt * yt) / (sy * sy));
+    const float car = (2.0f * 3.14159265358979323846f * xt) / lam + 0.0f;
+    bankT[t * MH_GB_KPAD + k] = expf(e) * cosf(car);
+}
+
+__global__ __launch_bounds__(256) void mh_gabor_bank_kernel(const float *__restrict__ bankT,
+                                                            const float *__restrict__ img, int H, int W,
+                                                            int32_t *__restrict__ orient, float *__restrict__ var_out,
+                                                            unsigned int *__restrict__ maxbits) {
+    __shared__ float tile[MH_GB_LDW * MH_GB_LDW];
+    const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
+    const int y0 = blockIdx.y * MH_GB_TILE, x0 = blockIdx.x * MH_GB_TILE;
+    for (int q = tid; q < MH_GB_LDW * MH_GB_LDW; q += 256) {
+        const int ly = q / MH_GB_LDW, lx = q - ly * MH_GB_LDW;
+        const int gy = y0 + ly - 8, gx = x0 + lx - 8;
+        tile[q] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : 0.0f;
+    }
+    __syncthreads();
+
+    float acc[MH_GB_NK];
+#pragma unroll
+    for (int k = 0; k < MH_GB_NK; ++k) acc[k] = 0.0f;
+    for (int i = 0; i < MH_GB_KS; ++i) {
+        for (int j = 0; j < MH_GB_KS; ++j) {
+            const float x = tile[(ty + i) * MH_GB_LDW + tx + j];
+            const float *__restrict__ wt = bankT + (i * MH_GB_KS + j) * MH_GB_KPAD;
+#pragma unroll
+            for (int k = 0; k < MH_GB_NK; ++k) acc[k] = mh_fma(x, wt[k], acc[k]);
+        }
+    }
+
+    // argmax of |response| (first maximum), GaborFilter.py:48-51
+    float M = __builtin_fabsf(acc[0]);
+    int b = 0;
+#pragma unroll
+    for (int k = 1; k < MH_GB_NK; ++k) {
+        const float r = __builtin_fabsf(acc[k]);
+        if (r > M) {
+            M = r;
+            b = k;
+        }
+    }
+    // variance of the response curve, GaborFilter.py:52-78; sum over k in ATen's cascade order
+    const float PI_F = 3.14159265358979323846f;
+    const float bh = mh_theta((float)b);
+    MhCasc s = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < MH_GB_NK; ++k) {
+        if (k > 0 && (k & 15) == 0) mh_casc_flush(s);
+        const float t1 = bh - mh_theta((float)k);
+        const float d = fminf(__builtin_fabsf(t1), fminf(__builtin_fabsf(t1 - PI_F), __builtin_fabsf(t1 + PI_F)));
+        const float rd = __builtin_fabsf(acc[k]) - M;
+        s.a0 = s.a0 + (d * rd) * rd;
+    }
+    const float var = __builtin_sqrtf(s.a0 + s.a1);
+    const int y = y0 + ty, x = x0 + tx;
+    float vmax = 0.0f;
+    if (y < H && x < W) {
+        var_out[(size_t)y * W + x] = var;
+        orient[(size_t)y * W + x] = (var > 0.0f) ? b : 0;
+        vmax = var;
+    }
+    // image-wide maximum: wave shuffle, then one atomic per wave (non-negative floats order like uints)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if ((tid & 63) == 0) atomicMax(maxbits, __float_as_uint(vmax));
+}
+
+__global__ __launch_bounds__(256) void mh_gabor_finish_kernel(const float *__restrict__ var,
+                                                              const unsigned int *__restrict__ maxbits, size_t npix,
+                                                              float *__restrict__ conf) {
+    const float mx = __uint_as_float(*maxbits);
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < npix; i += step) {
+        const float v = var[i] / mx;
+        conf[i] = mh_clampf((v - 0.0f) / 0.2f, 0.0f, 1.0f);
+    }
+}
+
+extern "C" int mh_launch_gabor_build(float *bankT, hipStream_t st) {
+    (void)hipMemsetAsync(bankT, 0, (size_t)MH_GB_NT * MH_GB_KPAD * sizeof(float), st);
+    hipLaunchKernelGGL(mh_gabor_build_kernel, dim3(MH_GB_NK), dim3(320), 0, st, bankT);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mh_launch_gabor_bank(const float *bankT, const float *img, int H, int W, int32_t *orient, float *conf,
+                                    float *var, unsigned int *maxbits, hipStream_t st) {
+    (void)hipMemsetAsync(maxbits, 0, sizeof(unsigned int), st);
+    const dim3 grid((W + MH_GB_TILE - 1) / MH_GB_TILE, (H + MH_GB_TILE - 1) / MH_GB_TILE);
+    hipLaunchKernelGGL(mh_gabor_bank_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);
+    const size_t npix = (size_t)H * W;
+    const int blocks = (int)((npix + 255) / 256 < 2048 ? (npix + 255) / 256 : 2048);
+    hipLaunchKernelGGL(mh_gabor_finish_kernel, dim3(blocks), dim3(256), 0, st, var, maxbits, npix, conf);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,103 @@
+// mh_device.h -- device-side arithmetic shared by the PMVO kernels (gfx950 only).
+//
+// Every helper evaluates its formula operation by operation in the order the reference's PyTorch-CPU
+// ops do (see oracle/pmvo_oracle.c for the probed rules); this file is compiled with -ffp-contract=off
+// so the only fused multiply-adds are the explicit __builtin_fmaf calls below.  HIP's default f32
+// division and sqrt are correctly rounded (no -ffast-math here), f32 denormals are kept.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MH_CAM_STRIDE 48
+#define MH_TOPK 20
+#define MH_WAVE 64
+
+struct MhViews {
+    int V, H, W;
+    const float4 *rec;   // [V][H][W] {ori_row, ori_col, conf, depth}
+    const float *mask;   // [V][H][W]
+    const float *cams;   // [V][MH_CAM_STRIDE]
+};
+
+__device__ __forceinline__ float mh_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// Camera.projection (Utils/Camera_utils.py:38-58): camera_v = pose@[X;1] and uv = proj@camera_v are
+// k-ordered fma chains (MKL sgemm); proj rows 0,1 are [fx,0,cx,0] / [0,fy,cy,0], so the chain collapses
+// to fma(cx, z, fx*x) and fma(cy, z, fy*y) exactly (the zero terms add +-0).
+__device__ __forceinline__ void mh_cam_project(const float *__restrict__ cam, float X0, float X1, float X2,
+                                               float &u, float &v, float &z) {
+    float c0 = cam[0] * X0;
+    c0 = mh_fma(cam[1], X1, c0);
+    c0 = mh_fma(cam[2], X2, c0);
+    c0 = mh_fma(cam[3], 1.0f, c0);
+    float c1 = cam[4] * X0;
+    c1 = mh_fma(cam[5], X1, c1);
+    c1 = mh_fma(cam[6], X2, c1);
+    c1 = mh_fma(cam[7], 1.0f, c1);
+    float c2 = cam[8] * X0;
+    c2 = mh_fma(cam[9], X1, c2);
+    c2 = mh_fma(cam[10], X2, c2);
+    c2 = mh_fma(cam[11], 1.0f, c2);
+    float q0 = mh_fma(cam[18], c2, cam[16] * c0);
+    float q1 = mh_fma(cam[22], c2, cam[21] * c1);
+    z = c2;
+    u = q0 / c2;
+    v = q1 / c2;
+}
+
+// ndc -> unrounded pixel (PMVO.py:380-382, Camera_utils.py:67-69)
+__device__ __forceinline__ void mh_ndc_to_pixel(float u, float v, float Hf, float Wf, float &row, float &col) {
+    col = ((-u + 1.0f) / 2.0f) * Wf;
+    row = ((v + 1.0f) / 2.0f) * Hf;
+}
+
+__device__ __forceinline__ void mh_pixel_of(const float *__restrict__ cam, float X0, float X1, float X2, float Hf,
+                                            float Wf, float &row, float &col) {
+    float u, v, z;
+    mh_cam_project(cam, X0, X1, X2, u, v, z);
+    mh_ndc_to_pixel(u, v, Hf, Wf, row, col);
+}
+
+// Camera.reprojection(to_world=True) (Camera_utils.py:81-106); the 3x3 product is
+// (a0*b0 + a2*b2) + a1*b1 with separately rounded products -- the MKL kernel the reference lands in for
+// fewer than ~28k columns (see oracle/pmvo_oracle.c: cam_unproject).
+__device__ __forceinline__ void mh_cam_unproject(const float *__restrict__ cam, float u, float v, float z,
+                                                 float &X0, float &X1, float &X2) {
+    float c0 = (u - cam[18]) / cam[16] * z;
+    float c1 = (v - cam[22]) / cam[21] * z;
+    float d0 = c0 - cam[3], d1 = c1 - cam[7], d2 = z - cam[11];
+    const float *Ri = cam + 32;
+    X0 = (Ri[0] * d0 + Ri[2] * d2) + Ri[1] * d1;
+    X1 = (Ri[3] * d0 + Ri[5] * d2) + Ri[4] * d1;
+    X2 = (Ri[6] * d0 + Ri[8] * d2) + Ri[7] * d1;
+}
+
+// x / max(|x|, 1e-8) of a 2-vector as torch.cosine_similarity normalises it (norm = sqrt of an fma chain)
+__device__ __forceinline__ void mh_unit2(float x0, float x1, float &o0, float &o1) {
+    float s = x0 * x0;
+    s = mh_fma(x1, x1, s);
+    float nrm = __builtin_sqrtf(s);
+    nrm = (nrm < 1e-8f) ? 1e-8f : nrm;   // clamp_min keeps NaN (comparison false)
+    o0 = x0 / nrm;
+    o1 = x1 / nrm;
+}
+
+__device__ __forceinline__ float mh_clampf(float x, float lo, float hi) {
+    return x < lo ? lo : (x > hi ? hi : x);
+}
+
+// PMVO.compute_visible (PMVO.py:525-529)
+__device__ __forceinline__ float mh_soft_visible(float depth, float z255) {
+    float d = z255 - depth;
+    float vis = (d < 0.1f) ? (1.0f - d / 0.1f) : -1.0f;
+    return mh_clampf(vis, -1.0f, 1.0f);
+}
+
+// ATen cascade sum over the view axis (valid for V < 256): 16-view blocks, then the block sums.
+struct MhCasc {
+    float a0, a1;
+};
+__device__ __forceinline__ void mh_casc_flush(MhCasc &c) {
+    c.a1 = c.a1 + c.a0;
+    c.a0 = 0.0f;
+}

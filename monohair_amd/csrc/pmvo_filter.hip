@@ -1,0 +1,118 @@
+// pmvo_filter.hip -- the per-view visibility / mask / confidence votes (K13), gfx950 only:
+//   PMVO.filter_points            (PMVO.py:402-459)  -> surface_index, filter_index
+//   PMVO.compute_unvisible_points (PMVO.py:461-480)  -> unvisible_index
+//   PMVO.filter_head_points       (PMVO.py:110-137)  -> head_filter (the mask vote only; the two scipy
+//                                                      KDTree queries of :98-107 stay on the host)
+// One wave per point, lane = view.  Each lane writes its per-view terms to LDS and lane 0 adds them in
+// ATen's cascade order (mask values in (0, 0.2] stay fractional, PMVO.py:427, so order can matter).
+#include "mh_device.h"
+
+#define MH_FILTER_VMAX 256
+#define MH_NTERM 8
+
+template <int PATCH>
+__global__ __launch_bounds__(256) void mh_filter_kernel(MhViews vw, const float *__restrict__ pts, int N, float thr,
+                                                        float vis_thr, uint8_t *__restrict__ surface_index,
+                                                        uint8_t *__restrict__ filter_index,
+                                                        uint8_t *__restrict__ unvisible_index,
+                                                        uint8_t *__restrict__ head_filter) {
+    constexpr int HP = PATCH / 2;
+    __shared__ float s_t[4][MH_NTERM][MH_FILTER_VMAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const int V = vw.V, H = vw.H, W = vw.W;
+    const float X0 = pts[3 * n], X1 = pts[3 * n + 1], X2 = pts[3 * n + 2];
+    for (int v = lane; v < V; v += MH_WAVE) {
+        const float *cam = vw.cams + v * MH_CAM_STRIDE;
+        float u, w, z, rowf, colf;
+        mh_cam_project(cam, X0, X1, X2, u, w, z);
+        mh_ndc_to_pixel(u, w, (float)H, (float)W, rowf, colf);
+        float cr = __builtin_rintf(colf), rr = __builtin_rintf(rowf);
+        const bool oob = !(cr <= (float)(W - 1)) || (cr < 0.0f) || !(rr <= (float)(H - 1)) || (rr < 0.0f);
+        cr = fminf(fmaxf(cr, 0.0f), (float)(W - 1));
+        rr = fminf(fmaxf(rr, 0.0f), (float)(H - 1));
+        const int r = (int)rr, c = (int)cr;
+        const float4 *__restrict__ rec = vw.rec + (size_t)v * H * W;
+        const float4 q = rec[(size_t)r * W + c];
+        float m = vw.mask[(size_t)v * H * W + (size_t)r * W + c];
+        const float gap = (-z / 2.0f) * 255.0f - q.w;
+        // raw (unclamped) patch confidences, zeroed when the point projects outside (PMVO.py:415-420)
+        float cmax = 0.0f;
+        if (surface_index || filter_index) {
+            cmax = q.z;
+            for (int i = -HP; i <= HP; ++i)
+                for (int j = -HP; j <= HP; ++j) {
+                    const int rr2 = min(max(r + i, 0), H - 1), cc2 = min(max(c + j, 0), W - 1);
+                    const float cv = rec[(size_t)rr2 * W + cc2].z;
+                    cmax = (cv > cmax) ? cv : cmax;
+                }
+            if (oob) cmax = 0.0f;
+        }
+        const float unv = (oob || gap > 0.1f) ? 1.0f : 0.0f;
+        const float unv1 = (oob || gap > vis_thr) ? 1.0f : 0.0f;
+        const float unv9 = (oob || gap > 0.9f) ? 1.0f : 0.0f;
+        const float unvh = (gap >= vis_thr) ? 1.0f : 0.0f;   // filter_head_points: '>=' and no oob override
+        const float lowc = (cmax < thr) ? 1.0f : 0.0f;
+        m = (m > 0.2f) ? 1.0f : m;
+        const float visb = 1.0f - unv, visb1 = 1.0f - unv1, visbh = 1.0f - unvh;
+        s_t[wave][0][v] = visb * lowc;    // visible with low confidence
+        s_t[wave][1][v] = visb;           // visibles
+        s_t[wave][2][v] = visb * m;       // visibles * masks
+        s_t[wave][3][v] = visb1;          // visibles1
+        s_t[wave][4][v] = visb1 * m;      // visibles1 * masks
+        s_t[wave][5][v] = 1.0f - unv9;    // compute_unvisible_points
+        s_t[wave][6][v] = visbh;          // filter_head_points visibles
+        s_t[wave][7][v] = visbh * m;      // filter_head_points indexs
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < MH_NTERM) {
+        MhCasc a = {0.f, 0.f};
+        for (int v = 0; v < V; ++v) {
+            if (v > 0 && (v & 15) == 0) mh_casc_flush(a);
+            a.a0 = a.a0 + s_t[wave][lane][v];
+        }
+        s_t[wave][lane][0] = a.a0 + a.a1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        const float s_idx = s_t[wave][0][0], s_vis = s_t[wave][1][0], s_vm = s_t[wave][2][0];
+        const float s_vis1 = s_t[wave][3][0], s_vm1 = s_t[wave][4][0], s_v9 = s_t[wave][5][0];
+        const float s_vh = s_t[wave][6][0], s_ih = s_t[wave][7][0];
+        const bool low_conf = s_idx > 4.0f;
+        const bool hair = (s_vis - s_vm) < (s_vis * 1.0f / 2.0f);
+        const bool hair1 = (s_vis1 - s_vm1) < (s_vis1 * 1.0f / 2.0f);
+        const bool surf0 = s_vis > 1.0f;
+        const bool filt0 = (s_vis1 > 1.0f) && !surf0;
+        if (surface_index) surface_index[n] = (surf0 && !low_conf && hair) ? 1 : 0;
+        if (filter_index) filter_index[n] = (filt0 && !low_conf && hair1) ? 1 : 0;
+        if (unvisible_index) unvisible_index[n] = (s_v9 > 2.0f) ? 0 : 1;
+        if (head_filter) head_filter[n] = ((s_vh - s_ih) < (s_vh * 1.0f / 2.0f)) ? 0 : 1;
+    }
+}
+
+extern "C" int mh_launch_filter_points(MhViews vw, const float *pts, int N, int patch, float thr, float vis_thr,
+                                       uint8_t *surface_index, uint8_t *filter_index, uint8_t *unvisible_index,
+                                       uint8_t *head_filter, hipStream_t st) {
+    if (vw.V > MH_FILTER_VMAX) return -1;
+    const dim3 grid((N + 3) / 4), block(256);
+#define MH_F_CASE(PS)                                                                                              \
+    case PS:                                                                                                       \
+        hipLaunchKernelGGL(mh_filter_kernel<PS>, grid, block, 0, st, vw, pts, N, thr, vis_thr, surface_index,       \
+                           filter_index, unvisible_index, head_filter);                                            \
+        break;
+    switch (patch) {
+        MH_F_CASE(1)
+        MH_F_CASE(3)
+        MH_F_CASE(5)
+        MH_F_CASE(7)
+        MH_F_CASE(9)
+        MH_F_CASE(11)
+        default:
+            return -1;
+    }
+#undef MH_F_CASE
+    return (int)hipGetLastError();
+}

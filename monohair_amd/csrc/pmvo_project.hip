@@ -1,0 +1,237 @@
+// pmvo_project.hip -- view packing, project-and-gather (K3+K4+K5), base-view ranking (K6) and the
+// tap-list preparation for the search kernel.  gfx950 only.
+//
+// HBM layout: every view is one array of 16-byte pixel records
+// {ori_row, ori_col, conf, depth} plus one fp32 mask plane.  A patch tap is ONE aligned dwordx4
+// load; the 7 (9) taps of a patch row are 112 (144) contiguous bytes.
+#include "mh_device.h"
+
+// ---------------------------------------------------------------------------------------------
+// pack one view: reference layout (depth[H,W,Cd], ori[H,W,2], conf[H,W], mask[H,W,Cm]) -> records
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mh_pack_view_kernel(float4 *__restrict__ rec, float *__restrict__ maskp,
+                                                           const float *__restrict__ depth, int dstride,
+                                                           const float *__restrict__ ori,
+                                                           const float *__restrict__ conf,
+                                                           const float *__restrict__ mask, int mstride,
+                                                           size_t npix) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < npix; i += step) {
+        const float2 o = reinterpret_cast<const float2 *>(ori)[i];
+        rec[i] = make_float4(o.x, o.y, conf[i], depth[i * dstride]);
+        maskp[i] = mask[i * mstride];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// PMVO.Compute_Visible_and_Ori (PMVO.py:346-376): one workgroup = one view x 64 consecutive points.
+//   phase 1: 64 lanes project their point (PMVO.project_points :378-397), fetch the centre record,
+//            write vis / ori / conf / mask / pixf coalesced over n;
+//   phase 2: all 256 lanes sweep the 64*P (point, tap) pairs of the tile in output order, so the
+//            ori_patch / conf_patch stores are fully coalesced (8 B + 4 B per lane) and the taps of
+//            one patch row are neighbouring lanes reading neighbouring 16-B records.
+// Workgroups are renumbered so that each XCD (block b runs on XCD b%8) owns a contiguous range of
+// views: its private L2 then holds the touched regions of ~V/8 maps instead of all V.
+// ---------------------------------------------------------------------------------------------
+#define MH_PG_TILE 64
+
+template <int PATCH>
+__global__ __launch_bounds__(256) void mh_project_gather_kernel(MhViews vw, const float *__restrict__ pts, int N,
+                                                                int tiles, float *__restrict__ vis,
+                                                                float *__restrict__ ori, float *__restrict__ conf,
+                                                                float *__restrict__ mask,
+                                                                float *__restrict__ ori_patch,
+                                                                float *__restrict__ conf_patch,
+                                                                float *__restrict__ pixf) {
+    constexpr int P = PATCH * PATCH, HP = PATCH / 2;
+    __shared__ int s_r[MH_PG_TILE], s_c[MH_PG_TILE];
+    const int total = gridDim.x;
+    int bid = blockIdx.x;
+    if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+    const int v = bid / tiles, tile = bid - v * tiles;
+    const int n0 = tile * MH_PG_TILE;
+    const int tid = threadIdx.x;
+    const int H = vw.H, W = vw.W;
+    const float4 *__restrict__ rec = vw.rec + (size_t)v * H * W;
+
+    if (tid < MH_PG_TILE) {
+        const int n = n0 + tid;
+        if (n < N) {
+            const float *cam = vw.cams + v * MH_CAM_STRIDE;
+            float u, w, z, rowf, colf;
+            mh_cam_project(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, w, z);
+            mh_ndc_to_pixel(u, w, (float)H, (float)W, rowf, colf);
+            // torch.round (half to even) -> long; bounds tests on the integers (PMVO.py:383-390)
+            float cr = __builtin_rintf(colf), rr = __builtin_rintf(rowf);
+            const bool oob = !(cr <= (float)(W - 1)) || (cr < 0.0f) || !(rr <= (float)(H - 1)) || (rr < 0.0f);
+            cr = fminf(fmaxf(cr, 0.0f), (float)(W - 1));
+            rr = fminf(fmaxf(rr, 0.0f), (float)(H - 1));
+            const int r = (int)rr, c = (int)cr;
+            s_r[tid] = r;
+            s_c[tid] = c;
+            const size_t pix = (size_t)r * W + c;
+            const float4 q = rec[pix];
+            const size_t vn = (size_t)v * N + n;
+            if (vis) {
+                const float zp = -z / 2.0f;
+                float vb = mh_soft_visible(q.w, zp * 255.0f);
+                vis[vn] = oob ? -1.0f : vb;
+            }
+            if (ori) reinterpret_cast<float2 *>(ori)[vn] = make_float2(q.x, q.y);
+            if (conf) conf[vn] = mh_clampf(q.z, 1e-6f, 1.0f);
+            if (mask) mask[vn] = vw.mask[(size_t)v * H * W + pix];
+            if (pixf) reinterpret_cast<float2 *>(pixf)[vn] = make_float2(rowf, colf);
+        }
+    }
+    if (!ori_patch && !conf_patch) return;
+    __syncthreads();
+    const int npts = min(MH_PG_TILE, N - n0);
+    const int cnt = npts * P;
+    const size_t obase = ((size_t)v * N + n0) * P;
+    for (int idx = tid; idx < cnt; idx += 256) {
+        const int nl = idx / P, p = idx - nl * P;
+        const int i = p / PATCH - HP, j = p - (p / PATCH) * PATCH - HP;
+        const int r = min(max(s_r[nl] + i, 0), H - 1);
+        const int c = min(max(s_c[nl] + j, 0), W - 1);
+        const float4 q = rec[(size_t)r * W + c];
+        if (ori_patch) reinterpret_cast<float2 *>(ori_patch)[obase + idx] = make_float2(q.x, q.y);
+        if (conf_patch) conf_patch[obase + idx] = mh_clampf(q.z, 1e-6f, 1.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// PMVO.Find_max_conf_from_visible_view (PMVO.py:339-343): one wave per point, rank-by-counting
+// (V^2/64 compares per lane, no sort network needed for V <= 1024).
+// ---------------------------------------------------------------------------------------------
+#define MH_TOPK_VMAX 1024
+__global__ __launch_bounds__(256) void mh_topk_kernel(const float *__restrict__ vis, const float *__restrict__ conf,
+                                                      int V, int N, int32_t *__restrict__ out_idx,
+                                                      float *__restrict__ out_val) {
+    __shared__ float s_cv[4][MH_TOPK_VMAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;   // whole wave leaves together; no block-wide barrier below
+    float *cv = s_cv[wave];
+    for (int v = lane; v < V; v += MH_WAVE) {
+        const float vb = vis[(size_t)v * N + n], c = conf[(size_t)v * N + n];
+        cv[v] = (vb < 1.0f) ? c * fmaxf(vb, 0.0f) : c;
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (int v = lane; v < V; v += MH_WAVE) {
+        const float x = cv[v];
+        int rank = 0;
+        for (int u = 0; u < V; ++u) {
+            const float y = cv[u];
+            rank += (y > x) || (y == x && u < v);
+        }
+        if (rank < MH_TOPK) {
+            out_idx[(size_t)rank * N + n] = v;
+            out_val[(size_t)rank * N + n] = x;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tap lists for the search kernel.  For every (view, point) the per-tap work that does not depend on
+// the candidate sample is done ONCE here instead of 900 times in the search:
+//   - normalise the tap orientation the way torch.cosine_similarity does (PMVO.py:171),
+//   - decide which taps can ever replace the running minimum (PMVO.py:162,177-182): tap 0 always;
+//     tap p>=1 iff (patch max conf <= thr) or conf_p > thr,
+//   - compact the eligible taps in their original order (strict '<' keeps first-index tie-breaking).
+// Record (v,n): float4 header {count(bits), vis, pix_row, pix_col} followed by `count` float4 taps
+// {ox_hat, oy_hat, conf, 0}; stride (P+1) float4.  One wave per (v,n), lane = tap.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mh_prep_taps_kernel(const float *__restrict__ ori_patch,
+                                                           const float *__restrict__ conf_patch,
+                                                           const float *__restrict__ vis,
+                                                           const float *__restrict__ pixf, int VN, int P, float thr,
+                                                           float4 *__restrict__ taps) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int vn = blockIdx.x * 4 + wave;
+    if (vn >= VN) return;
+    const float visv = vis[vn];
+    float4 *__restrict__ out = taps + (size_t)vn * (P + 1);
+    if (visv == -1.0f) {   // the search skips this view for this point: header only
+        if (lane == 0) out[0] = make_float4(__int_as_float(0), visv, 0.0f, 0.0f);
+        return;
+    }
+    const float *__restrict__ cp = conf_patch + (size_t)vn * P;
+    const float2 *__restrict__ op = reinterpret_cast<const float2 *>(ori_patch) + (size_t)vn * P;
+    float cmax = -1.0f;
+    for (int p = lane; p < P; p += MH_WAVE) cmax = fmaxf(cmax, cp[p]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o));
+    const bool hc = cmax > thr;
+    int base = 0;
+    for (int p0 = 0; p0 < P; p0 += MH_WAVE) {
+        const int p = p0 + lane;
+        bool el = false;
+        float c = 0.f, o0 = 0.f, o1 = 0.f;
+        if (p < P) {
+            c = cp[p];
+            const float2 o = op[p];
+            mh_unit2(o.x, o.y, o0, o1);
+            el = (p == 0) || (hc ? (c > thr) : true);
+        }
+        const unsigned long long m = __ballot(el);
+        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (el) out[1 + pos] = make_float4(o0, o1, c, 0.0f);
+        base += __popcll(m);
+    }
+    if (lane == 0) {
+        const float2 pf = reinterpret_cast<const float2 *>(pixf)[vn];
+        out[0] = make_float4(__int_as_float(base), visv, pf.x, pf.y);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers (called from capi.cpp)
+// ---------------------------------------------------------------------------------------------
+extern "C" int mh_launch_pack_view(float4 *rec, float *maskp, const float *depth, int dstride, const float *ori,
+                                   const float *conf, const float *mask, int mstride, size_t npix,
+                                   hipStream_t st) {
+    const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
+    hipLaunchKernelGGL(mh_pack_view_kernel, dim3(blocks), dim3(256), 0, st, rec, maskp, depth, dstride, ori, conf,
+                       mask, mstride, npix);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mh_launch_project_gather(MhViews vw, const float *pts, int N, int patch, float *vis, float *ori,
+                                        float *conf, float *mask, float *ori_patch, float *conf_patch,
+                                        float *pixf, hipStream_t st) {
+    const int tiles = (N + MH_PG_TILE - 1) / MH_PG_TILE;
+    const dim3 grid(vw.V * tiles), block(256);
+#define MH_PG_CASE(PS)                                                                                          \
+    case PS:                                                                                                    \
+        hipLaunchKernelGGL(mh_project_gather_kernel<PS>, grid, block, 0, st, vw, pts, N, tiles, vis, ori, conf,  \
+                           mask, ori_patch, conf_patch, pixf);                                                  \
+        break;
+    switch (patch) {
+        MH_PG_CASE(1)
+        MH_PG_CASE(3)
+        MH_PG_CASE(5)
+        MH_PG_CASE(7)
+        MH_PG_CASE(9)
+        MH_PG_CASE(11)
+        default:
+            return -1;
+    }
+#undef MH_PG_CASE
+    return (int)hipGetLastError();
+}
+
+extern "C" int mh_launch_topk(const float *vis, const float *conf, int V, int N, int32_t *out_idx, float *out_val,
+                              hipStream_t st) {
+    if (V > MH_TOPK_VMAX) return -1;
+    hipLaunchKernelGGL(mh_topk_kernel, dim3((N + 3) / 4), dim3(256), 0, st, vis, conf, V, N, out_idx, out_val);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mh_launch_prep_taps(const float *ori_patch, const float *conf_patch, const float *vis,
+                                   const float *pixf, int VN, int P, float thr, float4 *taps, hipStream_t st) {
+    hipLaunchKernelGGL(mh_prep_taps_kernel, dim3((VN + 3) / 4), dim3(256), 0, st, ori_patch, conf_patch, vis, pixf,
+                       VN, P, thr, taps);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,327 @@
+// pmvo_search.hip -- the fused loss search of PMVO.forward (PMVO.py:50-78), gfx950 only.
+//
+// One workgroup = one candidate 3D point.  Its nrank*S (= 10*90 = 900) candidate segment end-points
+// ("items") are spread over the lanes, K items per lane, and live in registers for the whole kernel:
+//   sample_next_3d_pos (PMVO.py:263-335)      -> item position X            (once, prologue)
+//   compute_reproject_ori (PMVO.py:219-241)    -> unit direction d_hat per view (registers)
+//   compute_prj_loss (PMVO.py:151-209)         -> masked min over the taps of the patch, weighted
+//                                                 sums over views in ATen's cascade order
+//   forward's best-so-far update (PMVO.py:57-70) -> LDS epilogue.
+// No [V,N,S] tensor ever exists.  The patch of (view, point) is the same for every lane of the
+// workgroup, so the tap list (pmvo_project.hip: mh_prep_taps_kernel) is read with scalar loads into
+// SGPRs and the inner loop is pure VALU: per (item, tap) 2 mul + add + (1-|x|) + cmp + 2 cndmask.
+// Views in which the point is not visible (vis == -1 => weight 0, PMVO.py:212) are skipped: adding
+// their exact zeros would not change any sum.
+#include "mh_device.h"
+
+#define MH_MAX_ITEMS 1024
+#define MH_MAX_RANKS 16
+
+// PMVO.sample_next_3d_pos for one item: pixel(unrounded) + 2*(ori_col, ori_row) -> ndc -> unproject
+__device__ __forceinline__ void mh_sample_next(const float *__restrict__ cam, float X0, float X1, float X2,
+                                               float ori_r, float ori_c, float Hf, float Wf, float off, float &S0,
+                                               float &S1, float &S2) {
+    float u, v, z, row, col;
+    mh_cam_project(cam, X0, X1, X2, u, v, z);
+    mh_ndc_to_pixel(u, v, Hf, Wf, row, col);
+    float nx = col + ori_c * 2.0f;
+    float ny = row + ori_r * 2.0f;
+    nx = nx / Wf;
+    ny = ny / Hf;
+    nx = nx * 2.0f - 1.0f;
+    ny = ny * 2.0f - 1.0f;
+    nx = -nx;
+    mh_cam_unproject(cam, nx, ny, z + off, S0, S1, S2);
+}
+
+// torch.min over a row with NaN propagation: NaN beats numbers, first index wins among equals
+__device__ __forceinline__ bool mh_min_better(float al, int ai, float bl, int bi) {
+    const bool an = al != al, bn = bl != bl;
+    if (an || bn) return (an && bn) ? (ai < bi) : an;
+    return (al < bl) || (al == bl && ai < bi);
+}
+
+template <int K, int T>
+__global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *__restrict__ offs, int S, int nrank,
+                                                      int rank_step, const float *__restrict__ pts, int N, int P1,
+                                                      float thr, const float *__restrict__ ori_c,
+                                                      const int32_t *__restrict__ base_idx,
+                                                      const float *__restrict__ base_val,
+                                                      const float4 *__restrict__ taps, float *__restrict__ line_ori,
+                                                      float *__restrict__ min_loss, uint8_t *__restrict__ high_conf,
+                                                      float *__restrict__ best_sample, int32_t *__restrict__ best_rank,
+                                                      int32_t *__restrict__ best_s) {
+    __shared__ float s_loss[MH_MAX_ITEMS];
+    __shared__ uint8_t s_pos[MH_MAX_ITEMS];
+    __shared__ float s_rl[MH_MAX_RANKS];
+    __shared__ int s_ri[MH_MAX_RANKS];
+    __shared__ int s_rh[MH_MAX_RANKS];
+
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int nitems = nrank * S;
+    const int V = vw.V;
+    const float Hf = (float)vw.H, Wf = (float)vw.W;
+    const float P0 = pts[3 * n], P1x = pts[3 * n + 1], P2 = pts[3 * n + 2];
+
+    float X0[K], X1[K], X2[K];
+    MhCasc num[K], den[K];
+    int cnt[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        int it = j * T + tid;
+        it = it < nitems ? it : 0;
+        const int r = it / S, s = it - r * S;
+        const int b = base_idx[(size_t)(r * rank_step) * N + n];
+        const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
+        mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[s], X0[j], X1[j], X2[j]);
+        num[j].a0 = num[j].a1 = den[j].a0 = den[j].a1 = 0.0f;
+        cnt[j] = 0;
+    }
+
+    for (int v = 0; v < V; ++v) {
+        if (v > 0 && (v & 15) == 0) {
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                mh_casc_flush(num[j]);
+                mh_casc_flush(den[j]);
+            }
+        }
+        const float4 *__restrict__ rec = taps + ((size_t)v * N + n) * P1;
+        const float4 hdr = rec[0];
+        if (hdr.y == -1.0f) continue;   // uniform: point not visible in this view, weight 0
+        const int ntap = __float_as_int(hdr.x);
+        const float *__restrict__ cam = vw.cams + v * MH_CAM_STRIDE;
+        float dx[K], dy[K], ml[K], bc[K];
+        const float4 t0 = rec[1];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            float row, col;
+            mh_pixel_of(cam, X0[j], X1[j], X2[j], Hf, Wf, row, col);
+            mh_unit2(row - hdr.z, col - hdr.w, dx[j], dy[j]);
+            const float cs = t0.x * dx[j] + t0.y * dy[j];
+            ml[j] = 1.0f - __builtin_fabsf(cs);
+            bc[j] = t0.z;
+        }
+        for (int t = 1; t < ntap; ++t) {
+            const float4 tp = rec[1 + t];
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const float cs = tp.x * dx[j] + tp.y * dy[j];
+                const float l = 1.0f - __builtin_fabsf(cs);
+                const bool upd = l < ml[j];
+                ml[j] = upd ? l : ml[j];
+                bc[j] = upd ? tp.z : bc[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float w = bc[j];   // (vis != -1) * best_conf
+            num[j].a0 = num[j].a0 + ml[j] * w;
+            den[j].a0 = den[j].a0 + w;
+            cnt[j] += (w > 0.0f) ? 1 : 0;
+        }
+    }
+
+    // ---- per-sample loss and "positive" flag (PMVO.py:198-201)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int it = j * T + tid;
+        if (it < nitems) {
+            const float dn = den[j].a0 + den[j].a1;
+            const float nm = num[j].a0 + num[j].a1;
+            const float ratio = dn / (float)cnt[j];
+            s_pos[it] = (ratio > thr) ? 1 : 0;
+            s_loss[it] = nm / dn;
+        }
+    }
+    __syncthreads();
+
+    // ---- per rank: low-confidence escape hatch, min / argmin over the S samples (PMVO.py:199-206)
+    const int wave = tid >> 6, lane = tid & 63, nwaves = T >> 6;
+    for (int r = wave; r < nrank; r += nwaves) {
+        int npos = 0;
+        for (int s0 = 0; s0 < S; s0 += MH_WAVE) {
+            const int s = s0 + lane;
+            npos += __popcll(__ballot(s < S && s_pos[r * S + s]));
+        }
+        const bool low = npos < 5;
+        float bl = 0.0f;
+        int bi = 0x7fffffff;
+        for (int s = lane; s < S; s += MH_WAVE) {
+            float l = s_loss[r * S + s];
+            if (!low && !s_pos[r * S + s]) l = 1.0f;
+            if (bi == 0x7fffffff || mh_min_better(l, s, bl, bi)) {
+                bl = l;
+                bi = s;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ol = __shfl_xor(bl, o);
+            const int oi = __shfl_xor(bi, o);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || mh_min_better(ol, oi, bl, bi))) {
+                bl = ol;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            s_rl[r] = bl;
+            s_ri[r] = bi;
+            s_rh[r] = s_pos[r * S + bi];
+        }
+    }
+    __syncthreads();
+
+    // ---- best candidate across base-view ranks (PMVO.py:57-70) and the 3D direction (:73-74)
+    if (tid == 0) {
+        float ml = s_rl[0];
+        int br = 0, bs = s_ri[0], hc = s_rh[0];
+        for (int r = 1; r < nrank; ++r) {
+            const float l = s_rl[r];
+            if ((l < ml) && (base_val[(size_t)(r * rank_step) * N + n] > 0.0f)) {
+                ml = l;
+                br = r;
+                bs = s_ri[r];
+                hc = s_rh[r];
+            }
+        }
+        const int b = base_idx[(size_t)(br * rank_step) * N + n];
+        const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
+        float B0, B1, B2;
+        mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[bs], B0, B1, B2);
+        const float d0 = B0 - P0, d1 = B1 - P1x, d2 = B2 - P2;
+        float s2 = d0 * d0;
+        s2 = mh_fma(d1, d1, s2);
+        s2 = mh_fma(d2, d2, s2);
+        const float nrm = __builtin_sqrtf(s2);
+        line_ori[3 * n] = d0 / nrm;
+        line_ori[3 * n + 1] = d1 / nrm;
+        line_ori[3 * n + 2] = d2 / nrm;
+        min_loss[n] = ml;
+        high_conf[n] = (uint8_t)hc;
+        if (best_sample) {
+            best_sample[3 * n] = B0;
+            best_sample[3 * n + 1] = B1;
+            best_sample[3 * n + 2] = B2;
+        }
+        if (best_rank) best_rank[n] = br;
+        if (best_s) best_s[n] = bs;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// PMVO.refine's loss of ONE given direction per point (PMVO.py:86-90): next = p + dir*mul/div,
+// compute_reproject_ori + compute_prj_loss with S = 1 (then `low_conf_index` is always true and the raw
+// num/den is returned, PMVO.py:199-204).  One wave per point, lane = view; the per-view terms go through
+// LDS so that lane 0 can add them in ATen's cascade order.  Patches are read raw ([V,N,P,..] layout).
+// ---------------------------------------------------------------------------------------------
+#define MH_REFINE_VMAX 256
+__global__ __launch_bounds__(256) void mh_refine_loss_kernel(MhViews vw, const float *__restrict__ pts,
+                                                             const float *__restrict__ dir, float mul, float dv,
+                                                             int N, int P, float thr, const float *__restrict__ vis,
+                                                             const float *__restrict__ ori_patch,
+                                                             const float *__restrict__ conf_patch,
+                                                             float *__restrict__ loss, uint8_t *__restrict__ hcout) {
+    __shared__ float s_num[4][MH_REFINE_VMAX], s_den[4][MH_REFINE_VMAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const int V = vw.V;
+    const float Hf = (float)vw.H, Wf = (float)vw.W;
+    const float P0 = pts[3 * n], P1 = pts[3 * n + 1], P2 = pts[3 * n + 2];
+    const float Q0 = P0 + dir[3 * n] * mul / dv, Q1 = P1 + dir[3 * n + 1] * mul / dv,
+                Q2 = P2 + dir[3 * n + 2] * mul / dv;
+    for (int v = lane; v < V; v += MH_WAVE) {
+        const float *cam = vw.cams + v * MH_CAM_STRIDE;
+        float r0, c0, r1, c1, dx, dy;
+        mh_pixel_of(cam, P0, P1, P2, Hf, Wf, r0, c0);
+        mh_pixel_of(cam, Q0, Q1, Q2, Hf, Wf, r1, c1);
+        mh_unit2(r1 - r0, c1 - c0, dx, dy);
+        const size_t vn = (size_t)v * N + n;
+        const float *__restrict__ cp = conf_patch + vn * P;
+        const float2 *__restrict__ op = reinterpret_cast<const float2 *>(ori_patch) + vn * P;
+        float cmax = cp[0];
+        for (int p = 1; p < P; ++p) cmax = (cp[p] > cmax) ? cp[p] : cmax;
+        const bool hc = cmax > thr;
+        float ml = 0.f, bc = 0.f;
+        for (int p = 0; p < P; ++p) {
+            float o0, o1;
+            const float2 o = op[p];
+            mh_unit2(o.x, o.y, o0, o1);
+            const float cs = o0 * dx + o1 * dy;
+            const float l = 1.0f - __builtin_fabsf(cs);
+            const float c = cp[p];
+            const bool upd = (p == 0) || ((l < ml) && (hc ? (c > thr) : true));
+            ml = upd ? l : ml;
+            bc = upd ? c : bc;
+        }
+        const float w = (vis[vn] == -1.0f ? 0.0f : 1.0f) * bc;
+        s_num[wave][v] = ml * w;
+        s_den[wave][v] = w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        MhCasc nm = {0.f, 0.f}, dn = {0.f, 0.f};
+        int cnt = 0;
+        for (int v = 0; v < V; ++v) {
+            if (v > 0 && (v & 15) == 0) {
+                mh_casc_flush(nm);
+                mh_casc_flush(dn);
+            }
+            const float w = s_den[wave][v];
+            nm.a0 = nm.a0 + s_num[wave][v];
+            dn.a0 = dn.a0 + w;
+            cnt += (w > 0.0f) ? 1 : 0;
+        }
+        const float d = dn.a0 + dn.a1;
+        loss[n] = (nm.a0 + nm.a1) / d;
+        if (hcout) hcout[n] = (d / (float)cnt > thr) ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank, int rank_step, const float *pts,
+                                int N, int P1, float thr, const float *ori_c, const int32_t *base_idx,
+                                const float *base_val, const float4 *taps, float *line_ori, float *min_loss,
+                                uint8_t *high_conf, float *best_sample, int32_t *best_rank, int32_t *best_s,
+                                int variant, hipStream_t st) {
+    const int nitems = nrank * S;
+    if (nitems > MH_MAX_ITEMS || nrank > MH_MAX_RANKS || nitems < 1) return -1;
+#define MH_SEARCH_LAUNCH(KK, TT)                                                                                   \
+    hipLaunchKernelGGL((mh_search_kernel<KK, TT>), dim3(N), dim3(TT), 0, st, vw, offs, S, nrank, rank_step, pts, N, \
+                       P1, thr, ori_c, base_idx, base_val, taps, line_ori, min_loss, high_conf, best_sample,        \
+                       best_rank, best_s)
+    // pick the smallest K*T that covers the items for the requested wave count
+    if (variant == 0) variant = (nitems <= 64) ? 64 : (nitems <= 320 ? 320 : 192);
+    if (variant == 64) {
+        if (nitems <= 64) MH_SEARCH_LAUNCH(1, 64);
+        else if (nitems <= 512) MH_SEARCH_LAUNCH(8, 64);
+        else if (nitems <= 960) MH_SEARCH_LAUNCH(15, 64);
+        else MH_SEARCH_LAUNCH(16, 64);
+    } else if (variant == 128) {
+        MH_SEARCH_LAUNCH(8, 128);
+    } else if (variant == 192) {
+        if (nitems <= 960) MH_SEARCH_LAUNCH(5, 192);
+        else MH_SEARCH_LAUNCH(6, 192);
+    } else if (variant == 256) {
+        MH_SEARCH_LAUNCH(4, 256);
+    } else if (variant == 320) {
+        if (nitems <= 320) MH_SEARCH_LAUNCH(1, 320);
+        else if (nitems <= 960) MH_SEARCH_LAUNCH(3, 320);
+        else MH_SEARCH_LAUNCH(4, 320);
+    } else {
+        return -1;
+    }
+#undef MH_SEARCH_LAUNCH
+    return (int)hipGetLastError();
+}
+
+extern "C" int mh_launch_refine_loss(MhViews vw, const float *pts, const float *dir, float mul, float dv, int N,
+                                     int P, float thr, const float *vis, const float *ori_patch,
+                                     const float *conf_patch, float *loss, uint8_t *hc, hipStream_t st) {
+    if (vw.V > MH_REFINE_VMAX) return -1;
+    hipLaunchKernelGGL(mh_refine_loss_kernel, dim3((N + 3) / 4), dim3(256), 0, st, vw, pts, dir, mul, dv, N, P, thr,
+                       vis, ori_patch, conf_patch, loss, hc);
+    return (int)hipGetLastError();
+}

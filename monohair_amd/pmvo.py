@@ -1,0 +1,256 @@
+"""class PMVO -- the host-side mirror of the reference's `PMVO.py::class PMVO` (lines 13-529) on top of
+the HIP library (include/mh_pmvo.h).  Same constructor, same methods, same return shapes/dtypes; every
+method is one or two C-ABI calls on torch-owned device buffers.  There is no CPU path in here: without a
+GPU and libmhpmvo.so construction fails loudly.
+
+State set by Compute_Visible_and_Ori (as in the reference, PMVO.py:369-376): self.visible [V,N],
+self.Ori [V,N,2], self.Conf [V,N], self.mask [V,N], self.Ori_patch [V,N,P,2], self.Conf_patch [V,N,P].
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .camera import CAM_STRIDE, camera_records
+
+_GOLDEN_OFFSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "depth_offsets.npy")
+
+
+def depth_offsets(num_sample=90):
+    """The depth offsets of sample_next_3d_pos (PMVO.py:274-278): three torch.arange pieces, concatenated,
+    cut to num_sample.  Built with the same CPU torch calls, so the values are the reference's bits."""
+    s1 = torch.arange(-0.005, -0.001, 0.004 / (num_sample / 4))
+    s2 = torch.arange(-0.001, 0.001, 0.002 / (num_sample / 2))
+    s3 = torch.arange(0.001, 0.005, 0.004 / (num_sample / 4))
+    return torch.cat([s1, s2, s3], 0)[:num_sample].numpy().astype(np.float32)
+
+
+class PMVO:
+    NUM_SAMPLE = 90          # PMVO.py:263
+    RANKS = range(0, 20, 2)  # PMVO.py:50
+
+    def __init__(self, camera, depths, Ori, Conf, masks, device="cuda:0", image_size=[1120, 1992], patch_size=5,
+                 visible_threshold=1, conf_threshold=0.4):
+        """camera: dict view -> Camera (insertion order = view order); depths[k] [H,W,3], Ori[k] [H,W,2],
+        Conf[k] [H,W], masks[k] [H,W,3] numpy arrays (reference PMVO.py:14-28)."""
+        self._init_common(device, image_size, patch_size, visible_threshold, conf_threshold)
+        self.camera_dict = camera
+        self.camera_key = list(camera.keys())
+        self.camera = [camera[k] for k in self.camera_key]
+        recs = camera_records(camera)
+        H, W = int(image_size[0]), int(image_size[1])
+        self._alloc(len(self.camera_key), H, W)
+        st = _lib.stream_ptr()
+        for i, k in enumerate(self.camera_key):
+            d = torch.from_numpy(np.ascontiguousarray(np.asarray(depths[k]))).to(self.device).type(torch.float)
+            o = torch.from_numpy(np.ascontiguousarray(np.asarray(Ori[k]))).to(self.device).type(torch.float)
+            c = torch.from_numpy(np.ascontiguousarray(np.asarray(Conf[k]))).to(self.device).type(torch.float)
+            m = torch.from_numpy(np.ascontiguousarray(np.asarray(masks[k]))).to(self.device).type(torch.float)
+            assert d.shape[:2] == (H, W) and o.shape == (H, W, 2) and c.shape == (H, W) and m.shape[:2] == (H, W), \
+                "map shapes do not match image_size=[H,W]"
+            ds = d.shape[2] if d.dim() == 3 else 1
+            ms = m.shape[2] if m.dim() == 3 else 1
+            self._set_view(i, recs[i], d, ds, o, c, m, ms, st)
+        torch.cuda.synchronize(self.device)
+
+    @classmethod
+    def from_planes(cls, cam_records, depth, ori, conf, mask, device="cuda:0", patch_size=5, visible_threshold=1,
+                    conf_threshold=0.4, camera=None):
+        """Device-resident compact planes: depth/conf/mask [V,H,W], ori [V,H,W,2] float32 tensors on `device`
+        (what an on-GPU producer such as the Gabor stage hands over) + [V,48] camera records."""
+        self = cls.__new__(cls)
+        V, H, W = depth.shape
+        self._init_common(device, [H, W], patch_size, visible_threshold, conf_threshold)
+        self.camera_dict = camera
+        self.camera_key = list(camera.keys()) if camera is not None else ["view_%03d" % i for i in range(V)]
+        self.camera = list(camera.values()) if camera is not None else None
+        recs = np.ascontiguousarray(cam_records, dtype=np.float32)
+        assert recs.shape == (V, CAM_STRIDE)
+        self._alloc(V, H, W)
+        st = _lib.stream_ptr()
+        for i in range(V):
+            self._set_view(i, recs[i], depth[i].contiguous(), 1, ori[i].contiguous(), conf[i].contiguous(),
+                           mask[i].contiguous(), 1, st)
+        torch.cuda.synchronize(self.device)
+        return self
+
+    # ------------------------------------------------------------------ plumbing
+    def _init_common(self, device, image_size, patch_size, visible_threshold, conf_threshold):
+        if not torch.cuda.is_available():
+            raise _lib.MhError("monohair_amd.PMVO needs a ROCm GPU: the hot path has no CPU fallback")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.MhError("monohair_amd.PMVO runs on HIP devices only (got %r)" % (device,))
+        torch.cuda.set_device(self.device)
+        self.image_size = [int(image_size[0]), int(image_size[1])]
+        self.patch_size = int(patch_size)
+        self.visible_threshold = visible_threshold
+        self.conf_threshold = conf_threshold
+        self._L = _lib.lib()
+        h = ctypes.c_void_p()
+        _lib.check(self._L.mh_ctx_create(self.device.index or 0, ctypes.byref(h)), "mh_ctx_create")
+        self._ctx = h
+        offs = depth_offsets(self.NUM_SAMPLE)
+        _lib.check(self._L.mh_ctx_set_depth_offsets(self._ctx, offs.ctypes.data_as(ctypes.c_void_p), len(offs)),
+                   "mh_ctx_set_depth_offsets")
+        self._scratch = None
+        self.bust_tree = self.scalp_tree = self.scalp_max = None
+        self.base_view_override = None
+
+    def _alloc(self, V, H, W):
+        self.num_view = V
+        _lib.check(self._L.mh_ctx_alloc_views(self._ctx, V, H, W), "mh_ctx_alloc_views")
+
+    def _set_view(self, i, rec, d, ds, o, c, m, ms, st):
+        rec = np.ascontiguousarray(rec, dtype=np.float32)
+        _lib.check(self._L.mh_ctx_set_view(self._ctx, i, rec.ctypes.data_as(ctypes.c_void_p), _lib.ptr(d), ds,
+                                           _lib.ptr(o), _lib.ptr(c), _lib.ptr(m), ms, st), "mh_ctx_set_view")
+        # the pack kernel reads d/o/c/m asynchronously: keep them alive until it has run
+        torch.cuda.current_stream().synchronize()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                self._L.mh_ctx_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        _lib.check(self._L.mh_ctx_set_option(self._ctx, key.encode(), int(value)), "mh_ctx_set_option")
+
+    def set_head(self, bust_tree, scalp_tree, scalp_max):
+        """The reference reads these from module globals (PMVO.py:99-106, 814-820)."""
+        self.bust_tree, self.scalp_tree, self.scalp_max = bust_tree, scalp_tree, scalp_max
+
+    def _dev_points(self, points):
+        if isinstance(points, np.ndarray):
+            points = torch.from_numpy(points)
+        return points.to(self.device).type(torch.float).contiguous()
+
+    # ------------------------------------------------------------------ reference methods
+    def Compute_Visible_and_Ori(self, points):
+        """PMVO.py:346-376 -> one mh_project_gather launch."""
+        points = self._dev_points(points)
+        V, N, P = self.num_view, points.shape[0], self.patch_size ** 2
+        f = dict(dtype=torch.float32, device=self.device)
+        self.visible = torch.empty((V, N), **f)
+        self.Ori = torch.empty((V, N, 2), **f)
+        self.Conf = torch.empty((V, N), **f)
+        self.mask = torch.empty((V, N), **f)
+        self.Ori_patch = torch.empty((V, N, P, 2), **f)
+        self.Conf_patch = torch.empty((V, N, P), **f)
+        self._pixf = torch.empty((V, N, 2), **f)
+        self._points = points
+        _lib.check(self._L.mh_project_gather(self._ctx, _lib.ptr(points), N, self.patch_size, _lib.ptr(self.visible),
+                                             _lib.ptr(self.Ori), _lib.ptr(self.Conf), _lib.ptr(self.mask),
+                                             _lib.ptr(self.Ori_patch), _lib.ptr(self.Conf_patch),
+                                             _lib.ptr(self._pixf), _lib.stream_ptr()), "mh_project_gather")
+
+    def Find_max_conf_from_visible_view(self):
+        """PMVO.py:339-343 -> (base_view_index [20,N] int64, base_view_conf [20,N])."""
+        V, N = self.visible.shape
+        idx = torch.empty((20, N), dtype=torch.int32, device=self.device)
+        val = torch.empty((20, N), dtype=torch.float32, device=self.device)
+        _lib.check(self._L.mh_topk_views(self._ctx, _lib.ptr(self.visible), _lib.ptr(self.Conf), N, _lib.ptr(idx),
+                                         _lib.ptr(val), _lib.stream_ptr()), "mh_topk_views")
+        return idx.long(), val
+
+    def _get_scratch(self, N):
+        need = int(self._L.mh_search_scratch_bytes(self._ctx, N, self.patch_size))
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._scratch, need
+
+    def forward(self, points, base_view=None, extras=False):
+        """PMVO.py:39-78.  points: numpy [N,3].  Returns (points, line_ori [N,3], min_loss [N],
+        high_conf [N] bool) on the device.  base_view=(idx [20,N], val [20,N]) injects a base-view ranking
+        (parity tests: torch.topk's tie order is unspecified)."""
+        self.Compute_Visible_and_Ori(points)
+        points = self._points
+        N = points.shape[0]
+        if base_view is None:
+            bidx, bval = self.Find_max_conf_from_visible_view()
+        else:
+            bidx = torch.as_tensor(base_view[0]).to(self.device)
+            bval = torch.as_tensor(base_view[1]).to(self.device).type(torch.float)
+        bidx32 = bidx.to(torch.int32).contiguous()
+        bval = bval.contiguous()
+        f = dict(dtype=torch.float32, device=self.device)
+        line_ori = torch.empty((N, 3), **f)
+        min_loss = torch.empty((N,), **f)
+        hc = torch.empty((N,), dtype=torch.uint8, device=self.device)
+        bs = torch.empty((N, 3), **f) if extras else None
+        br = torch.empty((N,), dtype=torch.int32, device=self.device) if extras else None
+        bi = torch.empty((N,), dtype=torch.int32, device=self.device) if extras else None
+        scratch, need = self._get_scratch(N)
+        ranks = list(self.RANKS)
+        _lib.check(self._L.mh_search_forward(
+            self._ctx, _lib.ptr(points), N, self.patch_size, float(self.conf_threshold), len(ranks),
+            ranks[1] - ranks[0], _lib.ptr(self.visible), _lib.ptr(self.Ori), _lib.ptr(self._pixf),
+            _lib.ptr(self.Ori_patch), _lib.ptr(self.Conf_patch), _lib.ptr(bidx32), _lib.ptr(bval),
+            _lib.ptr(scratch), need, _lib.ptr(line_ori), _lib.ptr(min_loss), _lib.ptr(hc), _lib.ptr(bs),
+            _lib.ptr(br), _lib.ptr(bi), _lib.stream_ptr()), "mh_search_forward")
+        out = (points, line_ori, min_loss, hc.bool())
+        if extras:
+            return out + (dict(best_sample=bs, best_rank=br, best_s=bi, base_idx=bidx, base_val=bval),)
+        return out
+
+    __call__ = forward
+
+    def prj_loss_of(self, points, ori):
+        """compute_reproject_ori + compute_prj_loss for next = points + ori*0.005/4 (PMVO.py:86-90) on the
+        state of the last Compute_Visible_and_Ori: (loss [N], high_conf [N] bool)."""
+        N = points.shape[0]
+        ori = ori.to(self.device).type(torch.float).contiguous()
+        loss = torch.empty((N,), dtype=torch.float32, device=self.device)
+        hc = torch.empty((N,), dtype=torch.uint8, device=self.device)
+        _lib.check(self._L.mh_refine_loss(self._ctx, _lib.ptr(points), _lib.ptr(ori), 0.005, 4.0, N,
+                                          self.patch_size, float(self.conf_threshold), _lib.ptr(self.visible),
+                                          _lib.ptr(self.Ori_patch), _lib.ptr(self.Conf_patch), _lib.ptr(loss),
+                                          _lib.ptr(hc), _lib.stream_ptr()), "mh_refine_loss")
+        return loss, hc.bool()
+
+    def refine(self, points, ori):
+        """PMVO.py:81-93: loss of a given direction; -1 where filter_head_points fires."""
+        self.Compute_Visible_and_Ori(points)
+        points = self._points
+        filter_index = self.filter_head_points(points, self.visible_threshold)
+        loss, _ = self.prj_loss_of(points, ori)
+        loss[filter_index] = -1
+        return loss
+
+    def _votes(self, points, want, visible_threshold=None):
+        points = self._dev_points(points)
+        N = points.shape[0]
+        bufs = [torch.empty((N,), dtype=torch.uint8, device=self.device) if w else None for w in want]
+        vt = self.visible_threshold if visible_threshold is None else visible_threshold
+        _lib.check(self._L.mh_filter_points(self._ctx, _lib.ptr(points), N, self.patch_size,
+                                            float(self.conf_threshold), float(vt), _lib.ptr(bufs[0]),
+                                            _lib.ptr(bufs[1]), _lib.ptr(bufs[2]), _lib.ptr(bufs[3]),
+                                            _lib.stream_ptr()), "mh_filter_points")
+        return points, [None if b is None else b.bool() for b in bufs]
+
+    def filter_points(self, points):
+        """PMVO.py:402-459 -> (surface_index, surface_points, filter_index)."""
+        points, (surf, filt, _, _) = self._votes(points, (True, True, False, False))
+        return surf, points[surf], filt
+
+    def compute_unvisible_points(self, points):
+        """PMVO.py:461-480."""
+        _, (_, _, unv, _) = self._votes(points, (False, False, True, False))
+        return unv
+
+    def filter_head_points(self, points, visible_threshold):
+        """PMVO.py:96-144: mask vote on the GPU; the two KDTree queries (scipy, float64) stay on the host
+        exactly as in the reference."""
+        pts, (_, _, _, head) = self._votes(points, (False, False, False, True), visible_threshold)
+        if self.scalp_tree is None:
+            raise _lib.MhError("filter_head_points needs set_head(bust_tree, scalp_tree, scalp_max)")
+        points_numpy = pts.clone().cpu().numpy()
+        nei_scalp_dist, _ = self.scalp_tree.query(points_numpy, k=1)
+        head_top = np.logical_and(nei_scalp_dist < 0.04, points_numpy[:, 2] < self.scalp_max[2] - 0.01)
+        head_top = torch.from_numpy(head_top).to(self.device)
+        return torch.logical_and(head, ~head_top)
