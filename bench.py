@@ -201,24 +201,23 @@ def cpu_baseline(a, scene, recs, chunk, gpu_ms):
                          scene["conf"].cpu().numpy(), scene["mask"].cpu().numpy())
     cores = oracle.num_threads()
     offs = depth_offsets(90)
-    n = a.cpu_points
-    if n <= 0:
-        # calibrate on a few points, then size the sample for ~15 s
+    n = a.cpu_points if a.cpu_points > 0 else len(chunk)
+    # repeat the sample until >= 12 s of CPU work have been timed (bounded: at most 40 repeats)
+    t, reps = 0.0, 0
+    while reps < 40 and (t < 12.0 or reps == 0):
         t0 = time.perf_counter()
-        oracle.forward(views, chunk[:2 * cores], a.patch, a.conf_threshold, offs)
-        per_pt = (time.perf_counter() - t0) / (2 * cores)
-        n = int(min(len(chunk), max(4 * cores, 15.0 / max(per_pt, 1e-6))))
-    t0 = time.perf_counter()
-    oracle.forward(views, chunk[:n], a.patch, a.conf_threshold, offs)
-    t = time.perf_counter() - t0
-    its = (n / float(CHUNK)) / t
+        oracle.forward(views, chunk[:n], a.patch, a.conf_threshold, offs)
+        t += time.perf_counter() - t0
+        reps += 1
+    n_total = n * reps
+    its = (n_total / float(CHUNK)) / t
     return {
         "value": round(its, 5),
         "unit": "iterations/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%d of the %d points of one iteration, all %d views, C oracle with OpenMP (%.1f s)" %
-                  (n, CHUNK, a.views, t),
+        "sample": "%d x %d points of one %d-point iteration, all %d views, C oracle (oracle/pmvo_oracle.c) with "
+                  "OpenMP on %d threads, %.1f s of wall time" % (reps, n, CHUNK, a.views, cores, t),
     }
 
 

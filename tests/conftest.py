@@ -36,13 +36,26 @@ def golden_scene(meta):
     return _scene_cache[key]
 
 
-def scene_views(scene):
+def golden_records(z):
+    """[V,48] camera records assembled from the REFERENCE's own camera tensors stored in a golden file
+    (pose, proj and torch.linalg.inv(pose[:3,:3]) as evaluated where the goldens were generated: MKL's
+    3x3 inverse is not bit-reproducible across host CPUs, and the goldens must be compared like for like)."""
+    V = z["cam_pose"].shape[0]
+    rec = np.zeros((V, 48), np.float32)
+    rec[:, 0:16] = z["cam_pose"].reshape(V, 16)
+    rec[:, 16:32] = z["cam_proj"].reshape(V, 16)
+    rec[:, 32:41] = z["cam_rinv"].reshape(V, 9)
+    return rec
+
+
+def scene_views(scene, records=None):
     """oracle.Views of a synth scene (host planes + camera records)."""
     import oracle
     from monohair_amd.camera import camera_records, cameras_from_list
 
-    cams = cameras_from_list(scene["cams"])
-    return oracle.Views(camera_records(cams), scene["depth"].cpu().numpy(), scene["ori"].cpu().numpy(),
+    if records is None:
+        records = camera_records(cameras_from_list(scene["cams"]))
+    return oracle.Views(records, scene["depth"].cpu().numpy(), scene["ori"].cpu().numpy(),
                         scene["conf"].cpu().numpy(), scene["mask"].cpu().numpy())
 
 

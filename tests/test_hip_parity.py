@@ -9,7 +9,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import golden_scene, load_golden, scene_views
+from conftest import golden_records, golden_scene, load_golden, scene_views
 
 pytestmark = pytest.mark.gpu
 
@@ -20,22 +20,41 @@ def eq_nan(a, b):
     return np.array_equal(a, b, equal_nan=True)
 
 
-def make_pmvo(meta, scene):
-    from monohair_amd import synth
-    from monohair_amd.camera import cameras_from_list
+def make_pmvo(meta, scene, records):
+    """PMVO on device-resident planes with the golden's camera records (see conftest.golden_records)."""
     from monohair_amd.pmvo import PMVO
 
-    cams = cameras_from_list(scene["cams"])
-    depths, Ori, Conf, masks = synth.scene_to_reference_dicts(scene)
-    return PMVO(cams, depths, Ori, Conf, masks, device="cuda:0", image_size=[meta["H"], meta["W"]],
-                patch_size=meta["patch"], visible_threshold=meta["vis_thr"], conf_threshold=meta["thr"])
+    dev = "cuda:0"
+    return PMVO.from_planes(records, scene["depth"].to(dev), scene["ori"].to(dev), scene["conf"].to(dev),
+                            scene["mask"].to(dev), device=dev, patch_size=meta["patch"],
+                            visible_threshold=meta["vis_thr"], conf_threshold=meta["thr"])
 
 
 @pytest.fixture(scope="module", params=CASES)
 def case(request):
     meta, z = load_golden(request.param)
     scene = golden_scene(meta)
-    return meta, z, scene, scene_views(scene), make_pmvo(meta, scene)
+    rec = golden_records(z)
+    return meta, z, scene, scene_views(scene, rec), make_pmvo(meta, scene, rec)
+
+
+def test_reference_style_constructor(case):
+    """PMVO(camera, depths, Ori, Conf, masks, ...) with the reference's dict-of-numpy arguments
+    (PMVO.py:14-28) packs the same maps as the device-plane constructor."""
+    from monohair_amd import synth
+    from monohair_amd.camera import cameras_from_list
+    from monohair_amd.pmvo import PMVO
+
+    meta, z, scene, views, pm = case
+    cams = cameras_from_list(scene["cams"])
+    depths, Ori, Conf, masks = synth.scene_to_reference_dicts(scene)
+    pm2 = PMVO(cams, depths, Ori, Conf, masks, device="cuda:0", image_size=[meta["H"], meta["W"]],
+               patch_size=meta["patch"], visible_threshold=meta["vis_thr"], conf_threshold=meta["thr"])
+    assert pm2.camera_key == [c["file"] for c in scene["cams"]]
+    pm.Compute_Visible_and_Ori(z["points"])
+    pm2.Compute_Visible_and_Ori(z["points"])
+    for k in ("visible", "Ori", "Conf", "mask", "Ori_patch", "Conf_patch"):
+        assert torch.equal(getattr(pm, k), getattr(pm2, k)), k
 
 
 def test_depth_offsets_match_fixture(depth_offsets):
