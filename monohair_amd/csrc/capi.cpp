@@ -168,8 +168,8 @@ extern "C" int mh_project_gather(mh_ctx *ctx, const float *points, int N, int pa
                                  float *conf, float *mask, float *ori_patch, float *conf_patch, float *pixf,
                                  void *stream) {
     if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_project_gather: views not set");
-    if (!points || N < 0 || patch < 1 || !(patch & 1)) return fail(MH_ERR_ARG, "mh_project_gather: bad arguments");
     if (N == 0) return MH_OK;
+    if (!points || N < 0 || patch < 1 || !(patch & 1)) return fail(MH_ERR_ARG, "mh_project_gather: bad arguments");
     return launched(mh_launch_project_gather(ctx->views(), points, N, patch, vis, ori, conf, mask, ori_patch,
                                              conf_patch, pixf, (hipStream_t)stream),
                     "mh_project_gather");
@@ -178,6 +178,7 @@ extern "C" int mh_project_gather(mh_ctx *ctx, const float *points, int N, int pa
 extern "C" int mh_topk_views(mh_ctx *ctx, const float *vis, const float *conf, int N, int32_t *out_idx,
                              float *out_val, void *stream) {
     if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_topk_views: views not set");
+    if (N == 0) return MH_OK;
     if (!vis || !conf || !out_idx || !out_val || N < 0) return fail(MH_ERR_ARG, "mh_topk_views: bad arguments");
     if (ctx->V < MH_TOPK)
         return fail(MH_ERR_ARG, "mh_topk_views: %d views < %d (the reference's torch.topk raises too, PMVO.py:341)",
@@ -199,6 +200,7 @@ extern "C" int mh_search_forward(mh_ctx *ctx, const float *points, int N, int pa
                                  int32_t *best_s, void *stream) {
     if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_search_forward: views not set");
     if (!ctx->offs) return fail(MH_ERR_STATE, "mh_search_forward: depth offsets not set");
+    if (N == 0) return MH_OK;
     if (!points || !vis || !ori || !pixf || !ori_patch || !conf_patch || !base_idx || !base_val || !scratch ||
         !line_ori || !min_loss || !high_conf || N < 0 || nrank < 1 || rank_step < 1 ||
         (nrank - 1) * rank_step >= MH_TOPK)
@@ -224,6 +226,7 @@ extern "C" int mh_refine_loss(mh_ctx *ctx, const float *points, const float *dir
                               int N, int patch, float conf_threshold, const float *vis, const float *ori_patch,
                               const float *conf_patch, float *loss, uint8_t *high_conf, void *stream) {
     if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_refine_loss: views not set");
+    if (N == 0) return MH_OK;
     if (!points || !dir || !vis || !ori_patch || !conf_patch || !loss || N < 0)
         return fail(MH_ERR_ARG, "mh_refine_loss: bad arguments");
     if (N == 0) return MH_OK;
@@ -237,8 +240,8 @@ extern "C" int mh_filter_points(mh_ctx *ctx, const float *points, int N, int pat
                                 float visible_threshold, uint8_t *surface_index, uint8_t *filter_index,
                                 uint8_t *unvisible_index, uint8_t *head_filter, void *stream) {
     if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_filter_points: views not set");
-    if (!points || N < 0 || patch < 1 || !(patch & 1)) return fail(MH_ERR_ARG, "mh_filter_points: bad arguments");
     if (N == 0) return MH_OK;
+    if (!points || N < 0 || patch < 1 || !(patch & 1)) return fail(MH_ERR_ARG, "mh_filter_points: bad arguments");
     return launched(mh_launch_filter_points(ctx->views(), points, N, patch, conf_threshold, visible_threshold,
                                             surface_index, filter_index, unvisible_index, head_filter,
                                             (hipStream_t)stream),

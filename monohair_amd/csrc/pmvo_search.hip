@@ -293,7 +293,7 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
                        P1, thr, ori_c, base_idx, base_val, taps, line_ori, min_loss, high_conf, best_sample,        \
                        best_rank, best_s)
     // pick the smallest K*T that covers the items for the requested wave count
-    if (variant == 0) variant = (nitems <= 64) ? 64 : (nitems <= 320 ? 320 : 192);
+    if (variant == 0) variant = (nitems <= 64) ? 64 : (nitems <= 320 ? 320 : 256);
     if (variant == 64) {
         if (nitems <= 64) MH_SEARCH_LAUNCH(1, 64);
         else if (nitems <= 512) MH_SEARCH_LAUNCH(8, 64);
