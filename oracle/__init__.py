@@ -196,3 +196,96 @@ def forward(views, pts, patch, thr, offsets, base_idx=None, base_val=None, nrank
     if extra:
         return pts, lo, ml, hc.astype(bool), dict(best_sample=bs, best_rank=br, best_s=bi)
     return pts, lo, ml, hc.astype(bool)
+
+
+def refine_loss(views, pts, dirs, patch, thr, mul=0.005, div=4.0):
+    """Loss of one given direction per point: the core of PMVO.refine (PMVO.py:86-90)."""
+    pts = np.ascontiguousarray(pts, np.float32)
+    dirs = np.ascontiguousarray(dirs, np.float32)
+    N = pts.shape[0]
+    loss = np.empty(N, np.float32)
+    hc = np.empty(N, np.uint8)
+    lib().orc_refine_loss(ctypes.byref(views.c), _p(pts), _p(dirs), ctypes.c_float(mul), ctypes.c_float(div), N,
+                          patch, ctypes.c_float(thr), _p(loss), _p(hc, c_u8))
+    return loss, hc.astype(bool)
+
+
+def filter_votes(views, pts, patch, thr, vis_thr):
+    """(surface_index, filter_index, unvisible_index, head_filter_votes) -- PMVO.py:402-480, :110-137."""
+    pts = np.ascontiguousarray(pts, np.float32)
+    N = pts.shape[0]
+    outs = [np.empty(N, np.uint8) for _ in range(4)]
+    lib().orc_filter_points(ctypes.byref(views.c), _p(pts), N, patch, ctypes.c_float(thr), ctypes.c_float(vis_thr),
+                            *[_p(o, c_u8) for o in outs])
+    return [o.astype(bool) for o in outs]
+
+
+def medoid_dense(ori):
+    """compute_points_similarity (PMVO_utils.py:366-382): ori [G,K,3] -> (medoid [G,3], index [G])."""
+    ori = np.ascontiguousarray(ori, np.float32)
+    G, K, _ = ori.shape
+    out = np.empty((G, 3), np.float32)
+    idx = np.empty(G, np.int32)
+    lib().orc_medoid_dense(_p(ori), G, K, _p(out), _p(idx, c_i))
+    return out, idx
+
+
+def medoid_segmented(ori, seg_start):
+    ori = np.ascontiguousarray(ori, np.float32)
+    seg_start = np.ascontiguousarray(seg_start, np.int32)
+    G = len(seg_start) - 1
+    out = np.zeros((G, 3), np.float32)
+    idx = np.zeros(G, np.int32)
+    lib().orc_medoid_segmented(_p(ori), _p(seg_start, c_i), G, _p(out), _p(idx, c_i))
+    return out, idx
+
+
+def p2v(points, voxel_min, voxel_size, grid_resolution):
+    """p2v (PMVO_utils.py:386-404): flips y,z IN PLACE, float64 round-half-even, clip."""
+    points[:, 1:] *= -1
+    idx = np.round((points - voxel_min) / voxel_size).astype(np.int32)
+    g = np.asarray(grid_resolution)
+    idx = np.clip(idx, 0, g - 1)
+    return idx[:, 0], idx[:, 1], idx[:, 2]
+
+
+def voxel_fit(select_points, select_ori, voxel_min, voxel_size, grid_resolution):
+    """The voxel fit of refine (PMVO.py:695-726): sign canonicalisation, p2v, groups in first-occurrence /
+    point order, per-voxel medoid.  Returns (occ [X,Y,Z] f64, ori [X,Y,Z,3] f64); mutates its inputs like the
+    reference does."""
+    g = np.asarray(grid_resolution).astype(np.int64)
+    occ = np.zeros(tuple(g))
+    ori = np.zeros(tuple(g) + (3,))
+    up = select_ori[:, 1] > 0
+    select_ori[up] *= -1
+    x, y, z = p2v(select_points, np.asarray(voxel_min), voxel_size, g)
+    key = (x.astype(np.int64) * g[1] + y) * g[2] + z
+    order = np.argsort(key, kind="stable")          # stable: point order inside every voxel is kept
+    ks = key[order]
+    starts = np.flatnonzero(np.concatenate([[True], ks[1:] != ks[:-1]]))
+    seg = np.concatenate([starts, [len(ks)]]).astype(np.int32)
+    med, _ = medoid_segmented(select_ori[order].astype(np.float32), seg)
+    vx, vy, vz = x[order][starts], y[order][starts], z[order][starts]
+    occ[vx, vy, vz] = 1
+    ori[vx, vy, vz] = med.astype(np.float64)
+    return occ, ori
+
+
+def mat_layout(occ, ori):
+    """The on-disk layout of Ori3D.mat / Occ3D.mat (PMVO.py:753-756): ori [X,Y,Z,3] -> [Y,X,3*Z] with last index
+    c*Z+z, occ [X,Y,Z] -> [Y,X,Z]."""
+    g = occ.shape
+    o = ori.transpose((0, 1, 3, 2)).reshape(g[0], g[1], g[2] * 3).transpose((1, 0, 2))
+    return o, occ.transpose((1, 0, 2))
+
+
+def gabor_bank(bank, img):
+    """calOrientationGabor.filter/forward, iter=1 (GaborFilter.py:29-113): (orient index, conf, variance)."""
+    bank = np.ascontiguousarray(bank, np.float32).reshape(180, 17, 17)
+    img = np.ascontiguousarray(img, np.float32)
+    H, W = img.shape
+    orient = np.empty((H, W), np.int32)
+    conf = np.empty((H, W), np.float32)
+    var = np.empty((H, W), np.float32)
+    lib().orc_gabor_bank(_p(bank), _p(img), H, W, _p(orient, c_i), _p(conf), _p(var))
+    return orient, conf, var

@@ -1,0 +1,74 @@
+/*
+ * oracle/gabor_oracle.c -- TEST INFRASTRUCTURE ONLY (see pmvo_oracle.c).
+ *
+ * calOrientationGabor.filter / forward with iter = 1
+ * (/root/reference/preprocess_capture_data/GaborFilter.py:29-113) given the 180 kernels of gabor_fn (:115-145):
+ *   R_k = | sum_{i,j} img[y+i-8, x+j-8] * g_k[i,j] |  (F.conv2d = cross-correlation, zero padding 8),
+ *   M = max_k R_k, b = first argmax, d_k = min(|bh-th_k|, |bh-th_k-pi|, |bh-th_k+pi|) in fp32,
+ *   var = sqrt( cascade-sum_k (d_k*(R_k-M))*(R_k-M) ), orient = var>0 ? b : 0,
+ *   conf = clamp( (var / max_image var) / 0.2, 0, 1 ).
+ * The 289-term correlation is accumulated tap by tap (row-major) with fma -- the order the HIP kernel uses; the
+ * reference's conv2d (oneDNN/MKL im2col GEMM) may associate differently, so a pixel whose two best responses tie
+ * to ~1e-7 relative can flip by one degree: parity against the reference's goldens is therefore reported as a
+ * match rate (tests/test_gabor.py), while HIP vs this oracle is exact.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#define NK 180
+#define KS 17
+
+static inline float theta_of(float k) { return (3.14159265358979323846f * k) / 180.0f; }
+
+void orc_gabor_bank(const float *bank /*[180][17][17]*/, const float *img, int H, int W, int32_t *orient,
+                    float *conf, float *var_out) {
+    float vmax = 0.0f;
+#pragma omp parallel for schedule(static) reduction(max : vmax)
+    for (int y = 0; y < H; ++y) {
+        float R[NK];
+        for (int x = 0; x < W; ++x) {
+            for (int k = 0; k < NK; ++k) R[k] = 0.0f;
+            for (int i = 0; i < KS; ++i) {
+                const int gy = y + i - 8;
+                for (int j = 0; j < KS; ++j) {
+                    const int gx = x + j - 8;
+                    const float v = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : 0.0f;
+                    const float *g = bank + i * KS + j;
+                    for (int k = 0; k < NK; ++k) R[k] = fmaf(v, g[(size_t)k * KS * KS], R[k]);
+                }
+            }
+            float M = fabsf(R[0]);
+            int b = 0;
+            for (int k = 1; k < NK; ++k) {
+                float r = fabsf(R[k]);
+                if (r > M) {
+                    M = r;
+                    b = k;
+                }
+            }
+            const float PI_F = 3.14159265358979323846f;
+            const float bh = theta_of((float)b);
+            float a0 = 0.f, a1 = 0.f;
+            for (int k = 0; k < NK; ++k) {
+                if (k > 0 && (k & 15) == 0) {
+                    a1 = a1 + a0;
+                    a0 = 0.f;
+                }
+                float t1 = bh - theta_of((float)k);
+                float d = fminf(fabsf(t1), fminf(fabsf(t1 - PI_F), fabsf(t1 + PI_F)));
+                float rd = fabsf(R[k]) - M;
+                a0 = a0 + (d * rd) * rd;
+            }
+            const float var = sqrtf(a0 + a1);
+            var_out[(size_t)y * W + x] = var;
+            orient[(size_t)y * W + x] = (var > 0.0f) ? b : 0;
+            if (var > vmax) vmax = var;
+        }
+    }
+    for (size_t i = 0; i < (size_t)H * W; ++i) {
+        float v = var_out[i] / vmax;
+        v = (v - 0.0f) / 0.2f;
+        conf[i] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    }
+}

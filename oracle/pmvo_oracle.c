@@ -504,3 +504,92 @@ void orc_forward(const orc_views *vw, const float *pts, int N, int patch, float 
     free(bidx);
     free(bval);
 }
+
+/*
+ * PMVO.refine's loss (PMVO.py:86-90): next = p + ori*0.005/4, compute_reproject_ori + compute_prj_loss with
+ * one candidate per point (S = 1: `low_conf_index` is always true, so the raw num/den comes back).
+ */
+void orc_refine_loss(const orc_views *vw, const float *pts, const float *dir, float mul, float dv, int N, int patch,
+                     float thr, float *loss, uint8_t *hc) {
+    const int V = vw->V, P = patch * patch;
+    float *vis = (float *)malloc(sizeof(float) * (size_t)V * N);
+    float *opatch = (float *)malloc(sizeof(float) * (size_t)V * N * P * 2);
+    float *cpatch = (float *)malloc(sizeof(float) * (size_t)V * N * P);
+    orc_visible_and_ori(vw, pts, N, patch, vis, NULL, NULL, NULL, opatch, cpatch, NULL);
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+        float *D = (float *)malloc(sizeof(float) * (size_t)V * 2);
+        const float *X = pts + 3 * n;
+        float Q[3];
+        for (int k = 0; k < 3; ++k) Q[k] = X[k] + dir[3 * n + k] * mul / dv;
+        for (int v = 0; v < V; ++v) {
+            const float *cam = vw->cams + (size_t)v * ORC_CAM_STRIDE;
+            float r0, c0, r1, c1;
+            pixel_of(cam, X, vw->H, vw->W, &r0, &c0);
+            pixel_of(cam, Q, vw->H, vw->W, &r1, &c1);
+            D[2 * v] = r1 - r0;
+            D[2 * v + 1] = c1 - c0;
+        }
+        float l;
+        int idx, h;
+        prj_loss_point(V, 1, P, thr, D, 2, opatch + (size_t)n * P * 2, (size_t)N * P * 2, cpatch + (size_t)n * P,
+                       (size_t)N * P, vis + n, (size_t)N, &l, &idx, &h, NULL);
+        loss[n] = l;
+        if (hc) hc[n] = (uint8_t)h;
+        free(D);
+    }
+    free(vis);
+    free(opatch);
+    free(cpatch);
+}
+
+/*
+ * The per-view votes of PMVO.filter_points (PMVO.py:402-459), PMVO.compute_unvisible_points (:461-480) and the
+ * mask vote of PMVO.filter_head_points (:110-137).  Sums over views in ATen's cascade order.
+ */
+void orc_filter_points(const orc_views *vw, const float *pts, int N, int patch, float thr, float vis_thr,
+                       uint8_t *surface_index, uint8_t *filter_index, uint8_t *unvisible_index,
+                       uint8_t *head_filter) {
+    const int V = vw->V, H = vw->H, W = vw->W, hp = patch / 2;
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+        casc t[8];
+        memset(t, 0, sizeof(t));
+        for (int v = 0; v < V; ++v) {
+            const float *cam = vw->cams + (size_t)v * ORC_CAM_STRIDE;
+            int r, c, oob;
+            float zp;
+            project_point(cam, pts + 3 * n, H, W, &r, &c, &zp, &oob, NULL, NULL);
+            const size_t pix = (size_t)r * W + c;
+            float m = vw->mask[v][pix];
+            const float gap = zp * 255.0f - vw->depth[v][pix];
+            float cmax = vw->conf[v][pix]; /* raw confidences (PMVO.py:415-418) */
+            for (int i = -hp; i <= hp; ++i)
+                for (int j = -hp; j <= hp; ++j) {
+                    float cv = vw->conf[v][(size_t)clampi(r + i, 0, H - 1) * W + clampi(c + j, 0, W - 1)];
+                    cmax = cv > cmax ? cv : cmax;
+                }
+            if (oob) cmax = 0.0f;
+            const float unv = (oob || gap > 0.1f) ? 1.0f : 0.0f;
+            const float unv1 = (oob || gap > vis_thr) ? 1.0f : 0.0f;
+            const float unv9 = (oob || gap > 0.9f) ? 1.0f : 0.0f;
+            const float unvh = (gap >= vis_thr) ? 1.0f : 0.0f;
+            const float lowc = (cmax < thr) ? 1.0f : 0.0f;
+            m = (m > 0.2f) ? 1.0f : m;
+            const float term[8] = {(1.0f - unv) * lowc, 1.0f - unv,          (1.0f - unv) * m, 1.0f - unv1,
+                                   (1.0f - unv1) * m,   1.0f - unv9,         1.0f - unvh,      (1.0f - unvh) * m};
+            for (int k = 0; k < 8; ++k) casc_step(&t[k], v, term[k]);
+        }
+        float s[8];
+        for (int k = 0; k < 8; ++k) s[k] = casc_done(&t[k]);
+        const int low_conf = s[0] > 4.0f;
+        const int hair = (s[1] - s[2]) < (s[1] * 1.0f / 2.0f);
+        const int hair1 = (s[3] - s[4]) < (s[3] * 1.0f / 2.0f);
+        const int surf0 = s[1] > 1.0f;
+        const int filt0 = (s[3] > 1.0f) && !surf0;
+        if (surface_index) surface_index[n] = (uint8_t)(surf0 && !low_conf && hair);
+        if (filter_index) filter_index[n] = (uint8_t)(filt0 && !low_conf && hair1);
+        if (unvisible_index) unvisible_index[n] = (uint8_t)!(s[5] > 2.0f);
+        if (head_filter) head_filter[n] = (uint8_t)!((s[6] - s[7]) < (s[6] * 1.0f / 2.0f));
+    }
+}

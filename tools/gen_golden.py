@@ -177,7 +177,7 @@ def main():
     for name, case in PMVO_CASES.items():
         if a.only in (None, name):
             gen_pmvo(R, name, case)
-    if a.only in (None, "consensus", "gabor"):
+    if a.only in (None, "consensus", "gabor", "e2e"):
         try:
             import gen_golden_more  # consensus / voxel-fit / gabor fixtures (added with those components)
 
