@@ -1,0 +1,116 @@
+#!/usr/bin/env python
+"""PMVO.py -- drop-in entry point of the exterior-geometry optimisation, same command line, YAML keys and
+files as the reference's PMVO.py (__main__ :805-880, config_parser :767-800):
+
+    python PMVO.py --yaml=configs/reconstruct/<case> [--PMVO.infer_inner] [--PMVO.optimize=] [--gpu=N] [--a.b=v]
+    python -m torch.distributed.run --nproc-per-node 8 PMVO.py --yaml=...        (one process per MI355X)
+
+in : data/<case>/ours/cam_params.json, capture_images/, render_depth/<view>.npy, best_ori/, conf/, hair_mask/,
+     ours/colmap_points.obj, ours/bust_long_tsfm.obj, ours/scalp_tsfm.obj [, ours/raw.npy]
+out: data/<case>/output/<name>/options.yaml, optimize/*.npy, refine/*.npy, refine|full/{Ori3D,Occ3D}.mat
+
+All arithmetic runs in the HIP library (monohair_amd/lib/libmhpmvo.so); this file is host orchestration.
+"""
+import os
+import sys
+
+import numpy as np
+
+from monohair_amd import options
+from monohair_amd.camera import load_cam, parsing_camera
+from monohair_amd.pmvo import PMVO, filter_negative_points, optimize, refine  # noqa: F401  (re-exported)
+from monohair_amd.pmvo_utils import (Load_Ori_And_Conf, load_bust, load_colmap_points, load_depth, load_mask,
+                                     read_obj)
+
+
+def config_parser(argv=None):
+    print("Process ID: {}".format(os.getpid()))
+    opt_cmd = options.parse_arguments(sys.argv[1:] if argv is None else argv)
+    args = options.set(opt_cmd=opt_cmd)
+    args.output_path = os.path.join(args.data.root, args.data.case, args.output_root, args.name)
+    os.makedirs(args.output_path, exist_ok=True)
+    options.save_options_file(args)
+    args.data.root = os.path.join(args.data.root, args.data.case)
+    args.bbox_min = np.array(args.bbox_min)
+    args.bust_to_origin = np.array(args.bust_to_origin)
+    for key in ("strands_path", "bust_path", "raw_points_path", "depth_path", "Ori2D_path", "Conf_path", "mask_path"):
+        args.data[key] = os.path.join(args.data.root, args.data[key])
+    args.image_camera_path = os.path.join(args.data.root, args.image_camera_path)
+    args.save_root = os.path.join(args.output_path, "optimize")
+    if args.PMVO.infer_inner and not args.PMVO.optimize:
+        args.save_path = os.path.join(args.output_path, "full")
+    else:
+        args.save_path = os.path.join(args.output_path, "refine")
+    os.makedirs(args.save_path, exist_ok=True)
+    return args
+
+
+def main(argv=None):
+    from scipy.spatial import KDTree
+
+    from monohair_amd import dist as mdist
+
+    print("Run PMVO...")
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        import torch
+        import torch.distributed as tdist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
+    args = config_parser(argv)
+
+    vertices, faces, normals = load_bust(args.data.bust_path)
+    vertices += args.bust_to_origin
+    bust_tree = KDTree(data=vertices)
+    scalp_vertices, _ = read_obj(os.path.join(args.data.root, "ours/scalp_tsfm.obj"))
+    scalp_vertices += args.bust_to_origin
+    scalp_tree = KDTree(data=scalp_vertices)
+    scalp_max = np.max(scalp_vertices, axis=0)
+
+    camera = parsing_camera(load_cam(args.image_camera_path), os.path.join(args.data.root, "capture_images"))
+    print("num of view:", len(camera))
+    depths = load_depth(camera, args.data.depth_path)
+    Ori, Conf = Load_Ori_And_Conf(camera, args.data.Ori2D_path, args.data.Conf_path)
+    masks = load_mask(camera, args.data.mask_path)
+
+    pmvo = PMVO(camera, depths, Ori, Conf, masks, device=args.device, image_size=args.data.image_size,
+                patch_size=args.PMVO.patch_size, visible_threshold=args.PMVO.visible_threshold,
+                conf_threshold=args.PMVO.conf_threshold)
+    pmvo.set_head(bust_tree, scalp_tree, scalp_max)
+    del depths, Ori, Conf, masks
+
+    if args.PMVO.optimize:
+        print("load raw mesh...")
+        points = load_colmap_points(args.data.raw_points_path, args.bbox_min, args.bust_to_origin, 0.005 / 4,
+                                    [512, 512, 384], True, args.PMVO.num_sample_per_grid)
+        raw_points = points.copy()
+        print("total points:", points.shape[0])
+        print("filter low conf points...")
+        if args.PMVO.filter_point:
+            surface_index, surface_points, filter_index = filter_negative_points(points, pmvo, args)
+            points = surface_points
+            if mdist.rank() == 0:
+                os.makedirs(args.save_root, exist_ok=True)
+                np.save(os.path.join(args.save_root, "surface.npy"), raw_points[:len(surface_index)][surface_index])
+                np.save(os.path.join(args.save_root, "filter_unvisible.npy"),
+                        raw_points[:len(filter_index)][filter_index])
+            mdist.barrier()
+        print("process points:", points.shape[0])
+        optimize(points, pmvo, args)
+        select_points = np.load(args.save_root + "/select_p.npy")
+        select_ori = np.load(args.save_root + "/select_o.npy")
+        min_loss = np.load(args.save_root + "/min_loss.npy")
+        filter_unvisible_points = np.load(args.save_root + "/filter_unvisible.npy")
+        refine(select_points, select_ori, min_loss, pmvo, filter_unvisible_points, args, infer_inner=False,
+               threshold=args.PMVO.threshold, genrate_ori_only=False)
+    else:
+        select_points = np.load(args.save_root + "/select_p.npy")
+        select_ori = np.load(args.save_root + "/select_o.npy")
+        min_loss = np.load(args.save_root + "/min_loss.npy")
+        filter_unvisible_points = np.load(args.save_root + "/filter_unvisible.npy")
+        refine(select_points, select_ori, min_loss, pmvo, filter_unvisible_points, args,
+               infer_inner=args.PMVO.infer_inner, threshold=args.PMVO.threshold, genrate_ori_only=True)
+
+
+if __name__ == "__main__":
+    main()

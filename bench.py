@@ -112,29 +112,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # --- per-kernel durations of the same steps (HIP events on the launch stream), outside the timed region
-    ev = lambda: torch.cuda.Event(enable_timing=True)  # noqa: E731
-    t_pg = t_tk = t_sr = 0.0
-    nvis = 0.0
-    reps = max(3, min(a.steps, 10))
+    # --- per-kernel durations on the same chunks, outside the timed region: HIP events on the launch stream,
+    # REP back-to-back launches per measurement so that launch gaps do not count as kernel time
+    def timed(fn, rep):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(rep):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / rep
+
+    t_pg = t_tk = t_sr = nvis = 0.0
+    reps = max(2, min(len(dev_chunks), 6))
     for i in range(reps):
         c = dev_chunks[i % len(dev_chunks)]
-        e = [ev() for _ in range(4)]
-        e[0].record()
-        pm.Compute_Visible_and_Ori(c)
-        e[1].record()
-        bidx, bval = pm.Find_max_conf_from_visible_view()
-        e[2].record()
-        torch.cuda.synchronize()
+        t_pg += timed(lambda: pm.Compute_Visible_and_Ori(c), 10)
+        t_tk += timed(lambda: pm.Find_max_conf_from_visible_view(), 10)
         nvis += float((pm.visible != -1).float().mean().item())
-        e2 = [ev(), ev()]
-        e2[0].record()
-        pm.forward(c)
-        e2[1].record()
-        torch.cuda.synchronize()
-        t_pg += e[0].elapsed_time(e[1])
-        t_tk += e[1].elapsed_time(e[2])
-        t_sr += e2[0].elapsed_time(e2[1])
+        t_sr += timed(lambda: pm.forward(c), 5)
     t_pg, t_tk, t_sr, nvis = t_pg / reps, t_tk / reps, t_sr / reps, nvis / reps
     t_search = max(t_sr - t_pg - t_tk, 1e-6)
 

@@ -1,0 +1,106 @@
+"""Multi-GPU plumbing of the PMVO path: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+The path shards by POINTS, not by views: a point's result needs every view but no other point, every GPU
+holds all packed views (2.5 GB at 60 x 1080p, nothing against 288 GB), so an iteration has no collective at
+all and results are bit-identical to the single-GPU run.  Exactly two kinds of exchange exist:
+  * map_chunks: independent chunks dealt round-robin, one all_gather of the per-chunk results at the end;
+  * voxel_fit_reduced: every rank fits a disjoint set of voxels and writes them into a zero volume; ONE
+    reduce(SUM) over xGMI assembles the shared 3D orientation/occupancy volume on rank 0 (x + 0 is exact,
+    so the reduced volume equals the single-GPU one bit for bit).
+"""
+import numpy as np
+import torch
+
+
+def _dist():
+    import torch.distributed as dist
+
+    return dist if (dist.is_available() and dist.is_initialized()) else None
+
+
+def rank():
+    d = _dist()
+    return d.get_rank() if d else 0
+
+
+def world():
+    d = _dist()
+    return d.get_world_size() if d else 1
+
+
+def barrier():
+    d = _dist()
+    if d:
+        d.barrier()
+
+
+def owner(i, n_ranks=None):
+    """rank that processes chunk i"""
+    return i % (world() if n_ranks is None else n_ranks)
+
+
+def map_chunks(chunks, fn, device, empty):
+    """Apply fn to every chunk (each rank takes chunks i with i % world == rank) and return the list of all
+    results in chunk order on every rank.  fn returns a 2-D tensor on `device`; `empty()` gives a [0,C] one."""
+    d = _dist()
+    w, r = world(), rank()
+    mine = {i: fn(c) if len(c) else empty() for i, c in enumerate(chunks) if owner(i, w) == r}
+    if not d:
+        return [mine[i] for i in range(len(chunks))]
+    # one all_gather of padded per-rank buffers (sizes are known on every rank: they are the chunk lengths)
+    lens = [len(c) for c in chunks]
+    cols = empty().shape[1]
+    dt = empty().dtype
+    per_rank = [sum(lens[i] for i in range(len(chunks)) if owner(i, w) == k) for k in range(w)]
+    cap = max(per_rank) if per_rank else 0
+    buf = torch.zeros((max(cap, 1), cols), dtype=dt, device=device)
+    if mine:
+        cat = torch.cat([mine[i] for i in sorted(mine)], 0)
+        buf[:cat.shape[0]] = cat
+    gathered = [torch.empty_like(buf) for _ in range(w)]
+    d.all_gather(gathered, buf)
+    out, cursor = [None] * len(chunks), [0] * w
+    for i in range(len(chunks)):
+        k = owner(i, w)
+        out[i] = gathered[k][cursor[k]:cursor[k] + lens[i]]
+        cursor[k] += lens[i]
+    return out
+
+
+def voxel_owner_mask(x, n_ranks, r, grid_x):
+    """Spatial partition of the volume into n_ranks slabs along x: rank r owns x in [r*G/n, (r+1)*G/n)."""
+    lo = (grid_x * r) // n_ranks
+    hi = (grid_x * (r + 1)) // n_ranks
+    return (x >= lo) & (x < hi)
+
+
+def voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size, grid_resolution, fit=None):
+    """Voxel fit with disjoint voxel ownership + the single reduce.  Returns dense (occ [X,Y,Z], ori [X,Y,Z,3])
+    float64 numpy arrays on rank 0 (zeros elsewhere)."""
+    from . import pmvo_utils as U
+
+    fit = U.voxel_fit if fit is None else fit
+    g = np.asarray(grid_resolution).astype(np.int64)
+    d = _dist()
+    w, r = world(), rank()
+    # sign canonicalisation and p2v mutate their inputs in the reference; do it once, here, on copies
+    pts = np.array(select_points, copy=True)
+    ori = np.array(select_ori, copy=True)
+    if not d:
+        res = fit(pts, ori, device, voxel_min, voxel_size, g, dense=True)
+        return res["occ"], res["ori_dense"]
+    probe = pts.copy()
+    x, _, _ = U.p2v(probe, np.asarray(voxel_min), voxel_size, g)
+    own = voxel_owner_mask(x, w, r, int(g[0]))
+    vol = torch.zeros((int(g[0]), int(g[1]), int(g[2]), 4), dtype=torch.float32, device=device)
+    if own.any():
+        res = fit(pts[own], ori[own], device, voxel_min, voxel_size, g, dense=False)
+        v = res["voxels"].to(device)
+        vol[v[:, 0], v[:, 1], v[:, 2], 0] = 1.0
+        vol[v[:, 0], v[:, 1], v[:, 2], 1:] = res["ori"].to(device)
+    d.reduce(vol, dst=0, op=d.ReduceOp.SUM)          # the one collective of the data path
+    if r != 0:
+        return np.zeros(tuple(g)), np.zeros(tuple(g) + (3,))
+    vol = vol.cpu().numpy()
+    return vol[..., 0].astype(np.float64), vol[..., 1:].astype(np.float64)

@@ -1,0 +1,150 @@
+"""Per-view Gabor orientation / confidence maps -- the host-side mirror of the reference's
+`preprocess_capture_data/GaborFilter.py` (calOrientationGabor :16-145, calculate_orientation :164-224,
+batch_generate :231-237) on top of the HIP kernel mh_gabor_bank (monohair_amd/csrc/gabor.hip).
+
+The 180 kernels are built on the host with the same CPU torch ops as gabor_fn (so the bank is the reference's
+bits) and installed once with mh_gabor_set_bank; the 1.49 GB response stack of the reference never exists.
+File IO uses PIL; the difference-of-Gaussians prefilter is scikit-image's documented definition evaluated with
+scipy.ndimage (third-party arithmetic, unpinned -- SURVEY.md §8c)."""
+import ctypes
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .pmvo_utils import _ctx_for
+
+NUM_KERNELS = 180
+KSIZE = 17
+
+
+def gabor_fn(kernel_size, theta, sigma_x=1.8, sigma_y=2.4, Lambda=4.0, phase=0.0):
+    """One real Gabor kernel [k,k] (GaborFilter.py:115-145): taps x,y in {-8.5..7.5} (x <-> row offset),
+    x_t = x cos t + y sin t, y_t = -x sin t + y cos t, exp(-.5 (x_t^2/sx^2 + y_t^2/sy^2)) cos(2 pi x_t / L + psi);
+    float32 CPU torch ops in the reference's order."""
+    half = kernel_size // 2
+    t = torch.ones(1) * theta
+    sx, sy = torch.ones(1) * sigma_x, torch.ones(1) * sigma_y
+    lam, psi = torch.ones(1) * Lambda, torch.ones(1) * phase
+    r = torch.arange(-half, half + 1).float() - 0.5
+    x = r.view(-1, 1).repeat(1, kernel_size)
+    y = r.view(1, -1).repeat(kernel_size, 1)
+    x_t = x * torch.cos(t) + y * torch.sin(t)
+    y_t = -x * torch.sin(t) + y * torch.cos(t)
+    return torch.exp(-.5 * (x_t ** 2 / sx ** 2 + y_t ** 2 / sy ** 2)) * torch.cos(2 * math.pi * x_t / lam + psi)
+
+
+_BANK = None
+
+
+def gabor_bank():
+    """[180,17,17] float32: theta_k = pi*k/180 (GaborFilter.py:32-34)."""
+    global _BANK
+    if _BANK is None:
+        _BANK = torch.stack([gabor_fn(KSIZE, math.pi * k / NUM_KERNELS) for k in range(NUM_KERNELS)]).numpy()
+    return _BANK
+
+
+def orientation_table():
+    """theta_k as fp32 exactly as the reference forms best_orientTensor (index * pi / 180, GaborFilter.py:51)."""
+    return (torch.arange(NUM_KERNELS).float() * math.pi / NUM_KERNELS)
+
+
+class calOrientationGabor:
+    def __init__(self, channel_in=1, channel_out=1, stride=1, device=None):
+        self.numKernels = NUM_KERNELS
+        self.clamp_confidence_low = 0.0
+        self.clamp_confidence_high = 0.2
+        if not torch.cuda.is_available():
+            raise _lib.MhError("calOrientationGabor needs a ROCm GPU (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._ctx = _ctx_for(self.device)
+        bank = np.ascontiguousarray(gabor_bank().reshape(NUM_KERNELS, KSIZE * KSIZE), dtype=np.float32)
+        _lib.check(_lib.lib().mh_gabor_set_bank(self._ctx, bank.ctypes.data_as(ctypes.c_void_p)), "mh_gabor_set_bank")
+        th = orientation_table()
+        self._theta = th.to(self.device)
+        self._sin = torch.sin(th).to(self.device)      # CPU transcendental values, gathered on the device
+        self._cos = torch.cos(th).to(self.device)
+
+    def cuda(self):
+        return self
+
+    def filter_index(self, image):
+        """image [H,W] float32 device tensor -> (orient index int32 [H,W], conf [H,W], variance [H,W])."""
+        image = image.to(self.device).type(torch.float).contiguous()
+        H, W = image.shape
+        idx = torch.empty((H, W), dtype=torch.int32, device=self.device)
+        conf = torch.empty((H, W), dtype=torch.float32, device=self.device)
+        var = torch.empty((H, W), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mh_gabor_bank(self._ctx, _lib.ptr(image), H, W, _lib.ptr(idx), _lib.ptr(conf),
+                                                _lib.ptr(var), _lib.stream_ptr()), "mh_gabor_bank")
+        return idx, conf, var
+
+    def forward(self, image, label=None, iter=1, threshold=0.0):
+        """GaborFilter.py:98-113.  image [1,1,H,W] -> (orientTwoChannel [1,2,H,W] = (sin,cos),
+        best_orient [1,1,H,W] radians, confidence [1,1,H,W]).  `label` is unused, as in the reference."""
+        if iter != 1:
+            raise NotImplementedError("the pipeline calls the Gabor bank with iter=1 only (GaborFilter.py:236)")
+        idx, conf, _ = self.filter_index(image[0, 0])
+        li = idx.long()
+        conf = torch.where(conf < threshold, torch.zeros_like(conf), conf)
+        best = self._theta[li]
+        two = torch.stack([self._sin[li], self._cos[li]], 0)[None]
+        return two, best[None, None], conf[None, None]
+
+    __call__ = forward
+
+
+def difference_of_gaussians(image, low_sigma, high_sigma):
+    """skimage.filters.difference_of_gaussians (scikit-image 0.23, the reference's pin): float image,
+    gaussian(low) - gaussian(high), mode='nearest', truncate=4.0."""
+    from scipy import ndimage as ndi
+
+    img = image.astype(np.float64) / 255.0 if image.dtype == np.uint8 else image.astype(np.float64)
+    lo = ndi.gaussian_filter(img, low_sigma, mode="nearest", truncate=4.0)
+    hi = ndi.gaussian_filter(img, high_sigma, mode="nearest", truncate=4.0)
+    return lo - hi
+
+
+def calculate_orientation(image_dir, label_dir, save_root, filename=None, iter=1, threshold=0.0, gabor=None):
+    """GaborFilter.py:164-224: gray image -> DoG -> Gabor bank -> best_ori/<file> (uint8 degrees),
+    conf/<file> (uint8, x255+0.5, 3 channels), Ori/<file> (colour visualisation)."""
+    from PIL import Image
+
+    paths = {}
+    for sub in ("Ori", "conf", "best_ori"):
+        os.makedirs(os.path.join(save_root, sub), exist_ok=True)
+        paths[sub] = os.path.join(save_root, sub, filename)
+    gabor = gabor or calOrientationGabor()
+    image = np.array(Image.open(image_dir).convert("L"))
+    image = difference_of_gaussians(image, 0.4, 10)
+    gray = torch.from_numpy(image).type(torch.float)[None, None]
+    two, best, confidence = gabor(gray, None, iter, threshold=threshold)
+    kw = dict(quality=100) if filename.lower().endswith((".jpg", ".jpeg")) else {}
+    deg = torch.round(best[0, 0] / math.pi * 180).clamp(0, 255).to(torch.uint8).cpu().numpy()
+    Image.fromarray(deg).save(paths["best_ori"], **kw)
+    c8 = (confidence[0, 0] * 255 + 0.5).clamp(0, 255).to(torch.uint8).cpu().numpy()
+    Image.fromarray(np.repeat(c8[..., None], 3, axis=2)).save(paths["conf"])
+    ori = ((two[0].permute(1, 2, 0) + 1) / 2).cpu().numpy()
+    H, W = ori.shape[:2]
+    viz = np.concatenate([np.ones((H, W, 1)), ori], axis=2) * 255          # RGB = (1, sin, cos) as cv2 BGR[::-1]
+    Image.fromarray(np.clip(np.round(viz), 0, 255).astype(np.uint8)).save(paths["Ori"], **kw)
+    return deg, c8
+
+
+def batch_generate(root, image_folder):
+    """GaborFilter.py:231-237.  With torch.distributed initialised the views are dealt to the ranks (the global
+    maximum in the confidence is per image, so views are independent)."""
+    from . import dist as mdist
+
+    files = sorted(os.listdir(os.path.join(root, image_folder)))
+    gabor = calOrientationGabor()
+    for i, file in enumerate(files):
+        if mdist.owner(i) != mdist.rank():
+            continue
+        calculate_orientation(os.path.join(root, image_folder, file), os.path.join(root, "hair_mask", file),
+                              save_root=root, filename=file, iter=1, threshold=0.0, gabor=gabor)
+    mdist.barrier()

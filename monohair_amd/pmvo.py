@@ -254,3 +254,174 @@ class PMVO:
         head_top = np.logical_and(nei_scalp_dist < 0.04, points_numpy[:, 2] < self.scalp_max[2] - 0.01)
         head_top = torch.from_numpy(head_top).to(self.device)
         return torch.logical_and(head, ~head_top)
+
+
+# =====================================================================================================
+# Drivers -- mirrors of the module-level functions of the reference's PMVO.py (:535-764).  Chunking, file
+# names and dtypes are the reference's (they are its checkpoint/resume mechanism); with torch.distributed
+# initialised the independent chunks are dealt round-robin to the ranks (monohair_amd.dist).
+# =====================================================================================================
+def filter_negative_points(points, pmvo, args, step=30):
+    """PMVO.py:535-557: surface / shell classification of the raw candidates, in N//30-sized pieces."""
+    from . import dist as mdist
+
+    if points.shape[0] % step != 0:
+        step = step + 1
+    num_sub_p = points.shape[0] // 30
+    pieces = [points[i * num_sub_p:(i + 1) * num_sub_p] for i in range(step)]
+
+    def work(sub):
+        s, _, f = pmvo.filter_points(torch.from_numpy(sub).to(pmvo.device).type(torch.float))
+        return torch.stack([s, f], 1).to(torch.uint8)
+
+    flags = mdist.map_chunks(pieces, work, pmvo.device, empty=lambda: torch.empty((0, 2), dtype=torch.uint8,
+                                                                               device=pmvo.device))
+    flags = torch.cat(flags, 0).cpu().numpy().astype(bool)
+    surface_indexs, filter_indexs = flags[:, 0], flags[:, 1]
+    covered = points[:flags.shape[0]]
+    surface_points = covered[surface_indexs].astype(np.float32)   # the reference returns the fp32 copies
+    print("surface_num:", surface_points.shape[:])
+    print("num filter_unvisible:", np.sum(filter_indexs))
+    return surface_indexs, surface_points, filter_indexs
+
+
+def optimize(points, pmvo, args):
+    """PMVO.py:565-595: forward() over chunks of 5000 points, results to optimize/*.npy."""
+    from . import dist as mdist
+
+    num_sub_p = 5000
+    step = points.shape[0] // num_sub_p + 1
+    chunks = [points[i * num_sub_p:(i + 1) * num_sub_p] for i in range(step)]
+
+    def work(sub):
+        p, o, l, h = pmvo.forward(sub)
+        return torch.cat([p, o, l[:, None], h[:, None].to(torch.float32)], 1)
+
+    res = mdist.map_chunks(chunks, work, pmvo.device,
+                           empty=lambda: torch.empty((0, 8), dtype=torch.float32, device=pmvo.device))
+    res = torch.cat(res, 0).cpu().numpy()
+    select_points, select_ori, min_loss = res[:, 0:3], res[:, 3:6], res[:, 6]
+    high_conf_index = res[:, 7] > 0.5
+    if mdist.rank() == 0:
+        os.makedirs(args.save_root, exist_ok=True)
+        np.save(args.save_root + "/select_p.npy", np.ascontiguousarray(select_points))
+        np.save(args.save_root + "/select_o.npy", np.ascontiguousarray(select_ori))
+        np.save(args.save_root + "/min_loss.npy", np.ascontiguousarray(min_loss))
+        np.save(args.save_root + "/high_conf_index.npy", high_conf_index)
+    mdist.barrier()
+    return select_points, select_ori, min_loss, high_conf_index
+
+
+def _knn(tree, sub_points, k, n_total):
+    # scipy returns index n for missing neighbours when k > n (the reference would raise on ori[index]);
+    # tiny inputs only: clamp k.
+    k = min(k, n_total)
+    _, index = tree.query(sub_points, k)
+    return index.reshape(len(sub_points), k)
+
+
+def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=True, threshold=0.001,
+           genrate_ori_only=False, voxel_min=None, voxel_size=None, grid_resolution=None):
+    """PMVO.py:602-764: KNN-medoid smoothing (sequentially dependent 5000-point chunks, in place), threshold,
+    orientations for the occluded shell points, voxel fit, Ori3D.mat / Occ3D.mat.
+    voxel_min/voxel_size/grid_resolution default to the reference's hard-coded 256x256x192 @ 2.5 mm grid."""
+    from scipy.spatial import KDTree
+
+    from . import dist as mdist
+    from . import pmvo_utils as U
+
+    device = pmvo.device
+    voxel_min = U.VOXEL_MIN if voxel_min is None else np.asarray(voxel_min, dtype=np.float64)
+    voxel_size = U.VOXEL_SIZE if voxel_size is None else voxel_size
+    grid_resolution = U.GRID_RESOLUTION if grid_resolution is None else np.asarray(grid_resolution).astype(np.int32)
+    is_root = mdist.rank() == 0
+    if not genrate_ori_only:
+        print("filter nosiy points...")
+        points_tree = KDTree(data=points)
+        sub_num = 5000
+        step = points.shape[0] // sub_num + 1
+        for i in range(step):
+            lo, hi = i * sub_num, min((i + 1) * sub_num, points.shape[0])
+            if hi <= lo:
+                continue
+            sub_points, sub_ori = points[lo:hi], ori[lo:hi]
+            index = _knn(points_tree, sub_points, 100, points.shape[0])
+            Neighbor_ori = torch.from_numpy(ori[index]).to(device)
+            center_ori = U.compute_points_similarity(Neighbor_ori)
+            update_loss = pmvo.refine(torch.from_numpy(sub_points).to(device), center_ori)
+            # replace where |cos(center, ori)| < 0.95 (PMVO.py:631-636): evaluated with the CPU torch ops the
+            # reference's CPU path uses
+            c_cpu, s_cpu = center_ori.cpu(), torch.from_numpy(sub_ori)
+            similar = torch.maximum(torch.cosine_similarity(c_cpu, s_cpu, dim=-1),
+                                    torch.cosine_similarity(c_cpu, -s_cpu, dim=-1))
+            rep = torch.lt(similar, 0.95)
+            s_cpu[rep] = c_cpu[rep]
+            sub_loss = update_loss.cpu()
+            sub_loss[sub_loss == -1] = 0.5
+            ori[lo:hi] = s_cpu.numpy()
+            loss[lo:hi] = sub_loss.numpy()
+        if is_root:
+            os.makedirs(args.output_path + "/refine", exist_ok=True)
+            np.save(args.output_path + "/refine/select_p.npy", points)
+            np.save(args.output_path + "/refine/select_o.npy", ori)
+            np.save(args.output_path + "/refine/min_loss.npy", loss)
+        mdist.barrier()
+
+    points = np.load(args.output_path + "/refine/select_p.npy")
+    ori = np.load(args.output_path + "/refine/select_o.npy")
+    min_loss = np.load(args.output_path + "/refine/min_loss.npy")
+    index = np.where(min_loss < threshold)[0]
+    select_ori = ori[index]
+    select_points = points[index]
+    points_tree = KDTree(data=select_points)
+
+    # orientation of the occluded shell points from their 100 nearest kept neighbours (PMVO.py:662-686)
+    sub_num = 5000
+    step = filter_unvisible_points.shape[0] // sub_num + 1
+    f_ori, f_pts = [], []
+    print("compute points orientation near the surface... ")
+    for i in range(step):
+        sub = filter_unvisible_points[i * sub_num:min((i + 1) * sub_num, filter_unvisible_points.shape[0])]
+        if len(sub) == 0 or len(select_points) == 0:
+            continue
+        index = _knn(points_tree, sub, 100, select_points.shape[0])
+        sub_dev = torch.from_numpy(sub).type(torch.float).to(device)
+        filter_index = pmvo.filter_head_points(sub_dev, args.PMVO.visible_threshold)
+        center_ori = U.compute_points_similarity(torch.from_numpy(select_ori[index]).to(device))
+        f_ori.append(center_ori[~filter_index])
+        f_pts.append(sub_dev[~filter_index])
+    if f_ori:
+        filter_unvisible_ori = torch.cat(f_ori, 0).cpu().numpy()
+        select_filter_unvisible_points = torch.cat(f_pts, 0).cpu().numpy()
+    else:
+        filter_unvisible_ori = np.zeros((0, 3), np.float32)
+        select_filter_unvisible_points = np.zeros((0, 3), np.float32)
+    if is_root:
+        np.save(args.output_path + "/refine/filter_unvisible.npy", select_filter_unvisible_points)
+        np.save(args.output_path + "/refine/filter_unvisible_ori.npy", filter_unvisible_ori)
+
+    select_ori = np.concatenate([select_ori, filter_unvisible_ori], 0)
+    select_points = np.concatenate([select_points, select_filter_unvisible_points], 0)
+
+    # voxel fit (PMVO.py:695-726): every rank fits a disjoint slab of voxels; one reduce assembles the volume
+    occ, ori_vol = mdist.voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size, grid_resolution)
+
+    if is_root:
+        if infer_inner:
+            # merge the network's orientation for points seen in <= 2 views (PMVO.py:733-751)
+            coarse_data = np.load(args.data.root + "/ours/raw.npy")
+            cpoints = coarse_data[:, :3].astype(np.float32)
+            coarse_ori = coarse_data[:, 3:6].astype(np.float32)
+            up_index = coarse_ori[:, 1] > 0
+            coarse_ori[up_index] *= -1
+            unvisible_index = pmvo.compute_unvisible_points(torch.from_numpy(cpoints).to(device)).cpu().numpy()
+            un_visible_points = cpoints[unvisible_index]
+            unvisible_ori = coarse_ori[unvisible_index]
+            x, y, z = U.p2v(un_visible_points.copy(), voxel_min, voxel_size, grid_resolution)
+            occ[x, y, z] = 1
+            ori_vol[x, y, z] = unvisible_ori
+            np.save(os.path.join(args.save_path, "coarse.npy"), un_visible_points)
+            np.save(os.path.join(args.save_path, "coarse_ori.npy"), unvisible_ori)
+        U.save_ori_occ_mat(args.save_path, occ, ori_vol)
+    mdist.barrier()
+    return occ, ori_vol

@@ -1,0 +1,306 @@
+"""Host-side helpers of the PMVO path -- the mirror of the parts of the reference's `Utils/PMVO_utils.py`
+that PMVO.py uses: loaders (:255-362), compute_points_similarity (:366-382), p2v (:386-404), voxel<->world
+(:407-421), .mat readers (:86-113) and .hair IO (:47-83, :662-680).
+
+Arithmetic that matters runs in HIP kernels (medoid consensus) or is a two-line numpy formula restated from
+the reference; image decoding uses PIL (OpenCV is not a dependency here), meshes are read with a small OBJ
+reader.  Names and argument order follow the reference so that PMVO.py reads the same.
+"""
+import math
+import os
+import struct
+
+import numpy as np
+import scipy.io
+import torch
+
+from . import _lib
+
+VOXEL_MIN = np.array([-0.32, -0.32, -0.24])
+VOXEL_SIZE = 0.005 / 2
+GRID_RESOLUTION = np.array([256, 256, 192]).astype(np.int32)
+
+
+# ----------------------------------------------------------------------------------------- images / maps
+def _imread_gray(path):
+    from PIL import Image
+
+    return np.array(Image.open(path).convert("L"))
+
+
+def _imread_bgr(path):
+    from PIL import Image
+
+    return np.array(Image.open(path).convert("RGB"))[..., ::-1].copy()
+
+
+def _find(path_dir, view, suffixes=(".png", ".JPG", ".jpg", ".jpeg", ".PNG")):
+    for s in suffixes:
+        p = os.path.join(path_dir, view + s)
+        if os.path.exists(p):
+            return p
+    raise FileNotFoundError("no image for view %r under %s" % (view, path_dir))
+
+
+def Load_Ori_And_Conf(camera, Ori_path, Conf_path):
+    """best_ori/<view>: gray u8 = orientation in degrees -> theta' = (180-pix)/180*pi -> (sin, cos) float64;
+    conf/<view>: gray u8 / 255 (PMVO_utils.py:255-276).  The reference's suffix sniffing (:258-264) only works
+    on case-insensitive file systems for .JPG data; we look for .png, .JPG, .jpg in that order."""
+    Ori, Conf = {}, {}
+    for view, _ in camera.items():
+        o = _imread_gray(_find(Ori_path, view)).astype(np.float64)
+        o = (180 - o) / 180 * math.pi
+        Ori[view] = np.stack([np.sin(o), np.cos(o)], -1)
+        Conf[view] = _imread_gray(_find(Conf_path, view)) / 255.0
+    return Ori, Conf
+
+
+def load_depth(camera, path, type="npy"):
+    """render_depth/<view>.npy, float32 [H,W,3] (value = -z_cam/2*255, background 255) (PMVO_utils.py:278-295)."""
+    return {view: np.load(os.path.join(path, view + ".npy")).astype(np.float32) for view, _ in camera.items()}
+
+
+def load_mask(camera, path):
+    """hair_mask/<view>: BGR u8, values < 50 zeroed, /255 (PMVO_utils.py:297-313)."""
+    masks = {}
+    for view, _ in camera.items():
+        mask = _imread_bgr(_find(path, view))
+        mask[mask < 50] = 0
+        masks[view] = mask / 255.0
+    return masks
+
+
+# ----------------------------------------------------------------------------------------- meshes / points
+def read_obj(path):
+    """Minimal Wavefront OBJ reader: (vertices [N,3] f64, faces [M,3] int) -- triangles / fan-triangulated polys."""
+    vs, fs = [], []
+    with open(path, "r") as f:
+        for line in f:
+            if line.startswith("v "):
+                p = line.split()
+                vs.append([float(p[1]), float(p[2]), float(p[3])])
+            elif line.startswith("f "):
+                idx = [int(t.split("/")[0]) for t in line.split()[1:]]
+                idx = [i - 1 if i > 0 else len(vs) + i for i in idx]
+                for k in range(1, len(idx) - 1):
+                    fs.append([idx[0], idx[k], idx[k + 1]])
+    return np.asarray(vs, dtype=np.float64).reshape(-1, 3), np.asarray(fs, dtype=np.int64).reshape(-1, 3)
+
+
+def vertex_normals(vertices, faces):
+    n = np.zeros_like(vertices)
+    if len(faces):
+        fn = np.cross(vertices[faces[:, 1]] - vertices[faces[:, 0]], vertices[faces[:, 2]] - vertices[faces[:, 0]])
+        for k in range(3):
+            np.add.at(n, faces[:, k], fn)
+    ln = np.linalg.norm(n, axis=1, keepdims=True)
+    return n / np.maximum(ln, 1e-12)
+
+
+def load_bust(path):
+    """(vertices, faces, normals) of the bust mesh (PMVO_utils.py:176-181)."""
+    v, f = read_obj(path)
+    return v, f, vertex_normals(v, f)
+
+
+def sample_points_uniformly(vertices, faces, number_of_points, rng=None):
+    """Area-weighted uniform surface sampling (what open3d's sample_points_uniformly does at PMVO_utils.py:346;
+    its RNG is not controlled by the reference's seed either, so this step is unpinned by construction)."""
+    rng = np.random.default_rng(0) if rng is None else rng
+    if len(faces) == 0:
+        return vertices[rng.integers(0, len(vertices), number_of_points)]
+    a, b, c = vertices[faces[:, 0]], vertices[faces[:, 1]], vertices[faces[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    tri = rng.choice(len(faces), size=number_of_points, p=area / area.sum())
+    r1 = np.sqrt(rng.random(number_of_points))[:, None]
+    r2 = rng.random(number_of_points)[:, None]
+    return (1 - r1) * a[tri] + r1 * (1 - r2) * b[tri] + r1 * r2 * c[tri]
+
+
+def SamplePointsAroundmesh(colmap_points, bbox_min, vsize, num_per_grid=32, grid_resolution=[512, 512, 384]):
+    """PMVO_utils.py:316-339: occupied voxels of the point set (y,z flipped), num_per_grid uniform jitters each
+    (np.random, seeded by options.process_options like the reference), flipped back."""
+    g = np.asarray(grid_resolution)
+    colmap_points = colmap_points.copy()
+    colmap_points[:, 1:] *= -1
+    idx = np.round((colmap_points - bbox_min) / vsize).astype(np.int32)
+    idx = np.clip(idx, 0, g - 1)
+    occ = np.zeros(tuple(g), dtype=bool)
+    occ[idx[:, 0], idx[:, 1], idx[:, 2]] = True
+    x, y, z = np.nonzero(occ)
+    indices = np.stack([x, y, z], 1)
+    base = np.concatenate([indices] * num_per_grid, 0)
+    sample = (base + np.random.random(base.shape)) * vsize + bbox_min
+    sample[:, 1:] *= -1
+    return sample
+
+
+def load_colmap_points(path, bbox_min, bust_to_origin, vsize=0.005, grid_resolution=[128, 128, 96], sample=True,
+                       num_per_grid=8):
+    """PMVO_utils.py:341-362."""
+    v, f = read_obj(path)
+    print("num_p:", v.shape[0])
+    pts = sample_points_uniformly(v, f, v.shape[0] * 5)
+    pts = pts + bust_to_origin
+    if sample:
+        out = SamplePointsAroundmesh(pts.copy(), np.asarray(bbox_min), vsize, num_per_grid=num_per_grid,
+                                     grid_resolution=grid_resolution)
+        print("num sample:", out.shape[:])
+        return out
+    return pts
+
+
+# ----------------------------------------------------------------------------------------- consensus (HIP)
+def _ctx_for(device):
+    """A bare library context for kernels that need no views (medoid, Gabor)."""
+    import ctypes
+
+    key = str(device)
+    if key not in _ctx_for.cache:
+        h = ctypes.c_void_p()
+        idx = torch.device(device).index or 0
+        _lib.check(_lib.lib().mh_ctx_create(idx, ctypes.byref(h)), "mh_ctx_create")
+        _ctx_for.cache[key] = h
+    return _ctx_for.cache[key]
+
+
+_ctx_for.cache = {}
+
+
+def compute_points_similarity(ori, return_index=False):
+    """PMVO_utils.py:366-382: ori [N,K,3] device tensor -> medoid orientation [N,3] (HIP kernel mh_medoid_dense)."""
+    if not ori.is_cuda:
+        raise _lib.MhError("compute_points_similarity runs on the GPU only (no CPU fallback)")
+    ori = ori.type(torch.float).contiguous()
+    N, K, _ = ori.shape
+    out = torch.empty((N, 3), dtype=torch.float32, device=ori.device)
+    idx = torch.empty((N,), dtype=torch.int32, device=ori.device)
+    with torch.cuda.device(ori.device):
+        _lib.check(_lib.lib().mh_medoid_dense(_ctx_for(ori.device), _lib.ptr(ori), N, K, _lib.ptr(out), _lib.ptr(idx),
+                                              _lib.stream_ptr()), "mh_medoid_dense")
+    return (out, idx) if return_index else out
+
+
+def p2v(points, voxel_min, voxel_size, grid_resolution):
+    """PMVO_utils.py:386-404: flips y,z IN PLACE (mutates the caller's array, like the reference), float64
+    round-half-even, clip.  Returns (x, y, z) int32 arrays."""
+    points[:, 1:] *= -1
+    idx = np.round((points - voxel_min) / voxel_size).astype(np.int32)
+    g = np.asarray(grid_resolution)
+    x = np.clip(idx[:, 0], 0, g[0] - 1)
+    y = np.clip(idx[:, 1], 0, g[1] - 1)
+    z = np.clip(idx[:, 2], 0, g[2] - 1)
+    return x, y, z
+
+
+def voxel_fit(select_points, select_ori, device, voxel_min=VOXEL_MIN, voxel_size=VOXEL_SIZE,
+              grid_resolution=GRID_RESOLUTION, dense=True):
+    """The volume fit of refine (PMVO.py:695-726) on the GPU: sign canonicalisation (ori.y > 0 -> negate),
+    p2v in float64, stable sort by voxel key (point order inside a voxel is preserved, which is what the
+    reference's dict of lists does), one segmented-medoid launch for all voxels.
+
+    Returns dict(voxels [G,3] int64 (x,y,z), ori [G,3] f32) and, with dense=True, occ [X,Y,Z] / ori [X,Y,Z,3]
+    float64 numpy arrays as the reference builds them.  Mutates select_points / select_ori like the reference."""
+    g = np.asarray(grid_resolution).astype(np.int64)
+    up = select_ori[:, 1] > 0
+    select_ori[up] *= -1
+    x, y, z = p2v(select_points, np.asarray(voxel_min), voxel_size, g)
+    dev = torch.device(device)
+    key = (torch.from_numpy(x.astype(np.int64)).to(dev) * int(g[1]) + torch.from_numpy(y.astype(np.int64)).to(dev)) \
+        * int(g[2]) + torch.from_numpy(z.astype(np.int64)).to(dev)
+    ks, order = torch.sort(key, stable=True)
+    first = torch.ones_like(ks, dtype=torch.bool)
+    first[1:] = ks[1:] != ks[:-1]
+    starts = torch.nonzero(first).flatten()
+    G = int(starts.numel())
+    seg = torch.cat([starts, torch.tensor([ks.numel()], device=dev)]).to(torch.int32).contiguous()
+    max_group = int((seg[1:] - seg[:-1]).max().item()) if G else 0
+    o = torch.from_numpy(np.ascontiguousarray(select_ori, dtype=np.float32)).to(dev)[order].contiguous()
+    med = torch.empty((G, 3), dtype=torch.float32, device=dev)
+    if G:
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().mh_medoid_segmented(_ctx_for(dev), _lib.ptr(o), _lib.ptr(seg), G, max_group,
+                                                      _lib.ptr(med), None, _lib.stream_ptr()), "mh_medoid_segmented")
+    kv = ks[starts]
+    vox = torch.stack([kv // (int(g[1]) * int(g[2])), (kv // int(g[2])) % int(g[1]), kv % int(g[2])], 1)
+    out = dict(voxels=vox, ori=med)
+    if dense:
+        occ = np.zeros(tuple(g))
+        ori = np.zeros(tuple(g) + (3,))
+        v = vox.cpu().numpy()
+        occ[v[:, 0], v[:, 1], v[:, 2]] = 1
+        ori[v[:, 0], v[:, 1], v[:, 2]] = med.cpu().numpy().astype(np.float64)
+        out["occ"], out["ori_dense"] = occ, ori
+    return out
+
+
+def save_ori_occ_mat(path, occ, ori):
+    """Layout + scipy.io.savemat of PMVO.py:753-764: Ori [Y,X,3*Z] (last index c*Z+z), Occ [Y,X,Z], float64."""
+    g = occ.shape
+    o = ori.transpose((0, 1, 3, 2)).reshape(g[0], g[1], g[2] * 3).transpose((1, 0, 2))
+    scipy.io.savemat(os.path.join(path, "Ori3D.mat"), {"Ori": o})
+    scipy.io.savemat(os.path.join(path, "Occ3D.mat"), {"Occ": occ.transpose((1, 0, 2))})
+
+
+def get_ground_truth_3D_occ(d, flip=False):
+    """PMVO_utils.py:86-95 -> [Z,Y,X,1] float32."""
+    occ = scipy.io.loadmat(d, verify_compressed_data_integrity=False)["Occ"].astype(np.float32)
+    occ = np.expand_dims(np.transpose(occ, [2, 0, 1]), -1)
+    if flip:
+        occ = occ[:, :, ::-1, :]
+    return np.ascontiguousarray(occ)
+
+
+def get_ground_truth_3D_ori(d, flip=False, growInv=False):
+    """PMVO_utils.py:98-113 -> [Z,Y,X,3] float32."""
+    ori = scipy.io.loadmat(d, verify_compressed_data_integrity=False)["Ori"].astype(np.float32)
+    ori = np.reshape(ori, [ori.shape[0], ori.shape[1], 3, -1])
+    ori = ori.transpose([0, 1, 3, 2]).transpose(2, 0, 1, 3)
+    if flip:
+        ori = ori[:, :, ::-1, :] * np.array([-1.0, 1.0, 1.0])
+    return np.ascontiguousarray(ori)
+
+
+def voxel_to_points(voxels):
+    """PMVO_utils.py:407-412."""
+    voxel_min = torch.tensor([-0.32, -0.32, -0.24], dtype=torch.float, device=voxels.device)
+    points = voxels * VOXEL_SIZE + voxel_min
+    points[..., 1:] *= -1
+    return points
+
+
+def points_to_voxel(points):
+    """PMVO_utils.py:414-420 (mutates its argument like the reference)."""
+    voxel_min = torch.tensor([-0.32, -0.32, -0.24], dtype=torch.float, device=points.device)
+    points[..., 1:] *= -1
+    return (points - voxel_min) / VOXEL_SIZE
+
+
+# ----------------------------------------------------------------------------------------- .hair strands
+def load_strand(file):
+    """.hair layout (PMVO_utils.py:47-66): u32 n_strands, u32 n_points, u16 count[n_strands], f32 xyz[...]."""
+    with open(file, "rb") as f:
+        (num_strand,) = struct.unpack("<I", f.read(4))
+        (_point_count,) = struct.unpack("<I", f.read(4))
+        segments = list(np.frombuffer(f.read(2 * num_strand), dtype="<u2").astype(int))
+        num_points = int(sum(segments))
+        points = np.frombuffer(f.read(4 * num_points * 3), dtype="<f4").astype(np.float64).reshape(-1, 3)
+    return segments, points
+
+
+def write_strand(points, path, segments):
+    """PMVO_utils.py:69-83."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", len(segments)))
+        f.write(struct.pack("<I", int(sum(segments))))
+        f.write(np.asarray(segments, dtype="<u2").tobytes())
+        f.write(np.asarray(points, dtype="<f4").reshape(-1, 3).tobytes())
+
+
+def save_hair_strands(path, strands, bust_to_origin, translate=True):
+    """PMVO_utils.py:662-680."""
+    segments = [s.shape[0] for s in strands]
+    points = np.concatenate(strands, 0)
+    if translate:
+        points = points - bust_to_origin
+    write_strand(points, path, segments)

@@ -1,0 +1,169 @@
+"""CPU-only tests of the host logic: options grammar, file formats, loaders, distributed plumbing (gloo x2)."""
+import os
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_options_grammar_and_parent_inheritance(tmp_path, monkeypatch):
+    from monohair_amd import options
+
+    (tmp_path / "base.yaml").write_text("seed: 0\ncpu:\ngpu: 0\nname: run\nPMVO:\n  patch_size: 9\n  optimize: true\n"
+                                        "  infer_inner: true\ndata:\n  root: data\n  case:\n")
+    (tmp_path / "case.yaml").write_text("_parent_: %s\ndata:\n  case: c1\nPMVO:\n  patch_size: 7\n" %
+                                        (tmp_path / "base.yaml"))
+    cmd = options.parse_arguments(["--yaml=%s" % (tmp_path / "case"), "--PMVO.infer_inner!", "--PMVO.optimize=",
+                                   "--data.root=elsewhere", "--brand.new=1"])
+    assert cmd.PMVO.infer_inner is False and cmd.PMVO.optimize is None
+    opt = options.set(cmd)      # unknown key "brand.new" must not block (non-interactive -> auto "y")
+    assert opt.PMVO.patch_size == 7 and opt.data.case == "c1" and opt.data.root == "elsewhere"
+    assert opt.PMVO.optimize is None and opt.brand.new == 1 and opt.name == "run"
+    assert opt.device in ("cpu",) or opt.device.startswith("cuda:")
+    opt.output_path = str(tmp_path)
+    options.save_options_file(opt)
+    opt.PMVO.patch_size = 5
+    options.save_options_file(opt)   # differing file: must not block either
+    import yaml
+
+    assert yaml.safe_load(open(tmp_path / "options.yaml"))["PMVO"]["patch_size"] == 5
+    cmd2 = options.parse_arguments(["--yaml=%s" % (tmp_path / "case"), "--seed=3"])
+    assert options.set(cmd2).name == "run_seed3"       # options.py:99-105
+
+
+def test_repo_configs_load():
+    from monohair_amd import options
+
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        opt = options.set(options.parse_arguments(["--yaml=configs/reconstruct/big_wavy1"]))
+    finally:
+        os.chdir(cwd)
+    assert opt.PMVO.patch_size == 7 and opt.PMVO.threshold == 0.025 and opt.PMVO.conf_threshold == 0.15
+    assert opt.data.image_size == [1920, 1080] and opt.data.depth_path == "render_depth"
+
+
+def test_hair_file_layout_roundtrip(tmp_path):
+    from monohair_amd.pmvo_utils import load_strand, save_hair_strands
+
+    rng = np.random.default_rng(0)
+    strands = [rng.normal(size=(n, 3)).astype(np.float32) for n in (5, 1, 17)]
+    p = str(tmp_path / "x.hair")
+    save_hair_strands(p, strands, np.zeros(3), translate=False)
+    raw = open(p, "rb").read()
+    assert struct.unpack("<II", raw[:8]) == (3, 23)
+    assert struct.unpack("<HHH", raw[8:14]) == (5, 1, 17)
+    assert len(raw) == 8 + 6 + 23 * 12
+    seg, pts = load_strand(p)
+    assert seg == [5, 1, 17] and np.allclose(pts, np.concatenate(strands))
+
+
+def test_mat_layout_roundtrip(tmp_path):
+    from monohair_amd.pmvo_utils import get_ground_truth_3D_occ, get_ground_truth_3D_ori, save_ori_occ_mat
+
+    g = (8, 6, 4)
+    rng = np.random.default_rng(1)
+    occ = (rng.random(g) > 0.5).astype(np.float64)
+    ori = rng.normal(size=g + (3,))
+    save_ori_occ_mat(str(tmp_path), occ, ori)
+    o = get_ground_truth_3D_ori(str(tmp_path / "Ori3D.mat"))     # [Z,Y,X,3]
+    c = get_ground_truth_3D_occ(str(tmp_path / "Occ3D.mat"))     # [Z,Y,X,1]
+    assert o.shape == (4, 6, 8, 3) and c.shape == (4, 6, 8, 1)
+    assert np.allclose(o, ori.transpose(2, 1, 0, 3).astype(np.float32))
+    assert np.allclose(c[..., 0], occ.transpose(2, 1, 0).astype(np.float32))
+
+
+def test_loaders_formulas(tmp_path):
+    from PIL import Image
+
+    from monohair_amd.pmvo_utils import Load_Ori_And_Conf, load_depth, load_mask
+
+    for d in ("best_ori", "conf", "hair_mask", "render_depth"):
+        os.makedirs(tmp_path / d)
+    deg = np.array([[0, 45], [90, 179]], np.uint8)
+    Image.fromarray(deg).save(tmp_path / "best_ori" / "v0.png")
+    Image.fromarray(np.array([[0, 51], [102, 255]], np.uint8)).save(tmp_path / "conf" / "v0.png")
+    m = np.zeros((2, 2, 3), np.uint8)
+    m[0, 0] = 49
+    m[0, 1] = 50
+    m[1, 1] = 255
+    Image.fromarray(m).save(tmp_path / "hair_mask" / "v0.png")
+    np.save(tmp_path / "render_depth" / "v0.npy", np.full((2, 2, 3), 255.0))
+    cam = {"v0": None}
+    Ori, Conf = Load_Ori_And_Conf(cam, str(tmp_path / "best_ori"), str(tmp_path / "conf"))
+    th = (180 - deg.astype(np.float64)) / 180 * np.pi
+    assert np.array_equal(Ori["v0"], np.stack([np.sin(th), np.cos(th)], -1))
+    assert np.array_equal(Conf["v0"], np.array([[0, 51], [102, 255]]) / 255.0)
+    mask = load_mask(cam, str(tmp_path / "hair_mask"))["v0"]
+    assert mask[0, 0, 0] == 0 and mask[0, 1, 0] == 50 / 255.0 and mask[1, 1, 0] == 1.0
+    assert load_depth(cam, str(tmp_path / "render_depth"))["v0"].dtype == np.float32
+
+
+def test_obj_reader_and_sampling(tmp_path):
+    from monohair_amd.pmvo_utils import SamplePointsAroundmesh, load_bust, sample_points_uniformly
+
+    (tmp_path / "m.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nf 1 2 3\nf 1/1 3/2 4/3\n")
+    v, f, n = load_bust(str(tmp_path / "m.obj"))
+    assert v.shape == (4, 3) and f.tolist() == [[0, 1, 2], [0, 2, 3]] and n.shape == (4, 3)
+    s = sample_points_uniformly(v, f, 1000)
+    assert s.shape == (1000, 3) and s.min() >= 0 and s.max() <= 1
+    np.random.seed(0)
+    pts = SamplePointsAroundmesh(np.array([[0.0, 0.0, 0.0], [0.01, 0.0, 0.0]]), np.array([-0.32, -0.32, -0.24]),
+                                 0.00125, num_per_grid=4, grid_resolution=[512, 512, 384])
+    assert pts.shape == (8, 3)
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from monohair_amd import dist as mdist
+dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+r = dist.get_rank()
+# --- map_chunks: results come back in chunk order on every rank, whichever rank produced them
+chunks = [np.arange(n * 3, dtype=np.float64).reshape(n, 3) + 100 * i for i, n in enumerate([5, 0, 7, 3, 4])]
+out = mdist.map_chunks(chunks, lambda c: torch.from_numpy(c).float() * 2, "cpu", lambda: torch.empty((0, 3)))
+for c, o in zip(chunks, out):
+    assert torch.equal(o, torch.from_numpy(c).float() * 2)
+# --- voxel_fit_reduced: disjoint ownership + ONE reduce == single-process fit, bit for bit
+import oracle
+def fit(p, o, device, vmin, vsize, g, dense=True):
+    occ, ori = oracle.voxel_fit(p, o, vmin, vsize, g)
+    vx = np.argwhere(occ != 0)
+    return dict(voxels=torch.from_numpy(vx), ori=torch.from_numpy(ori[vx[:, 0], vx[:, 1], vx[:, 2]].astype(np.float32)),
+                occ=occ, ori_dense=ori)
+rng = np.random.default_rng(5)
+pts = rng.uniform(-0.1, 0.1, size=(4000, 3)); ori = rng.normal(size=(4000, 3)).astype(np.float32)
+g = [64, 64, 48]
+occ, vol = mdist.voxel_fit_reduced(pts, ori, "cpu", [-0.32, -0.32, -0.24], 0.01, g, fit=fit)
+if r == 0:
+    occ1, vol1 = oracle.voxel_fit(pts.copy(), ori.copy(), [-0.32, -0.32, -0.24], 0.01, g)
+    assert np.array_equal(occ, occ1), "occupancy differs from the single-process fit"
+    assert np.array_equal(vol.astype(np.float32), vol1.astype(np.float32)), "volume differs"
+    print("DIST_OK", int(occ.sum()))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_distributed_sharding_and_volume_reduce_gloo(tmp_path):
+    """world_size 2 on CPU (gloo): chunk dealing + all_gather ordering, and the single volume reduce."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER % dict(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "DIST_OK" in outs[0]
