@@ -53,7 +53,9 @@ def orientation_table():
 
 
 class calOrientationGabor:
-    def __init__(self, channel_in=1, channel_out=1, stride=1, device=None):
+    def __init__(self, channel_in=1, channel_out=1, stride=1, device=None, bank=None):
+        """bank: optional [180,17,17] kernels to install instead of gabor_bank() (torch's CPU sin/cos/exp differ
+        in the last bit between host CPU types; tests pin the reference's own kernels this way)."""
         self.numKernels = NUM_KERNELS
         self.clamp_confidence_low = 0.0
         self.clamp_confidence_high = 0.2
@@ -61,7 +63,8 @@ class calOrientationGabor:
             raise _lib.MhError("calOrientationGabor needs a ROCm GPU (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._ctx = _ctx_for(self.device)
-        bank = np.ascontiguousarray(gabor_bank().reshape(NUM_KERNELS, KSIZE * KSIZE), dtype=np.float32)
+        bank = gabor_bank() if bank is None else np.asarray(bank)
+        bank = np.ascontiguousarray(bank.reshape(NUM_KERNELS, KSIZE * KSIZE), dtype=np.float32)
         _lib.check(_lib.lib().mh_gabor_set_bank(self._ctx, bank.ctypes.data_as(ctypes.c_void_p)), "mh_gabor_set_bank")
         th = orientation_table()
         self._theta = th.to(self.device)

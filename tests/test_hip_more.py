@@ -109,8 +109,10 @@ def test_gabor_vs_oracle_and_golden():
     from monohair_amd.gabor import calOrientationGabor, gabor_bank
 
     z = load_npz("gabor")
-    assert np.array_equal(gabor_bank(), z["bank"])
-    gab = calOrientationGabor(device=DEV)
+    # same formula, same torch ops; the last bit of torch's CPU sin/cos/exp depends on the host CPU type, so
+    # the reference's own kernels are installed for the bitwise comparisons below
+    assert np.allclose(gabor_bank(), z["bank"], rtol=0, atol=2e-7)
+    gab = calOrientationGabor(device=DEV, bank=z["bank"])
     for name in ("stripes0", "stripes30", "stripes90", "stripes135", "noise", "mixed"):
         img = z[name + "_img"]
         t = torch.from_numpy(img)[None, None].to(DEV)
