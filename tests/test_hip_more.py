@@ -144,13 +144,10 @@ def test_gabor_odd_sizes_and_border():
 
 
 def _e2e_setup(tmp_path):
-    from monohair_amd.camera import camera_records, cameras_from_list
-
     z = load_npz("e2e_small")
     meta = ast.literal_eval(str(z["meta"]))
     scene = golden_scene(meta)
-    rec = camera_records(cameras_from_list(scene["cams"]))
-    pm = make_pmvo(meta, scene, rec)
+    pm = make_pmvo(meta, scene, golden_records(z))      # the reference's own camera tensors (see conftest)
     scalp = z["toy_scalp"]
     pm.set_head(KDTree(data=z["toy_bust"]), KDTree(data=scalp), np.max(scalp, axis=0))
     args = types.SimpleNamespace(device=DEV, output_path=str(tmp_path), save_root=str(tmp_path / "optimize"),

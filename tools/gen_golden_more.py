@@ -124,6 +124,9 @@ def gen_e2e(R):
     args.data = types.SimpleNamespace(root=tmp)
     points = synth.candidate_points(res=case["res"], seed=case["pt_seed"])
     out = dict(candidates=points.copy(), toy_bust=bust, toy_scalp=scalp)
+    out["cam_pose"] = np.stack([c.pose.numpy() for c in pm.camera])
+    out["cam_proj"] = np.stack([c.proj.numpy() for c in pm.camera])
+    out["cam_rinv"] = np.stack([torch.linalg.inv(c.pose[:3, :3]).numpy() for c in pm.camera])
     surface_index, surface_points, filter_index = ref.filter_negative_points(points, pm, args)
     out["surface_index"] = surface_index
     out["filter_index"] = filter_index
