@@ -173,7 +173,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": pmc_traffic("mh_project_gather_kernel<%d>" % a.patch, V, H, W),
             "algorithmic_bytes_per_launch": pg_bytes,
             "launch_ms": round(t_pg, 4),
         },
@@ -188,6 +188,18 @@ def main():
     if not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a, scene, recs, my[0], ms)
     print(json.dumps(out))
+
+
+def pmc_traffic(kernel, V, H, W):
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC pass (profiles/traffic.json;
+    counters cannot be read from inside this process).  None when no pass exists for this workload."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if t.get("workload", "").startswith("%d views @ %dx%d" % (V, H, W)):
+            return t[kernel]["traffic_bytes"]
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(a, scene, recs, chunk, gpu_ms):
