@@ -143,11 +143,14 @@ __global__ __launch_bounds__(256) void mh_topk_kernel(const float *__restrict__ 
 // Record (v,n): float4 header {count(bits), vis, pix_row, pix_col} followed by `count` float4 taps
 // {ox_hat, oy_hat, conf, 0}; stride (P+1) float4.  One wave per (v,n), lane = tap.
 // ---------------------------------------------------------------------------------------------
+#define MH_PREP_PMAX 128
 __global__ __launch_bounds__(256) void mh_prep_taps_kernel(const float *__restrict__ ori_patch,
                                                            const float *__restrict__ conf_patch,
                                                            const float *__restrict__ vis,
                                                            const float *__restrict__ pixf, int VN, int P, float thr,
                                                            float4 *__restrict__ taps) {
+    __shared__ float2 s_o[4][MH_PREP_PMAX];
+    __shared__ unsigned char s_el[4][MH_PREP_PMAX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int vn = blockIdx.x * 4 + wave;
     if (vn >= VN) return;
@@ -164,20 +167,41 @@ __global__ __launch_bounds__(256) void mh_prep_taps_kernel(const float *__restri
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o));
     const bool hc = cmax > thr;
+    // pass 1: normalise, eligibility -> LDS (one wave owns its slice; same-wave LDS traffic is in order)
+    for (int p = lane; p < P; p += MH_WAVE) {
+        float o0, o1;
+        const float2 o = op[p];
+        mh_unit2(o.x, o.y, o0, o1);
+        s_o[wave][p] = make_float2(o0, o1);
+        s_el[wave][p] = (p == 0) || (hc ? (cp[p] > thr) : true);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // pass 2: a tap whose unit orientation is bit-identical to an EARLIER eligible tap can never win the strict
+    // '<' of PMVO.py:177 (its loss equals that tap's for every candidate), so it is dropped -- exact, and on
+    // 8-bit orientation maps (<= 180 distinct angles) it removes most of a patch.
     int base = 0;
     for (int p0 = 0; p0 < P; p0 += MH_WAVE) {
         const int p = p0 + lane;
         bool el = false;
-        float c = 0.f, o0 = 0.f, o1 = 0.f;
+        float2 o = make_float2(0.f, 0.f);
         if (p < P) {
-            c = cp[p];
-            const float2 o = op[p];
-            mh_unit2(o.x, o.y, o0, o1);
-            el = (p == 0) || (hc ? (c > thr) : true);
+            el = s_el[wave][p] != 0;
+            o = s_o[wave][p];
+            if (el) {
+                const unsigned ox = __float_as_uint(o.x), oy = __float_as_uint(o.y);
+                for (int q = 0; q < p; ++q) {
+                    const float2 e = s_o[wave][q];
+                    if (s_el[wave][q] && __float_as_uint(e.x) == ox && __float_as_uint(e.y) == oy) {
+                        el = false;
+                        break;
+                    }
+                }
+            }
         }
         const unsigned long long m = __ballot(el);
         const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (el) out[1 + pos] = make_float4(o0, o1, c, 0.0f);
+        if (el) out[1 + pos] = make_float4(o.x, o.y, cp[p], 0.0f);
         base += __popcll(m);
     }
     if (lane == 0) {
@@ -231,6 +255,7 @@ extern "C" int mh_launch_topk(const float *vis, const float *conf, int V, int N,
 
 extern "C" int mh_launch_prep_taps(const float *ori_patch, const float *conf_patch, const float *vis,
                                    const float *pixf, int VN, int P, float thr, float4 *taps, hipStream_t st) {
+    if (P > MH_PREP_PMAX) return -1;
     hipLaunchKernelGGL(mh_prep_taps_kernel, dim3((VN + 3) / 4), dim3(256), 0, st, ori_patch, conf_patch, vis, pixf,
                        VN, P, thr, taps);
     return (int)hipGetLastError();
