@@ -182,3 +182,61 @@ def candidate_points(res=256, seed=0, n_per_voxel=4, sphere_r=SPHERE_R, limit=No
     if limit is not None:
         sample = sample[:limit]
     return sample
+
+
+def write_case(root, case="synthetic_sphere", V=24, H=480, W=270, seed=0, scale=1.7, rings=1, res=64):
+    """Write a complete on-disk capture in the reference's layout (SURVEY.md §8b "files in") so that
+    `python PMVO.py --yaml=configs/reconstruct/<case>` runs through the real loaders:
+      ours/cam_params.json, capture_images/<view>.png, render_depth/<view>.npy [H,W,3] f32,
+      best_ori/<view>.png (u8 degrees), conf/<view>.png (u8), hair_mask/<view>.png (BGR u8),
+      ours/colmap_points.obj (the sphere), ours/bust_long_tsfm.obj, ours/scalp_tsfm.obj."""
+    import json
+    import os
+
+    from PIL import Image
+
+    base = os.path.join(root, case)
+    for d in ("ours", "capture_images", "render_depth", "best_ori", "conf", "hair_mask"):
+        os.makedirs(os.path.join(base, d), exist_ok=True)
+    cams = make_cameras(V, H, W, scale=scale, rings=rings)
+    with open(os.path.join(base, "ours", "cam_params.json"), "w") as f:
+        json.dump({"cam_list": cams}, f)
+    for i, cam in enumerate(cams):
+        d, o, c, m = render_view(cam, i, H, W, seed=seed, quantize=False)
+        ang = torch.atan2(-o[..., 0].double(), o[..., 1].double()) * (180.0 / math.pi)
+        k = torch.remainder(torch.round(ang), 180.0).to(torch.uint8).numpy()
+        c8 = torch.floor(c.double() * 255.0 + 0.5).clamp(0, 255).to(torch.uint8).numpy()
+        m8 = (m.numpy() * 255).astype(np.uint8)
+        name = cam["file"]
+        np.save(os.path.join(base, "render_depth", name + ".npy"), np.repeat(d.numpy()[..., None], 3, axis=2))
+        Image.fromarray(k).save(os.path.join(base, "best_ori", name + ".png"))
+        Image.fromarray(c8).save(os.path.join(base, "conf", name + ".png"))
+        Image.fromarray(np.repeat(m8[..., None], 3, axis=2)).save(os.path.join(base, "hair_mask", name + ".png"))
+        Image.fromarray(c8).save(os.path.join(base, "capture_images", name + ".png"))
+
+    def sphere_obj(path, radius, n_lat=48, n_lon=96, y_min=None):
+        vs, fs = [], []
+        for a in range(n_lat + 1):
+            th = math.pi * a / n_lat
+            for b in range(n_lon):
+                ph = 2 * math.pi * b / n_lon
+                vs.append((radius * math.sin(th) * math.cos(ph), radius * math.cos(th), radius * math.sin(th) * math.sin(ph)))
+        for a in range(n_lat):
+            for b in range(n_lon):
+                p00, p01 = a * n_lon + b, a * n_lon + (b + 1) % n_lon
+                p10, p11 = p00 + n_lon, p01 + n_lon
+                fs.append((p00, p10, p11))
+                fs.append((p00, p11, p01))
+        if y_min is not None:
+            keep = {i for i, v in enumerate(vs) if v[1] >= y_min}
+            fs = [t for t in fs if all(i in keep for i in t)]
+        with open(path, "w") as f:
+            for v in vs:
+                f.write("v %.9f %.9f %.9f\n" % v)
+            for t in fs:
+                f.write("f %d %d %d\n" % (t[0] + 1, t[1] + 1, t[2] + 1))
+
+    sphere_obj(os.path.join(base, "ours", "colmap_points.obj"), SPHERE_R, n_lat=4 * res // 8, n_lon=8 * res // 8)
+    sphere_obj(os.path.join(base, "ours", "bust_long_tsfm.obj"), 0.09, 24, 48)
+    sphere_obj(os.path.join(base, "ours", "scalp_tsfm.obj"), 0.10, 24, 48, y_min=0.03)
+    return base

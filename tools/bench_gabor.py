@@ -1,0 +1,39 @@
+#!/usr/bin/env python
+"""Gabor bank throughput (views/s) at a given image size on cuda:0; optional check against the CPU oracle on a crop."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from monohair_amd.gabor import calOrientationGabor, difference_of_gaussians  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--height", type=int, default=1920)
+ap.add_argument("--width", type=int, default=1080)
+ap.add_argument("--reps", type=int, default=10)
+a = ap.parse_args()
+rng = np.random.default_rng(0)
+r, c = np.meshgrid(np.arange(a.height), np.arange(a.width), indexing="ij")
+img = (127 + 60 * np.cos(2 * np.pi * (0.6 * r + 0.8 * c) / 4.0) + rng.normal(0, 5, r.shape)).clip(0, 255).astype(np.uint8)
+t0 = time.perf_counter()
+dog = difference_of_gaussians(img, 0.4, 10).astype(np.float32)
+t_dog = time.perf_counter() - t0
+gab = calOrientationGabor(device="cuda:0")
+x = torch.from_numpy(dog).cuda()
+gab.filter_index(x)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.reps):
+    idx, conf, var = gab.filter_index(x)
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / a.reps
+flop = 2.0 * 180 * 289 * a.height * a.width
+print({"image": [a.height, a.width], "ms_per_view": round(ms, 3), "views_per_s": round(1e3 / ms, 1),
+       "TFLOP_s": round(flop / ms / 1e9, 2), "frac_of_157TF": round(flop / ms / 1e9 / 157.3, 3),
+       "host_dog_ms": round(t_dog * 1e3, 1)})
