@@ -151,6 +151,7 @@ __global__ __launch_bounds__(256) void mh_prep_taps_kernel(const float *__restri
                                                            float4 *__restrict__ taps) {
     __shared__ float2 s_o[4][MH_PREP_PMAX];
     __shared__ unsigned char s_el[4][MH_PREP_PMAX];
+    __shared__ unsigned int s_first[4][256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int vn = blockIdx.x * 4 + wave;
     if (vn >= VN) return;
@@ -167,19 +168,29 @@ __global__ __launch_bounds__(256) void mh_prep_taps_kernel(const float *__restri
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o));
     const bool hc = cmax > thr;
-    // pass 1: normalise, eligibility -> LDS (one wave owns its slice; same-wave LDS traffic is in order)
+    for (int b = lane; b < 256; b += MH_WAVE) s_first[wave][b] = 0xffffffffu;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // pass 1: normalise, eligibility; every eligible tap bids for "first tap with this orientation" in a
+    // 256-bucket table keyed by a hash of the unit vector's bits (one wave owns its LDS slice)
     for (int p = lane; p < P; p += MH_WAVE) {
         float o0, o1;
         const float2 o = op[p];
         mh_unit2(o.x, o.y, o0, o1);
+        const bool el = (p == 0) || (hc ? (cp[p] > thr) : true);
         s_o[wave][p] = make_float2(o0, o1);
-        s_el[wave][p] = (p == 0) || (hc ? (cp[p] > thr) : true);
+        s_el[wave][p] = el;
+        if (el) {
+            const unsigned h = ((__float_as_uint(o0) * 0x9E3779B1u) ^ (__float_as_uint(o1) * 0x85EBCA77u)) >> 24;
+            atomicMin(&s_first[wave][h], (unsigned)p);
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // pass 2: a tap whose unit orientation is bit-identical to an EARLIER eligible tap can never win the strict
     // '<' of PMVO.py:177 (its loss equals that tap's for every candidate), so it is dropped -- exact, and on
-    // 8-bit orientation maps (<= 180 distinct angles) it removes most of a patch.
+    // 8-bit orientation maps (<= 180 distinct angles) it removes most of a patch.  A hash collision only means
+    // that a duplicate survives (harmless); nothing distinct is ever dropped because the bits are compared.
     int base = 0;
     for (int p0 = 0; p0 < P; p0 += MH_WAVE) {
         const int p = p0 + lane;
@@ -190,12 +201,10 @@ __global__ __launch_bounds__(256) void mh_prep_taps_kernel(const float *__restri
             o = s_o[wave][p];
             if (el) {
                 const unsigned ox = __float_as_uint(o.x), oy = __float_as_uint(o.y);
-                for (int q = 0; q < p; ++q) {
+                const unsigned q = s_first[wave][((ox * 0x9E3779B1u) ^ (oy * 0x85EBCA77u)) >> 24];
+                if (q < (unsigned)p) {
                     const float2 e = s_o[wave][q];
-                    if (s_el[wave][q] && __float_as_uint(e.x) == ox && __float_as_uint(e.y) == oy) {
-                        el = false;
-                        break;
-                    }
+                    if (__float_as_uint(e.x) == ox && __float_as_uint(e.y) == oy) el = false;
                 }
             }
         }
