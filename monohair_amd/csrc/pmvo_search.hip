@@ -41,7 +41,27 @@ __device__ __forceinline__ bool mh_min_better(float al, int ai, float bl, int bi
     return (al < bl) || (al == bl && ai < bi);
 }
 
-template <int K, int T>
+typedef float mh_v2f __attribute__((ext_vector_type(2)));
+
+// 1 - |x| as ONE instruction (abs is a source modifier); kept out of the SLP vectoriser's reach
+__device__ __forceinline__ float mh_one_minus_abs(float x) {
+    float r;
+    asm("v_sub_f32_e64 %0, 1.0, |%1|" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// if (l.x < mb.x) mb = (l.x, c.x):  v_cmpx writes EXEC, v_pk_mov_b32 moves both halves under it, EXEC restored.
+__device__ __forceinline__ void mh_update_min_pair(mh_v2f &mb, mh_v2f l, mh_v2f c, unsigned long long exec_all) {
+    asm volatile(
+        "v_cmpx_lt_f32_e32 vcc, %[lx], %[ml]\n\t"
+        "v_pk_mov_b32 %[mb], %[l], %[c] op_sel:[0,0]\n\t"
+        "s_mov_b64 exec, %[ex]"
+        : [mb] "+v"(mb)
+        : [lx] "v"(l.x), [ml] "v"(mb.x), [l] "v"(l), [c] "v"(c), [ex] "s"(exec_all)
+        : "vcc");
+}
+
+template <int K, int T, bool FAST>
 __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *__restrict__ offs, int S, int nrank,
                                                       int rank_step, const float *__restrict__ pts, int N, int P1,
                                                       float thr, const float *__restrict__ ori_c,
@@ -78,6 +98,7 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
         cnt[j] = 0;
     }
 
+    const unsigned long long exec_all = __builtin_amdgcn_read_exec();
     for (int v = 0; v < V; ++v) {
         if (v > 0 && (v & 15) == 0) {
 #pragma unroll
@@ -91,34 +112,78 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
         if (hdr.y == -1.0f) continue;   // uniform: point not visible in this view, weight 0
         const int ntap = __float_as_int(hdr.x);
         const float *__restrict__ cam = vw.cams + v * MH_CAM_STRIDE;
-        float dx[K], dy[K], ml[K], bc[K];
         const float4 t0 = rec[1];
+        if constexpr (FAST && (K % 2 == 0)) {
+            // Hand-scheduled tap loop.  Items are processed in pairs: the unit directions of two items sit in
+            // one 64-bit register pair per component, so the two products and the sum of the cosine are
+            // v_pk_mul_f32 / v_pk_add_f32 (separately rounded, no fma -- same bits as the scalar form); the
+            // running (min loss, conf of argmin) of an item is ONE register pair that a single v_pk_mov_b32
+            // overwrites under the EXEC mask written by v_cmpx_lt_f32: 4.5 VALU instructions per (item, tap)
+            // instead of the 6.75 the compiler emits for the portable loop below.
+            mh_v2f DX[K / 2], DY[K / 2], MB[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            float row, col;
-            mh_pixel_of(cam, X0[j], X1[j], X2[j], Hf, Wf, row, col);
-            mh_unit2(row - hdr.z, col - hdr.w, dx[j], dy[j]);
-            const float cs = t0.x * dx[j] + t0.y * dy[j];
-            ml[j] = 1.0f - __builtin_fabsf(cs);
-            bc[j] = t0.z;
-        }
-        for (int t = 1; t < ntap; ++t) {
-            const float4 tp = rec[1 + t];
+            for (int jp = 0; jp < K / 2; ++jp) {
+                float r0, c0, r1, c1, a0, b0, a1, b1;
+                mh_pixel_of_fast(cam, X0[2 * jp], X1[2 * jp], X2[2 * jp], Hf, Wf, r0, c0);
+                mh_pixel_of_fast(cam, X0[2 * jp + 1], X1[2 * jp + 1], X2[2 * jp + 1], Hf, Wf, r1, c1);
+                mh_unit2_fast(r0 - hdr.z, c0 - hdr.w, a0, b0);
+                mh_unit2_fast(r1 - hdr.z, c1 - hdr.w, a1, b1);
+                DX[jp] = mh_v2f{a0, a1};
+                DY[jp] = mh_v2f{b0, b1};
+                const mh_v2f cs = mh_v2f{t0.x, t0.x} * DX[jp] + mh_v2f{t0.y, t0.y} * DY[jp];
+                MB[2 * jp] = mh_v2f{mh_one_minus_abs(cs.x), t0.z};
+                MB[2 * jp + 1] = mh_v2f{mh_one_minus_abs(cs.y), t0.z};
+            }
+            for (int t = 1; t < ntap; ++t) {
+                const float4 tp = rec[1 + t];
+                const mh_v2f ox2 = mh_v2f{tp.x, tp.x}, oy2 = mh_v2f{tp.y, tp.y};
+                const mh_v2f cpair = mh_v2f{tp.z, tp.z};
+#pragma unroll
+                for (int jp = 0; jp < K / 2; ++jp) {
+                    const mh_v2f cs = ox2 * DX[jp] + oy2 * DY[jp];
+                    mh_v2f L0, L1;
+                    L0.x = mh_one_minus_abs(cs.x);
+                    L1.x = mh_one_minus_abs(cs.y);
+                    mh_update_min_pair(MB[2 * jp], L0, cpair, exec_all);
+                    mh_update_min_pair(MB[2 * jp + 1], L1, cpair, exec_all);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                const float cs = tp.x * dx[j] + tp.y * dy[j];
-                const float l = 1.0f - __builtin_fabsf(cs);
-                const bool upd = l < ml[j];
-                ml[j] = upd ? l : ml[j];
-                bc[j] = upd ? tp.z : bc[j];
+                const float w = MB[j].y;   // (vis != -1) * best_conf
+                num[j].a0 = num[j].a0 + MB[j].x * w;
+                den[j].a0 = den[j].a0 + w;
+                cnt[j] += (w > 0.0f) ? 1 : 0;
             }
-        }
+        } else {
+            float dx[K], dy[K], ml[K], bc[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const float w = bc[j];   // (vis != -1) * best_conf
-            num[j].a0 = num[j].a0 + ml[j] * w;
-            den[j].a0 = den[j].a0 + w;
-            cnt[j] += (w > 0.0f) ? 1 : 0;
+            for (int j = 0; j < K; ++j) {
+                float row, col;
+                mh_pixel_of(cam, X0[j], X1[j], X2[j], Hf, Wf, row, col);
+                mh_unit2(row - hdr.z, col - hdr.w, dx[j], dy[j]);
+                const float cs = t0.x * dx[j] + t0.y * dy[j];
+                ml[j] = 1.0f - __builtin_fabsf(cs);
+                bc[j] = t0.z;
+            }
+            for (int t = 1; t < ntap; ++t) {
+                const float4 tp = rec[1 + t];
+#pragma unroll
+                for (int j = 0; j < K; ++j) {
+                    const float cs = tp.x * dx[j] + tp.y * dy[j];
+                    const float l = 1.0f - __builtin_fabsf(cs);
+                    const bool upd = l < ml[j];
+                    ml[j] = upd ? l : ml[j];
+                    bc[j] = upd ? tp.z : bc[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const float w = bc[j];   // (vis != -1) * best_conf
+                num[j].a0 = num[j].a0 + ml[j] * w;
+                den[j].a0 = den[j].a0 + w;
+                cnt[j] += (w > 0.0f) ? 1 : 0;
+            }
         }
     }
 
@@ -288,10 +353,11 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
                                 int variant, hipStream_t st) {
     const int nitems = nrank * S;
     if (nitems > MH_MAX_ITEMS || nrank > MH_MAX_RANKS || nitems < 1) return -1;
-#define MH_SEARCH_LAUNCH(KK, TT)                                                                                   \
-    hipLaunchKernelGGL((mh_search_kernel<KK, TT>), dim3(N), dim3(TT), 0, st, vw, offs, S, nrank, rank_step, pts, N, \
+#define MH_SEARCH_LAUNCH_F(KK, TT, FF)                                                                                   \
+    hipLaunchKernelGGL((mh_search_kernel<KK, TT, FF>), dim3(N), dim3(TT), 0, st, vw, offs, S, nrank, rank_step, pts, N, \
                        P1, thr, ori_c, base_idx, base_val, taps, line_ori, min_loss, high_conf, best_sample,        \
                        best_rank, best_s)
+#define MH_SEARCH_LAUNCH(KK, TT) MH_SEARCH_LAUNCH_F(KK, TT, false)
     // pick the smallest K*T that covers the items for the requested wave count
     if (variant == 0) variant = (nitems <= 64) ? 64 : (nitems <= 320 ? 320 : 256);
     if (variant == 64) {
@@ -305,7 +371,11 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
         if (nitems <= 960) MH_SEARCH_LAUNCH(5, 192);
         else MH_SEARCH_LAUNCH(6, 192);
     } else if (variant == 256) {
+        MH_SEARCH_LAUNCH_F(4, 256, true);
+    } else if (variant == 1256) {   // portable loop, for A/B and cross-checks
         MH_SEARCH_LAUNCH(4, 256);
+    } else if (variant == 1128) {
+        MH_SEARCH_LAUNCH_F(8, 128, true);
     } else if (variant == 320) {
         if (nitems <= 320) MH_SEARCH_LAUNCH(1, 320);
         else if (nitems <= 960) MH_SEARCH_LAUNCH(3, 320);
@@ -314,6 +384,7 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
         return -1;
     }
 #undef MH_SEARCH_LAUNCH
+#undef MH_SEARCH_LAUNCH_F
     return (int)hipGetLastError();
 }
 
