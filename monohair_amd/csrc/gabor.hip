@@ -54,16 +54,26 @@ __global__ __launch_bounds__(256) void mh_gabor_bank_kernel(const float *__restr
     }
     __syncthreads();
 
-    float acc[MH_GB_NK];
+    // 180 accumulators as 90 register pairs: v_pk_fma_f32 retires two fp32 FMAs per 4-cycle issue slot
+    // (measured: v_fma_f32 3.5 cycles for one) and is, per element, the same single-rounded fma.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f acc2[MH_GB_NK / 2];
 #pragma unroll
-    for (int k = 0; k < MH_GB_NK; ++k) acc[k] = 0.0f;
+    for (int k = 0; k < MH_GB_NK / 2; ++k) acc2[k] = v2f{0.0f, 0.0f};
     for (int i = 0; i < MH_GB_KS; ++i) {
         for (int j = 0; j < MH_GB_KS; ++j) {
             const float x = tile[(ty + i) * MH_GB_LDW + tx + j];
-            const float *__restrict__ wt = bankT + (i * MH_GB_KS + j) * MH_GB_KPAD;
+            const v2f x2 = v2f{x, x};
+            const v2f *__restrict__ wt = reinterpret_cast<const v2f *>(bankT + (i * MH_GB_KS + j) * MH_GB_KPAD);
 #pragma unroll
-            for (int k = 0; k < MH_GB_NK; ++k) acc[k] = mh_fma(x, wt[k], acc[k]);
+            for (int k = 0; k < MH_GB_NK / 2; ++k) acc2[k] = __builtin_elementwise_fma(x2, wt[k], acc2[k]);
         }
+    }
+    float acc[MH_GB_NK];
+#pragma unroll
+    for (int k = 0; k < MH_GB_NK / 2; ++k) {
+        acc[2 * k] = acc2[k].x;
+        acc[2 * k + 1] = acc2[k].y;
     }
 
     // argmax of |response| (first maximum), GaborFilter.py:48-51
