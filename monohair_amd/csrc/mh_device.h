@@ -136,6 +136,61 @@ __device__ __forceinline__ void mh_unit2_fast(float x0, float x1, float &o0, flo
     mh_div2(x0, x1, nrm, o0, o1);
 }
 
+// ---- two items at a time: the same operations, element by element, on 64-bit register pairs, so that the fma
+// chains become v_pk_fma_f32 (two single-rounded fp32 FMAs per issue slot) -- bit-identical to the scalar forms.
+typedef float mh_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ mh_v2f mh_fma2(mh_v2f a, mh_v2f b, mh_v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ mh_v2f mh_splat(float x) { return mh_v2f{x, x}; }
+
+__device__ __forceinline__ void mh_div2x2(mh_v2f n0, mh_v2f n1, mh_v2f d, mh_v2f &q0, mh_v2f &q1) {
+    mh_v2f r = mh_v2f{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const mh_v2f nd = -d;
+    mh_v2f e = mh_fma2(nd, r, mh_splat(1.0f));
+    r = mh_fma2(e, r, r);
+    mh_v2f a = n0 * r;
+    mh_v2f ea = mh_fma2(nd, a, n0);
+    a = mh_fma2(ea, r, a);
+    ea = mh_fma2(nd, a, n0);
+    q0 = mh_fma2(ea, r, a);
+    mh_v2f b = n1 * r;
+    mh_v2f eb = mh_fma2(nd, b, n1);
+    b = mh_fma2(eb, r, b);
+    eb = mh_fma2(nd, b, n1);
+    q1 = mh_fma2(eb, r, b);
+}
+
+// pixel (row, col) of two world points in one view (mh_pixel_of_fast, pairwise)
+__device__ __forceinline__ void mh_pixel_of_fast2(const float *__restrict__ cam, mh_v2f X0, mh_v2f X1, mh_v2f X2,
+                                                  float Hf, float Wf, mh_v2f &row, mh_v2f &col) {
+    mh_v2f c0 = mh_splat(cam[0]) * X0;
+    c0 = mh_fma2(mh_splat(cam[1]), X1, c0);
+    c0 = mh_fma2(mh_splat(cam[2]), X2, c0);
+    c0 = mh_fma2(mh_splat(cam[3]), mh_splat(1.0f), c0);
+    mh_v2f c1 = mh_splat(cam[4]) * X0;
+    c1 = mh_fma2(mh_splat(cam[5]), X1, c1);
+    c1 = mh_fma2(mh_splat(cam[6]), X2, c1);
+    c1 = mh_fma2(mh_splat(cam[7]), mh_splat(1.0f), c1);
+    mh_v2f c2 = mh_splat(cam[8]) * X0;
+    c2 = mh_fma2(mh_splat(cam[9]), X1, c2);
+    c2 = mh_fma2(mh_splat(cam[10]), X2, c2);
+    c2 = mh_fma2(mh_splat(cam[11]), mh_splat(1.0f), c2);
+    const mh_v2f q0 = mh_fma2(mh_splat(cam[18]), c2, mh_splat(cam[16]) * c0);
+    const mh_v2f q1 = mh_fma2(mh_splat(cam[22]), c2, mh_splat(cam[21]) * c1);
+    mh_v2f u, v;
+    mh_div2x2(q0, q1, c2, u, v);
+    col = ((-u + mh_splat(1.0f)) / mh_splat(2.0f)) * mh_splat(Wf);   // /2 is exact: the compiler emits a multiply
+    row = ((v + mh_splat(1.0f)) / mh_splat(2.0f)) * mh_splat(Hf);
+}
+
+__device__ __forceinline__ void mh_unit2_fast2(mh_v2f x0, mh_v2f x1, mh_v2f &o0, mh_v2f &o1) {
+    mh_v2f s = x0 * x0;
+    s = mh_fma2(x1, x1, s);
+    mh_v2f nrm = mh_v2f{__builtin_sqrtf(s.x), __builtin_sqrtf(s.y)};
+    nrm.x = (nrm.x < 1e-8f) ? 1e-8f : nrm.x;
+    nrm.y = (nrm.y < 1e-8f) ? 1e-8f : nrm.y;
+    mh_div2x2(x0, x1, nrm, o0, o1);
+}
+
 __device__ __forceinline__ float mh_clampf(float x, float lo, float hi) {
     return x < lo ? lo : (x > hi ? hi : x);
 }

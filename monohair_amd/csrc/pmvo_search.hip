@@ -41,8 +41,6 @@ __device__ __forceinline__ bool mh_min_better(float al, int ai, float bl, int bi
     return (al < bl) || (al == bl && ai < bi);
 }
 
-typedef float mh_v2f __attribute__((ext_vector_type(2)));
-
 // 1 - |x| as ONE instruction (abs is a source modifier); kept out of the SLP vectoriser's reach
 __device__ __forceinline__ float mh_one_minus_abs(float x) {
     float r;
@@ -123,13 +121,10 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
             mh_v2f DX[K / 2], DY[K / 2], MB[K];
 #pragma unroll
             for (int jp = 0; jp < K / 2; ++jp) {
-                float r0, c0, r1, c1, a0, b0, a1, b1;
-                mh_pixel_of_fast(cam, X0[2 * jp], X1[2 * jp], X2[2 * jp], Hf, Wf, r0, c0);
-                mh_pixel_of_fast(cam, X0[2 * jp + 1], X1[2 * jp + 1], X2[2 * jp + 1], Hf, Wf, r1, c1);
-                mh_unit2_fast(r0 - hdr.z, c0 - hdr.w, a0, b0);
-                mh_unit2_fast(r1 - hdr.z, c1 - hdr.w, a1, b1);
-                DX[jp] = mh_v2f{a0, a1};
-                DY[jp] = mh_v2f{b0, b1};
+                mh_v2f row, col;
+                mh_pixel_of_fast2(cam, mh_v2f{X0[2 * jp], X0[2 * jp + 1]}, mh_v2f{X1[2 * jp], X1[2 * jp + 1]},
+                                  mh_v2f{X2[2 * jp], X2[2 * jp + 1]}, Hf, Wf, row, col);
+                mh_unit2_fast2(row - mh_splat(hdr.z), col - mh_splat(hdr.w), DX[jp], DY[jp]);
                 const mh_v2f cs = mh_v2f{t0.x, t0.x} * DX[jp] + mh_v2f{t0.y, t0.y} * DY[jp];
                 MB[2 * jp] = mh_v2f{mh_one_minus_abs(cs.x), t0.z};
                 MB[2 * jp + 1] = mh_v2f{mh_one_minus_abs(cs.y), t0.z};
