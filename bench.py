@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the independent iterations alternate on (as monohair_amd.pmvo.optimize does)")
     return ap.parse_args()
 
 
@@ -85,8 +87,13 @@ def main():
     my = [chunks[i] for i in range(rank, nchunk, world)] or chunks[:1]
     dev_chunks = [torch.from_numpy(c).to(dev).float() for c in my]
 
+    # consecutive iterations are independent chunks of `optimize` (PMVO.py:572-574); like the driver in
+    # monohair_amd/pmvo.py they alternate between HIP streams so one chunk's tail overlaps the next one's head
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
+
     def step(i):
-        return pm.forward(dev_chunks[i % len(dev_chunks)])
+        with torch.cuda.stream(streams[i % len(streams)]):
+            return pm.forward(dev_chunks[i % len(dev_chunks)])
 
     for i in range(a.warmup):
         step(i)
@@ -165,6 +172,7 @@ def main():
             "conf_threshold": a.conf_threshold, "surface_points": int(len(pts)), "iterations_full_pass": nchunk,
             "parallelism": "points sharded over %d GPU(s), views replicated" % world,
             "maps": "quantized-8bit" if a.quantize else "continuous",
+            "streams": len(streams),
         },
         "roofline": {
             "kernel": "mh_project_gather_kernel<%d>" % a.patch,

@@ -159,10 +159,17 @@ class PMVO:
         return idx.long(), val
 
     def _get_scratch(self, N):
+        """Tap-list scratch of the search, one buffer per launch stream (chunks of `optimize` are independent and
+        may be in flight on different streams)."""
         need = int(self._L.mh_search_scratch_bytes(self._ctx, N, self.patch_size))
-        if self._scratch is None or self._scratch.numel() < need:
-            self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._scratch, need
+        key = torch.cuda.current_stream().cuda_stream
+        if self._scratch is None:
+            self._scratch = {}
+        buf = self._scratch.get(key)
+        if buf is None or buf.numel() < need:
+            buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._scratch[key] = buf
+        return buf, need
 
     def forward(self, points, base_view=None, extras=False):
         """PMVO.py:39-78.  points: numpy [N,3].  Returns (points, line_ori [N,3], min_loss [N],
@@ -293,12 +300,25 @@ def optimize(points, pmvo, args):
     step = points.shape[0] // num_sub_p + 1
     chunks = [points[i * num_sub_p:(i + 1) * num_sub_p] for i in range(step)]
 
+    # consecutive chunks are independent: alternate two HIP streams so that the tail of one chunk's search
+    # kernel (workgroups of points that see many views) overlaps the head of the next chunk
+    streams = [torch.cuda.Stream(device=pmvo.device) for _ in range(2)]
+    counter = [0]
+
     def work(sub):
-        p, o, l, h = pmvo.forward(sub)
-        return torch.cat([p, o, l[:, None], h[:, None].to(torch.float32)], 1)
+        st = streams[counter[0] % 2]
+        counter[0] += 1
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            p, o, l, h = pmvo.forward(sub)
+            out = torch.cat([p, o, l[:, None], h[:, None].to(torch.float32)], 1)
+        out.record_stream(torch.cuda.current_stream())
+        return out
 
     res = mdist.map_chunks(chunks, work, pmvo.device,
                            empty=lambda: torch.empty((0, 8), dtype=torch.float32, device=pmvo.device))
+    for st in streams:
+        torch.cuda.current_stream().wait_stream(st)
     res = torch.cat(res, 0).cpu().numpy()
     select_points, select_ori, min_loss = res[:, 0:3], res[:, 3:6], res[:, 6]
     high_conf_index = res[:, 7] > 0.5
