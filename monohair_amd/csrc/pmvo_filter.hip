@@ -7,7 +7,7 @@
 // ATen's cascade order (mask values in (0, 0.2] stay fractional, PMVO.py:427, so order can matter).
 #include "mh_device.h"
 
-#define MH_FILTER_VMAX 256
+#define MH_FILTER_VMAX 128
 #define MH_NTERM 8
 
 template <int PATCH>
@@ -40,13 +40,18 @@ __global__ __launch_bounds__(256) void mh_filter_kernel(MhViews vw, const float 
         // raw (unclamped) patch confidences, zeroed when the point projects outside (PMVO.py:415-420)
         float cmax = 0.0f;
         if (surface_index || filter_index) {
-            cmax = q.z;
+            // all PATCH*PATCH loads are issued before the first use (fully unrolled): the lane is latency bound
+            float cv[PATCH * PATCH];
+#pragma unroll
             for (int i = -HP; i <= HP; ++i)
+#pragma unroll
                 for (int j = -HP; j <= HP; ++j) {
                     const int rr2 = min(max(r + i, 0), H - 1), cc2 = min(max(c + j, 0), W - 1);
-                    const float cv = rec[(size_t)rr2 * W + cc2].z;
-                    cmax = (cv > cmax) ? cv : cmax;
+                    cv[(i + HP) * PATCH + j + HP] = rec[(size_t)rr2 * W + cc2].z;
                 }
+            cmax = q.z;
+#pragma unroll
+            for (int t = 0; t < PATCH * PATCH; ++t) cmax = (cv[t] > cmax) ? cv[t] : cmax;
             if (oob) cmax = 0.0f;
         }
         const float unv = (oob || gap > 0.1f) ? 1.0f : 0.0f;

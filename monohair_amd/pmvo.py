@@ -336,7 +336,7 @@ def _knn(tree, sub_points, k, n_total):
     # scipy returns index n for missing neighbours when k > n (the reference would raise on ori[index]);
     # tiny inputs only: clamp k.
     k = min(k, n_total)
-    _, index = tree.query(sub_points, k)
+    _, index = tree.query(sub_points, k, workers=-1)   # same neighbours, all host cores
     return index.reshape(len(sub_points), k)
 
 

@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Time the full exterior pass (filter -> optimize -> refine -> volume) on the synthetic workload, stage by stage.
+   python tools/full_pass.py [--views 60 --height 1920 --width 1080 --volume 256 --patch 7]"""
+import argparse
+import os
+import sys
+import tempfile
+import time
+import types
+
+import numpy as np
+import torch
+from scipy.spatial import KDTree
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from monohair_amd import synth  # noqa: E402
+from monohair_amd.camera import camera_records, cameras_from_list  # noqa: E402
+from monohair_amd.pmvo import PMVO, filter_negative_points, optimize, refine  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--views", type=int, default=60)
+ap.add_argument("--height", type=int, default=1920)
+ap.add_argument("--width", type=int, default=1080)
+ap.add_argument("--volume", type=int, default=256)
+ap.add_argument("--patch", type=int, default=7)
+ap.add_argument("--quantize", action="store_true")
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+T = {}
+
+
+def tic(name, t0):
+    torch.cuda.synchronize()
+    T[name] = round(time.perf_counter() - t0, 3)
+
+
+t0 = time.perf_counter()
+scene = synth.make_scene(a.views, a.height, a.width, device=dev, quantize=a.quantize)
+cams = cameras_from_list(scene["cams"])
+pm = PMVO.from_planes(camera_records(cams), scene["depth"], scene["ori"], scene["conf"], scene["mask"], device=dev,
+                      patch_size=a.patch, visible_threshold=1, conf_threshold=0.15, camera=cams)
+rng = np.random.default_rng(1)
+b = rng.normal(size=(2000, 3))
+b = b / np.linalg.norm(b, axis=1, keepdims=True) * 0.09
+scalp = b[b[:, 1] > 0.03] * (0.1 / 0.09)
+pm.set_head(KDTree(b), KDTree(scalp), scalp.max(0))
+tic("scene+pack_s", t0)
+cand = synth.candidate_points(res=a.volume, seed=0)
+tmp = tempfile.mkdtemp()
+args = types.SimpleNamespace(device=str(dev), output_path=tmp, save_root=tmp + "/optimize", save_path=tmp + "/refine",
+                             PMVO=types.SimpleNamespace(visible_threshold=1), data=types.SimpleNamespace(root=tmp))
+os.makedirs(args.save_path, exist_ok=True)
+t0 = time.perf_counter()
+s_idx, s_pts, f_idx = filter_negative_points(cand, pm, args)
+tic("filter_s", t0)
+t0 = time.perf_counter()
+sp, so, ml, hc = optimize(s_pts, pm, args)
+tic("optimize_s", t0)
+t0 = time.perf_counter()
+occ, ori = refine(sp.copy(), so.copy(), ml.copy(), pm, cand[:len(f_idx)][f_idx].astype(np.float32), args,
+                  infer_inner=False, threshold=0.025)
+tic("refine+volume_s", t0)
+print({"candidates": len(cand), "surface": int(s_idx.sum()), "shell": int(f_idx.sum()),
+       "iterations": len(s_pts) // 5000 + 1, "voxels": int(occ.sum()), **T})
