@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--quantize", action="store_true", help="8-bit orientation/confidence maps (file hand-off)")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the extra 8-bit-maps measurement")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the independent iterations alternate on (as monohair_amd.pmvo.optimize does)")
@@ -195,7 +196,33 @@ def main():
     }
     if not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(a, scene, recs, my[0], ms)
+    if not a.quantize and not a.no_secondary and world == 1:
+        out["secondary_8bit_maps"] = secondary_quantized(a, dev, recs, cams, dev_chunks)
     print(json.dumps(out))
+
+
+def secondary_quantized(a, dev, recs, cams, dev_chunks):
+    """The same iteration on maps pushed through the reference's 8-bit file hand-off (integer degrees, conf/255 --
+    what a real capture delivers): duplicate tap orientations are dropped exactly."""
+    scene_q = synth.make_scene(a.views, a.height, a.width, device=dev, seed=0, quantize=True)
+    pm = PMVO.from_planes(recs, scene_q["depth"], scene_q["ori"], scene_q["conf"], scene_q["mask"], device=dev,
+                          patch_size=a.patch, visible_threshold=1, conf_threshold=a.conf_threshold, camera=cams)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
+
+    def step(i):
+        with torch.cuda.stream(streams[i % len(streams)]):
+            return pm.forward(dev_chunks[i % len(dev_chunks)])
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": round(a.steps / dt, 3), "unit": "iterations/s", "ms_per_step": round(dt / a.steps * 1e3, 4),
+            "maps": "quantized-8bit"}
 
 
 def pmc_traffic(kernel, V, H, W):
