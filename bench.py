@@ -194,7 +194,7 @@ def main():
             "gpair_per_s_nominal": round(pairs_nominal / (t_search * 1e-3) / 1e9, 1),
         },
     }
-    if not a.no_cpu:
+    if not a.no_cpu and world == 1:      # the CPU leg runs on rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(a, scene, recs, my[0], ms)
     if not a.quantize and not a.no_secondary and world == 1:
         out["secondary_8bit_maps"] = secondary_quantized(a, dev, recs, cams, dev_chunks)
