@@ -89,14 +89,30 @@ __global__ __launch_bounds__(256) void mh_project_gather_kernel(MhViews vw, cons
     const int npts = min(MH_PG_TILE, N - n0);
     const int cnt = npts * P;
     const size_t obase = ((size_t)v * N + n0) * P;
-    for (int idx = tid; idx < cnt; idx += 256) {
-        const int nl = idx / P, p = idx - nl * P;
-        const int i = p / PATCH - HP, j = p - (p / PATCH) * PATCH - HP;
-        const int r = min(max(s_r[nl] + i, 0), H - 1);
-        const int c = min(max(s_c[nl] + j, 0), W - 1);
-        const float4 q = rec[(size_t)r * W + c];
-        if (ori_patch) reinterpret_cast<float2 *>(ori_patch)[obase + idx] = make_float2(q.x, q.y);
-        if (conf_patch) conf_patch[obase + idx] = mh_clampf(q.z, 1e-6f, 1.0f);
+    // 4 independent 16-B gathers in flight per lane before the first store: the kernel is bound by bytes in
+    // flight (Little's law at ~2 us loaded HBM latency), not by issue.
+    constexpr int UNR = 4;
+    for (int base = 0; base < cnt; base += 256 * UNR) {
+        float4 q[UNR];
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const int idx = base + k * 256 + tid;
+            if (idx < cnt) {
+                const int nl = idx / P, p = idx - nl * P;
+                const int i = p / PATCH - HP, j = p - (p / PATCH) * PATCH - HP;
+                const int r = min(max(s_r[nl] + i, 0), H - 1);
+                const int c = min(max(s_c[nl] + j, 0), W - 1);
+                q[k] = rec[(size_t)r * W + c];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const int idx = base + k * 256 + tid;
+            if (idx < cnt) {
+                if (ori_patch) reinterpret_cast<float2 *>(ori_patch)[obase + idx] = make_float2(q[k].x, q[k].y);
+                if (conf_patch) conf_patch[obase + idx] = mh_clampf(q[k].z, 1e-6f, 1.0f);
+            }
+        }
     }
 }
 
