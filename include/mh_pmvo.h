@@ -83,6 +83,18 @@ int mh_search_forward(mh_ctx *ctx, const float *points, int N, int patch, float 
                       float *min_loss, uint8_t *high_conf, float *best_sample, int32_t *best_rank,
                       int32_t *best_s, void *stream);
 
+/* ---- The same path without materialising the patch tensors (what PMVO.forward uses): mh_forward_prepare is
+ * the projection / visibility / centre-sample part of Compute_Visible_and_Ori (PMVO.py:346-376) fused with the
+ * tap-list preparation, straight from the packed maps (patches of views that fail the depth test are not even
+ * gathered); mh_topk_views then ranks the base views; mh_search_prepared runs the fused loss search on the
+ * prepared scratch.  Results are identical to mh_project_gather + mh_search_forward.  mask may be NULL. */
+int mh_forward_prepare(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, float *vis,
+                       float *ori, float *conf, float *mask, void *scratch, size_t scratch_bytes, void *stream);
+int mh_search_prepared(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank,
+                       int rank_step, const float *ori, const int32_t *base_idx, const float *base_val,
+                       const void *scratch, float *line_ori, float *min_loss, uint8_t *high_conf, float *best_sample,
+                       int32_t *best_rank, int32_t *best_s, void *stream);
+
 /* ---- compute_reproject_ori + compute_prj_loss with ONE given candidate per point: the core of
  * PMVO.refine (PMVO.py:86-90), next = point + ori*step_mul/step_div
  * (0.005 and 4 in the reference, applied in that order).  loss[N] (raw num/den, PMVO.py:199-204). */

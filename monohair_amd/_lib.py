@@ -27,6 +27,8 @@ _SIGS = {
     "mh_search_scratch_bytes": (csz, [vp, ci, ci]),
     "mh_search_forward": (ci, [vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, csz, vp, vp, vp, vp, vp,
                                vp, vp]),
+    "mh_forward_prepare": (ci, [vp, vp, ci, ci, cf, vp, vp, vp, vp, vp, csz, vp]),
+    "mh_search_prepared": (ci, [vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mh_refine_loss": (ci, [vp, vp, vp, cf, cf, ci, ci, cf, vp, vp, vp, vp, vp, vp]),
     "mh_filter_points": (ci, [vp, vp, ci, ci, cf, cf, vp, vp, vp, vp, vp]),
     "mh_medoid_dense": (ci, [vp, vp, ci, ci, vp, vp, vp]),

@@ -39,6 +39,8 @@ int mh_launch_project_gather(MhViews, const float *, int, int, float *, float *,
 int mh_launch_topk(const float *, const float *, int, int, int32_t *, float *, hipStream_t);
 int mh_launch_prep_taps(const float *, const float *, const float *, const float *, int, int, float, float4 *,
                         hipStream_t);
+int mh_launch_project_taps(MhViews, const float *, int, int, float, float *, float *, float *, float *, float4 *,
+                           hipStream_t);
 int mh_launch_search(MhViews, const float *, int, int, int, const float *, int, int, float, const float *,
                      const int32_t *, const float *, const float4 *, float *, float *, uint8_t *, float *, int32_t *,
                      int32_t *, int, hipStream_t);
@@ -220,6 +222,38 @@ extern "C" int mh_search_forward(mh_ctx *ctx, const float *points, int N, int pa
                                      conf_threshold, ori, base_idx, base_val, (const float4 *)scratch, line_ori,
                                      min_loss, high_conf, best_sample, best_rank, best_s, ctx->search_variant, st),
                     "mh_search_forward");
+}
+
+extern "C" int mh_forward_prepare(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold,
+                                  float *vis, float *ori, float *conf, float *mask, void *scratch,
+                                  size_t scratch_bytes, void *stream) {
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_forward_prepare: views not set");
+    if (N == 0) return MH_OK;
+    if (!points || !vis || !ori || !conf || !scratch || N < 0 || patch < 1 || !(patch & 1))
+        return fail(MH_ERR_ARG, "mh_forward_prepare: bad arguments");
+    if (scratch_bytes < mh_search_scratch_bytes(ctx, N, patch))
+        return fail(MH_ERR_ARG, "mh_forward_prepare: scratch too small");
+    return launched(mh_launch_project_taps(ctx->views(), points, N, patch, conf_threshold, vis, ori, conf, mask,
+                                           (float4 *)scratch, (hipStream_t)stream),
+                    "mh_forward_prepare");
+}
+
+extern "C" int mh_search_prepared(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank,
+                                  int rank_step, const float *ori, const int32_t *base_idx, const float *base_val,
+                                  const void *scratch, float *line_ori, float *min_loss, uint8_t *high_conf,
+                                  float *best_sample, int32_t *best_rank, int32_t *best_s, void *stream) {
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_search_prepared: views not set");
+    if (!ctx->offs) return fail(MH_ERR_STATE, "mh_search_prepared: depth offsets not set");
+    if (N == 0) return MH_OK;
+    if (!points || !ori || !base_idx || !base_val || !scratch || !line_ori || !min_loss || !high_conf || N < 0 ||
+        nrank < 1 || rank_step < 1 || (nrank - 1) * rank_step >= MH_TOPK)
+        return fail(MH_ERR_ARG, "mh_search_prepared: bad arguments");
+    if (ctx->V >= 256) return fail(MH_ERR_ARG, "mh_search_prepared: V >= 256 needs a third cascade level");
+    return launched(mh_launch_search(ctx->views(), ctx->offs, ctx->S, nrank, rank_step, points, N,
+                                     patch * patch + 1, conf_threshold, ori, base_idx, base_val,
+                                     (const float4 *)scratch, line_ori, min_loss, high_conf, best_sample, best_rank,
+                                     best_s, ctx->search_variant, (hipStream_t)stream),
+                    "mh_search_prepared");
 }
 
 extern "C" int mh_refine_loss(mh_ctx *ctx, const float *points, const float *dir, float step_mul, float step_div,

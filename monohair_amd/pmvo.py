@@ -140,14 +140,31 @@ class PMVO:
         self.Ori = torch.empty((V, N, 2), **f)
         self.Conf = torch.empty((V, N), **f)
         self.mask = torch.empty((V, N), **f)
-        self.Ori_patch = torch.empty((V, N, P, 2), **f)
-        self.Conf_patch = torch.empty((V, N, P), **f)
+        self._Ori_patch = torch.empty((V, N, P, 2), **f)
+        self._Conf_patch = torch.empty((V, N, P), **f)
         self._pixf = torch.empty((V, N, 2), **f)
         self._points = points
         _lib.check(self._L.mh_project_gather(self._ctx, _lib.ptr(points), N, self.patch_size, _lib.ptr(self.visible),
                                              _lib.ptr(self.Ori), _lib.ptr(self.Conf), _lib.ptr(self.mask),
-                                             _lib.ptr(self.Ori_patch), _lib.ptr(self.Conf_patch),
+                                             _lib.ptr(self._Ori_patch), _lib.ptr(self._Conf_patch),
                                              _lib.ptr(self._pixf), _lib.stream_ptr()), "mh_project_gather")
+
+    def _materialise_patches(self):
+        """forward() does not write the [V,N,P,..] patch tensors (its fused front end builds the search's tap
+        lists straight from the maps); they are produced on first access so the attribute surface of the
+        reference (PMVO.py:374-376) is kept."""
+        if getattr(self, "_Ori_patch", None) is None and getattr(self, "_points", None) is not None:
+            self.Compute_Visible_and_Ori(self._points)
+
+    @property
+    def Ori_patch(self):
+        self._materialise_patches()
+        return self._Ori_patch
+
+    @property
+    def Conf_patch(self):
+        self._materialise_patches()
+        return self._Conf_patch
 
     def Find_max_conf_from_visible_view(self):
         """PMVO.py:339-343 -> (base_view_index [20,N] int64, base_view_conf [20,N])."""
@@ -171,13 +188,32 @@ class PMVO:
             self._scratch[key] = buf
         return buf, need
 
-    def forward(self, points, base_view=None, extras=False):
+    def forward(self, points, base_view=None, extras=False, fused=True):
         """PMVO.py:39-78.  points: numpy [N,3].  Returns (points, line_ori [N,3], min_loss [N],
         high_conf [N] bool) on the device.  base_view=(idx [20,N], val [20,N]) injects a base-view ranking
-        (parity tests: torch.topk's tie order is unspecified)."""
-        self.Compute_Visible_and_Ori(points)
-        points = self._points
-        N = points.shape[0]
+        (parity tests: torch.topk's tie order is unspecified).  fused=False runs Compute_Visible_and_Ori and
+        the tap preparation as separate kernels through the materialised patch tensors (same results)."""
+        ranks = list(self.RANKS)
+        f = dict(dtype=torch.float32, device=self.device)
+        if fused:
+            points = self._dev_points(points)
+            V, N = self.num_view, points.shape[0]
+            self.visible = torch.empty((V, N), **f)
+            self.Ori = torch.empty((V, N, 2), **f)
+            self.Conf = torch.empty((V, N), **f)
+            self.mask = torch.empty((V, N), **f)
+            self._Ori_patch = self._Conf_patch = self._pixf = None
+            self._points = points
+            scratch, need = self._get_scratch(N)
+            _lib.check(self._L.mh_forward_prepare(self._ctx, _lib.ptr(points), N, self.patch_size,
+                                                  float(self.conf_threshold), _lib.ptr(self.visible),
+                                                  _lib.ptr(self.Ori), _lib.ptr(self.Conf), _lib.ptr(self.mask),
+                                                  _lib.ptr(scratch), need, _lib.stream_ptr()), "mh_forward_prepare")
+        else:
+            self.Compute_Visible_and_Ori(points)
+            points = self._points
+            N = points.shape[0]
+            scratch, need = self._get_scratch(N)
         if base_view is None:
             bidx, bval = self.Find_max_conf_from_visible_view()
         else:
@@ -185,21 +221,25 @@ class PMVO:
             bval = torch.as_tensor(base_view[1]).to(self.device).type(torch.float)
         bidx32 = bidx.to(torch.int32).contiguous()
         bval = bval.contiguous()
-        f = dict(dtype=torch.float32, device=self.device)
         line_ori = torch.empty((N, 3), **f)
         min_loss = torch.empty((N,), **f)
         hc = torch.empty((N,), dtype=torch.uint8, device=self.device)
         bs = torch.empty((N, 3), **f) if extras else None
         br = torch.empty((N,), dtype=torch.int32, device=self.device) if extras else None
         bi = torch.empty((N,), dtype=torch.int32, device=self.device) if extras else None
-        scratch, need = self._get_scratch(N)
-        ranks = list(self.RANKS)
-        _lib.check(self._L.mh_search_forward(
-            self._ctx, _lib.ptr(points), N, self.patch_size, float(self.conf_threshold), len(ranks),
-            ranks[1] - ranks[0], _lib.ptr(self.visible), _lib.ptr(self.Ori), _lib.ptr(self._pixf),
-            _lib.ptr(self.Ori_patch), _lib.ptr(self.Conf_patch), _lib.ptr(bidx32), _lib.ptr(bval),
-            _lib.ptr(scratch), need, _lib.ptr(line_ori), _lib.ptr(min_loss), _lib.ptr(hc), _lib.ptr(bs),
-            _lib.ptr(br), _lib.ptr(bi), _lib.stream_ptr()), "mh_search_forward")
+        if fused:
+            _lib.check(self._L.mh_search_prepared(
+                self._ctx, _lib.ptr(points), N, self.patch_size, float(self.conf_threshold), len(ranks),
+                ranks[1] - ranks[0], _lib.ptr(self.Ori), _lib.ptr(bidx32), _lib.ptr(bval), _lib.ptr(scratch),
+                _lib.ptr(line_ori), _lib.ptr(min_loss), _lib.ptr(hc), _lib.ptr(bs), _lib.ptr(br), _lib.ptr(bi),
+                _lib.stream_ptr()), "mh_search_prepared")
+        else:
+            _lib.check(self._L.mh_search_forward(
+                self._ctx, _lib.ptr(points), N, self.patch_size, float(self.conf_threshold), len(ranks),
+                ranks[1] - ranks[0], _lib.ptr(self.visible), _lib.ptr(self.Ori), _lib.ptr(self._pixf),
+                _lib.ptr(self._Ori_patch), _lib.ptr(self._Conf_patch), _lib.ptr(bidx32), _lib.ptr(bval),
+                _lib.ptr(scratch), need, _lib.ptr(line_ori), _lib.ptr(min_loss), _lib.ptr(hc), _lib.ptr(bs),
+                _lib.ptr(br), _lib.ptr(bi), _lib.stream_ptr()), "mh_search_forward")
         out = (points, line_ori, min_loss, hc.bool())
         if extras:
             return out + (dict(best_sample=bs, best_rank=br, best_s=bi, base_idx=bidx, base_val=bval),)

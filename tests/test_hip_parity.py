@@ -124,6 +124,22 @@ def test_forward_vs_reference_golden(case, depth_offsets):
     assert np.abs(ori[both] - z["fwd_ori"][both]).max() <= 1e-4
 
 
+def test_fused_and_unfused_front_ends_agree(case):
+    """forward(fused=True) (projection + tap lists straight from the maps, invisible views never gathered) and
+    forward(fused=False) (materialised patch tensors) are the same computation; the patch attributes appear lazily."""
+    meta, z, scene, views, pm = case
+    pts = z["points"]
+    _, o1, l1, h1 = pm.forward(pts, fused=True)
+    vis1, ori1, conf1, mask1 = pm.visible.clone(), pm.Ori.clone(), pm.Conf.clone(), pm.mask.clone()
+    lazy = pm.Ori_patch.clone()          # materialised on first access
+    _, o2, l2, h2 = pm.forward(pts, fused=False)
+    for a, b in ((o1, o2), (l1, l2)):
+        assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+    assert torch.equal(h1, h2)
+    assert torch.equal(vis1, pm.visible) and torch.equal(ori1, pm.Ori) and torch.equal(conf1, pm.Conf)
+    assert torch.equal(mask1, pm.mask) and torch.equal(lazy, pm.Ori_patch)
+
+
 def test_forward_own_ranking_runs_and_matches_oracle(case, depth_offsets):
     meta, z, scene, views, pm = case
     pts = z["points"]
