@@ -116,6 +116,11 @@ int mh_medoid_dense(mh_ctx *ctx, const float *ori, int G, int K, float *out, int
 int mh_medoid_segmented(mh_ctx *ctx, const float *ori, const int32_t *seg_start, int G, int max_group,
                         float *out, int32_t *out_index, void *stream);
 
+/* refine's in-place replacement rule (PMVO.py:631-636): ori[n] <- center[n] where |cos(center[n], ori[n])| < threshold
+ * (0.95 in the reference), cos evaluated as torch.cosine_similarity does on [N,3] fp32 tensors. */
+int mh_replace_dissimilar(mh_ctx *ctx, const float *center, float *ori /*in/out [N,3]*/, float threshold, int N,
+                          void *stream);
+
 /* ---- K1+K2: calOrientationGabor.forward with iter=1 (preprocess_capture_data/GaborFilter.py:29-145):
  * 180 real Gabor kernels 17x17 (sigma 1.8/2.4, lambda 4), |response| argmax -> orientation index,
  * response-curve variance -> confidence normalised by the image maximum.

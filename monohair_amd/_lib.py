@@ -33,6 +33,7 @@ _SIGS = {
     "mh_filter_points": (ci, [vp, vp, ci, ci, cf, cf, vp, vp, vp, vp, vp]),
     "mh_medoid_dense": (ci, [vp, vp, ci, ci, vp, vp, vp]),
     "mh_medoid_segmented": (ci, [vp, vp, vp, ci, ci, vp, vp, vp]),
+    "mh_replace_dissimilar": (ci, [vp, vp, vp, cf, ci, vp]),
     "mh_gabor_bank": (ci, [vp, vp, ci, ci, vp, vp, vp, vp]),
     "mh_gabor_set_bank": (ci, [vp, vp]),
 }

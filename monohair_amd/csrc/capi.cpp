@@ -53,6 +53,7 @@ int mh_launch_medoid_segmented(const float *, const int32_t *, int, int, float *
 int mh_launch_gabor_bank(const float *, const float *, int, int, int32_t *, float *, float *, unsigned int *,
                          hipStream_t);
 int mh_launch_gabor_build(float *, hipStream_t);
+int mh_launch_replace_dissimilar(const float *, float *, float, int, hipStream_t);
 }
 
 static thread_local char g_err[512] = "";
@@ -296,6 +297,14 @@ extern "C" int mh_medoid_segmented(mh_ctx *ctx, const float *ori, const int32_t 
     if (G == 0) return MH_OK;
     return launched(mh_launch_medoid_segmented(ori, seg_start, G, max_group, out, out_index, (hipStream_t)stream),
                     "mh_medoid_segmented");
+}
+
+extern "C" int mh_replace_dissimilar(mh_ctx *ctx, const float *center, float *ori, float threshold, int N,
+                                     void *stream) {
+    if (N == 0) return MH_OK;
+    if (!ctx || !center || !ori || N < 0) return fail(MH_ERR_ARG, "mh_replace_dissimilar: bad arguments");
+    return launched(mh_launch_replace_dissimilar(center, ori, threshold, N, (hipStream_t)stream),
+                    "mh_replace_dissimilar");
 }
 
 static int gabor_alloc(mh_ctx *ctx) {

@@ -82,6 +82,45 @@ __global__ __launch_bounds__(256) void mh_medoid_kernel(const float *__restrict_
     }
 }
 
+// refine's replacement rule (PMVO.py:631-636): ori[n] <- center[n] where max(cos(center,ori), cos(center,-ori))
+// < thr, with cos as torch.cosine_similarity evaluates it on [N,3] fp32 tensors (norms = sqrt of an fma chain,
+// clamped at 1e-8; products rounded separately, added left to right; the second cosine is the exact negation).
+__global__ __launch_bounds__(256) void mh_replace_dissimilar_kernel(const float *__restrict__ center,
+                                                                    float *__restrict__ ori, float thr, int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float c[3], o[3], cu[3], ou[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        c[k] = center[3 * n + k];
+        o[k] = ori[3 * n + k];
+    }
+    float sc = c[0] * c[0];
+    sc = mh_fma(c[1], c[1], sc);
+    sc = mh_fma(c[2], c[2], sc);
+    float so = o[0] * o[0];
+    so = mh_fma(o[1], o[1], so);
+    so = mh_fma(o[2], o[2], so);
+    float nc = __builtin_sqrtf(sc), no = __builtin_sqrtf(so);
+    nc = (nc < 1e-8f) ? 1e-8f : nc;
+    no = (no < 1e-8f) ? 1e-8f : no;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        cu[k] = c[k] / nc;
+        ou[k] = o[k] / no;
+    }
+    const float cs = (cu[0] * ou[0] + cu[1] * ou[1]) + cu[2] * ou[2];
+    if (__builtin_fabsf(cs) < thr) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ori[3 * n + k] = c[k];
+    }
+}
+
+extern "C" int mh_launch_replace_dissimilar(const float *center, float *ori, float thr, int N, hipStream_t st) {
+    hipLaunchKernelGGL(mh_replace_dissimilar_kernel, dim3((N + 255) / 256), dim3(256), 0, st, center, ori, thr, N);
+    return (int)hipGetLastError();
+}
+
 extern "C" int mh_launch_medoid_dense(const float *ori, int G, int K, float *out, int32_t *out_index,
                                       hipStream_t st) {
     if (K > MH_MEDOID_MAXK) return -1;

@@ -260,14 +260,29 @@ class PMVO:
                                           _lib.ptr(hc), _lib.stream_ptr()), "mh_refine_loss")
         return loss, hc.bool()
 
-    def refine(self, points, ori):
-        """PMVO.py:81-93: loss of a given direction; -1 where filter_head_points fires."""
+    def refine(self, points, ori, head_top=None):
+        """PMVO.py:81-93: loss of a given direction; -1 where filter_head_points fires.  head_top: optional
+        precomputed host part of filter_head_points (head_top_mask) so that the call does not synchronise."""
         self.Compute_Visible_and_Ori(points)
         points = self._points
-        filter_index = self.filter_head_points(points, self.visible_threshold)
+        filter_index = self.filter_head_points(points, self.visible_threshold, head_top=head_top)
         loss, _ = self.prj_loss_of(points, ori)
-        loss[filter_index] = -1
-        return loss
+        return torch.where(filter_index, torch.full_like(loss, -1.0), loss)
+
+    def head_top_mask(self, points_numpy):
+        """The host half of filter_head_points (PMVO.py:98-107): within 4 cm of the scalp and more than 1 cm below
+        its top (scipy KDTree in float64, as the reference).  Depends on the points only."""
+        if self.scalp_tree is None:
+            raise _lib.MhError("filter_head_points needs set_head(bust_tree, scalp_tree, scalp_max)")
+        pts = np.asarray(points_numpy, dtype=np.float32)
+        nei_scalp_dist, _ = self.scalp_tree.query(pts, k=1, workers=-1)
+        return np.logical_and(nei_scalp_dist < 0.04, pts[:, 2] < self.scalp_max[2] - 0.01)
+
+    def replace_dissimilar(self, center, ori, threshold=0.95):
+        """ori[n] <- center[n] where |cos(center, ori)| < threshold, in place on the device (PMVO.py:631-636)."""
+        N = ori.shape[0]
+        _lib.check(self._L.mh_replace_dissimilar(self._ctx, _lib.ptr(center), _lib.ptr(ori), float(threshold), N,
+                                                 _lib.stream_ptr()), "mh_replace_dissimilar")
 
     def _votes(self, points, want, visible_threshold=None):
         points = self._dev_points(points)
@@ -290,16 +305,13 @@ class PMVO:
         _, (_, _, unv, _) = self._votes(points, (False, False, True, False))
         return unv
 
-    def filter_head_points(self, points, visible_threshold):
-        """PMVO.py:96-144: mask vote on the GPU; the two KDTree queries (scipy, float64) stay on the host
-        exactly as in the reference."""
+    def filter_head_points(self, points, visible_threshold, head_top=None):
+        """PMVO.py:96-144: mask vote on the GPU; the scalp KDTree query (scipy, float64) stays on the host exactly
+        as in the reference (the bust query's result is unused there, :99).  head_top: optional precomputed
+        head_top_mask of the same points (bool tensor on the device)."""
         pts, (_, _, _, head) = self._votes(points, (False, False, False, True), visible_threshold)
-        if self.scalp_tree is None:
-            raise _lib.MhError("filter_head_points needs set_head(bust_tree, scalp_tree, scalp_max)")
-        points_numpy = pts.clone().cpu().numpy()
-        nei_scalp_dist, _ = self.scalp_tree.query(points_numpy, k=1)
-        head_top = np.logical_and(nei_scalp_dist < 0.04, points_numpy[:, 2] < self.scalp_max[2] - 0.01)
-        head_top = torch.from_numpy(head_top).to(self.device)
+        if head_top is None:
+            head_top = torch.from_numpy(self.head_top_mask(pts.cpu().numpy())).to(self.device)
         return torch.logical_and(head, ~head_top)
 
 
@@ -397,29 +409,27 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     is_root = mdist.rank() == 0
     if not genrate_ori_only:
         print("filter nosiy points...")
-        points_tree = KDTree(data=points)
+        # Neighbour indices and the head-top mask depend on the points only: ONE host query for all chunks (all
+        # cores), then the sequentially dependent smoothing loop (chunk k+1 reads the orientations chunk k wrote,
+        # PMVO.py:614,640) runs entirely on the device, stream-ordered, without a host round trip per chunk.
+        n_all = points.shape[0]
+        index_all = torch.from_numpy(_knn(KDTree(data=points), points, 100, n_all)).to(device)
+        head_top_all = torch.from_numpy(pmvo.head_top_mask(points)).to(device)
+        pts_dev = torch.from_numpy(points).to(device).type(torch.float)
+        ori_dev = torch.from_numpy(ori).to(device).type(torch.float).contiguous()
+        loss_dev = torch.from_numpy(loss).to(device).type(torch.float).contiguous()
         sub_num = 5000
-        step = points.shape[0] // sub_num + 1
+        step = n_all // sub_num + 1
         for i in range(step):
-            lo, hi = i * sub_num, min((i + 1) * sub_num, points.shape[0])
+            lo, hi = i * sub_num, min((i + 1) * sub_num, n_all)
             if hi <= lo:
                 continue
-            sub_points, sub_ori = points[lo:hi], ori[lo:hi]
-            index = _knn(points_tree, sub_points, 100, points.shape[0])
-            Neighbor_ori = torch.from_numpy(ori[index]).to(device)
-            center_ori = U.compute_points_similarity(Neighbor_ori)
-            update_loss = pmvo.refine(torch.from_numpy(sub_points).to(device), center_ori)
-            # replace where |cos(center, ori)| < 0.95 (PMVO.py:631-636): evaluated with the CPU torch ops the
-            # reference's CPU path uses
-            c_cpu, s_cpu = center_ori.cpu(), torch.from_numpy(sub_ori)
-            similar = torch.maximum(torch.cosine_similarity(c_cpu, s_cpu, dim=-1),
-                                    torch.cosine_similarity(c_cpu, -s_cpu, dim=-1))
-            rep = torch.lt(similar, 0.95)
-            s_cpu[rep] = c_cpu[rep]
-            sub_loss = update_loss.cpu()
-            sub_loss[sub_loss == -1] = 0.5
-            ori[lo:hi] = s_cpu.numpy()
-            loss[lo:hi] = sub_loss.numpy()
+            center_ori = U.compute_points_similarity(ori_dev[index_all[lo:hi]])
+            update_loss = pmvo.refine(pts_dev[lo:hi], center_ori, head_top=head_top_all[lo:hi])
+            pmvo.replace_dissimilar(center_ori, ori_dev[lo:hi], 0.95)       # in place (a contiguous row slice)
+            loss_dev[lo:hi] = torch.where(update_loss == -1, torch.full_like(update_loss, 0.5), update_loss)
+        ori[:] = ori_dev.cpu().numpy()
+        loss[:] = loss_dev.cpu().numpy()
         if is_root:
             os.makedirs(args.output_path + "/refine", exist_ok=True)
             np.save(args.output_path + "/refine/select_p.npy", points)
@@ -440,16 +450,21 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     step = filter_unvisible_points.shape[0] // sub_num + 1
     f_ori, f_pts = [], []
     print("compute points orientation near the surface... ")
-    for i in range(step):
-        sub = filter_unvisible_points[i * sub_num:min((i + 1) * sub_num, filter_unvisible_points.shape[0])]
-        if len(sub) == 0 or len(select_points) == 0:
-            continue
-        index = _knn(points_tree, sub, 100, select_points.shape[0])
-        sub_dev = torch.from_numpy(sub).type(torch.float).to(device)
-        filter_index = pmvo.filter_head_points(sub_dev, args.PMVO.visible_threshold)
-        center_ori = U.compute_points_similarity(torch.from_numpy(select_ori[index]).to(device))
-        f_ori.append(center_ori[~filter_index])
-        f_pts.append(sub_dev[~filter_index])
+    if len(select_points) and len(filter_unvisible_points):
+        fu = np.ascontiguousarray(filter_unvisible_points)
+        index_all = torch.from_numpy(_knn(points_tree, fu, 100, select_points.shape[0])).to(device)
+        head_top_all = torch.from_numpy(pmvo.head_top_mask(fu.astype(np.float32))).to(device)
+        fu_dev = torch.from_numpy(fu).type(torch.float).to(device)
+        sel_ori_dev = torch.from_numpy(select_ori).to(device)
+        for i in range(step):
+            lo, hi = i * sub_num, min((i + 1) * sub_num, fu.shape[0])
+            if hi <= lo:
+                continue
+            filter_index = pmvo.filter_head_points(fu_dev[lo:hi], args.PMVO.visible_threshold,
+                                                   head_top=head_top_all[lo:hi])
+            center_ori = U.compute_points_similarity(sel_ori_dev[index_all[lo:hi]])
+            f_ori.append(center_ori[~filter_index])
+            f_pts.append(fu_dev[lo:hi][~filter_index])
     if f_ori:
         filter_unvisible_ori = torch.cat(f_ori, 0).cpu().numpy()
         select_filter_unvisible_points = torch.cat(f_pts, 0).cpu().numpy()
