@@ -132,6 +132,22 @@ int mh_gabor_bank(mh_ctx *ctx, const float *image, int H, int W, int32_t *orient
  * functions bit for bit. */
 int mh_gabor_set_bank(mh_ctx *ctx, const float *bank_host);
 
+/* ---- strand tracing on the fitted volume (HairGrow.py).
+ * mh_volume_pack: occ[Z,H,W] + ori[Z,H,W,3] (the .mat readers' layout, Utils/PMVO_utils.py:86-113) -> 16-byte voxels
+ *   {ori_x, -ori_y, -ori_z, occ} (HairGrowing.__init__, HairGrow.py:41-55); vox: W*H*Z*16 bytes.
+ * mh_trace_seeds: HairGrowing.trace (:59-149) for n already-jittered seeds, WITHOUT the flag gate: strand i occupies
+ *   out[i][first[i] .. first[i]+len[i]) of a 513-point row.
+ * mh_trace_scalp: HairGrowing.traceFromScalp (:154-223): rows of 257 points, len 0 where the reference returns None.
+ * mh_strands_accept: the sequential flag gate of GenerateGuideStrandFromScalp (:226-265) / randomlyGenerateSegments
+ *   (:269-299) replayed over the finished traces -- HOST pointers, runs on the calling thread. */
+int mh_volume_pack(mh_ctx *ctx, const float *occ, const float *ori, int W, int H, int Z, void *vox, void *stream);
+int mh_trace_seeds(mh_ctx *ctx, const void *vox, int W, int H, int Z, const float *seeds, int n, float thr_dot,
+                   float *out, int32_t *first, int32_t *len, void *stream);
+int mh_trace_scalp(mh_ctx *ctx, const void *vox, int W, int H, int Z, const float *seeds, const float *normals, int n,
+                   float thr_dot, float *out, int32_t *len, void *stream);
+int mh_strands_accept(int W, int H, int Z, float *flag, const float *pts, const int32_t *first, const int32_t *len,
+                      int stride, const float *seeds, int n, int mode, uint8_t *accepted);
+
 /* Tuning knobs (e.g. "search_variant": threads per point in the search kernel; 0 = default). */
 int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value);
 

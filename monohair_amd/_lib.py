@@ -34,6 +34,10 @@ _SIGS = {
     "mh_medoid_dense": (ci, [vp, vp, ci, ci, vp, vp, vp]),
     "mh_medoid_segmented": (ci, [vp, vp, vp, ci, ci, vp, vp, vp]),
     "mh_replace_dissimilar": (ci, [vp, vp, vp, cf, ci, vp]),
+    "mh_volume_pack": (ci, [vp, vp, vp, ci, ci, ci, vp, vp]),
+    "mh_trace_seeds": (ci, [vp, vp, ci, ci, ci, vp, ci, cf, vp, vp, vp, vp]),
+    "mh_trace_scalp": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, cf, vp, vp, vp]),
+    "mh_strands_accept": (ci, [ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, vp]),
     "mh_gabor_bank": (ci, [vp, vp, ci, ci, vp, vp, vp, vp]),
     "mh_gabor_set_bank": (ci, [vp, vp]),
 }

@@ -54,6 +54,11 @@ int mh_launch_gabor_bank(const float *, const float *, int, int, int32_t *, floa
                          hipStream_t);
 int mh_launch_gabor_build(float *, hipStream_t);
 int mh_launch_replace_dissimilar(const float *, float *, float, int, hipStream_t);
+int mh_launch_pack_volume(const float *, const float *, size_t, float4 *, hipStream_t);
+int mh_launch_trace_seeds(const float4 *, int, int, int, const float *, int, float, float *, int32_t *, int32_t *,
+                          hipStream_t);
+int mh_launch_trace_scalp(const float4 *, int, int, int, const float *, const float *, int, float, float *, int32_t *,
+                          hipStream_t);
 }
 
 static thread_local char g_err[512] = "";
@@ -305,6 +310,72 @@ extern "C" int mh_replace_dissimilar(mh_ctx *ctx, const float *center, float *or
     if (!ctx || !center || !ori || N < 0) return fail(MH_ERR_ARG, "mh_replace_dissimilar: bad arguments");
     return launched(mh_launch_replace_dissimilar(center, ori, threshold, N, (hipStream_t)stream),
                     "mh_replace_dissimilar");
+}
+
+// ---- strand tracing on the fitted volume (HairGrow.py:59-299) ------------------------------------------------
+extern "C" int mh_volume_pack(mh_ctx *ctx, const float *occ, const float *ori, int W, int H, int Z, void *vox,
+                              void *stream) {
+    if (!ctx || !occ || !ori || !vox || W < 1 || H < 1 || Z < 1) return fail(MH_ERR_ARG, "mh_volume_pack: bad arguments");
+    return launched(mh_launch_pack_volume(occ, ori, (size_t)W * H * Z, (float4 *)vox, (hipStream_t)stream),
+                    "mh_volume_pack");
+}
+
+extern "C" int mh_trace_seeds(mh_ctx *ctx, const void *vox, int W, int H, int Z, const float *seeds, int n,
+                              float thr_dot, float *out, int32_t *first, int32_t *len, void *stream) {
+    if (n == 0) return MH_OK;
+    if (!ctx || !vox || !seeds || !out || !first || !len || n < 0) return fail(MH_ERR_ARG, "mh_trace_seeds: bad arguments");
+    return launched(mh_launch_trace_seeds((const float4 *)vox, W, H, Z, seeds, n, thr_dot, out, first, len,
+                                          (hipStream_t)stream),
+                    "mh_trace_seeds");
+}
+
+extern "C" int mh_trace_scalp(mh_ctx *ctx, const void *vox, int W, int H, int Z, const float *seeds,
+                              const float *normals, int n, float thr_dot, float *out, int32_t *len, void *stream) {
+    if (n == 0) return MH_OK;
+    if (!ctx || !vox || !seeds || !normals || !out || !len || n < 0)
+        return fail(MH_ERR_ARG, "mh_trace_scalp: bad arguments");
+    return launched(mh_launch_trace_scalp((const float4 *)vox, W, H, Z, seeds, normals, n, thr_dot, out, len,
+                                          (hipStream_t)stream),
+                    "mh_trace_scalp");
+}
+
+// The sequential `flag` gate (HairGrow.py:72,144,247,260,292), replayed on the HOST over finished traces: all
+// pointers are host pointers.  mode 0: voxel seeds (skip if flag[seed voxel] >= 3 or fewer than 5 points; an accepted
+// strand adds 1 to every distinct voxel it touches); mode 1: scalp roots (kept when len > 0; their voxels are set to 1).
+extern "C" int mh_strands_accept(int W, int H, int Z, float *flag, const float *pts, const int32_t *first,
+                                 const int32_t *len, int stride, const float *seeds, int n, int mode,
+                                 uint8_t *accepted) {
+    if (!flag || !pts || !first || !len || !seeds || !accepted || n < 0 || stride < 1)
+        return fail(MH_ERR_ARG, "mh_strands_accept: bad arguments");
+    const size_t nvox = (size_t)W * H * Z;
+    int32_t *stamp = new (std::nothrow) int32_t[nvox];
+    if (!stamp) return fail(MH_ERR_NOMEM, "mh_strands_accept: out of host memory");
+    memset(stamp, 0xff, sizeof(int32_t) * nvox);
+    auto clampi = [](int x, int hi) { return x < 0 ? 0 : (x > hi ? hi : x); };
+    for (int i = 0; i < n; ++i) {
+        accepted[i] = 0;
+        if (mode == 0) {
+            const float *s = seeds + 3 * (size_t)i;
+            const size_t q = ((size_t)clampi((int)s[2], Z - 1) * H + clampi((int)s[1], H - 1)) * W + clampi((int)s[0], W - 1);
+            if (flag[q] >= 3.0f || len[i] < 5) continue;
+        } else if (len[i] <= 0) {
+            continue;
+        }
+        accepted[i] = 1;
+        const float *p = pts + ((size_t)i * stride + first[i]) * 3;
+        for (int k = 0; k < len[i]; ++k) {
+            const size_t q = ((size_t)clampi((int)p[3 * k + 2], Z - 1) * H + clampi((int)p[3 * k + 1], H - 1)) * W +
+                             clampi((int)p[3 * k], W - 1);
+            if (mode == 1) {
+                flag[q] = 1.0f;
+            } else if (stamp[q] != i) {
+                stamp[q] = i;
+                flag[q] += 1.0f;
+            }
+        }
+    }
+    delete[] stamp;
+    return MH_OK;
 }
 
 static int gabor_alloc(mh_ctx *ctx) {

@@ -289,3 +289,85 @@ def gabor_bank(bank, img):
     var = np.empty((H, W), np.float32)
     lib().orc_gabor_bank(_p(bank), _p(img), H, W, _p(orient, c_i), _p(conf), _p(var))
     return orient, conf, var
+
+
+# ------------------------------------------------------------------------------------------- strand tracing
+class _Volume(ctypes.Structure):
+    _fields_ = [("W", ctypes.c_int), ("H", ctypes.c_int), ("Z", ctypes.c_int), ("vox", c_f)]
+
+
+class Volume:
+    """vox[Z,H,W,4] = (ori_x, ori_y, ori_z, occ) as HairGrowing.__init__ holds it (HairGrow.py:41-55: ori[1:] negated)."""
+
+    def __init__(self, occ_zyx, ori_zyx3):
+        occ = np.asarray(occ_zyx, np.float32)
+        ori = np.asarray(ori_zyx3, np.float32).copy()
+        ori[..., 1:] *= -1
+        self.vox = np.ascontiguousarray(np.concatenate([ori, occ[..., None]], -1), np.float32)
+        self.Z, self.H, self.W = occ.shape
+        self.c = _Volume(self.W, self.H, self.Z, _p(self.vox))
+
+
+def trace_seeds(vol, seeds, thr):
+    seeds = np.ascontiguousarray(seeds, np.float32)
+    n = len(seeds)
+    out = np.zeros((n, 513, 3), np.float32)
+    first = np.zeros(n, np.int32)
+    ln = np.zeros(n, np.int32)
+    lib().orc_trace_seeds(ctypes.byref(vol.c), _p(seeds), n, ctypes.c_float(thr), _p(out), _p(first, c_i), _p(ln, c_i))
+    return out, first, ln
+
+
+def trace_scalp(vol, seeds, normals, thr):
+    seeds = np.ascontiguousarray(seeds, np.float32)
+    normals = np.ascontiguousarray(normals, np.float32)
+    n = len(seeds)
+    out = np.zeros((n, 257, 3), np.float32)
+    ln = np.zeros(n, np.int32)
+    lib().orc_trace_scalp(ctypes.byref(vol.c), _p(seeds), _p(normals), n, ctypes.c_float(thr), _p(out), _p(ln, c_i))
+    return out, ln
+
+
+def accept_strands(vol, flag, pts, first, ln, seeds, mode):
+    n, stride = pts.shape[0], pts.shape[1]
+    acc = np.zeros(n, np.uint8)
+    seeds = np.ascontiguousarray(seeds, np.float32)
+    lib().orc_accept_strands(vol.W, vol.H, vol.Z, _p(flag), _p(pts), _p(first, c_i), _p(ln, c_i), stride, _p(seeds), n,
+                             mode, _p(acc, c_u8))
+    return acc.astype(bool)
+
+
+def voxel_seed_rounds(vol, flag, thr, jitter, rounds):
+    """`rounds` passes of trace() over the occupied voxels (HairGrow.py:254-262 / :286-294).  The seed tensor is
+    shifted IN PLACE by every call (:62-63: += 0.5, += rand*0.5), so the shifts accumulate from round to round.
+    jitter: [rounds*n_occ, 3] uniform draws in the order the reference consumes them.  Mutates flag."""
+    occ_idx = np.argwhere(vol.vox[..., 3] != 0)[:, ::-1].astype(np.float32)      # (x,y,z), z-major order (torch.nonzero)
+    n = len(occ_idx)
+    seeds_all, pos = [], occ_idx.copy()
+    for rnd in range(rounds):
+        pos = (pos + np.float32(0.5)).astype(np.float32)
+        pos = (pos + (jitter[rnd * n:(rnd + 1) * n].astype(np.float32) * np.float32(0.5)).astype(np.float32)).astype(
+            np.float32)
+        seeds_all.append(pos.copy())
+    seeds_all = np.concatenate(seeds_all, 0)
+    tp, tf, tl = trace_seeds(vol, seeds_all, thr)
+    acc = accept_strands(vol, flag, tp, tf, tl, seeds_all, 0)
+    return [tp[i, tf[i]:tf[i] + tl[i]].copy() for i in np.flatnonzero(acc)]
+
+
+def generate_guide_strands(vol, scalp_points, scalp_normals, thr, jitter):
+    """GenerateGuideStrandFromScalp (HairGrow.py:226-265): roots traced from the scalp, then two rounds of
+    voxel-seeded tracing gated by the flag volume.  Returns (strands in voxel space, num_root, flag)."""
+    flag = np.zeros((vol.Z, vol.H, vol.W), np.float32)
+    sp, sl = trace_scalp(vol, scalp_points, scalp_normals, thr)
+    acc = accept_strands(vol, flag, sp, np.zeros(len(sl), np.int32), sl, scalp_points, 1)
+    strands = [sp[i, :sl[i]].copy() for i in np.flatnonzero(acc)]
+    num_root = len(strands)
+    strands += voxel_seed_rounds(vol, flag, thr, jitter, 2)
+    return strands, num_root, flag
+
+
+def randomly_generate_segments(vol, thr, jitter):
+    """randomlyGenerateSegments (HairGrow.py:269-299): three rounds of voxel-seeded tracing."""
+    flag = np.zeros((vol.Z, vol.H, vol.W), np.float32)
+    return voxel_seed_rounds(vol, flag, thr, jitter, 3), flag

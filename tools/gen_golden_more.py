@@ -157,12 +157,76 @@ def gen_e2e(R):
           (len(points), int(surface_index.sum()), int(filter_index.sum()), len(nz)))
 
 
+def hair_volume(G=(40, 40, 36), R=11.0, seed=0):
+    """A small synthetic fitted volume in the reference's array layout: occ [X,Y,Z], ori [X,Y,Z,3] (unit meridian
+    tangents + noise on a spherical shell, as refine() would write them before the .mat layout transform)."""
+    rng = np.random.default_rng(seed)
+    x, y, z = np.meshgrid(*[np.arange(g) for g in G], indexing="ij")
+    c = np.array([G[0] / 2, G[1] / 2, G[2] / 2])
+    p = np.stack([x - c[0], y - c[1], z - c[2]], -1).astype(np.float64)
+    r = np.linalg.norm(p, axis=-1)
+    shell = np.abs(r - R) <= 1.0
+    n = p / np.maximum(r[..., None], 1e-9)
+    t = -np.array([0, 1.0, 0]) + n[..., 1:2] * n
+    t = t / np.maximum(np.linalg.norm(t, axis=-1, keepdims=True), 1e-9)
+    t = t + 0.12 * rng.normal(size=t.shape)
+    t = t / np.linalg.norm(t, axis=-1, keepdims=True)
+    occ = shell.astype(np.float64)
+    ori = np.where(shell[..., None], t, 0.0)
+    drop = rng.random(G) < 0.03          # a few occupied voxels without orientation / holes in the occupancy
+    ori[drop] = 0
+    occ[rng.random(G) < 0.01] = 0
+    return occ, ori
+
+
+def gen_hairgrow(R_):
+    """HairGrowing.GenerateGuideStrandFromScalp / randomlyGenerateSegments (HairGrow.py:59-299) run by the reference."""
+    import scipy.io
+    import HairGrow
+
+    G = (40, 40, 36)
+    occ, ori = hair_volume(G)
+    tmp = tempfile.mkdtemp(prefix="mh_hg_")
+    o = ori.transpose((0, 1, 3, 2)).reshape(G[0], G[1], G[2] * 3).transpose((1, 0, 2))
+    scipy.io.savemat(os.path.join(tmp, "Ori3D.mat"), {"Ori": o})
+    scipy.io.savemat(os.path.join(tmp, "Occ3D.mat"), {"Occ": occ.transpose((1, 0, 2))})
+    rng = np.random.default_rng(3)
+    nrm = rng.normal(size=(400, 3))
+    nrm = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    nrm[:, 1] = -np.abs(nrm[:, 1]) * 0.5                       # mostly pointing sideways / "up" in voxel space
+    nrm = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    # reader layout is [Z,Y,X]: positions are (x,y,z) voxel coordinates of THAT array
+    centre = np.array([G[0] / 2, G[1] / 2, G[2] / 2])
+    pts = (centre + nrm * 5.0 + rng.normal(0, 0.3, size=(400, 3))).astype(np.float32)
+    nrm = nrm.astype(np.float32)
+    out = dict(occ=occ.astype(np.float32), ori=ori.astype(np.float32), scalp_points=pts, scalp_normals=nrm,
+               thr=np.float32(0.8))
+    for name in ("guide", "random"):
+        solver = HairGrow.HairGrowing(os.path.join(tmp, "Occ3D.mat"), os.path.join(tmp, "Ori3D.mat"), device="cpu")
+        torch.manual_seed(77)
+        if name == "guide":
+            strands, num_root = solver.GenerateGuideStrandFromScalp(torch.from_numpy(pts.copy()),
+                                                                    torch.from_numpy(nrm.copy()), None, 0.8)
+            out["guide_num_root"] = np.int32(num_root)
+        else:
+            strands = solver.randomlyGenerateSegments(0.8)
+        out[name + "_len"] = np.array([s.shape[0] for s in strands], np.int32)
+        out[name + "_pts"] = torch.cat(strands, 0).numpy()
+        print(name, "strands:", len(strands), "points:", out[name + "_pts"].shape[0])
+    out["vol_occ_zyx"] = solver.occ[0].numpy()
+    shutil.rmtree(tmp)
+    np.savez_compressed(os.path.join(OUT, "hairgrow.npz"), **out)
+    print("hairgrow written")
+
+
 def main(only=None):
     os.makedirs(OUT, exist_ok=True)
     cwd = os.getcwd()
     os.chdir("/tmp")
-    if only in (None, "consensus", "e2e"):
+    if only in (None, "consensus", "e2e", "hairgrow"):
         R = import_reference(gabor=False)
+        if only in (None, "hairgrow"):
+            gen_hairgrow(R)
         if only in (None, "consensus"):
             gen_consensus(R)
         if only in (None, "e2e"):

@@ -39,6 +39,12 @@ def import_reference(gabor=False):
         ident = lambda self, *a, **k: self
         torch.Tensor.cuda = ident
         torch.nn.Module.cuda = ident
+    # extra stand-ins needed only to IMPORT HairGrow.py / Utils/Utils.py (never called on the paths we run)
+    o3 = sys.modules["open3d"]
+    o3.core = _stub("open3d.core")
+    tm = sys.modules["trimesh"]
+    tmv = _stub("trimesh.visual", texture=None, TextureVisuals=None)
+    tm.visual = tmv
     if REF not in sys.path:
         sys.path.insert(0, REF)
     import PMVO as ref_pmvo  # noqa
