@@ -68,6 +68,25 @@ def map_chunks(chunks, fn, device, empty):
     return out
 
 
+def all_gather_views(local, n_views, shape, dtype, device):
+    """Per-view tensors computed by their owning rank (view i belongs to rank i % world, `local` in ascending view
+    order) -> [n_views, *shape] on every rank with ONE all_gather (SURVEY.md §8e "map distribution")."""
+    d = _dist()
+    w, r = world(), rank()
+    if not d:
+        return torch.stack(local, 0) if local else torch.empty((0,) + tuple(shape), dtype=dtype, device=device)
+    cap = (n_views + w - 1) // w
+    buf = torch.zeros((cap,) + tuple(shape), dtype=dtype, device=device)
+    for j, t in enumerate(local):
+        buf[j] = t
+    gathered = [torch.empty_like(buf) for _ in range(w)]
+    d.all_gather(gathered, buf)
+    out = torch.empty((n_views,) + tuple(shape), dtype=dtype, device=device)
+    for i in range(n_views):
+        out[i] = gathered[owner(i, w)][i // w]
+    return out
+
+
 def voxel_owner_mask(x, n_ranks, r, grid_x):
     """Spatial partition of the volume into n_ranks slabs along x: rank r owns x in [r*G/n, (r+1)*G/n)."""
     lo = (grid_x * r) // n_ranks

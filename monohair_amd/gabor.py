@@ -112,6 +112,95 @@ def difference_of_gaussians(image, low_sigma, high_sigma):
     return lo - hi
 
 
+def _gaussian_kernel1d(sigma, truncate=4.0):
+    """scipy.ndimage's 1-D Gaussian weights (float64): radius = int(truncate*sigma + 0.5), normalised."""
+    radius = int(truncate * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return phi / phi.sum(), radius
+
+
+def _correlate1d_nearest(x, w, radius, axis):
+    """scipy.ndimage.correlate1d of a symmetric kernel, mode='nearest', in its accumulation order
+    (ni_filters.c: tmp = x[l]*w[c]; for j = -r..-1: tmp += (x[l+j] + x[l-j]) * w[j+r]) -- float64 torch ops."""
+    n = x.shape[axis]
+    idx = torch.arange(-radius, n + radius, device=x.device).clamp(0, n - 1)
+    xp = x.index_select(axis, idx)                       # 'nearest' padding
+    centre = xp.narrow(axis, radius, n)
+    acc = centre * float(w[radius])
+    for j in range(-radius, 0):
+        acc = acc + (xp.narrow(axis, radius + j, n) + xp.narrow(axis, radius - j, n)) * float(w[j + radius])
+    return acc
+
+
+def difference_of_gaussians_device(image, low_sigma, high_sigma, device):
+    """difference_of_gaussians on the GPU in float64 with scipy's operation order (separable passes along axis 0
+    then 1); image: uint8 [H,W] (scaled by 1/255 like skimage's img_as_float) or float array."""
+    img = np.asarray(image)
+    x = torch.from_numpy(img).to(device)
+    x = x.to(torch.float64) / 255.0 if img.dtype == np.uint8 else x.to(torch.float64)
+    out = []
+    for sigma in (low_sigma, high_sigma):
+        w, r = _gaussian_kernel1d(sigma)
+        y = _correlate1d_nearest(x, w, r, 0)
+        out.append(_correlate1d_nearest(y, w, r, 1))
+    return out[0] - out[1]
+
+
+_FILE_LUT = None
+
+
+def pmvo_maps_from_gabor(index, conf):
+    """GPU-resident hand-off Gabor -> PMVO that reproduces the reference's round trip through 8-bit image files
+    (SURVEY.md Appendix A.18): best_ori/<view> stores the orientation in integer degrees (GaborFilter.py:209), conf/<view>
+    stores floor(conf*255+0.5) (torchvision.save_image, :210); the loaders turn them into (sin t', cos t') with
+    t' = (180-pix)/180*pi and conf = pix/255 in float64 (PMVO_utils.py:265-272), cast to fp32 by PMVO.__init__.
+    index: int32 [H,W] (degrees), conf: fp32 [H,W] in [0,1] -> (ori [H,W,2] fp32, conf [H,W] fp32) on the device.
+    Also returns the two uint8 planes (2 B/px: what travels between GPUs)."""
+    global _FILE_LUT
+    if _FILE_LUT is None:
+        pix = np.arange(256, dtype=np.float64)
+        th = (180 - pix) / 180 * math.pi
+        _FILE_LUT = (torch.from_numpy(np.stack([np.sin(th), np.cos(th)], -1).astype(np.float32)),
+                     torch.from_numpy((pix / 255.0).astype(np.float32)))
+    dev = index.device
+    k8 = index.clamp(0, 255).to(torch.uint8)
+    c8 = (conf * 255 + 0.5).clamp(0, 255).to(torch.uint8)
+    ori = _FILE_LUT[0].to(dev)[k8.long()]
+    cf = _FILE_LUT[1].to(dev)[c8.long()]
+    return ori, cf, k8, c8
+
+
+def pmvo_maps_from_u8(k8, c8):
+    """(ori, conf) fp32 planes from the two uint8 planes, as the loaders would produce them."""
+    pmvo_maps_from_gabor(torch.zeros((1, 1), dtype=torch.int32, device=k8.device),
+                         torch.zeros((1, 1), dtype=torch.float32, device=k8.device))     # builds the LUT
+    return _FILE_LUT[0].to(k8.device)[k8.long()], _FILE_LUT[1].to(k8.device)[c8.long()]
+
+
+def orientation_maps_device(images, device=None, gabor=None):
+    """The Gabor stage for a list of gray uint8 images, device-resident, views dealt to the ranks of an initialised
+    torch.distributed group (the image-wide confidence maximum is per view, so views are independent) and
+    all-gathered as 2 B/px uint8 planes.  Returns (ori [V,H,W,2], conf [V,H,W]) fp32 tensors on every rank."""
+    from . import dist as mdist
+
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    gabor = gabor or calOrientationGabor(device=device)
+    V = len(images)
+    H, W = np.asarray(images[0]).shape
+    local = []
+    for i in range(V):
+        if mdist.owner(i) != mdist.rank():
+            continue
+        dog = difference_of_gaussians_device(images[i], 0.4, 10, device).to(torch.float32)
+        idx, conf, _ = gabor.filter_index(dog)
+        _, _, k8, c8 = pmvo_maps_from_gabor(idx, conf)
+        local.append(torch.stack([k8, c8], 0))
+    planes = mdist.all_gather_views(local, V, (2, H, W), torch.uint8, device)      # [V,2,H,W]
+    ori, conf = pmvo_maps_from_u8(planes[:, 0], planes[:, 1])
+    return ori, conf
+
+
 def calculate_orientation(image_dir, label_dir, save_root, filename=None, iter=1, threshold=0.0, gabor=None):
     """GaborFilter.py:164-224: gray image -> DoG -> Gabor bank -> best_ori/<file> (uint8 degrees),
     conf/<file> (uint8, x255+0.5, 3 channels), Ori/<file> (colour visualisation)."""

@@ -220,3 +220,39 @@ def test_drivers_end_to_end_vs_reference(tmp_path):
     # the consumer's readers (HairGrow.py:41-55) see the documented shapes
     assert get_ground_truth_3D_occ(os.path.join(args.save_path, "Occ3D.mat")).shape == (192, 256, 256, 1)
     assert get_ground_truth_3D_ori(os.path.join(args.save_path, "Ori3D.mat")).shape == (192, 256, 256, 3)
+
+
+def test_gabor_to_pmvo_device_handoff_equals_file_roundtrip(tmp_path):
+    """orientation_maps_device (DoG + Gabor bank + 8-bit emulation, all on the GPU) gives exactly the maps that the
+    reference-style file pipeline gives: calculate_orientation -> best_ori/conf PNGs -> Load_Ori_And_Conf."""
+    from PIL import Image
+
+    from monohair_amd.gabor import (batch_generate, difference_of_gaussians, difference_of_gaussians_device,
+                                    orientation_maps_device)
+    from monohair_amd.pmvo_utils import Load_Ori_And_Conf
+
+    rng = np.random.default_rng(5)
+    H, W, V = 96, 72, 3
+    os.makedirs(tmp_path / "capture_images")
+    os.makedirs(tmp_path / "hair_mask")
+    imgs = []
+    for v in range(V):
+        r, c = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        th = np.deg2rad(25 + 40 * v)
+        im = (127 + 70 * np.cos(2 * np.pi * (r * np.cos(th) + c * np.sin(th)) / 4.0) + rng.normal(0, 6, (H, W)))
+        im = im.clip(0, 255).astype(np.uint8)
+        imgs.append(im)
+        Image.fromarray(im).save(tmp_path / "capture_images" / ("v%d.png" % v))
+        Image.fromarray(np.full((H, W), 255, np.uint8)).save(tmp_path / "hair_mask" / ("v%d.png" % v))
+    # device DoG == scipy DoG (float64 torch ops in scipy's accumulation order)
+    a = difference_of_gaussians(imgs[0], 0.4, 10)
+    b = difference_of_gaussians_device(imgs[0], 0.4, 10, DEV).cpu().numpy()
+    assert np.array_equal(a, b)
+    ori, conf = orientation_maps_device(imgs, device=DEV)
+    batch_generate(str(tmp_path), "capture_images")
+    cam = {"v%d" % v: None for v in range(V)}
+    Ori, Conf = Load_Ori_And_Conf(cam, str(tmp_path / "best_ori"), str(tmp_path / "conf"))
+    for v in range(V):
+        assert np.array_equal(ori[v].cpu().numpy(), Ori["v%d" % v].astype(np.float32))
+        assert np.array_equal(conf[v].cpu().numpy(), Conf["v%d" % v].astype(np.float32))
+    assert ori.shape == (V, H, W, 2) and float(conf.max()) == 1.0

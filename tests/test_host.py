@@ -130,6 +130,11 @@ chunks = [np.arange(n * 3, dtype=np.float64).reshape(n, 3) + 100 * i for i, n in
 out = mdist.map_chunks(chunks, lambda c: torch.from_numpy(c).float() * 2, "cpu", lambda: torch.empty((0, 3)))
 for c, o in zip(chunks, out):
     assert torch.equal(o, torch.from_numpy(c).float() * 2)
+# --- all_gather_views: every rank ends up with all per-view planes, in view order
+V = 7
+local = [torch.full((2, 3, 4), i, dtype=torch.uint8) for i in range(V) if mdist.owner(i) == r]
+allv = mdist.all_gather_views(local, V, (2, 3, 4), torch.uint8, "cpu")
+assert allv.shape == (V, 2, 3, 4) and all(int(allv[i].max()) == i and int(allv[i].min()) == i for i in range(V))
 # --- voxel_fit_reduced: disjoint ownership + ONE reduce == single-process fit, bit for bit
 import oracle
 def fit(p, o, device, vmin, vsize, g, dense=True):
