@@ -138,7 +138,9 @@ def difference_of_gaussians_device(image, low_sigma, high_sigma, device):
     then 1); image: uint8 [H,W] (scaled by 1/255 like skimage's img_as_float) or float array."""
     img = np.asarray(image)
     x = torch.from_numpy(img).to(device)
-    x = x.to(torch.float64) / 255.0 if img.dtype == np.uint8 else x.to(torch.float64)
+    # true IEEE division: torch's GPU kernels turn `tensor / python_scalar` into a multiplication by the reciprocal
+    x = x.to(torch.float64) / torch.tensor(255.0, dtype=torch.float64, device=device) if img.dtype == np.uint8 \
+        else x.to(torch.float64)
     out = []
     for sigma in (low_sigma, high_sigma):
         w, r = _gaussian_kernel1d(sigma)
