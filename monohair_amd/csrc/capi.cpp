@@ -27,6 +27,7 @@ struct mh_ctx {
     unsigned int *gabor_max = nullptr;
     int S = 0;
     int search_variant = 0;
+    int gabor_variant = 0;    // 0: VALU v_pk_fma kernel, 1: FP32-MFMA im2col kernel
     MhViews views() const { return MhViews{V, H, W, rec, mask, cams}; }
 };
 
@@ -50,7 +51,7 @@ int mh_launch_filter_points(MhViews, const float *, int, int, float, float, uint
                             uint8_t *, hipStream_t);
 int mh_launch_medoid_dense(const float *, int, int, float *, int32_t *, hipStream_t);
 int mh_launch_medoid_segmented(const float *, const int32_t *, int, int, float *, int32_t *, hipStream_t);
-int mh_launch_gabor_bank(const float *, const float *, int, int, int32_t *, float *, float *, unsigned int *,
+int mh_launch_gabor_bank(const float *, const float *, int, int, int32_t *, float *, float *, unsigned int *, int,
                          hipStream_t);
 int mh_launch_gabor_build(float *, hipStream_t);
 int mh_launch_replace_dissimilar(const float *, float *, float, int, hipStream_t);
@@ -167,6 +168,10 @@ extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return fail(MH_ERR_ARG, "mh_ctx_set_option: bad arguments");
     if (!strcmp(key, "search_variant")) {
         ctx->search_variant = value;
+        return MH_OK;
+    }
+    if (!strcmp(key, "gabor_variant")) {
+        ctx->gabor_variant = value;
         return MH_OK;
     }
     return fail(MH_ERR_ARG, "mh_ctx_set_option: unknown key %s", key);
@@ -381,7 +386,7 @@ extern "C" int mh_strands_accept(int W, int H, int Z, float *flag, const float *
 static int gabor_alloc(mh_ctx *ctx) {
     if (ctx->gabor) return MH_OK;
     MH_HIP(hipSetDevice(ctx->device));
-    MH_HIP(hipMalloc(&ctx->gabor, 289 * 192 * sizeof(float)));
+    MH_HIP(hipMalloc(&ctx->gabor, 290 * 192 * sizeof(float)));   // 289 taps + one zero pad tap (MFMA K = 290)
     MH_HIP(hipMalloc(&ctx->gabor_max, sizeof(unsigned int)));
     return MH_OK;
 }
@@ -391,11 +396,11 @@ extern "C" int mh_gabor_set_bank(mh_ctx *ctx, const float *bank_host) {
     int rc = gabor_alloc(ctx);
     if (rc) return rc;
     // kernel-major [180][289] -> tap-major [289][192], zero padded
-    float *tmp = new (std::nothrow) float[289 * 192]();
+    float *tmp = new (std::nothrow) float[290 * 192]();
     if (!tmp) return fail(MH_ERR_NOMEM, "mh_gabor_set_bank: out of host memory");
     for (int k = 0; k < 180; ++k)
         for (int t = 0; t < 289; ++t) tmp[t * 192 + k] = bank_host[k * 289 + t];
-    hipError_t e = hipMemcpy(ctx->gabor, tmp, 289 * 192 * sizeof(float), hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpy(ctx->gabor, tmp, 290 * 192 * sizeof(float), hipMemcpyHostToDevice);
     delete[] tmp;
     if (e != hipSuccess) return fail(MH_ERR_HIP, "mh_gabor_set_bank: %s", hipGetErrorString(e));
     return MH_OK;
@@ -412,6 +417,7 @@ extern "C" int mh_gabor_bank(mh_ctx *ctx, const float *image, int H, int W, int3
         rc = launched(mh_launch_gabor_build(ctx->gabor, st), "mh_gabor_bank(build)");
         if (rc) return rc;
     }
-    return launched(mh_launch_gabor_bank(ctx->gabor, image, H, W, orient_index, conf, variance, ctx->gabor_max, st),
+    return launched(mh_launch_gabor_bank(ctx->gabor, image, H, W, orient_index, conf, variance, ctx->gabor_max,
+                                         ctx->gabor_variant, st),
                     "mh_gabor_bank");
 }

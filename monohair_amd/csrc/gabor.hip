@@ -113,6 +113,132 @@ __global__ __launch_bounds__(256) void mh_gabor_bank_kernel(const float *__restr
     if ((tid & 63) == 0) atomicMax(maxbits, __float_as_uint(vmax));
 }
 
+// ---------------------------------------------------------------------------------------------
+// FP32-MFMA variant: the bank as an im2col contraction  C[pixel, k] = sum_t A[pixel, t] * B[t, k]
+// (pixels x 289 taps x 180 orientations) on v_mfma_f32_32x32x2_f32.  The MFMA result is bit for bit a
+// k-ordered fp32 fma chain, i.e. exactly the tap-ordered chain of the VALU kernel above, so both variants (and
+// the CPU oracle) produce identical maps.
+//   workgroup = 4 waves = 8 image rows x 32 columns; wave w owns rows 2w, 2w+1 (two 32-pixel M-tiles) and all
+//   six 32-wide orientation N-tiles: 12 accumulators x 16 registers.  Per K-step (2 taps): the A fragments are
+//   one ds_read each from the LDS image tile (lane l: pixel l&31, tap 2s + (l>>5)), the B fragments are six
+//   coalesced 256-B global reads of the tap-major bank, prefetched one step ahead; 12 MFMAs (768 cycles).
+//   Epilogue per M-tile: |responses| go through LDS ([k][33] padded) so that one lane per pixel can walk the 180
+//   values in index order (first-max argmax, cascade-ordered variance) exactly like the VALU kernel.
+// ---------------------------------------------------------------------------------------------
+#define MH_GM_ROWS 8
+#define MH_GM_COLS 32
+#define MH_GM_LDW (MH_GM_COLS + MH_GB_KS - 1)        // 48
+#define MH_GM_LDH (MH_GM_ROWS + MH_GB_KS)            // 25 (one spare row for the zero-weight pad tap)
+#define MH_GM_RS 33
+
+typedef float mh_f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(256, 1) void mh_gabor_mfma_kernel(const float *__restrict__ bankT,
+                                                               const float *__restrict__ img, int H, int W,
+                                                               int32_t *__restrict__ orient,
+                                                               float *__restrict__ var_out,
+                                                               unsigned int *__restrict__ maxbits) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *tile = smem;                                        // [25][48]
+    float *resp = smem + MH_GM_LDH * MH_GM_LDW;                // [4 waves][180][33]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int y0 = blockIdx.y * MH_GM_ROWS, x0 = blockIdx.x * MH_GM_COLS;
+    for (int q = tid; q < MH_GM_LDH * MH_GM_LDW; q += 256) {
+        const int ly = q / MH_GM_LDW, lx = q - ly * MH_GM_LDW;
+        const int gy = y0 + ly - 8, gx = x0 + lx - 8;
+        tile[q] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : 0.0f;
+    }
+    __syncthreads();
+
+    mh_f32x16 acc[2][6];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int n = 0; n < 6; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][n][r] = 0.0f;
+
+    const int pix = lane & 31, kk = lane >> 5;
+    int ti = 0, tj = kk;                                       // tap of this lane in step 0: t = kk
+    const float *__restrict__ brow = bankT + (size_t)kk * MH_GB_KPAD + pix;
+    float bcur[6], bnxt[6];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) bcur[n] = brow[n * 32];
+    constexpr int NSTEP = (MH_GB_NT + 1) / 2;                  // 145; tap 289 is a zero row of the bank
+    for (int s = 0; s < NSTEP; ++s) {
+        const float *__restrict__ bn = brow + (size_t)(2 * (s + 1 < NSTEP ? s + 1 : s)) * MH_GB_KPAD;
+#pragma unroll
+        for (int n = 0; n < 6; ++n) bnxt[n] = bn[n * 32];
+        const float a0 = tile[(2 * wave + ti) * MH_GM_LDW + pix + tj];
+        const float a1 = tile[(2 * wave + 1 + ti) * MH_GM_LDW + pix + tj];
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+            acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bcur[n], acc[0][n], 0, 0, 0);
+            acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bcur[n], acc[1][n], 0, 0, 0);
+        }
+#pragma unroll
+        for (int n = 0; n < 6; ++n) bcur[n] = bnxt[n];
+        tj += 2;
+        if (tj >= MH_GB_KS) {
+            tj -= MH_GB_KS;
+            ++ti;
+        }
+    }
+
+    float *__restrict__ rw = resp + wave * (MH_GB_NK * MH_GM_RS);
+    const float PI_F = 3.14159265358979323846f;
+    float vmax = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        // C layout of the 32x32 MFMA: column (orientation) = lane&31, row (pixel) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+            const int k = n * 32 + pix;
+            if (k < MH_GB_NK) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    rw[k * MH_GM_RS + row] = __builtin_fabsf(acc[p][n][r]);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 32) {
+            float M = rw[lane];
+            int b = 0;
+            for (int k = 1; k < MH_GB_NK; ++k) {
+                const float r = rw[k * MH_GM_RS + lane];
+                if (r > M) {
+                    M = r;
+                    b = k;
+                }
+            }
+            const float bh = mh_theta((float)b);
+            MhCasc sc = {0.f, 0.f};
+            for (int k = 0; k < MH_GB_NK; ++k) {
+                if (k > 0 && (k & 15) == 0) mh_casc_flush(sc);
+                const float t1 = bh - mh_theta((float)k);
+                const float d = fminf(__builtin_fabsf(t1), fminf(__builtin_fabsf(t1 - PI_F), __builtin_fabsf(t1 + PI_F)));
+                const float rd = rw[k * MH_GM_RS + lane] - M;
+                sc.a0 = sc.a0 + (d * rd) * rd;
+            }
+            const float var = __builtin_sqrtf(sc.a0 + sc.a1);
+            const int y = y0 + 2 * wave + p, x = x0 + lane;
+            if (y < H && x < W) {
+                var_out[(size_t)y * W + x] = var;
+                orient[(size_t)y * W + x] = (var > 0.0f) ? b : 0;
+                vmax = fmaxf(vmax, var);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if (lane == 0) atomicMax(maxbits, __float_as_uint(vmax));
+}
+
 __global__ __launch_bounds__(256) void mh_gabor_finish_kernel(const float *__restrict__ var,
                                                               const unsigned int *__restrict__ maxbits, size_t npix,
                                                               float *__restrict__ conf) {
@@ -126,16 +252,22 @@ __global__ __launch_bounds__(256) void mh_gabor_finish_kernel(const float *__res
 }
 
 extern "C" int mh_launch_gabor_build(float *bankT, hipStream_t st) {
-    (void)hipMemsetAsync(bankT, 0, (size_t)MH_GB_NT * MH_GB_KPAD * sizeof(float), st);
+    (void)hipMemsetAsync(bankT, 0, (size_t)(MH_GB_NT + 1) * MH_GB_KPAD * sizeof(float), st);   // + zero pad tap
     hipLaunchKernelGGL(mh_gabor_build_kernel, dim3(MH_GB_NK), dim3(320), 0, st, bankT);
     return (int)hipGetLastError();
 }
 
 extern "C" int mh_launch_gabor_bank(const float *bankT, const float *img, int H, int W, int32_t *orient, float *conf,
-                                    float *var, unsigned int *maxbits, hipStream_t st) {
+                                    float *var, unsigned int *maxbits, int variant, hipStream_t st) {
     (void)hipMemsetAsync(maxbits, 0, sizeof(unsigned int), st);
-    const dim3 grid((W + MH_GB_TILE - 1) / MH_GB_TILE, (H + MH_GB_TILE - 1) / MH_GB_TILE);
-    hipLaunchKernelGGL(mh_gabor_bank_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);
+    if (variant == 1) {
+        const dim3 grid((W + MH_GM_COLS - 1) / MH_GM_COLS, (H + MH_GM_ROWS - 1) / MH_GM_ROWS);
+        const size_t lds = (size_t)(MH_GM_LDH * MH_GM_LDW + 4 * MH_GB_NK * MH_GM_RS) * sizeof(float);
+        hipLaunchKernelGGL(mh_gabor_mfma_kernel, grid, dim3(256), lds, st, bankT, img, H, W, orient, var, maxbits);
+    } else {
+        const dim3 grid((W + MH_GB_TILE - 1) / MH_GB_TILE, (H + MH_GB_TILE - 1) / MH_GB_TILE);
+        hipLaunchKernelGGL(mh_gabor_bank_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);
+    }
     const size_t npix = (size_t)H * W;
     const int blocks = (int)((npix + 255) / 256 < 2048 ? (npix + 255) / 256 : 2048);
     hipLaunchKernelGGL(mh_gabor_finish_kernel, dim3(blocks), dim3(256), 0, st, var, maxbits, npix, conf);

@@ -53,7 +53,7 @@ def orientation_table():
 
 
 class calOrientationGabor:
-    def __init__(self, channel_in=1, channel_out=1, stride=1, device=None, bank=None):
+    def __init__(self, channel_in=1, channel_out=1, stride=1, device=None, bank=None, variant="valu"):
         """bank: optional [180,17,17] kernels to install instead of gabor_bank() (torch's CPU sin/cos/exp differ
         in the last bit between host CPU types; tests pin the reference's own kernels this way)."""
         self.numKernels = NUM_KERNELS
@@ -66,10 +66,17 @@ class calOrientationGabor:
         bank = gabor_bank() if bank is None else np.asarray(bank)
         bank = np.ascontiguousarray(bank.reshape(NUM_KERNELS, KSIZE * KSIZE), dtype=np.float32)
         _lib.check(_lib.lib().mh_gabor_set_bank(self._ctx, bank.ctypes.data_as(ctypes.c_void_p)), "mh_gabor_set_bank")
+        self.set_variant(variant)
         th = orientation_table()
         self._theta = th.to(self.device)
         self._sin = torch.sin(th).to(self.device)      # CPU transcendental values, gathered on the device
         self._cos = torch.cos(th).to(self.device)
+
+    def set_variant(self, variant):
+        """'valu': direct form on v_pk_fma_f32; 'mfma': im2col contraction on v_mfma_f32_32x32x2_f32.  Same bits."""
+        self.variant = variant
+        _lib.check(_lib.lib().mh_ctx_set_option(self._ctx, b"gabor_variant", {"valu": 0, "mfma": 1}[variant]),
+                   "mh_ctx_set_option")
 
     def cuda(self):
         return self

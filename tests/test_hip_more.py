@@ -114,6 +114,7 @@ def test_gabor_vs_oracle_and_golden():
     assert np.allclose(gabor_bank(), z["bank"], rtol=0, atol=2e-7)
     gab = calOrientationGabor(device=DEV, bank=z["bank"])
     for name in ("stripes0", "stripes30", "stripes90", "stripes135", "noise", "mixed"):
+        gab.set_variant("mfma" if name in ("stripes30", "noise") else "valu")
         img = z[name + "_img"]
         t = torch.from_numpy(img)[None, None].to(DEV)
         two, best, conf = gab(t, None, 1, threshold=0.0)
@@ -130,13 +131,15 @@ def test_gabor_vs_oracle_and_golden():
         assert two.shape == (1, 2) + img.shape and best.shape == (1, 1) + img.shape
 
 
-def test_gabor_odd_sizes_and_border():
-    """ragged sizes (not multiples of the 16x16 tile) incl. an image smaller than the kernel"""
+@pytest.mark.parametrize("variant", ["valu", "mfma"])
+def test_gabor_odd_sizes_and_border(variant):
+    """ragged sizes (not multiples of the pixel tiles) incl. an image smaller than the kernel; both kernel variants
+    (direct v_pk_fma form and the FP32-MFMA im2col contraction) are bit-identical to the oracle"""
     from monohair_amd.gabor import calOrientationGabor, gabor_bank
 
-    gab = calOrientationGabor(device=DEV)
+    gab = calOrientationGabor(device=DEV, variant=variant)
     rng = np.random.default_rng(3)
-    for shape in ((9, 7), (17, 33), (50, 31)):
+    for shape in ((9, 7), (17, 33), (50, 31), (64, 96), (75, 130)):
         img = rng.normal(size=shape).astype(np.float32)
         idx, conf, var = gab.filter_index(torch.from_numpy(img).to(DEV))
         o_idx, o_conf, o_var = oracle.gabor_bank(gabor_bank(), img)

@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--height", type=int, default=1920)
 ap.add_argument("--width", type=int, default=1080)
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--variant", default="valu")
 a = ap.parse_args()
 rng = np.random.default_rng(0)
 r, c = np.meshgrid(np.arange(a.height), np.arange(a.width), indexing="ij")
@@ -22,7 +23,7 @@ img = (127 + 60 * np.cos(2 * np.pi * (0.6 * r + 0.8 * c) / 4.0) + rng.normal(0, 
 t0 = time.perf_counter()
 dog = difference_of_gaussians(img, 0.4, 10).astype(np.float32)
 t_dog = time.perf_counter() - t0
-gab = calOrientationGabor(device="cuda:0")
+gab = calOrientationGabor(device="cuda:0", variant=a.variant)
 x = torch.from_numpy(dog).cuda()
 gab.filter_index(x)
 torch.cuda.synchronize()
@@ -34,6 +35,6 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / a.reps
 flop = 2.0 * 180 * 289 * a.height * a.width
-print({"image": [a.height, a.width], "ms_per_view": round(ms, 3), "views_per_s": round(1e3 / ms, 1),
+print({"variant": a.variant, "image": [a.height, a.width], "ms_per_view": round(ms, 3), "views_per_s": round(1e3 / ms, 1),
        "TFLOP_s": round(flop / ms / 1e9, 2), "frac_of_157TF": round(flop / ms / 1e9 / 157.3, 3),
        "host_dog_ms": round(t_dog * 1e3, 1)})
