@@ -1,0 +1,110 @@
+"""GPU: shapes off the beaten path -- large patches (more taps than lanes), many views (several cascade blocks),
+views < 20 (the reference raises), points outside every frustum, zero-confidence maps (NaN losses)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(V, H, W, patch, thr=0.15, quantize=False, seed=2, rings=1):
+    from monohair_amd import synth
+    from monohair_amd.camera import camera_records, cameras_from_list
+    from monohair_amd.pmvo import PMVO
+
+    scene = synth.make_scene(V, H, W, seed=seed, quantize=quantize, rings=rings)
+    rec = camera_records(cameras_from_list(scene["cams"]))
+    pm = PMVO.from_planes(rec, scene["depth"].to(DEV), scene["ori"].to(DEV), scene["conf"].to(DEV),
+                          scene["mask"].to(DEV), device=DEV, patch_size=patch, visible_threshold=1, conf_threshold=thr)
+    views = oracle.Views(rec, scene["depth"].numpy(), scene["ori"].numpy(), scene["conf"].numpy(), scene["mask"].numpy())
+    return scene, pm, views
+
+
+def check_forward(pm, views, pts, patch, thr):
+    from monohair_amd.pmvo import depth_offsets
+
+    for fused in (True, False):
+        _, ori, loss, hc = pm.forward(pts, fused=fused)
+        _, o_ori, o_loss, o_hc = oracle.forward(views, pts, patch, thr, depth_offsets(90))
+        assert np.array_equal(loss.cpu().numpy(), o_loss, equal_nan=True)
+        assert np.array_equal(ori.cpu().numpy(), o_ori, equal_nan=True)
+        assert np.array_equal(hc.cpu().numpy(), o_hc)
+    return o_loss
+
+
+@pytest.mark.parametrize("patch", [1, 9, 11])
+def test_patch_sizes_beyond_one_wave(patch):
+    """patch 9 / 11 have 81 / 121 taps: more than the 64 lanes of the wave that prepares a tap list"""
+    from monohair_amd import synth
+
+    scene, pm, views = build(24, 200, 120, patch)
+    pts = synth.candidate_points(res=32, seed=3, limit=150)
+    loss = check_forward(pm, views, pts, patch, 0.15)
+    assert np.isfinite(loss).sum() > 30
+    o = oracle.visible_and_ori(views, pts, patch)
+    pm.Compute_Visible_and_Ori(pts)
+    assert np.array_equal(pm.Conf_patch.cpu().numpy(), o["Conf_patch"])
+    surf, _, filt = pm.filter_points(pts)
+    o_s, o_f, _, _ = oracle.filter_votes(views, pts, patch, 0.15, 1.0)
+    assert np.array_equal(surf.cpu().numpy(), o_s) and np.array_equal(filt.cpu().numpy(), o_f)
+
+
+def test_many_views_cascade_blocks():
+    """V = 120 (BASELINE config 5): eight 16-view blocks in the cascade sum, two rounds of lanes-over-views"""
+    from monohair_amd import synth
+
+    scene, pm, views = build(120, 96, 64, 3, rings=3)
+    pts = synth.candidate_points(res=32, seed=4, limit=120)
+    check_forward(pm, views, pts, 3, 0.15)
+    loss, _ = pm.prj_loss_of(pm._points, torch.tensor([[0.0, -1.0, 0.0]], device=DEV).repeat(len(pts), 1)) \\
+        if pm.Compute_Visible_and_Ori(pts) is None else (None, None)
+    o_loss, _ = oracle.refine_loss(views, pts, np.tile([[0.0, -1.0, 0.0]], (len(pts), 1)), 3, 0.15)
+    assert np.array_equal(loss.cpu().numpy(), o_loss, equal_nan=True)
+
+
+def test_fewer_than_twenty_views_fails_like_the_reference():
+    """torch.topk(Conf, 20, dim=0) raises for V < 20 (PMVO.py:341); so does mh_topk_views"""
+    from monohair_amd import _lib, synth
+
+    scene, pm, views = build(8, 64, 48, 3)
+    pts = synth.candidate_points(res=32, seed=5, limit=20)
+    with pytest.raises(_lib.MhError, match="views < 20"):
+        pm.forward(pts)
+    pm.Compute_Visible_and_Ori(pts)                      # everything that does not rank base views still works
+    assert pm.visible.shape == (8, 20)
+
+
+def test_points_outside_and_dead_maps():
+    from monohair_amd import synth
+
+    scene, pm, views = build(24, 96, 64, 5)
+    far = np.array([[9.0, 9.0, 9.0], [0.0, 0.0, 5.0], [-3.0, 0.1, 0.0]])
+    pts = np.concatenate([synth.candidate_points(res=32, seed=6, limit=40), far])
+    loss = check_forward(pm, views, pts, 5, 0.15)
+    assert np.all(np.isnan(loss[-3:]))                   # no visible view: 0/0 (PMVO.py:201)
+    # all-zero confidence: every tap clamps to 1e-6 (PMVO.py:372,376), 'positive' never fires
+    scene["conf"].zero_()
+    from monohair_amd.camera import camera_records, cameras_from_list
+    from monohair_amd.pmvo import PMVO
+
+    rec = camera_records(cameras_from_list(scene["cams"]))
+    pm0 = PMVO.from_planes(rec, scene["depth"].to(DEV), scene["ori"].to(DEV), scene["conf"].to(DEV),
+                           scene["mask"].to(DEV), device=DEV, patch_size=5, visible_threshold=1, conf_threshold=0.15)
+    views0 = oracle.Views(rec, scene["depth"].numpy(), scene["ori"].numpy(), scene["conf"].numpy(),
+                          scene["mask"].numpy())
+    check_forward(pm0, views0, pts[:40], 5, 0.15)
+
+
+def test_bad_arguments_are_reported_not_crashed():
+    from monohair_amd import _lib, synth
+
+    scene, pm, views = build(24, 64, 48, 3)
+    with pytest.raises(_lib.MhError):
+        pm.patch_size = 4                                 # even patch sizes do not exist
+        pm.forward(synth.candidate_points(res=32, seed=6, limit=10))
+    pm.patch_size = 13                                    # larger than the instantiated kernels
+    with pytest.raises(_lib.MhError):
+        pm.Compute_Visible_and_Ori(synth.candidate_points(res=32, seed=6, limit=10))
