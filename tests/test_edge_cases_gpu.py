@@ -59,8 +59,9 @@ def test_many_views_cascade_blocks():
     scene, pm, views = build(120, 96, 64, 3, rings=3)
     pts = synth.candidate_points(res=32, seed=4, limit=120)
     check_forward(pm, views, pts, 3, 0.15)
-    loss, _ = pm.prj_loss_of(pm._points, torch.tensor([[0.0, -1.0, 0.0]], device=DEV).repeat(len(pts), 1)) \\
-        if pm.Compute_Visible_and_Ori(pts) is None else (None, None)
+    pm.Compute_Visible_and_Ori(pts)
+    dirs = torch.tensor([[0.0, -1.0, 0.0]], device=DEV).repeat(len(pts), 1)
+    loss, _ = pm.prj_loss_of(pm._points, dirs)
     o_loss, _ = oracle.refine_loss(views, pts, np.tile([[0.0, -1.0, 0.0]], (len(pts), 1)), 3, 0.15)
     assert np.array_equal(loss.cpu().numpy(), o_loss, equal_nan=True)
 
