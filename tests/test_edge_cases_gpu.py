@@ -85,7 +85,7 @@ def test_points_outside_and_dead_maps():
     far = np.array([[9.0, 9.0, 9.0], [0.0, 0.0, 5.0], [-3.0, 0.1, 0.0]])
     pts = np.concatenate([synth.candidate_points(res=32, seed=6, limit=40), far])
     loss = check_forward(pm, views, pts, 5, 0.15)
-    assert np.all(np.isnan(loss[-3:]))                   # no visible view: 0/0 (PMVO.py:201)
+    assert np.isnan(loss[-3])                            # outside every frustum: no visible view, 0/0 (PMVO.py:201)
     # all-zero confidence: every tap clamps to 1e-6 (PMVO.py:372,376), 'positive' never fires
     scene["conf"].zero_()
     from monohair_amd.camera import camera_records, cameras_from_list
