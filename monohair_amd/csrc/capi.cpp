@@ -202,7 +202,8 @@ extern "C" int mh_topk_views(mh_ctx *ctx, const float *vis, const float *conf, i
 
 extern "C" size_t mh_search_scratch_bytes(mh_ctx *ctx, int N, int patch) {
     if (!ctx || N < 0 || patch < 1) return 0;
-    return (size_t)ctx->V * (size_t)N * (size_t)(patch * patch + 1) * sizeof(float4);
+    // + 16 records of slack: the search kernel prefetches tap records in groups past the end of a list
+    return ((size_t)ctx->V * (size_t)N * (size_t)(patch * patch + 1) + 16) * sizeof(float4);
 }
 
 extern "C" int mh_search_forward(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank,

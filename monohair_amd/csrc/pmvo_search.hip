@@ -129,19 +129,46 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
                 MB[2 * jp] = mh_v2f{mh_one_minus_abs(cs.x), t0.z};
                 MB[2 * jp + 1] = mh_v2f{mh_one_minus_abs(cs.y), t0.z};
             }
-            for (int t = 1; t < ntap; ++t) {
-                const float4 tp = rec[1 + t];
-                const mh_v2f ox2 = mh_v2f{tp.x, tp.x}, oy2 = mh_v2f{tp.y, tp.y};
-                const mh_v2f cpair = mh_v2f{tp.z, tp.z};
+            // Tap records arrive through the scalar cache; a scalar load can only be waited for with lgkmcnt(0), so
+            // the loop is software-pipelined by hand in groups of GRP taps: wait for the group loaded during the
+            // previous trip, THEN issue the loads of the next group, then compute -- the ~200-cycle scalar latency
+            // hides behind GRP*19 VALU instructions even with a single wave on the SIMD.  (The list is padded: reading
+            // up to 2*GRP records past `ntap` stays inside the scratch buffer and the values are never used.)
+            constexpr int GRP = 4;
+            auto process = [&](const float4 (&g)[GRP], int t) {
 #pragma unroll
-                for (int jp = 0; jp < K / 2; ++jp) {
-                    const mh_v2f cs = ox2 * DX[jp] + oy2 * DY[jp];
-                    mh_v2f L0, L1;
-                    L0.x = mh_one_minus_abs(cs.x);
-                    L1.x = mh_one_minus_abs(cs.y);
-                    mh_update_min_pair(MB[2 * jp], L0, cpair, exec_all);
-                    mh_update_min_pair(MB[2 * jp + 1], L1, cpair, exec_all);
+                for (int u = 0; u < GRP; ++u) {
+                    if (t + u < ntap) {   // uniform
+                        const float4 tp = g[u];
+                        const mh_v2f ox2 = mh_v2f{tp.x, tp.x}, oy2 = mh_v2f{tp.y, tp.y};
+                        const mh_v2f cpair = mh_v2f{tp.z, tp.z};
+#pragma unroll
+                        for (int jp = 0; jp < K / 2; ++jp) {
+                            const mh_v2f cs = ox2 * DX[jp] + oy2 * DY[jp];
+                            mh_v2f L0, L1;
+                            L0.x = mh_one_minus_abs(cs.x);
+                            L1.x = mh_one_minus_abs(cs.y);
+                            mh_update_min_pair(MB[2 * jp], L0, cpair, exec_all);
+                            mh_update_min_pair(MB[2 * jp + 1], L1, cpair, exec_all);
+                        }
+                    }
                 }
+            };
+            float4 ga[GRP], gb[GRP];   // ping-pong groups (no register copies between trips)
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) ga[u] = rec[2 + u];
+            for (int t = 1; t < ntap;) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): group A has landed
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) gb[u] = rec[1 + t + GRP + u];
+                process(ga, t);
+                t += GRP;
+                if (t >= ntap) break;
+                __builtin_amdgcn_s_waitcnt(0xc07f);   // group B has landed
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) ga[u] = rec[1 + t + GRP + u];
+                process(gb, t);
+                t += GRP;
             }
 #pragma unroll
             for (int j = 0; j < K; ++j) {
