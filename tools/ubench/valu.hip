@@ -43,6 +43,15 @@ KERNEL(k_sqrt, ALL8_1("v_sqrt_f32 %0, %0"), 8)
 KERNEL(k_min, ALL8_1("v_min_f32 %0, %0, %1"), 8)
 KERNEL(k_min3, ALL8_1("v_min3_f32 %0, %0, %1, %1"), 8)
 
+// update sequences: (a) cmp -> sgpr mask + 2 cndmask, (b) cmpx + pk_mov + exec restore, (c) cmp vcc + 2 cndmask e32
+#define SEQ_A(R) asm volatile("v_cmp_lt_f32_e64 s[40:41], %1, %0\n v_cndmask_b32_e64 %0, %0, %1, s[40:41]\n v_cndmask_b32_e64 %2, %2, %1, s[40:41]" : "+v"(R.x), "+v"(s.x), "+v"(R.y) : : "s40", "s41");
+#define SEQ_B(R) asm volatile("v_cmpx_lt_f32_e32 vcc, %1, %0\n v_pk_mov_b32 %2, %3, %3 op_sel:[0,0]\n s_mov_b64 exec, -1" : "+v"(R.x), "+v"(s.x), "+v"(R) : "v"(s) : "vcc");
+#define SEQ_C(R) asm volatile("v_cmp_lt_f32_e32 vcc, %1, %0\n v_cndmask_b32_e32 %0, %0, %1, vcc\n v_cndmask_b32_e32 %2, %2, %1, vcc" : "+v"(R.x), "+v"(s.x), "+v"(R.y) : : "vcc");
+#define ALL8(S) S(r0) S(r1) S(r2) S(r3) S(r4) S(r5) S(r6) S(r7)
+KERNEL(k_seq_a, ALL8(SEQ_A), 8)
+KERNEL(k_seq_b, ALL8(SEQ_B), 8)
+KERNEL(k_seq_c, ALL8(SEQ_C), 8)
+
 template <typename K>
 double run(K kern, const char *name, float *d_out) {
     const int blocks = 256 * 8;   // 8 waves per SIMD
@@ -82,6 +91,10 @@ int main() {
     run(k_pk_fma, "v_pk_fma", d);
     run(k_pk_mov, "v_pk_mov", d);
     run(k_mov_b64, "v_mov_b64", d);
+    printf("--- update sequences (3 instructions each; cycles are per INSTRUCTION, multiply by 3 per update)\n");
+    run(k_seq_a, "cmp+2cnd e64", d);
+    run(k_seq_b, "cmpx+pkmov", d);
+    run(k_seq_c, "cmp+2cnd vcc", d);
     run(k_rcp, "v_rcp", d);
     run(k_sqrt, "v_sqrt", d);
     return 0;
