@@ -118,7 +118,8 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
             // running (min loss, conf of argmin) of an item is ONE register pair that a single v_pk_mov_b32
             // overwrites under the EXEC mask written by v_cmpx_lt_f32: 4.5 VALU instructions per (item, tap)
             // instead of the 6.75 the compiler emits for the portable loop below.
-            mh_v2f DX[K / 2], DY[K / 2], MB[K];
+            mh_v2f DX[K / 2], DY[K / 2];
+            float ML[K], BC[K];
 #pragma unroll
             for (int jp = 0; jp < K / 2; ++jp) {
                 mh_v2f row, col;
@@ -126,8 +127,9 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
                                   mh_v2f{X2[2 * jp], X2[2 * jp + 1]}, Hf, Wf, row, col);
                 mh_unit2_fast2(row - mh_splat(hdr.z), col - mh_splat(hdr.w), DX[jp], DY[jp]);
                 const mh_v2f cs = mh_v2f{t0.x, t0.x} * DX[jp] + mh_v2f{t0.y, t0.y} * DY[jp];
-                MB[2 * jp] = mh_v2f{mh_one_minus_abs(cs.x), t0.z};
-                MB[2 * jp + 1] = mh_v2f{mh_one_minus_abs(cs.y), t0.z};
+                ML[2 * jp] = mh_one_minus_abs(cs.x);
+                ML[2 * jp + 1] = mh_one_minus_abs(cs.y);
+                BC[2 * jp] = BC[2 * jp + 1] = t0.z;
             }
             // Tap records arrive through the scalar cache; a scalar load can only be waited for with lgkmcnt(0), so
             // the loop is software-pipelined by hand in groups of GRP taps: wait for the group loaded during the
@@ -141,15 +143,20 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
                     if (t + u < ntap) {   // uniform
                         const float4 tp = g[u];
                         const mh_v2f ox2 = mh_v2f{tp.x, tp.x}, oy2 = mh_v2f{tp.y, tp.y};
-                        const mh_v2f cpair = mh_v2f{tp.z, tp.z};
+                        float l[K];
 #pragma unroll
                         for (int jp = 0; jp < K / 2; ++jp) {
                             const mh_v2f cs = ox2 * DX[jp] + oy2 * DY[jp];
-                            mh_v2f L0, L1;
-                            L0.x = mh_one_minus_abs(cs.x);
-                            L1.x = mh_one_minus_abs(cs.y);
-                            mh_update_min_pair(MB[2 * jp], L0, cpair, exec_all);
-                            mh_update_min_pair(MB[2 * jp + 1], L1, cpair, exec_all);
+                            l[2 * jp] = mh_one_minus_abs(cs.x);
+                            l[2 * jp + 1] = mh_one_minus_abs(cs.y);
+                        }
+                        // compare into an SGPR mask, two selects: measured 10 cycles per update against 12 for the
+                        // v_cmpx + v_pk_mov_b32 + EXEC-restore form (tools/ubench/valu.hip), and no SALU traffic
+#pragma unroll
+                        for (int j = 0; j < K; ++j) {
+                            const bool upd = l[j] < ML[j];
+                            ML[j] = upd ? l[j] : ML[j];
+                            BC[j] = upd ? tp.z : BC[j];
                         }
                     }
                 }
@@ -172,8 +179,8 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
             }
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                const float w = MB[j].y;   // (vis != -1) * best_conf
-                num[j].a0 = num[j].a0 + MB[j].x * w;
+                const float w = BC[j];   // (vis != -1) * best_conf
+                num[j].a0 = num[j].a0 + ML[j] * w;
                 den[j].a0 = den[j].a0 + w;
                 cnt[j] += (w > 0.0f) ? 1 : 0;
             }
