@@ -48,17 +48,6 @@ __device__ __forceinline__ float mh_one_minus_abs(float x) {
     return r;
 }
 
-// if (l.x < mb.x) mb = (l.x, c.x):  v_cmpx writes EXEC, v_pk_mov_b32 moves both halves under it, EXEC restored.
-__device__ __forceinline__ void mh_update_min_pair(mh_v2f &mb, mh_v2f l, mh_v2f c, unsigned long long exec_all) {
-    asm volatile(
-        "v_cmpx_lt_f32_e32 vcc, %[lx], %[ml]\n\t"
-        "v_pk_mov_b32 %[mb], %[l], %[c] op_sel:[0,0]\n\t"
-        "s_mov_b64 exec, %[ex]"
-        : [mb] "+v"(mb)
-        : [lx] "v"(l.x), [ml] "v"(mb.x), [l] "v"(l), [c] "v"(c), [ex] "s"(exec_all)
-        : "vcc");
-}
-
 template <int K, int T, bool FAST>
 __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *__restrict__ offs, int S, int nrank,
                                                       int rank_step, const float *__restrict__ pts, int N, int P1,
@@ -96,7 +85,6 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
         cnt[j] = 0;
     }
 
-    const unsigned long long exec_all = __builtin_amdgcn_read_exec();
     for (int v = 0; v < V; ++v) {
         if (v > 0 && (v & 15) == 0) {
 #pragma unroll
@@ -112,12 +100,11 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
         const float *__restrict__ cam = vw.cams + v * MH_CAM_STRIDE;
         const float4 t0 = rec[1];
         if constexpr (FAST && (K % 2 == 0)) {
-            // Hand-scheduled tap loop.  Items are processed in pairs: the unit directions of two items sit in
-            // one 64-bit register pair per component, so the two products and the sum of the cosine are
-            // v_pk_mul_f32 / v_pk_add_f32 (separately rounded, no fma -- same bits as the scalar form); the
-            // running (min loss, conf of argmin) of an item is ONE register pair that a single v_pk_mov_b32
-            // overwrites under the EXEC mask written by v_cmpx_lt_f32: 4.5 VALU instructions per (item, tap)
-            // instead of the 6.75 the compiler emits for the portable loop below.
+            // Hand-shaped tap loop.  Items are processed in pairs: the unit directions of two items sit in one
+            // 64-bit register pair per component, so the two products and the sum of the cosine are
+            // v_pk_mul_f32 / v_pk_add_f32 (separately rounded, no fma -- same bits as the scalar form), 1-|x| is one
+            // v_sub_f32 with the abs source modifier, and the running minimum is a compare into an SGPR mask plus
+            // two selects: 23 VALU instructions per tap per 4 items instead of the 27 of the portable loop below.
             mh_v2f DX[K / 2], DY[K / 2];
             float ML[K], BC[K];
 #pragma unroll
