@@ -109,8 +109,13 @@ __global__ __launch_bounds__(256) void mh_project_gather_kernel(MhViews vw, cons
         for (int k = 0; k < UNR; ++k) {
             const int idx = base + k * 256 + tid;
             if (idx < cnt) {
-                if (ori_patch) reinterpret_cast<float2 *>(ori_patch)[obase + idx] = make_float2(q[k].x, q[k].y);
-                if (conf_patch) conf_patch[obase + idx] = mh_clampf(q[k].z, 1e-6f, 1.0f);
+                // streaming (non-temporal) stores: the 176 MB of patch output would otherwise wash the map lines
+                // that neighbouring points re-read out of the XCD's 4 MB L2
+                if (ori_patch) {
+                    __builtin_nontemporal_store(q[k].x, ori_patch + 2 * (obase + idx));
+                    __builtin_nontemporal_store(q[k].y, ori_patch + 2 * (obase + idx) + 1);
+                }
+                if (conf_patch) __builtin_nontemporal_store(mh_clampf(q[k].z, 1e-6f, 1.0f), conf_patch + obase + idx);
             }
         }
     }
