@@ -46,9 +46,10 @@ __global__ __launch_bounds__(256) void mh_project_gather_kernel(MhViews vw, cons
                                                                 float *__restrict__ pixf) {
     constexpr int P = PATCH * PATCH, HP = PATCH / 2;
     __shared__ int s_r[MH_PG_TILE], s_c[MH_PG_TILE];
-    const int total = gridDim.x;
-    int bid = blockIdx.x;
-    if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);
+    // the grid is padded to a multiple of 8 workgroups; XCD x (= blockIdx % 8) takes the x-th eighth of the
+    // (view, tile) list, i.e. a contiguous range of views
+    const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (bid >= vw.V * tiles) return;
     const int v = bid / tiles, tile = bid - v * tiles;
     const int n0 = tile * MH_PG_TILE;
     const int tid = threadIdx.x;
@@ -259,9 +260,7 @@ __global__ __launch_bounds__(256) void mh_project_taps_kernel(MhViews vw, const 
     __shared__ unsigned char s_el[4][MH_PREP_PMAX];
     __shared__ unsigned int s_first[4][256];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int total = gridDim.x;
-    int bid = blockIdx.x;
-    if ((total & 7) == 0) bid = (bid & 7) * (total >> 3) + (bid >> 3);   // XCD-contiguous view ranges
+    const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous view ranges
     const int vn = bid * 4 + wave;
     const int V = vw.V, H = vw.H, W = vw.W;
     if (vn >= V * N) return;
@@ -362,7 +361,7 @@ extern "C" int mh_launch_project_gather(MhViews vw, const float *pts, int N, int
                                         float *conf, float *mask, float *ori_patch, float *conf_patch,
                                         float *pixf, hipStream_t st) {
     const int tiles = (N + MH_PG_TILE - 1) / MH_PG_TILE;
-    const dim3 grid(vw.V * tiles), block(256);
+    const dim3 grid((vw.V * tiles + 7) & ~7), block(256);
 #define MH_PG_CASE(PS)                                                                                          \
     case PS:                                                                                                    \
         hipLaunchKernelGGL(mh_project_gather_kernel<PS>, grid, block, 0, st, vw, pts, N, tiles, vis, ori, conf,  \
@@ -401,7 +400,7 @@ extern "C" int mh_launch_project_taps(MhViews vw, const float *pts, int N, int p
                                       float *ori, float *conf, float *mask, float4 *taps, hipStream_t st) {
     if (patch * patch > MH_PREP_PMAX) return -1;
     const long long vn = (long long)vw.V * N;
-    const dim3 grid((unsigned)((vn + 3) / 4)), block(256);
+    const dim3 grid((unsigned)((((vn + 3) / 4) + 7) & ~7LL)), block(256);
 #define MH_PT_CASE(PS)                                                                                           \
     case PS:                                                                                                     \
         hipLaunchKernelGGL(mh_project_taps_kernel<PS>, grid, block, 0, st, vw, pts, N, thr, vis, ori, conf, mask,  \
