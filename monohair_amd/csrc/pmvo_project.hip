@@ -246,103 +246,141 @@ __global__ __launch_bounds__(256) void mh_prep_taps_kernel(const float *__restri
 // Compute_Visible_and_Ori that the base-view ranking and the sampler need) AND the tap list of the search,
 // straight from the packed maps -- the [V,N,P,..] patch tensors are never written or re-read, and for the
 // (view, point) pairs whose depth test fails (weight 0 in the loss, ~2/3 of them on a closed surface) the
-// patch is not even gathered.  One wave per (view, point), lane = tap.  Same arithmetic, same eligibility /
-// duplicate rules and same record layout as mh_project_gather_kernel + mh_prep_taps_kernel.
+// patch is not even gathered.  Same arithmetic, same eligibility / duplicate rules and same record layout as
+// mh_project_gather_kernel + mh_prep_taps_kernel.
 // ---------------------------------------------------------------------------------------------
 template <int PATCH>
 __global__ __launch_bounds__(256) void mh_project_taps_kernel(MhViews vw, const float *__restrict__ pts, int N,
-                                                              float thr, float *__restrict__ vis,
+                                                              int tiles, float thr, float *__restrict__ vis,
                                                               float *__restrict__ ori, float *__restrict__ conf,
                                                               float *__restrict__ mask, float4 *__restrict__ taps) {
+    // One workgroup = one view x 64 consecutive points (the tiling and XCD mapping of mh_project_gather_kernel).
+    //   phase 1: 64 lanes project their point, fetch the centre record, decide visibility, write the per-(v,n)
+    //            outputs coalesced and the header of points that fail the depth test;
+    //   phase 2: the 4 waves share the VISIBLE points of the tile; per point, lane = tap: gather, normalise,
+    //            eligibility, duplicate removal (hash table in LDS), order-preserving compaction, list + header.
+    //            The gather of the wave's next point is issued before the current one is processed.
     constexpr int P = PATCH * PATCH, HP = PATCH / 2;
+    __shared__ int s_r[MH_PG_TILE], s_cc[MH_PG_TILE];
+    __shared__ float s_vis[MH_PG_TILE], s_rowf[MH_PG_TILE], s_colf[MH_PG_TILE];
     __shared__ float2 s_o[4][MH_PREP_PMAX];
     __shared__ float s_c[4][MH_PREP_PMAX];
     __shared__ unsigned char s_el[4][MH_PREP_PMAX];
     __shared__ unsigned int s_first[4][256];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous view ranges
-    const int vn = bid * 4 + wave;
     const int V = vw.V, H = vw.H, W = vw.W;
-    if (vn >= V * N) return;
-    const int v = vn / N, n = vn - v * N;
+    if (bid >= V * tiles) return;
+    const int v = bid / tiles, tile = bid - v * tiles;
+    const int n0 = tile * MH_PG_TILE;
+    const int npts = min(MH_PG_TILE, N - n0);
     const float4 *__restrict__ rec = vw.rec + (size_t)v * H * W;
-    const float *cam = vw.cams + v * MH_CAM_STRIDE;
-    float u, w, z, rowf, colf;
-    mh_cam_project(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, w, z);
-    mh_ndc_to_pixel(u, w, (float)H, (float)W, rowf, colf);
-    float cr = __builtin_rintf(colf), rr = __builtin_rintf(rowf);
-    const bool oob = !(cr <= (float)(W - 1)) || (cr < 0.0f) || !(rr <= (float)(H - 1)) || (rr < 0.0f);
-    cr = fminf(fmaxf(cr, 0.0f), (float)(W - 1));
-    rr = fminf(fmaxf(rr, 0.0f), (float)(H - 1));
-    const int r = (int)rr, c = (int)cr;
-    const float4 q0 = rec[(size_t)r * W + c];
-    float visv = mh_soft_visible(q0.w, (-z / 2.0f) * 255.0f);
-    visv = oob ? -1.0f : visv;
-    float4 *__restrict__ out = taps + (size_t)vn * (P + 1);
-    if (lane == 0) {
-        vis[vn] = visv;
-        reinterpret_cast<float2 *>(ori)[vn] = make_float2(q0.x, q0.y);
-        conf[vn] = mh_clampf(q0.z, 1e-6f, 1.0f);
-        if (mask) mask[vn] = vw.mask[(size_t)v * H * W + (size_t)r * W + c];
-    }
-    if (visv == -1.0f) {
-        if (lane == 0) out[0] = make_float4(__int_as_float(0), visv, 0.0f, 0.0f);
-        return;
-    }
-    for (int b = lane; b < 256; b += MH_WAVE) s_first[wave][b] = 0xffffffffu;
-    // gather + clamp + patch maximum
-    float cmax = -1.0f;
-    for (int p = lane; p < P; p += MH_WAVE) {
-        const int i = p / PATCH - HP, j = p - (p / PATCH) * PATCH - HP;
-        const float4 q = rec[(size_t)min(max(r + i, 0), H - 1) * W + min(max(c + j, 0), W - 1)];
-        const float cc = mh_clampf(q.z, 1e-6f, 1.0f);
-        float o0, o1;
-        mh_unit2(q.x, q.y, o0, o1);
-        s_o[wave][p] = make_float2(o0, o1);
-        s_c[wave][p] = cc;
-        cmax = fmaxf(cmax, cc);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o));
-    const bool hc = cmax > thr;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int p = lane; p < P; p += MH_WAVE) {
-        const bool el = (p == 0) || (hc ? (s_c[wave][p] > thr) : true);
-        s_el[wave][p] = el;
-        if (el) {
-            const float2 o = s_o[wave][p];
-            const unsigned h = ((__float_as_uint(o.x) * 0x9E3779B1u) ^ (__float_as_uint(o.y) * 0x85EBCA77u)) >> 24;
-            atomicMin(&s_first[wave][h], (unsigned)p);
+
+    if (tid < MH_PG_TILE) {
+        float visv = -1.0f;
+        if (tid < npts) {
+            const int n = n0 + tid;
+            const float *cam = vw.cams + v * MH_CAM_STRIDE;
+            float u, w, z, rowf, colf;
+            mh_cam_project(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, w, z);
+            mh_ndc_to_pixel(u, w, (float)H, (float)W, rowf, colf);
+            float cr = __builtin_rintf(colf), rr = __builtin_rintf(rowf);
+            const bool oob = !(cr <= (float)(W - 1)) || (cr < 0.0f) || !(rr <= (float)(H - 1)) || (rr < 0.0f);
+            cr = fminf(fmaxf(cr, 0.0f), (float)(W - 1));
+            rr = fminf(fmaxf(rr, 0.0f), (float)(H - 1));
+            const int r = (int)rr, c = (int)cr;
+            const float4 q0 = rec[(size_t)r * W + c];
+            visv = mh_soft_visible(q0.w, (-z / 2.0f) * 255.0f);
+            visv = oob ? -1.0f : visv;
+            const size_t vn = (size_t)v * N + n;
+            vis[vn] = visv;
+            reinterpret_cast<float2 *>(ori)[vn] = make_float2(q0.x, q0.y);
+            conf[vn] = mh_clampf(q0.z, 1e-6f, 1.0f);
+            if (mask) mask[vn] = vw.mask[(size_t)v * H * W + (size_t)r * W + c];
+            if (visv == -1.0f) taps[vn * (P + 1)] = make_float4(__int_as_float(0), visv, 0.0f, 0.0f);
+            s_r[tid] = r;
+            s_cc[tid] = c;
+            s_rowf[tid] = rowf;
+            s_colf[tid] = colf;
         }
+        s_vis[tid] = visv;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    int base = 0;
-    for (int p0 = 0; p0 < P; p0 += MH_WAVE) {
-        const int p = p0 + lane;
-        bool el = false;
-        float2 o = make_float2(0.f, 0.f);
-        float cc = 0.f;
-        if (p < P) {
-            el = s_el[wave][p] != 0;
-            o = s_o[wave][p];
-            cc = s_c[wave][p];
+    __syncthreads();
+
+    auto gather = [&](int nl, int p) -> float4 {
+        const int i = p / PATCH - HP, j = p - (p / PATCH) * PATCH - HP;
+        return rec[(size_t)min(max(s_r[nl] + i, 0), H - 1) * W + min(max(s_cc[nl] + j, 0), W - 1)];
+    };
+    auto next_visible = [&](int nl) -> int {   // uniform per wave
+        while (nl < npts && s_vis[nl] == -1.0f) nl += 4;
+        return nl;
+    };
+    int cur = next_visible(wave);
+    float4 qcur = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cur < npts && lane < P) qcur = gather(cur, lane);
+    while (cur < npts) {
+        const int nxt = next_visible(cur + 4);
+        float4 qnxt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nxt < npts && lane < P) qnxt = gather(nxt, lane);
+        const size_t vn = (size_t)v * N + n0 + cur;
+        float4 *__restrict__ out = taps + vn * (P + 1);
+        for (int b = lane; b < 256; b += MH_WAVE) s_first[wave][b] = 0xffffffffu;
+        float cmax = -1.0f;
+        for (int p = lane; p < P; p += MH_WAVE) {
+            const float4 q = (p < MH_WAVE) ? qcur : gather(cur, p);
+            const float cc = mh_clampf(q.z, 1e-6f, 1.0f);
+            float o0, o1;
+            mh_unit2(q.x, q.y, o0, o1);
+            s_o[wave][p] = make_float2(o0, o1);
+            s_c[wave][p] = cc;
+            cmax = fmaxf(cmax, cc);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o));
+        const bool hc = cmax > thr;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int p = lane; p < P; p += MH_WAVE) {
+            const bool el = (p == 0) || (hc ? (s_c[wave][p] > thr) : true);
+            s_el[wave][p] = el;
             if (el) {
-                const unsigned ox = __float_as_uint(o.x), oy = __float_as_uint(o.y);
-                const unsigned q = s_first[wave][((ox * 0x9E3779B1u) ^ (oy * 0x85EBCA77u)) >> 24];
-                if (q < (unsigned)p) {
-                    const float2 e = s_o[wave][q];
-                    if (__float_as_uint(e.x) == ox && __float_as_uint(e.y) == oy) el = false;
-                }
+                const float2 o = s_o[wave][p];
+                const unsigned h = ((__float_as_uint(o.x) * 0x9E3779B1u) ^ (__float_as_uint(o.y) * 0x85EBCA77u)) >> 24;
+                atomicMin(&s_first[wave][h], (unsigned)p);
             }
         }
-        const unsigned long long m = __ballot(el);
-        const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (el) out[1 + pos] = make_float4(o.x, o.y, cc, 0.0f);
-        base += __popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int base = 0;
+        for (int p0 = 0; p0 < P; p0 += MH_WAVE) {
+            const int p = p0 + lane;
+            bool el = false;
+            float2 o = make_float2(0.f, 0.f);
+            float cc = 0.f;
+            if (p < P) {
+                el = s_el[wave][p] != 0;
+                o = s_o[wave][p];
+                cc = s_c[wave][p];
+                if (el) {
+                    const unsigned ox = __float_as_uint(o.x), oy = __float_as_uint(o.y);
+                    const unsigned q = s_first[wave][((ox * 0x9E3779B1u) ^ (oy * 0x85EBCA77u)) >> 24];
+                    if (q < (unsigned)p) {
+                        const float2 e = s_o[wave][q];
+                        if (__float_as_uint(e.x) == ox && __float_as_uint(e.y) == oy) el = false;
+                    }
+                }
+            }
+            const unsigned long long m = __ballot(el);
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (el) out[1 + pos] = make_float4(o.x, o.y, cc, 0.0f);
+            base += __popcll(m);
+        }
+        if (lane == 0) out[0] = make_float4(__int_as_float(base), s_vis[cur], s_rowf[cur], s_colf[cur]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        cur = nxt;
+        qcur = qnxt;
     }
-    if (lane == 0) out[0] = make_float4(__int_as_float(base), visv, rowf, colf);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -399,12 +437,12 @@ extern "C" int mh_launch_prep_taps(const float *ori_patch, const float *conf_pat
 extern "C" int mh_launch_project_taps(MhViews vw, const float *pts, int N, int patch, float thr, float *vis,
                                       float *ori, float *conf, float *mask, float4 *taps, hipStream_t st) {
     if (patch * patch > MH_PREP_PMAX) return -1;
-    const long long vn = (long long)vw.V * N;
-    const dim3 grid((unsigned)((((vn + 3) / 4) + 7) & ~7LL)), block(256);
+    const int tiles = (N + MH_PG_TILE - 1) / MH_PG_TILE;
+    const dim3 grid((vw.V * tiles + 7) & ~7), block(256);
 #define MH_PT_CASE(PS)                                                                                           \
     case PS:                                                                                                     \
-        hipLaunchKernelGGL(mh_project_taps_kernel<PS>, grid, block, 0, st, vw, pts, N, thr, vis, ori, conf, mask,  \
-                           taps);                                                                                \
+        hipLaunchKernelGGL(mh_project_taps_kernel<PS>, grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, conf, \
+                           mask, taps);                                                                          \
         break;
     switch (patch) {
         MH_PT_CASE(1)
