@@ -145,6 +145,11 @@ def main():
     t_search = max(t_sr - t_tk, 1e-6)     # forward = fused front end + top-k + search
 
     if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+            dist.destroy_process_group()
         return
     ms = dt / a.steps * 1e3
     value = a.steps * world / dt
@@ -196,10 +201,21 @@ def main():
         },
     }
     if not a.no_cpu and world == 1:      # the CPU leg runs on rank 0 at N=1 only
-        out["cpu_baseline"] = cpu_baseline(a, scene, recs, my[0], ms)
+        try:
+            out["cpu_baseline"] = cpu_baseline(a, scene, recs, my[0], ms)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)[:200]}
     if not a.quantize and not a.no_secondary and world == 1:
-        out["secondary_8bit_maps"] = secondary_quantized(a, dev, recs, cams, dev_chunks)
-    print(json.dumps(out))
+        try:
+            out["secondary_8bit_maps"] = secondary_quantized(a, dev, recs, cams, dev_chunks)
+        except Exception as e:   # the secondary number must never cost the headline line
+            out["secondary_8bit_maps"] = {"error": repr(e)[:200]}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def secondary_quantized(a, dev, recs, cams, dev_chunks):
