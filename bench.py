@@ -56,11 +56,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks: MH_DEVICE_OVERRIDE pins every rank to one GPU and MH_DIST_BACKEND=gloo replaces RCCL, so that the
+    # world_size > 1 code path can be exercised on a single-GPU box (RCCL refuses two ranks on one device)
+    if os.environ.get("MH_DEVICE_OVERRIDE") is not None:
+        local = int(os.environ["MH_DEVICE_OVERRIDE"])
+    backend = os.environ.get("MH_DIST_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
     n_gpus = max(a.gpus, world) if world > 1 else 1
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
@@ -116,7 +124,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
