@@ -56,7 +56,11 @@ def main(argv=None):
         import torch.distributed as tdist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
+        # MH_DIST_BACKEND=gloo + MH_DEVICE_OVERRIDE: test hooks to run several ranks on one GPU (RCCL refuses that)
+        if os.environ.get("MH_DIST_BACKEND", "nccl") == "nccl":
+            tdist.init_process_group(backend="nccl", device_id=torch.device("cuda", int(os.environ["LOCAL_RANK"])))
+        else:
+            tdist.init_process_group(backend=os.environ["MH_DIST_BACKEND"])
     args = config_parser(argv)
 
     vertices, faces, normals = load_bust(args.data.bust_path)

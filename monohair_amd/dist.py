@@ -35,6 +35,12 @@ def barrier():
         d.barrier()
 
 
+def _comm_device(device):
+    """collectives run on the GPU with RCCL; the gloo backend (CPU tests, single-GPU multi-rank tests) stages on the host"""
+    d = _dist()
+    return device if (d and d.get_backend() == "nccl") else "cpu"
+
+
 def owner(i, n_ranks=None):
     """rank that processes chunk i"""
     return i % (world() if n_ranks is None else n_ranks)
@@ -54,12 +60,14 @@ def map_chunks(chunks, fn, device, empty):
     dt = empty().dtype
     per_rank = [sum(lens[i] for i in range(len(chunks)) if owner(i, w) == k) for k in range(w)]
     cap = max(per_rank) if per_rank else 0
-    buf = torch.zeros((max(cap, 1), cols), dtype=dt, device=device)
+    cdev = _comm_device(device)
+    buf = torch.zeros((max(cap, 1), cols), dtype=dt, device=cdev)
     if mine:
         cat = torch.cat([mine[i] for i in sorted(mine)], 0)
-        buf[:cat.shape[0]] = cat
+        buf[:cat.shape[0]] = cat.to(cdev)
     gathered = [torch.empty_like(buf) for _ in range(w)]
     d.all_gather(gathered, buf)
+    gathered = [g.to(device) for g in gathered]
     out, cursor = [None] * len(chunks), [0] * w
     for i in range(len(chunks)):
         k = owner(i, w)
@@ -76,14 +84,15 @@ def all_gather_views(local, n_views, shape, dtype, device):
     if not d:
         return torch.stack(local, 0) if local else torch.empty((0,) + tuple(shape), dtype=dtype, device=device)
     cap = (n_views + w - 1) // w
-    buf = torch.zeros((cap,) + tuple(shape), dtype=dtype, device=device)
+    cdev = _comm_device(device)
+    buf = torch.zeros((cap,) + tuple(shape), dtype=dtype, device=cdev)
     for j, t in enumerate(local):
-        buf[j] = t
+        buf[j] = t.to(cdev)
     gathered = [torch.empty_like(buf) for _ in range(w)]
     d.all_gather(gathered, buf)
     out = torch.empty((n_views,) + tuple(shape), dtype=dtype, device=device)
     for i in range(n_views):
-        out[i] = gathered[owner(i, w)][i // w]
+        out[i] = gathered[owner(i, w)][i // w].to(device)
     return out
 
 
@@ -118,6 +127,8 @@ def voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size, 
         v = res["voxels"].to(device)
         vol[v[:, 0], v[:, 1], v[:, 2], 0] = 1.0
         vol[v[:, 0], v[:, 1], v[:, 2], 1:] = res["ori"].to(device)
+    cdev = _comm_device(device)
+    vol = vol.to(cdev)
     d.reduce(vol, dst=0, op=d.ReduceOp.SUM)          # the one collective of the data path
     if r != 0:
         return np.zeros(tuple(g)), np.zeros(tuple(g) + (3,))

@@ -117,7 +117,7 @@ def process_options(opt):
     else:
         opt.name = str(opt.name) + "_" + "".join(random.choice(string.ascii_uppercase) for _ in range(4))
     assert isinstance(opt.gpu, int)
-    local = os.environ.get("LOCAL_RANK")
+    local = os.environ.get("MH_DEVICE_OVERRIDE", os.environ.get("LOCAL_RANK"))
     gpu = int(local) if local is not None else opt.gpu      # one process per GPU under torchrun
     opt.device = "cpu" if opt.get("cpu") or not torch.cuda.is_available() else "cuda:{}".format(gpu)
 
