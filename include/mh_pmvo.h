@@ -121,6 +121,14 @@ int mh_medoid_segmented(mh_ctx *ctx, const float *ori, const int32_t *seg_start,
 int mh_replace_dissimilar(mh_ctx *ctx, const float *center, float *ori /*in/out [N,3]*/, float threshold, int N,
                           void *stream);
 
+/* Exact k nearest neighbours on a uniform grid: the `points_tree.query(sub_points, 100)` of refine (PMVO.py:612,671).
+ * pts_sorted[M,3]: the data points sorted by cell (x fastest), order[M]: their original indices, cell_start[ncell+1];
+ * grid_origin_h (host): {ox, oy, oz, cell size}, grid_dims (host): {dx, dy, dz}.  out_idx[Q,k] sorted by (fp64 distance,
+ * index); status[Q] != 0 marks queries the kernel could not finish (candidate buffer / ring limit): redo on the host. */
+int mh_knn_grid(mh_ctx *ctx, const float *grid_origin_h, const int32_t *grid_dims, const float *pts_sorted,
+                const int32_t *order, const int32_t *cell_start, const float *queries, int Q, int k,
+                int32_t *out_idx, int32_t *status, void *stream);
+
 /* ---- K1+K2: calOrientationGabor.forward with iter=1 (preprocess_capture_data/GaborFilter.py:29-145):
  * 180 real Gabor kernels 17x17 (sigma 1.8/2.4, lambda 4), |response| argmax -> orientation index,
  * response-curve variance -> confidence normalised by the image maximum.

@@ -55,6 +55,8 @@ int mh_launch_gabor_bank(const float *, const float *, int, int, int32_t *, floa
                          hipStream_t);
 int mh_launch_gabor_build(float *, hipStream_t);
 int mh_launch_replace_dissimilar(const float *, float *, float, int, hipStream_t);
+int mh_launch_knn(float, float, float, float, int, int, int, const float *, const int32_t *, const int32_t *,
+                  const float *, int, int, int32_t *, int32_t *, hipStream_t);
 int mh_launch_pack_volume(const float *, const float *, size_t, float4 *, hipStream_t);
 int mh_launch_trace_seeds(const float4 *, int, int, int, const float *, int, float, float *, int32_t *, int32_t *,
                           hipStream_t);
@@ -316,6 +318,19 @@ extern "C" int mh_replace_dissimilar(mh_ctx *ctx, const float *center, float *or
     if (!ctx || !center || !ori || N < 0) return fail(MH_ERR_ARG, "mh_replace_dissimilar: bad arguments");
     return launched(mh_launch_replace_dissimilar(center, ori, threshold, N, (hipStream_t)stream),
                     "mh_replace_dissimilar");
+}
+
+extern "C" int mh_knn_grid(mh_ctx *ctx, const float *grid_origin_h /*host: ox,oy,oz,h*/, const int32_t *grid_dims /*host*/,
+                           const float *pts_sorted, const int32_t *order, const int32_t *cell_start,
+                           const float *queries, int Q, int k, int32_t *out_idx, int32_t *status, void *stream) {
+    if (Q == 0) return MH_OK;
+    if (!ctx || !grid_origin_h || !grid_dims || !pts_sorted || !order || !cell_start || !queries || !out_idx ||
+        !status || Q < 0)
+        return fail(MH_ERR_ARG, "mh_knn_grid: bad arguments");
+    return launched(mh_launch_knn(grid_origin_h[0], grid_origin_h[1], grid_origin_h[2], grid_origin_h[3], grid_dims[0],
+                                  grid_dims[1], grid_dims[2], pts_sorted, order, cell_start, queries, Q, k, out_idx,
+                                  status, (hipStream_t)stream),
+                    "mh_knn_grid");
 }
 
 // ---- strand tracing on the fitted volume (HairGrow.py:59-299) ------------------------------------------------

@@ -384,21 +384,27 @@ def optimize(points, pmvo, args):
     return select_points, select_ori, min_loss, high_conf_index
 
 
-def _knn(tree, sub_points, k, n_total):
-    # scipy returns index n for missing neighbours when k > n (the reference would raise on ori[index]);
-    # tiny inputs only: clamp k.
-    k = min(k, n_total)
-    _, index = tree.query(sub_points, k, workers=-1)   # same neighbours, all host cores
-    return index.reshape(len(sub_points), k)
+def _knn(data_points, query_points, k, device, mode="device"):
+    """The `KDTree(data).query(queries, k)` of refine (PMVO.py:605,612,660,671) -> index [Q,k] int64 tensor on `device`.
+    mode "device": exact grid k-NN kernel (csrc/knn.hip, scipy's result and order); "host": scipy on all cores.
+    scipy returns index n for missing neighbours when k > n (the reference would raise on ori[index]); k is clamped."""
+    k = min(k, data_points.shape[0])
+    if mode == "device":
+        from .pmvo_utils import GridKNN
+
+        return GridKNN(data_points, k_hint=k, device=device).query(query_points, k)
+    from scipy.spatial import KDTree
+
+    _, index = KDTree(data=data_points).query(query_points, k, workers=-1)
+    return torch.from_numpy(np.asarray(index).reshape(len(query_points), k)).to(device)
 
 
 def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=True, threshold=0.001,
            genrate_ori_only=False, voxel_min=None, voxel_size=None, grid_resolution=None):
     """PMVO.py:602-764: KNN-medoid smoothing (sequentially dependent 5000-point chunks, in place), threshold,
     orientations for the occluded shell points, voxel fit, Ori3D.mat / Occ3D.mat.
-    voxel_min/voxel_size/grid_resolution default to the reference's hard-coded 256x256x192 @ 2.5 mm grid."""
-    from scipy.spatial import KDTree
-
+    voxel_min/voxel_size/grid_resolution default to the reference's hard-coded 256x256x192 @ 2.5 mm grid.
+    args.knn = "host" switches the neighbour queries back to scipy's KDTree (default: the device kernel)."""
     from . import dist as mdist
     from . import pmvo_utils as U
 
@@ -413,7 +419,7 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         # cores), then the sequentially dependent smoothing loop (chunk k+1 reads the orientations chunk k wrote,
         # PMVO.py:614,640) runs entirely on the device, stream-ordered, without a host round trip per chunk.
         n_all = points.shape[0]
-        index_all = torch.from_numpy(_knn(KDTree(data=points), points, 100, n_all)).to(device)
+        index_all = _knn(points, points, 100, device, getattr(args, "knn", "device"))
         head_top_all = torch.from_numpy(pmvo.head_top_mask(points)).to(device)
         pts_dev = torch.from_numpy(points).to(device).type(torch.float)
         ori_dev = torch.from_numpy(ori).to(device).type(torch.float).contiguous()
@@ -443,7 +449,6 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     index = np.where(min_loss < threshold)[0]
     select_ori = ori[index]
     select_points = points[index]
-    points_tree = KDTree(data=select_points)
 
     # orientation of the occluded shell points from their 100 nearest kept neighbours (PMVO.py:662-686)
     sub_num = 5000
@@ -452,7 +457,7 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     print("compute points orientation near the surface... ")
     if len(select_points) and len(filter_unvisible_points):
         fu = np.ascontiguousarray(filter_unvisible_points)
-        index_all = torch.from_numpy(_knn(points_tree, fu, 100, select_points.shape[0])).to(device)
+        index_all = _knn(select_points, fu, 100, device, getattr(args, "knn", "device"))
         head_top_all = torch.from_numpy(pmvo.head_top_mask(fu.astype(np.float32))).to(device)
         fu_dev = torch.from_numpy(fu).type(torch.float).to(device)
         sel_ori_dev = torch.from_numpy(select_ori).to(device)

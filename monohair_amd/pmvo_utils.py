@@ -181,6 +181,79 @@ def compute_points_similarity(ori, return_index=False):
     return (out, idx) if return_index else out
 
 
+class GridKNN:
+    """Exact k-nearest-neighbour search on the GPU (csrc/knn.hip) with scipy.spatial.KDTree's query semantics:
+    neighbours sorted by distance (fp64 from the fp32 coordinates), self included when the query is a data point.
+    Used for the two `points_tree.query(sub_points, 100)` of refine (PMVO.py:612,671).  The uniform grid only
+    affects speed: queries the kernel cannot finish inside its candidate buffer are answered by a host KDTree."""
+
+    def __init__(self, points, k_hint=100, device="cuda:0"):
+        self.device = torch.device(device)
+        self.points_host = np.ascontiguousarray(points)
+        pts = torch.from_numpy(self.points_host.astype(np.float32)).to(self.device)
+        self.M = pts.shape[0]
+        lo = pts.min(0).values
+        hi = pts.max(0).values
+        ext = float((hi - lo).max().item()) + 1e-6
+
+        def occupancy(h):
+            c = torch.floor((pts - lo) / h).long().clamp(min=0)
+            key = (c[:, 2] * 4096 + c[:, 1]) * 4096 + c[:, 0]
+            return self.M / float(torch.unique(key).numel())
+
+        # local dimension and density from the mean occupancy at two scales -> radius of the k-ball -> cell size
+        h0 = max(ext / 128.0, 1e-6)
+        c1, c2 = occupancy(h0), occupancy(2 * h0)
+        dim = min(3.0, max(1.0, math.log(max(c2 / c1, 1.01), 2)))
+        ball = {1: 2.0, 2: math.pi, 3: 4.18879}[int(round(dim))]
+        rk = h0 * (max(k_hint, 1) / (c1 * ball)) ** (1.0 / dim)
+        h = max(rk / 1.5, ext / 480.0)
+        self.h = float(np.float32(h))
+        self.origin = lo.cpu().numpy().astype(np.float32)
+        dims = np.floor((hi.cpu().numpy().astype(np.float64) - self.origin) / self.h).astype(np.int64) + 1
+        self.dims = np.maximum(dims, 1).astype(np.int32)
+        c = torch.floor((pts - torch.from_numpy(self.origin).to(self.device)) / torch.tensor(self.h, device=self.device))
+        c = c.long()
+        for a in range(3):
+            c[:, a].clamp_(0, int(self.dims[a]) - 1)
+        cell = (c[:, 2] * int(self.dims[1]) + c[:, 1]) * int(self.dims[0]) + c[:, 0]
+        cs, order = torch.sort(cell, stable=True)
+        self._order = order.to(torch.int32).contiguous()
+        self._pts = pts[order].contiguous()
+        ncell = int(self.dims[0]) * int(self.dims[1]) * int(self.dims[2])
+        self._cell_start = torch.searchsorted(cs, torch.arange(ncell + 1, device=self.device)).to(torch.int32).contiguous()
+        self._grid = np.array([self.origin[0], self.origin[1], self.origin[2], self.h], dtype=np.float32)
+        self._tree = None
+
+    def query(self, queries, k):
+        """-> index [Q,k] int64 device tensor (k clamped to the number of points, like the drivers do)."""
+        import ctypes
+
+        k = min(int(k), self.M)
+        q_host = np.ascontiguousarray(queries)
+        q = torch.from_numpy(q_host.astype(np.float32)).to(self.device).contiguous()
+        Q = q.shape[0]
+        out = torch.empty((Q, k), dtype=torch.int32, device=self.device)
+        status = torch.empty((Q,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mh_knn_grid(_ctx_for(self.device), self._grid.ctypes.data_as(ctypes.c_void_p),
+                                              self.dims.ctypes.data_as(ctypes.c_void_p), _lib.ptr(self._pts),
+                                              _lib.ptr(self._order), _lib.ptr(self._cell_start), _lib.ptr(q), Q, k,
+                                              _lib.ptr(out), _lib.ptr(status), _lib.stream_ptr()), "mh_knn_grid")
+        out = out.long()
+        bad = torch.nonzero(status != 0).flatten()
+        if bad.numel():
+            from scipy.spatial import KDTree
+
+            if self._tree is None:
+                self._tree = KDTree(data=self.points_host)
+            bi = bad.cpu().numpy()
+            _, idx = self._tree.query(q_host[bi], k, workers=-1)
+            out[bad] = torch.from_numpy(np.asarray(idx).reshape(len(bi), k)).to(self.device)
+        self.last_fallbacks = int(bad.numel())
+        return out
+
+
 def p2v(points, voxel_min, voxel_size, grid_resolution):
     """PMVO_utils.py:386-404: flips y,z IN PLACE (mutates the caller's array, like the reference), float64
     round-half-even, clip.  Returns (x, y, z) int32 arrays."""

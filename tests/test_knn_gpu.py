@@ -1,0 +1,79 @@
+"""GPU: exact grid k-NN (csrc/knn.hip) against scipy.spatial.KDTree -- identical index arrays, in scipy's order."""
+import numpy as np
+import pytest
+from scipy.spatial import KDTree
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def check(points, queries, k, exact=True):
+    from monohair_amd.pmvo_utils import GridKNN
+
+    knn = GridKNN(points, k_hint=k, device=DEV)
+    got = knn.query(queries, k).cpu().numpy()
+    kk = min(k, len(points))
+    d, ref = KDTree(data=points).query(queries, kk)
+    ref = np.asarray(ref).reshape(len(queries), kk)
+    if exact:
+        assert np.array_equal(got, ref)
+    else:   # ties: same distances
+        dg = np.linalg.norm(points[got].astype(np.float64) - queries[:, None].astype(np.float64), axis=-1)
+        assert np.allclose(dg, np.asarray(d).reshape(len(queries), kk), rtol=0, atol=1e-12)
+    return knn
+
+
+def test_surface_points_like_refine():
+    from monohair_amd import synth
+
+    pts = synth.candidate_points(res=128, seed=0).astype(np.float32)          # ~116 k points on a sphere shell
+    knn = check(pts, pts[::37], 100)
+    assert knn.last_fallbacks == 0
+    shell = (pts[::53] * 1.02).astype(np.float64)                              # queries that are not data points
+    check(pts, shell, 100)
+
+
+def test_volume_clusters_and_small_sets():
+    rng = np.random.default_rng(0)
+    vol = rng.random((20000, 3)).astype(np.float32)
+    check(vol, vol[:500], 100)
+    check(vol, rng.random((300, 3)), 1)
+    clus = np.concatenate([rng.normal(0, 0.01, (5000, 3)), rng.normal(1, 0.2, (5000, 3)), rng.random((200, 3)) * 5])
+    check(clus.astype(np.float32), clus[::17].astype(np.float32), 64)
+    few = rng.random((37, 3)).astype(np.float32)
+    check(few, few, 100)                                                      # k > number of points
+    line = np.stack([np.linspace(0, 1, 3000), np.zeros(3000), np.zeros(3000)], 1).astype(np.float32)
+    check(line, line[::29], 50, exact=False)                                  # collinear: exact distance ties
+
+
+def test_refine_driver_uses_it_and_matches_host_kdtree(tmp_path):
+    """the refine driver with device k-NN reproduces the run with scipy's KDTree"""
+    import ast
+    import os
+    import types
+
+    from conftest import GOLDEN, golden_records, golden_scene
+    from monohair_amd.pmvo import PMVO, refine
+
+    z = np.load(os.path.join(GOLDEN, "e2e_small.npz"), allow_pickle=False)
+    meta = ast.literal_eval(str(z["meta"]))
+    scene = golden_scene(meta)
+    pm = PMVO.from_planes(golden_records(z), scene["depth"].to(DEV), scene["ori"].to(DEV), scene["conf"].to(DEV),
+                          scene["mask"].to(DEV), device=DEV, patch_size=meta["patch"],
+                          visible_threshold=meta["vis_thr"], conf_threshold=meta["thr"])
+    scalp = z["toy_scalp"]
+    pm.set_head(KDTree(data=z["toy_bust"]), KDTree(data=scalp), np.max(scalp, axis=0))
+    outs = []
+    for mode in ("device", "host"):
+        d = tmp_path / mode
+        os.makedirs(d / "refine")
+        args = types.SimpleNamespace(device=DEV, output_path=str(d), save_root=str(d / "optimize"),
+                                     save_path=str(d / "refine"), knn=mode,
+                                     PMVO=types.SimpleNamespace(visible_threshold=meta["vis_thr"]),
+                                     data=types.SimpleNamespace(root=str(d)))
+        fu = z["candidates"][z["filter_index"]]
+        occ, ori = refine(z["opt_select_p"].copy(), z["opt_select_o"].copy(), z["opt_min_loss"].copy(), pm, fu, args,
+                          infer_inner=False, threshold=meta["threshold"])
+        outs.append((occ, ori, np.load(d / "refine" / "select_o.npy"), np.load(d / "refine" / "min_loss.npy")))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b, equal_nan=True)
