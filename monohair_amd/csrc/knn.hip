@@ -6,7 +6,8 @@
 // Points are pre-sorted by cell (x fastest), so a row of cells is ONE contiguous range.  One wave per query: for
 // ring = 1, 2, ... gather every point of the (2 ring + 1)^3 cell block into LDS (ballot-prefix append), bitonic-sort
 // the candidates by (d2, index) and stop as soon as the k-th distance is <= ring * h -- nothing outside the block can
-// be closer than that.  Queries that overflow the candidate buffer or the ring limit are flagged for the host.
+// be closer than that.  Queries that overflow the candidate buffer (status 2) or reach the ring limit (status 1)
+// are flagged; the host wrapper re-runs just those on a finer / coarser grid (still on the GPU).
 #include "mh_device.h"
 
 #define MH_KNN_CAP 2048
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(128) void mh_knn_kernel(MhGrid g, const float *__re
     const int cy = min(max((int)floorf((qy - g.oy) / g.h), 0), g.dy - 1);
     const int cz = min(max((int)floorf((qz - g.oz) / g.h), 0), g.dz - 1);
     const double dqx = (double)qx, dqy = (double)qy, dqz = (double)qz;
-    int st = 1;
+    int st = 1;   // 1: ring limit reached (cells too small for this query), 2: candidate buffer overflow (too large)
     for (int ring = 1; ring <= MH_KNN_MAXRING; ++ring) {
         int cnt = 0;
         bool overflow = false;
@@ -69,7 +70,10 @@ __global__ __launch_bounds__(128) void mh_knn_kernel(MhGrid g, const float *__re
         if (cnt > MH_KNN_CAP) overflow = true;
         const bool whole_grid = (cx - ring <= 0) && (cy - ring <= 0) && (cz - ring <= 0) && (cx + ring >= g.dx - 1) &&
                                 (cy + ring >= g.dy - 1) && (cz + ring >= g.dz - 1);
-        if (overflow) break;
+        if (overflow) {
+            st = 2;
+            break;
+        }
         if (cnt < k && !whole_grid) continue;
         // bitonic sort of the next power of two >= cnt, padded with +inf
         int n2 = 64;

@@ -185,15 +185,16 @@ class GridKNN:
     """Exact k-nearest-neighbour search on the GPU (csrc/knn.hip) with scipy.spatial.KDTree's query semantics:
     neighbours sorted by distance (fp64 from the fp32 coordinates), self included when the query is a data point.
     Used for the two `points_tree.query(sub_points, 100)` of refine (PMVO.py:612,671).  The uniform grid only
-    affects speed: queries the kernel cannot finish inside its candidate buffer are answered by a host KDTree."""
+    affects speed: queries the kernel cannot finish with one cell size (candidate buffer overflow in dense spots,
+    ring limit in sparse ones) are re-run on a finer / coarser grid, still on the GPU."""
 
     def __init__(self, points, k_hint=100, device="cuda:0"):
         self.device = torch.device(device)
-        self.points_host = np.ascontiguousarray(points)
-        pts = torch.from_numpy(self.points_host.astype(np.float32)).to(self.device)
+        pts = torch.from_numpy(np.ascontiguousarray(points).astype(np.float32)).to(self.device)
+        self._raw = pts
         self.M = pts.shape[0]
-        lo = pts.min(0).values
-        hi = pts.max(0).values
+        lo, hi = pts.min(0).values, pts.max(0).values
+        self._lo, self._hi = lo, hi
         ext = float((hi - lo).max().item()) + 1e-6
 
         def occupancy(h):
@@ -207,50 +208,64 @@ class GridKNN:
         dim = min(3.0, max(1.0, math.log(max(c2 / c1, 1.01), 2)))
         ball = {1: 2.0, 2: math.pi, 3: 4.18879}[int(round(dim))]
         rk = h0 * (max(k_hint, 1) / (c1 * ball)) ** (1.0 / dim)
-        h = max(rk / 1.5, ext / 480.0)
-        self.h = float(np.float32(h))
-        self.origin = lo.cpu().numpy().astype(np.float32)
-        dims = np.floor((hi.cpu().numpy().astype(np.float64) - self.origin) / self.h).astype(np.int64) + 1
-        self.dims = np.maximum(dims, 1).astype(np.int32)
-        c = torch.floor((pts - torch.from_numpy(self.origin).to(self.device)) / torch.tensor(self.h, device=self.device))
-        c = c.long()
-        for a in range(3):
-            c[:, a].clamp_(0, int(self.dims[a]) - 1)
-        cell = (c[:, 2] * int(self.dims[1]) + c[:, 1]) * int(self.dims[0]) + c[:, 0]
-        cs, order = torch.sort(cell, stable=True)
-        self._order = order.to(torch.int32).contiguous()
-        self._pts = pts[order].contiguous()
-        ncell = int(self.dims[0]) * int(self.dims[1]) * int(self.dims[2])
-        self._cell_start = torch.searchsorted(cs, torch.arange(ncell + 1, device=self.device)).to(torch.int32).contiguous()
-        self._grid = np.array([self.origin[0], self.origin[1], self.origin[2], self.h], dtype=np.float32)
-        self._tree = None
+        self._ext = ext
+        self._grids = {}
+        self.h = max(rk / 1.5, ext / 480.0)
+        self.last_retries = 0
 
-    def query(self, queries, k):
-        """-> index [Q,k] int64 device tensor (k clamped to the number of points, like the drivers do)."""
+    def _grid(self, h):
+        """(origin+h [4] f32 host, dims [3] i32 host, points sorted by cell, original indices, cell_start)"""
+        h = float(np.float32(max(h, self._ext / 480.0)))
+        if h not in self._grids:
+            pts, dev = self._raw, self.device
+            origin = self._lo.cpu().numpy().astype(np.float32)
+            dims = np.floor((self._hi.cpu().numpy().astype(np.float64) - origin) / h).astype(np.int64) + 1
+            dims = np.maximum(dims, 1).astype(np.int32)
+            c = torch.floor((pts - torch.from_numpy(origin).to(dev)) / torch.tensor(h, device=dev)).long()
+            for a in range(3):
+                c[:, a].clamp_(0, int(dims[a]) - 1)
+            cell = (c[:, 2] * int(dims[1]) + c[:, 1]) * int(dims[0]) + c[:, 0]
+            cs, order = torch.sort(cell, stable=True)
+            ncell = int(dims[0]) * int(dims[1]) * int(dims[2])
+            start = torch.searchsorted(cs, torch.arange(ncell + 1, device=dev)).to(torch.int32).contiguous()
+            self._grids[h] = (np.array([origin[0], origin[1], origin[2], h], dtype=np.float32), dims,
+                              pts[order].contiguous(), order.to(torch.int32).contiguous(), start)
+        return self._grids[h]
+
+    def _run(self, h, q, k):
         import ctypes
 
-        k = min(int(k), self.M)
-        q_host = np.ascontiguousarray(queries)
-        q = torch.from_numpy(q_host.astype(np.float32)).to(self.device).contiguous()
+        grid, dims, pts, order, start = self._grid(h)
         Q = q.shape[0]
         out = torch.empty((Q, k), dtype=torch.int32, device=self.device)
         status = torch.empty((Q,), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().mh_knn_grid(_ctx_for(self.device), self._grid.ctypes.data_as(ctypes.c_void_p),
-                                              self.dims.ctypes.data_as(ctypes.c_void_p), _lib.ptr(self._pts),
-                                              _lib.ptr(self._order), _lib.ptr(self._cell_start), _lib.ptr(q), Q, k,
-                                              _lib.ptr(out), _lib.ptr(status), _lib.stream_ptr()), "mh_knn_grid")
-        out = out.long()
-        bad = torch.nonzero(status != 0).flatten()
-        if bad.numel():
-            from scipy.spatial import KDTree
+            _lib.check(_lib.lib().mh_knn_grid(_ctx_for(self.device), grid.ctypes.data_as(ctypes.c_void_p),
+                                              dims.ctypes.data_as(ctypes.c_void_p), _lib.ptr(pts), _lib.ptr(order),
+                                              _lib.ptr(start), _lib.ptr(q), Q, k, _lib.ptr(out), _lib.ptr(status),
+                                              _lib.stream_ptr()), "mh_knn_grid")
+        return out.long(), status
 
-            if self._tree is None:
-                self._tree = KDTree(data=self.points_host)
-            bi = bad.cpu().numpy()
-            _, idx = self._tree.query(q_host[bi], k, workers=-1)
-            out[bad] = torch.from_numpy(np.asarray(idx).reshape(len(bi), k)).to(self.device)
-        self.last_fallbacks = int(bad.numel())
+    def query(self, queries, k):
+        """-> index [Q,k] int64 device tensor (k clamped to the number of points, like the drivers do)."""
+        k = min(int(k), self.M)
+        q = torch.from_numpy(np.ascontiguousarray(queries).astype(np.float32)).to(self.device).contiguous()
+        out, status = self._run(self.h, q, k)
+        self.last_retries = 0
+        for code, factor in ((2, 0.5), (1, 2.0)):        # overflow -> finer cells, ring limit -> coarser cells
+            h = self.h
+            for _ in range(6):
+                bad = torch.nonzero(status == code).flatten()
+                if not bad.numel():
+                    break
+                h *= factor
+                o2, s2 = self._run(h, q[bad].contiguous(), k)
+                out[bad] = o2
+                status[bad] = s2
+                self.last_retries += 1
+        left = int((status != 0).sum().item())
+        if left:
+            raise _lib.MhError("GridKNN: %d queries could not be answered on any grid (degenerate point set?)" % left)
         return out
 
 

@@ -28,7 +28,7 @@ def test_surface_points_like_refine():
 
     pts = synth.candidate_points(res=128, seed=0).astype(np.float32)          # ~116 k points on a sphere shell
     knn = check(pts, pts[::37], 100)
-    assert knn.last_fallbacks == 0
+    assert knn.last_retries == 0
     shell = (pts[::53] * 1.02).astype(np.float64)                              # queries that are not data points
     check(pts, shell, 100)
 
