@@ -263,9 +263,17 @@ class GridKNN:
                 out[bad] = o2
                 status[bad] = s2
                 self.last_retries += 1
-        left = int((status != 0).sum().item())
-        if left:
-            raise _lib.MhError("GridKNN: %d queries could not be answered on any grid (degenerate point set?)" % left)
+        # extreme density contrast (a sparse query whose k-ball swallows a dense cluster) defeats every cell size:
+        # those few queries are answered by exhaustive search, also on the GPU (same fp64 distances, stable sort =
+        # ties by index)
+        left = torch.nonzero(status != 0).flatten()
+        self.last_exhaustive = int(left.numel())
+        if left.numel():
+            p64 = self._raw.to(torch.float64)
+            for i in left.tolist():
+                d = p64 - q[i].to(torch.float64)
+                d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+                out[i] = torch.sort(d2, stable=True).indices[:k]
         return out
 
 
