@@ -46,12 +46,15 @@ def owner(i, n_ranks=None):
     return i % (world() if n_ranks is None else n_ranks)
 
 
-def map_chunks(chunks, fn, device, empty):
+def map_chunks(chunks, fn, device, empty, after=None):
     """Apply fn to every chunk (each rank takes chunks i with i % world == rank) and return the list of all
-    results in chunk order on every rank.  fn returns a 2-D tensor on `device`; `empty()` gives a [0,C] one."""
+    results in chunk order on every rank.  fn returns a 2-D tensor on `device`; `empty()` gives a [0,C] one.
+    after(): called once all chunks have been issued and before any result is read (e.g. to join side streams)."""
     d = _dist()
     w, r = world(), rank()
     mine = {i: fn(c) if len(c) else empty() for i, c in enumerate(chunks) if owner(i, w) == r}
+    if after is not None:
+        after()
     if not d:
         return [mine[i] for i in range(len(chunks))]
     # one all_gather of padded per-rank buffers (sizes are known on every rank: they are the chunk lengths)

@@ -356,21 +356,25 @@ def optimize(points, pmvo, args):
     # kernel (workgroups of points that see many views) overlaps the head of the next chunk
     streams = [torch.cuda.Stream(device=pmvo.device) for _ in range(2)]
     counter = [0]
+    main = torch.cuda.current_stream()
+    for st in streams:
+        st.wait_stream(main)          # whatever produced the maps / points has finished
 
     def work(sub):
         st = streams[counter[0] % 2]
         counter[0] += 1
-        st.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(st):
             p, o, l, h = pmvo.forward(sub)
             out = torch.cat([p, o, l[:, None], h[:, None].to(torch.float32)], 1)
-        out.record_stream(torch.cuda.current_stream())
+        out.record_stream(main)
         return out
 
+    def join():                        # results are read on the main stream: join the side streams first
+        for st in streams:
+            main.wait_stream(st)
+
     res = mdist.map_chunks(chunks, work, pmvo.device,
-                           empty=lambda: torch.empty((0, 8), dtype=torch.float32, device=pmvo.device))
-    for st in streams:
-        torch.cuda.current_stream().wait_stream(st)
+                           empty=lambda: torch.empty((0, 8), dtype=torch.float32, device=pmvo.device), after=join)
     res = torch.cat(res, 0).cpu().numpy()
     select_points, select_ori, min_loss = res[:, 0:3], res[:, 3:6], res[:, 6]
     high_conf_index = res[:, 7] > 0.5
