@@ -1,0 +1,80 @@
+#!/usr/bin/env python
+"""Randomised HIP-vs-oracle parity sweep (GPU box): many scenes with random camera counts / image sizes / patch sizes /
+thresholds / map quantisation / point sets, every result compared bit for bit with the CPU oracle.
+
+    python tools/stress_parity.py --minutes 5 [--seed 0]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402  (this tool is a checker, like the tests)
+from monohair_amd import synth  # noqa: E402
+from monohair_amd.camera import camera_records, cameras_from_list  # noqa: E402
+from monohair_amd.pmvo import PMVO, depth_offsets  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--minutes", type=float, default=3.0)
+ap.add_argument("--seed", type=int, default=0)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+DEV = "cuda:0"
+offs = depth_offsets(90)
+t_end = time.time() + a.minutes * 60
+n_scene = n_pts = 0
+bad = []
+
+
+def eq(x, y):
+    return np.array_equal(x, y, equal_nan=True)
+
+
+while time.time() < t_end:
+    V = int(rng.integers(20, 70))
+    H = int(rng.integers(48, 400))
+    W = int(rng.integers(40, 300))
+    patch = int(rng.choice([1, 3, 5, 7, 9, 11]))
+    thr = float(rng.choice([0.05, 0.1, 0.15, 0.3, 0.6]))
+    quant = bool(rng.integers(0, 2))
+    rings = int(rng.integers(1, 4))
+    scale = float(rng.uniform(0.8, 2.6))
+    seed = int(rng.integers(0, 1 << 30))
+    scene = synth.make_scene(V, H, W, seed=seed, quantize=quant, rings=rings, scale=scale)
+    # perturb the cameras off the ring (translations, principal point) so that projections are generic
+    for c in scene["cams"]:
+        c["pose"] = (np.array(c["pose"]) + np.pad(rng.normal(0, 0.01, (3, 1)), ((0, 1), (3, 0)))).tolist()
+        c["ndc_prj"][2] = float(rng.normal(0, 0.02))
+        c["ndc_prj"][3] = float(rng.normal(0, 0.02))
+    rec = camera_records(cameras_from_list(scene["cams"]))
+    pm = PMVO.from_planes(rec, scene["depth"].to(DEV), scene["ori"].to(DEV), scene["conf"].to(DEV),
+                          scene["mask"].to(DEV), device=DEV, patch_size=patch, visible_threshold=1, conf_threshold=thr)
+    views = oracle.Views(rec, scene["depth"].numpy(), scene["ori"].numpy(), scene["conf"].numpy(), scene["mask"].numpy())
+    N = int(rng.integers(1, 400))
+    cand = synth.candidate_points(res=int(rng.choice([32, 64])), seed=seed % 1000)
+    pts = cand[rng.choice(len(cand), N, replace=False)] * rng.uniform(0.9, 1.1)
+    for fused in (True, False):
+        _, ori, loss, hc = pm.forward(pts, fused=fused)
+        _, o_ori, o_loss, o_hc = oracle.forward(views, pts, patch, thr, offs)
+        if not (eq(loss.cpu().numpy(), o_loss) and eq(ori.cpu().numpy(), o_ori) and eq(hc.cpu().numpy(), o_hc)):
+            bad.append(("forward", fused, V, H, W, patch, thr, quant, seed, N))
+    surf, _, filt = pm.filter_points(pts)
+    unv = pm.compute_unvisible_points(pts)
+    o_s, o_f, o_u, _ = oracle.filter_votes(views, pts, patch, thr, 1.0)
+    if not (eq(surf.cpu().numpy(), o_s) and eq(filt.cpu().numpy(), o_f) and eq(unv.cpu().numpy(), o_u)):
+        bad.append(("filter", V, H, W, patch, thr, quant, seed, N))
+    dirs = rng.normal(size=(N, 3)).astype(np.float32)
+    pm.Compute_Visible_and_Ori(pts)
+    rl, _ = pm.prj_loss_of(pm._points, torch.from_numpy(dirs).to(DEV))
+    o_rl, _ = oracle.refine_loss(views, pts, dirs, patch, thr)
+    if not eq(rl.cpu().numpy(), o_rl):
+        bad.append(("refine_loss", V, H, W, patch, thr, quant, seed, N))
+    n_scene += 1
+    n_pts += N
+print({"scenes": n_scene, "points": n_pts, "mismatching_cases": len(bad), "first": bad[:5]})
+sys.exit(1 if bad else 0)
