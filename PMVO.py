@@ -19,8 +19,8 @@ import numpy as np
 from monohair_amd import options
 from monohair_amd.camera import load_cam, parsing_camera
 from monohair_amd.pmvo import PMVO, filter_negative_points, optimize, refine  # noqa: F401  (re-exported)
-from monohair_amd.pmvo_utils import (Load_Ori_And_Conf, load_bust, load_colmap_points, load_depth, load_mask,
-                                     read_obj)
+from monohair_amd.pmvo_utils import (Load_Ori_And_Conf, load_bust, load_colmap_points, load_depth,  # noqa: F401
+                                     load_depth_plane, load_maps_u8, load_mask, read_obj)
 
 
 def config_parser(argv=None):
@@ -43,6 +43,31 @@ def config_parser(argv=None):
         args.save_path = os.path.join(args.output_path, "refine")
     os.makedirs(args.save_path, exist_ok=True)
     return args
+
+
+def load_views(camera, args):
+    """The map upload of the reference's __main__ (PMVO.py:822-840).  The 8-bit files are uploaded as pixel codes
+    and decoded on the GPU (PMVO.from_u8: same values as Load_Ori_And_Conf/load_mask + the float constructor);
+    with `data.maps_pack` set, one memory-mapped pack replaces the four files per view (written on first use)."""
+    from monohair_amd import dist as mdist
+    from monohair_amd import mapspack
+
+    kw = dict(device=args.device, image_size=args.data.image_size, patch_size=args.PMVO.patch_size,
+              visible_threshold=args.PMVO.visible_threshold, conf_threshold=args.PMVO.conf_threshold)
+    pack = args.data.get("maps_pack")
+    if pack:
+        pack = pack if os.path.isabs(pack) else os.path.join(args.data.root, pack)
+        if not os.path.exists(pack):
+            if mdist.rank() == 0:
+                print("writing maps pack", pack)
+                mapspack.pack_case(camera, args.data.Ori2D_path, args.data.Conf_path, args.data.mask_path,
+                                   args.data.depth_path, pack)
+            mdist.barrier()
+        m = mapspack.read_pack(pack, views=list(camera.keys()))
+        return PMVO.from_u8(camera, m["depth"], m["ori"], m["conf"], m["mask"], **kw)
+    ori, conf, mask = load_maps_u8(camera, args.data.Ori2D_path, args.data.Conf_path, args.data.mask_path)
+    depths = load_depth_plane(camera, args.data.depth_path)
+    return PMVO.from_u8(camera, depths, ori, conf, mask, **kw)
 
 
 def main(argv=None):
@@ -73,15 +98,8 @@ def main(argv=None):
 
     camera = parsing_camera(load_cam(args.image_camera_path), os.path.join(args.data.root, "capture_images"))
     print("num of view:", len(camera))
-    depths = load_depth(camera, args.data.depth_path)
-    Ori, Conf = Load_Ori_And_Conf(camera, args.data.Ori2D_path, args.data.Conf_path)
-    masks = load_mask(camera, args.data.mask_path)
-
-    pmvo = PMVO(camera, depths, Ori, Conf, masks, device=args.device, image_size=args.data.image_size,
-                patch_size=args.PMVO.patch_size, visible_threshold=args.PMVO.visible_threshold,
-                conf_threshold=args.PMVO.conf_threshold)
+    pmvo = load_views(camera, args)
     pmvo.set_head(bust_tree, scalp_tree, scalp_max)
-    del depths, Ori, Conf, masks
 
     if args.PMVO.optimize:
         print("load raw mesh...")

@@ -54,6 +54,14 @@ int mh_ctx_set_view(mh_ctx *ctx, int view, const float *cam_host, const float *d
                     const float *ori /*[H,W,2]*/, const float *conf /*[H,W]*/, const float *mask,
                     int mask_stride, void *stream);
 
+/* Same, from the 8-bit image files the maps are stored in (Utils/PMVO_utils.py:255-313: best_ori/ gray u8,
+ * conf/ gray u8, hair_mask/ channel 0 u8) without the float64 host decode: lut_host is 256 x {ori_row, ori_col,
+ * conf, mask} floats -- the loader's value for each pixel code -- and the decode is a table lookup in the pack
+ * kernel (bit-identical to uploading the decoded float maps).  ori_u8/conf_u8/mask_u8: device [H,W] planes. */
+int mh_ctx_set_view_u8(mh_ctx *ctx, int view, const float *cam_host, const float *depth, int depth_stride,
+                       const unsigned char *ori_u8, const unsigned char *conf_u8, const unsigned char *mask_u8,
+                       const float *lut_host /*[256][4]*/, void *stream);
+
 /* The S depth offsets of PMVO.sample_next_3d_pos (PMVO.py:274-278), host pointer, S <= 256. */
 int mh_ctx_set_depth_offsets(mh_ctx *ctx, const float *offsets_host, int S);
 

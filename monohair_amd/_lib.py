@@ -20,6 +20,7 @@ _SIGS = {
     "mh_ctx_destroy": (None, [vp]),
     "mh_ctx_alloc_views": (ci, [vp, ci, ci, ci]),
     "mh_ctx_set_view": (ci, [vp, ci, vp, vp, ci, vp, vp, vp, ci, vp]),
+    "mh_ctx_set_view_u8": (ci, [vp, ci, vp, vp, ci, vp, vp, vp, vp, vp]),
     "mh_ctx_set_depth_offsets": (ci, [vp, vp, ci]),
     "mh_ctx_set_option": (ci, [vp, ctypes.c_char_p, ci]),
     "mh_project_gather": (ci, [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]),

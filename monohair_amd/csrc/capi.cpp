@@ -25,6 +25,7 @@ struct mh_ctx {
     float *offs = nullptr;    // [S]
     float *gabor = nullptr;   // tap-major Gabor bank [289][192]
     unsigned int *gabor_max = nullptr;
+    float4 *lut = nullptr;    // [256] pixel-code table of the 8-bit map files
     int S = 0;
     int search_variant = 0;
     int gabor_variant = 0;    // 0: VALU v_pk_fma kernel, 1: FP32-MFMA im2col kernel
@@ -35,6 +36,8 @@ struct mh_ctx {
 extern "C" {
 int mh_launch_pack_view(float4 *, float *, const float *, int, const float *, const float *, const float *, int,
                         size_t, hipStream_t);
+int mh_launch_pack_view_u8(float4 *, float *, const float *, int, const uint8_t *, const uint8_t *, const uint8_t *,
+                           const float4 *, size_t, hipStream_t);
 int mh_launch_project_gather(MhViews, const float *, int, int, float *, float *, float *, float *, float *, float *,
                              float *, hipStream_t);
 int mh_launch_topk(const float *, const float *, int, int, int32_t *, float *, hipStream_t);
@@ -118,6 +121,7 @@ extern "C" void mh_ctx_destroy(mh_ctx *ctx) {
     if (ctx->offs) (void)hipFree(ctx->offs);
     if (ctx->gabor) (void)hipFree(ctx->gabor);
     if (ctx->gabor_max) (void)hipFree(ctx->gabor_max);
+    if (ctx->lut) (void)hipFree(ctx->lut);
     delete ctx;
 }
 
@@ -153,6 +157,25 @@ extern "C" int mh_ctx_set_view(mh_ctx *ctx, int view, const float *cam_host, con
     return launched(mh_launch_pack_view(ctx->rec + (size_t)view * npix, ctx->mask + (size_t)view * npix, depth,
                                         depth_stride, ori, conf, mask, mask_stride, npix, st),
                     "mh_ctx_set_view");
+}
+
+extern "C" int mh_ctx_set_view_u8(mh_ctx *ctx, int view, const float *cam_host, const float *depth, int depth_stride,
+                                  const unsigned char *ori_u8, const unsigned char *conf_u8,
+                                  const unsigned char *mask_u8, const float *lut_host, void *stream) {
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_ctx_set_view_u8: views not allocated");
+    if (view < 0 || view >= ctx->V || !cam_host || !depth || !ori_u8 || !conf_u8 || !mask_u8 || !lut_host ||
+        depth_stride < 1)
+        return fail(MH_ERR_ARG, "mh_ctx_set_view_u8: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t npix = (size_t)ctx->H * ctx->W;
+    MH_HIP(hipSetDevice(ctx->device));
+    if (!ctx->lut) MH_HIP(hipMalloc(&ctx->lut, 256 * sizeof(float4)));
+    MH_HIP(hipMemcpyAsync(ctx->lut, lut_host, 256 * sizeof(float4), hipMemcpyHostToDevice, st));
+    MH_HIP(hipMemcpyAsync(ctx->cams + (size_t)view * MH_CAM_STRIDE, cam_host, MH_CAM_STRIDE * sizeof(float),
+                          hipMemcpyHostToDevice, st));
+    return launched(mh_launch_pack_view_u8(ctx->rec + (size_t)view * npix, ctx->mask + (size_t)view * npix, depth,
+                                           depth_stride, ori_u8, conf_u8, mask_u8, ctx->lut, npix, st),
+                    "mh_ctx_set_view_u8");
 }
 
 extern "C" int mh_ctx_set_depth_offsets(mh_ctx *ctx, const float *offsets_host, int S) {

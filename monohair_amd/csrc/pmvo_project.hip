@@ -24,6 +24,25 @@ __global__ __launch_bounds__(256) void mh_pack_view_kernel(float4 *__restrict__ 
     }
 }
 
+// the same from the 8-bit files (Utils/PMVO_utils.py:255-313): pixel code -> loader value through a 256-entry LUT
+__global__ __launch_bounds__(256) void mh_pack_view_u8_kernel(float4 *__restrict__ rec, float *__restrict__ maskp,
+                                                              const float *__restrict__ depth, int dstride,
+                                                              const uint8_t *__restrict__ ori,
+                                                              const uint8_t *__restrict__ conf,
+                                                              const uint8_t *__restrict__ mask,
+                                                              const float4 *__restrict__ lut, size_t npix) {
+    __shared__ float4 s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < npix; i += step) {
+        const float4 o = s_lut[ori[i]];
+        rec[i] = make_float4(o.x, o.y, s_lut[conf[i]].z, depth[i * dstride]);
+        maskp[i] = s_lut[mask[i]].w;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // PMVO.Compute_Visible_and_Ori (PMVO.py:346-376): one workgroup = one view x 64 consecutive points.
 //   phase 1: 64 lanes project their point (PMVO.project_points :378-397), fetch the centre record,
@@ -392,6 +411,15 @@ extern "C" int mh_launch_pack_view(float4 *rec, float *maskp, const float *depth
     const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
     hipLaunchKernelGGL(mh_pack_view_kernel, dim3(blocks), dim3(256), 0, st, rec, maskp, depth, dstride, ori, conf,
                        mask, mstride, npix);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mh_launch_pack_view_u8(float4 *rec, float *maskp, const float *depth, int dstride, const uint8_t *ori,
+                                      const uint8_t *conf, const uint8_t *mask, const float4 *lut, size_t npix,
+                                      hipStream_t st) {
+    const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
+    hipLaunchKernelGGL(mh_pack_view_u8_kernel, dim3(blocks), dim3(256), 0, st, rec, maskp, depth, dstride, ori, conf,
+                       mask, lut, npix);
     return (int)hipGetLastError();
 }
 

@@ -76,6 +76,45 @@ class PMVO:
         torch.cuda.synchronize(self.device)
         return self
 
+    @classmethod
+    def from_u8(cls, camera, depths, ori_u8, conf_u8, mask_u8, device="cuda:0", image_size=None, patch_size=5,
+                visible_threshold=1, conf_threshold=0.4, lut=None):
+        """The constructor for maps kept as their 8-bit pixel codes (pmvo_utils.load_maps_u8 or a maps pack):
+        dicts view -> uint8 [H,W] for orientation / confidence / mask (or [V,H,W] arrays in view order), depth
+        float32 [H,W] or [H,W,3].  Decoded on the GPU through the 256-entry table of the loaders
+        (pmvo_utils.map_code_lut), so the resident records equal those of PMVO(camera, <decoded float maps>)."""
+        from .pmvo_utils import map_code_lut
+
+        self = cls.__new__(cls)
+        keys = list(camera.keys())
+
+        def get(maps, i):
+            return maps[keys[i]] if isinstance(maps, dict) else maps[i]
+
+        H, W = (int(image_size[0]), int(image_size[1])) if image_size is not None else get(ori_u8, 0).shape[:2]
+        self._init_common(device, [H, W], patch_size, visible_threshold, conf_threshold)
+        self.camera_dict = camera
+        self.camera_key = keys
+        self.camera = [camera[k] for k in keys]
+        recs = camera_records(camera)
+        lut = np.ascontiguousarray(map_code_lut() if lut is None else lut, dtype=np.float32)
+        assert lut.shape == (256, 4)
+        self._alloc(len(keys), H, W)
+        st = _lib.stream_ptr()
+        for i in range(len(keys)):
+            d = torch.from_numpy(np.ascontiguousarray(get(depths, i), dtype=np.float32)).to(self.device)
+            planes = [torch.from_numpy(np.ascontiguousarray(get(m, i))).to(self.device)
+                      for m in (ori_u8, conf_u8, mask_u8)]
+            assert d.shape[:2] == (H, W) and all(p.dtype == torch.uint8 and p.shape == (H, W) for p in planes), \
+                "map shapes/dtypes do not match image_size=[H,W] / uint8"
+            rec = np.ascontiguousarray(recs[i], dtype=np.float32)
+            _lib.check(self._L.mh_ctx_set_view_u8(self._ctx, i, rec.ctypes.data_as(ctypes.c_void_p), _lib.ptr(d),
+                                                  d.shape[2] if d.dim() == 3 else 1, _lib.ptr(planes[0]),
+                                                  _lib.ptr(planes[1]), _lib.ptr(planes[2]),
+                                                  lut.ctypes.data_as(ctypes.c_void_p), st), "mh_ctx_set_view_u8")
+            torch.cuda.current_stream().synchronize()      # d / planes are read asynchronously by the pack kernel
+        return self
+
     # ------------------------------------------------------------------ plumbing
     def _init_common(self, device, image_size, patch_size, visible_threshold, conf_threshold):
         if not torch.cuda.is_available():

@@ -70,6 +70,51 @@ def load_mask(camera, path):
     return masks
 
 
+def map_code_lut():
+    """[256,4] float32 table {ori_row, ori_col, conf, mask}: what Load_Ori_And_Conf / load_mask above give for each
+    8-bit pixel code (the same float64 numpy expressions, then the float32 cast of PMVO.__init__, PMVO.py:23-26)."""
+    code = np.arange(256, dtype=np.uint8)
+    o = (180 - code.astype(np.float64)) / 180 * math.pi
+    m = code.copy()
+    m[m < 50] = 0
+    return np.stack([np.sin(o), np.cos(o), code / 255.0, m / 255.0], -1).astype(np.float32)
+
+
+def _threaded(fn, items, threads):
+    if threads <= 1 or len(items) <= 1:
+        return [fn(x) for x in items]
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(threads) as ex:      # PIL and numpy IO release the GIL while decoding
+        return list(ex.map(fn, items))
+
+
+def load_maps_u8(camera, Ori_path, Conf_path, mask_path, threads=8):
+    """The three 8-bit map sets as pixel codes (no float64 decode on the host): dicts view -> uint8 [H,W] of
+    best_ori/ (gray), conf/ (gray) and hair_mask/ (channel 0 of the BGR image, which is all PMVO reads,
+    PMVO.py:523).  PMVO.from_u8 decodes them on the GPU through map_code_lut()."""
+    views = list(camera.keys())
+
+    def one(view):
+        return (_imread_gray(_find(Ori_path, view)), _imread_gray(_find(Conf_path, view)),
+                np.ascontiguousarray(_imread_bgr(_find(mask_path, view))[..., 0]))
+
+    got = _threaded(one, views, threads)
+    return ({v: g[0] for v, g in zip(views, got)}, {v: g[1] for v, g in zip(views, got)},
+            {v: g[2] for v, g in zip(views, got)})
+
+
+def load_depth_plane(camera, path, threads=8):
+    """render_depth/<view>.npy -> channel 0 only, float32 [H,W] (the only channel PMVO reads, PMVO.py:485)."""
+    views = list(camera.keys())
+
+    def one(view):
+        d = np.load(os.path.join(path, view + ".npy"), mmap_mode="r")
+        return np.ascontiguousarray(d[..., 0] if d.ndim == 3 else d, dtype=np.float32)
+
+    return dict(zip(views, _threaded(one, views, threads)))
+
+
 # ----------------------------------------------------------------------------------------- meshes / points
 def read_obj(path):
     """Minimal Wavefront OBJ reader: (vertices [N,3] f64, faces [M,3] int) -- triangles / fan-triangulated polys."""

@@ -83,3 +83,47 @@ def test_two_ranks_give_the_single_rank_volume_bit_for_bit(tmp_path):
     for f, k in (("refine/Ori3D.mat", "Ori"), ("refine/Occ3D.mat", "Occ")):
         a, b = scipy.io.loadmat(out / "one" / f)[k], scipy.io.loadmat(out / "two" / f)[k]
         assert np.array_equal(a, b), f
+
+
+def test_u8_upload_and_maps_pack_equal_the_float_loaders(tmp_path):
+    """The GPU decode of the 8-bit files (PMVO.from_u8) must leave the same resident maps as the reference's
+    float64 host decode + constructor, and a run from a maps pack must write the same files as a run from the tree."""
+    import torch
+
+    from monohair_amd import pmvo_utils as U
+    from monohair_amd import synth
+    from monohair_amd.camera import load_cam, parsing_camera
+    from monohair_amd.pmvo import PMVO
+
+    data = tmp_path / "data"
+    base = synth.write_case(str(data), "synthetic_sphere", V=24, H=240, W=136, res=32)
+    camera = parsing_camera(load_cam(os.path.join(base, "ours/cam_params.json")), os.path.join(base, "capture_images"))
+    p = lambda d: os.path.join(base, d)   # noqa: E731
+    Ori, Conf = U.Load_Ori_And_Conf(camera, p("best_ori"), p("conf"))
+    a = PMVO(camera, U.load_depth(camera, p("render_depth")), Ori, Conf, U.load_mask(camera, p("hair_mask")),
+             device="cuda:0", image_size=[240, 136], patch_size=5, conf_threshold=0.15)
+    o8, c8, m8 = U.load_maps_u8(camera, p("best_ori"), p("conf"), p("hair_mask"))
+    b = PMVO.from_u8(camera, U.load_depth_plane(camera, p("render_depth")), o8, c8, m8, device="cuda:0",
+                     image_size=[240, 136], patch_size=5, conf_threshold=0.15)
+    pts = synth.candidate_points(res=32, seed=3)[:3000]
+    for pm in (a, b):
+        pm.Compute_Visible_and_Ori(pts)
+    for name in ("visible", "Ori", "Conf", "mask", "Ori_patch", "Conf_patch"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    ra, rb = a.forward(pts[:500]), b.forward(pts[:500])
+    assert all(torch.equal(x, y) or (x != x).equal(y != y) for x, y in zip(ra[1:], rb[1:]))
+
+    common = [sys.executable, os.path.join(ROOT, "PMVO.py"), "--yaml=configs/reconstruct/synthetic_sphere",
+              "--data.root=%s" % data, "--data.image_size=[240,136]", "--PMVO.patch_size=3"]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for extra in (["--name=tree"], ["--name=pack", "--data.maps_pack=maps.mhpk"],
+                  ["--name=pack2", "--data.maps_pack=maps.mhpk"]):        # pack2 reads the pack written by `pack`
+        r = subprocess.run(common + extra, cwd=ROOT, env=env, stdin=subprocess.DEVNULL, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert os.path.getsize(p("maps.mhpk")) > 24 * 240 * 136 * 7
+    out = data / "synthetic_sphere" / "output"
+    for f in ("optimize/select_p.npy", "optimize/select_o.npy", "optimize/min_loss.npy", "refine/select_o.npy",
+              "refine/min_loss.npy"):
+        for other in ("pack", "pack2"):
+            assert np.array_equal(np.load(out / "tree" / f), np.load(out / other / f), equal_nan=True), (f, other)

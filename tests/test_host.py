@@ -172,3 +172,56 @@ def test_distributed_sharding_and_volume_reduce_gloo(tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "DIST_OK" in outs[0]
+
+
+def test_pixel_code_lut_matches_the_float_loaders(tmp_path):
+    """map_code_lut()[code] must be exactly what Load_Ori_And_Conf / load_mask + the float32 cast of the constructor
+    give for a pixel of that code (Utils/PMVO_utils.py:255-313, PMVO.py:23-26); load_maps_u8 returns the raw codes."""
+    from PIL import Image
+
+    from monohair_amd import pmvo_utils as U
+
+    codes = np.arange(256, dtype=np.uint8).reshape(16, 16)
+    for d in ("best_ori", "conf", "hair_mask"):
+        os.makedirs(tmp_path / d)
+    Image.fromarray(codes).save(tmp_path / "best_ori" / "v0.png")
+    Image.fromarray(codes.T.copy()).save(tmp_path / "conf" / "v0.png")
+    bgr = np.stack([codes[::-1], codes, 255 - codes], -1)          # channel 0 (B) is the one PMVO reads
+    Image.fromarray(bgr[..., ::-1].copy()).save(tmp_path / "hair_mask" / "v0.png")
+    cam = {"v0": None}
+    Ori, Conf = U.Load_Ori_And_Conf(cam, str(tmp_path / "best_ori"), str(tmp_path / "conf"))
+    mask = U.load_mask(cam, str(tmp_path / "hair_mask"))
+    o8, c8, m8 = U.load_maps_u8(cam, str(tmp_path / "best_ori"), str(tmp_path / "conf"), str(tmp_path / "hair_mask"),
+                                threads=2)
+    assert np.array_equal(o8["v0"], codes) and np.array_equal(c8["v0"], codes.T) and np.array_equal(m8["v0"], codes[::-1])
+    lut = U.map_code_lut()
+    assert lut.shape == (256, 4) and lut.dtype == np.float32
+    assert np.array_equal(lut[o8["v0"]][..., :2], Ori["v0"].astype(np.float32))
+    assert np.array_equal(lut[c8["v0"]][..., 2], Conf["v0"].astype(np.float32))
+    assert np.array_equal(lut[m8["v0"]][..., 3], mask["v0"][..., 0].astype(np.float32))
+    assert lut[49, 3] == 0.0 and lut[50, 3] == np.float32(50 / 255.0)
+
+
+def test_maps_pack_roundtrip(tmp_path):
+    from monohair_amd import mapspack
+
+    rng = np.random.default_rng(0)
+    views = ["a", "b", "c"]
+    o, c, m = (rng.integers(0, 256, (3, 20, 12)).astype(np.uint8) for _ in range(3))
+    d = rng.random((3, 20, 12)).astype(np.float32)
+    path = str(tmp_path / "maps.mhpk")
+    mapspack.write_pack(path, views, {v: o[i] for i, v in enumerate(views)}, c, m, d)
+    got = mapspack.read_pack(path)
+    assert got["views"] == views and (got["H"], got["W"]) == (20, 12)
+    for name, want in (("ori", o), ("conf", c), ("mask", m), ("depth", d)):
+        assert np.array_equal(np.asarray(got[name]), want) and got[name].dtype == want.dtype
+    sub = mapspack.read_pack(path, views=["c", "a"])
+    assert sub["views"] == ["c", "a"] and np.array_equal(sub["ori"][0], o[2]) and np.array_equal(sub["depth"][1], d[0])
+    with pytest.raises(KeyError):
+        mapspack.read_pack(path, views=["zz"])
+    bad = tmp_path / "bad.mhpk"
+    bad.write_bytes(b"not a pack at all")
+    with pytest.raises(ValueError):
+        mapspack.read_pack(str(bad))
+    with pytest.raises(ValueError):
+        mapspack.write_pack(path, views, o, c, m[:2], d)
