@@ -7,6 +7,7 @@ State set by Compute_Visible_and_Ori (as in the reference, PMVO.py:369-376): sel
 self.Ori [V,N,2], self.Conf [V,N], self.mask [V,N], self.Ori_patch [V,N,P,2], self.Conf_patch [V,N,P].
 """
 import ctypes
+import warnings
 import os
 
 import numpy as np
@@ -101,10 +102,14 @@ class PMVO:
         assert lut.shape == (256, 4)
         self._alloc(len(keys), H, W)
         st = _lib.stream_ptr()
+        def up(x, dtype=None):      # read-only memory maps are fine here: the tensor is only the source of a copy
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", UserWarning)
+                return torch.from_numpy(np.ascontiguousarray(x, dtype=dtype)).to(self.device)
+
         for i in range(len(keys)):
-            d = torch.from_numpy(np.ascontiguousarray(get(depths, i), dtype=np.float32)).to(self.device)
-            planes = [torch.from_numpy(np.ascontiguousarray(get(m, i))).to(self.device)
-                      for m in (ori_u8, conf_u8, mask_u8)]
+            d = up(get(depths, i), np.float32)
+            planes = [up(get(m, i)) for m in (ori_u8, conf_u8, mask_u8)]
             assert d.shape[:2] == (H, W) and all(p.dtype == torch.uint8 and p.shape == (H, W) for p in planes), \
                 "map shapes/dtypes do not match image_size=[H,W] / uint8"
             rec = np.ascontiguousarray(recs[i], dtype=np.float32)
