@@ -137,6 +137,17 @@ int mh_knn_grid(mh_ctx *ctx, const float *grid_origin_h, const int32_t *grid_dim
                 const int32_t *order, const int32_t *cell_start, const float *queries, int Q, int k,
                 int32_t *out_idx, int32_t *status, void *stream);
 
+/* ---- depth-map producer (the step before the path): Utils/Render_utils.py:310-347 render_bust_hair_depth with
+ * the BustObj shader (:146-188) and Renderer.draw/ReadBuffer (:239-262) -- triangles drawn with a LESS depth test,
+ * value (-z_camera / 2) * 255, background 255, top-left image origin.  verts[Nv,3] (world, bust offset applied),
+ * faces[Nf,3] int32 (several meshes: concatenate them, earlier primitives win depth ties as in GL draw order).
+ * pixel_center: 0.5 = OpenGL's sample position, 0.0 = the integer positions PMVO.project_points rounds to.
+ * out[H,W,channels] float32 (channels = 3 gives the reference's .npy layout).  scratch: mh_render_scratch_bytes. */
+size_t mh_render_scratch_bytes(int Nv, int H, int W);
+int mh_render_depth(mh_ctx *ctx, const float *cam_host, const float *verts, int Nv, const int32_t *faces, int Nf,
+                    int H, int W, float pixel_center, void *scratch, size_t scratch_bytes, float *out, int channels,
+                    void *stream);
+
 /* ---- K1+K2: calOrientationGabor.forward with iter=1 (preprocess_capture_data/GaborFilter.py:29-145):
  * 180 real Gabor kernels 17x17 (sigma 1.8/2.4, lambda 4), |response| argmax -> orientation index,
  * response-curve variance -> confidence normalised by the image maximum.

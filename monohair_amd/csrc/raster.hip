@@ -1,0 +1,163 @@
+// raster.hip -- depth-map producer for PMVO, gfx950 only.
+//
+// Replaces the moderngl/EGL pass of Utils/Render_utils.py:310-347 (render_bust_hair_depth) with its BustObj
+// shader (:146-188): triangles of the hair + bust meshes are drawn with a depth test, the colour written is
+// depth/2 with depth = -z_camera, the clear colour is 1.0, the image is flipped to a top-left origin and saved
+// times 255.  OpenGL leaves sub-pixel snapping and attribute interpolation precision to the implementation, so
+// this is a specified rasteriser of its own (oracle/raster_oracle.c restates it; parity with a GL driver is
+// unpinned):
+//   * vertex: (u, v, z) = Camera.projection (mh_cam_project), pixel = PMVO's own ndc->pixel map, so a depth
+//     map is sampled exactly where PMVO.project_points will look it up; snapped to 1/256 pixel;
+//   * coverage: exact int64 edge functions at the pixel centre (+centre offset), top-left fill rule -> every
+//     pixel of a shared edge belongs to exactly one triangle, independent of draw order;
+//   * depth test: window z (screen-space linear, as GL), LESS, ties -> lowest primitive index (GL draw order),
+//     as one 64-bit atomicMin of (z bits << 32 | primitive);
+//   * colour: perspective-correct -z_camera = 1 / sum(lambda_i / w_i).
+#include "mh_device.h"
+
+struct MhRVert {
+    int x, y;      // window position in 1/256 pixel (x = INT_MIN: vertex unusable)
+    float zw, iw;  // window depth in [0,1], 1 / w_clip
+};
+
+#define MH_R_SUB 256
+#define MH_R_BAD INT_MIN
+
+__global__ __launch_bounds__(256) void mh_raster_vertex_kernel(const float *__restrict__ cam,
+                                                               const float *__restrict__ verts, int Nv, float Hf,
+                                                               float Wf, MhRVert *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nv) return;
+    float u, v, z, rowf, colf;
+    mh_cam_project(cam, verts[3 * i], verts[3 * i + 1], verts[3 * i + 2], u, v, z);
+    mh_ndc_to_pixel(u, v, Hf, Wf, rowf, colf);
+    MhRVert r;
+    const float w = -z;
+    const float zc = mh_fma(cam[27], 1.0f, cam[26] * z);
+    r.zw = (zc / w) * 0.5f + 0.5f;
+    r.iw = 1.0f / w;
+    const bool ok = (w > 0.0f) && (__builtin_fabsf(colf) < 1.0e5f) && (__builtin_fabsf(rowf) < 1.0e5f);
+    r.x = ok ? (int)__builtin_rintf(colf * (float)MH_R_SUB) : MH_R_BAD;
+    r.y = ok ? (int)__builtin_rintf(rowf * (float)MH_R_SUB) : MH_R_BAD;
+    out[i] = r;
+}
+
+__device__ __forceinline__ long long mh_edge(int sx, int sy, int tx, int ty, int px, int py) {
+    return (long long)(tx - sx) * (long long)(py - sy) - (long long)(ty - sy) * (long long)(px - sx);
+}
+// fill rule for pixels exactly on the edge s->t of a positively oriented triangle
+__device__ __forceinline__ bool mh_owns_edge(int sx, int sy, int tx, int ty) {
+    const int dx = tx - sx, dy = ty - sy;
+    return (dy < 0) || (dy == 0 && dx > 0);
+}
+__device__ __forceinline__ int mh_floor_div(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+struct MhRTri {
+    int ax, ay, bx, by, cx, cy;
+    long long area;
+    float za, zb, zc, ia, ib, ic;
+    int c0, c1, r0, r1;
+};
+
+// load + orient + bound one triangle; false if it cannot produce fragments
+__device__ __forceinline__ bool mh_setup_tri(const MhRVert *__restrict__ vt, const int32_t *__restrict__ faces,
+                                             int f, int Nv, int H, int W, int off, MhRTri &t) {
+    const int i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+    if ((unsigned)i0 >= (unsigned)Nv || (unsigned)i1 >= (unsigned)Nv || (unsigned)i2 >= (unsigned)Nv) return false;
+    MhRVert a = vt[i0], b = vt[i1], c = vt[i2];
+    if (a.x == MH_R_BAD || b.x == MH_R_BAD || c.x == MH_R_BAD) return false;
+    long long area = mh_edge(a.x, a.y, b.x, b.y, c.x, c.y);
+    if (area == 0) return false;
+    if (area < 0) {
+        MhRVert s = b;
+        b = c;
+        c = s;
+        area = -area;
+    }
+    t.ax = a.x, t.ay = a.y, t.bx = b.x, t.by = b.y, t.cx = c.x, t.cy = c.y;
+    t.area = area;
+    t.za = a.zw, t.zb = b.zw, t.zc = c.zw, t.ia = a.iw, t.ib = b.iw, t.ic = c.iw;
+    const int minx = min(a.x, min(b.x, c.x)), maxx = max(a.x, max(b.x, c.x));
+    const int miny = min(a.y, min(b.y, c.y)), maxy = max(a.y, max(b.y, c.y));
+    t.c0 = max(-mh_floor_div(-(minx - off), MH_R_SUB), 0);   // ceil
+    t.c1 = min(mh_floor_div(maxx - off, MH_R_SUB), W - 1);
+    t.r0 = max(-mh_floor_div(-(miny - off), MH_R_SUB), 0);
+    t.r1 = min(mh_floor_div(maxy - off, MH_R_SUB), H - 1);
+    return t.c0 <= t.c1 && t.r0 <= t.r1;
+}
+
+// coverage + barycentrics of pixel (r, c); false if outside
+__device__ __forceinline__ bool mh_cover(const MhRTri &t, int r, int c, int off, float &l0, float &l1, float &l2) {
+    const int px = c * MH_R_SUB + off, py = r * MH_R_SUB + off;
+    const long long e0 = mh_edge(t.bx, t.by, t.cx, t.cy, px, py);
+    const long long e1 = mh_edge(t.cx, t.cy, t.ax, t.ay, px, py);
+    const long long e2 = mh_edge(t.ax, t.ay, t.bx, t.by, px, py);
+    if (e0 < 0 || e1 < 0 || e2 < 0) return false;
+    if (e0 == 0 && !mh_owns_edge(t.bx, t.by, t.cx, t.cy)) return false;
+    if (e1 == 0 && !mh_owns_edge(t.cx, t.cy, t.ax, t.ay)) return false;
+    if (e2 == 0 && !mh_owns_edge(t.ax, t.ay, t.bx, t.by)) return false;
+    const float fa = (float)t.area;
+    l0 = (float)e0 / fa;
+    l1 = (float)e1 / fa;
+    l2 = (float)e2 / fa;
+    return true;
+}
+
+// One wave per triangle: the lanes sweep the bounding box (64 pixels per step, row-major inside the box).
+__global__ __launch_bounds__(256) void mh_raster_tri_kernel(const MhRVert *__restrict__ vt,
+                                                            const int32_t *__restrict__ faces, int Nf, int Nv,
+                                                            int H, int W, int off,
+                                                            unsigned long long *__restrict__ zbuf) {
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (f >= Nf) return;
+    MhRTri t;
+    if (!mh_setup_tri(vt, faces, f, Nv, H, W, off, t)) return;
+    const int bw = t.c1 - t.c0 + 1, n = bw * (t.r1 - t.r0 + 1);
+    for (int k = lane; k < n; k += MH_WAVE) {
+        const int r = t.r0 + k / bw, c = t.c0 + k % bw;
+        float l0, l1, l2;
+        if (!mh_cover(t, r, c, off, l0, l1, l2)) continue;
+        const float zw = (l0 * t.za + l1 * t.zb) + l2 * t.zc;
+        if (!(zw >= 0.0f && zw <= 1.0f)) continue;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(zw) << 32) | (unsigned)f;
+        atomicMin(&zbuf[(size_t)r * W + c], key);
+    }
+}
+
+__global__ __launch_bounds__(256) void mh_raster_resolve_kernel(const MhRVert *__restrict__ vt,
+                                                                const int32_t *__restrict__ faces, int Nv, int H,
+                                                                int W, int off,
+                                                                const unsigned long long *__restrict__ zbuf,
+                                                                float *__restrict__ out, int channels) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)H * W) return;
+    const unsigned long long key = zbuf[i];
+    float val = 255.0f;   // clear colour 1.0, saved times 255 (Render_utils.py:239-251,338)
+    if (key != ~0ull) {
+        const int r = (int)(i / W), c = (int)(i % W);
+        MhRTri t;
+        float l0, l1, l2;
+        mh_setup_tri(vt, faces, (int)(key & 0xffffffffu), Nv, H, W, off, t);
+        mh_cover(t, r, c, off, l0, l1, l2);
+        const float s = (l0 * t.ia + l1 * t.ib) + l2 * t.ic;
+        const float depth = 1.0f / s;          // perspective-correct -z_camera
+        val = (depth / 2.0f) * 255.0f;         // shader: depth / depth_range; saved as depth * 255
+    }
+    for (int k = 0; k < channels; ++k) out[i * channels + k] = val;
+}
+
+extern "C" int mh_launch_render_depth(const float *cam, const float *verts, int Nv, const int32_t *faces, int Nf,
+                                      int H, int W, int off, MhRVert *vt, unsigned long long *zbuf, float *out,
+                                      int channels, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(zbuf, 0xff, (size_t)H * W * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return (int)e;
+    if (Nv > 0 && Nf > 0) {
+        hipLaunchKernelGGL(mh_raster_vertex_kernel, dim3((Nv + 255) / 256), dim3(256), 0, st, cam, verts, Nv, (float)H,
+                           (float)W, vt);
+        hipLaunchKernelGGL(mh_raster_tri_kernel, dim3((Nf + 3) / 4), dim3(256), 0, st, vt, faces, Nf, Nv, H, W, off,
+                           zbuf);
+    }
+    hipLaunchKernelGGL(mh_raster_resolve_kernel, dim3((unsigned)(((size_t)H * W + 255) / 256)), dim3(256), 0, st, vt,
+                       faces, Nv, H, W, off, zbuf, out, channels);
+    return (int)hipGetLastError();
+}

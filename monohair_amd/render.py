@@ -1,0 +1,97 @@
+"""Depth-map producer on the GPU: the host mirror of the reference's
+`Utils/Render_utils.py::render_bust_hair_depth` (:310-347) on top of `mh_render_depth` (csrc/raster.hip).
+
+The reference draws the COLMAP hair mesh and the bust mesh with moderngl/EGL and the BustObj shader (:146-188) and
+writes `render_depth/<view>.npy` = float32 [H,W,3], value (-z_cam / 2) * 255, background 255.  Here the same maps
+come from a specified HIP rasteriser (no OpenGL context needed) and can stay on the device: `render_depth_planes`
+returns a [V,H,W] tensor that `PMVO.from_planes` / `PMVO.from_u8` take as is.  Parity with an OpenGL driver is
+unpinned: sub-pixel snapping and fill-rule ties are implementation-defined in GL.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .camera import camera_records, load_cam, parsing_camera
+from .pmvo_utils import _ctx_for, read_obj
+
+BUST_TO_ORIGIN = np.array([0.006, -1.644, 0.010])      # Render_utils.py:312
+
+
+class DepthRenderer:
+    """Holds the meshes on the device (several meshes are concatenated in draw order, Render_utils.py:322-331)."""
+
+    def __init__(self, meshes, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise _lib.MhError("monohair_amd.render needs a ROCm GPU: there is no CPU fallback")
+        self.device = torch.device(device)
+        verts, faces, base = [], [], 0
+        for v, f in meshes:
+            v = np.asarray(v, dtype=np.float64).reshape(-1, 3)
+            f = np.asarray(f, dtype=np.int64).reshape(-1, 3)
+            verts.append(v.astype(np.float32))
+            faces.append((f + base).astype(np.int32))
+            base += len(v)
+        self.verts = torch.from_numpy(np.concatenate(verts) if verts else np.zeros((0, 3), np.float32)).to(self.device)
+        self.faces = torch.from_numpy(np.concatenate(faces) if faces else np.zeros((0, 3), np.int32)).to(self.device)
+        self._L = _lib.lib()
+        self._ctx = _ctx_for(self.device)
+        self._scratch = None
+
+    def render(self, cam_record, H, W, pixel_center=0.5, out=None, channels=1):
+        """One view -> float32 [H,W] (channels=1) or [H,W,channels] device tensor."""
+        H, W = int(H), int(W)
+        Nv, Nf = self.verts.shape[0], self.faces.shape[0]
+        need = int(self._L.mh_render_scratch_bytes(Nv, H, W))
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if out is None:
+            out = torch.empty((H, W) if channels == 1 else (H, W, channels), dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and out.numel() == H * W * channels and out.dtype == torch.float32
+        rec = np.ascontiguousarray(cam_record, dtype=np.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.mh_render_depth(self._ctx, rec.ctypes.data_as(ctypes.c_void_p), _lib.ptr(self.verts), Nv,
+                                               _lib.ptr(self.faces), Nf, H, W, float(pixel_center),
+                                               _lib.ptr(self._scratch), need, _lib.ptr(out), channels,
+                                               _lib.stream_ptr()), "mh_render_depth")
+        return out
+
+
+def render_depth_planes(camera, meshes, image_size, device="cuda:0", pixel_center=0.5):
+    """camera: dict view -> Camera; meshes: [(vertices, faces), ...] -> depth [V,H,W] float32 on `device`."""
+    H, W = int(image_size[0]), int(image_size[1])
+    r = DepthRenderer(meshes, device)
+    recs = camera_records(camera)
+    out = torch.empty((len(recs), H, W), dtype=torch.float32, device=r.device)
+    for i in range(len(recs)):
+        r.render(recs[i], H, W, pixel_center, out=out[i])
+    return out
+
+
+def render_bust_hair_depth(colmap_points_path, camera_path, save_root, image_size=[1280, 720], capture_imgs=False,
+                           bust_path=None, Headless=True, device="cuda:0", pixel_center=0.5):
+    """Same arguments and files as Render_utils.py:310-347: with capture_imgs, `<save_root>/<view>.npy`
+    (float32 [H,W,3] = depth*255) and a `<view>.JPG` preview; otherwise `<save_root>/<view>/bust_hair_depth.png`."""
+    from PIL import Image
+
+    v, f = read_obj(colmap_points_path)
+    meshes = [(v + BUST_TO_ORIGIN, f)]
+    if bust_path is not None:
+        bv, bf = read_obj(bust_path)
+        meshes.append((bv + BUST_TO_ORIGIN, bf))
+    camera = parsing_camera(load_cam(camera_path))
+    H, W = int(image_size[0]), int(image_size[1])
+    r = DepthRenderer(meshes, device)
+    recs = camera_records(camera)
+    for i, view in enumerate(camera.keys()):
+        d3 = r.render(recs[i], H, W, pixel_center, channels=3).cpu().numpy()
+        u8 = np.clip(np.rint(d3), 0, 255).astype(np.uint8)       # cv2.imwrite saturate-rounds floats to 8 bits
+        if capture_imgs:
+            os.makedirs(save_root, exist_ok=True)
+            np.save(os.path.join(save_root, view + ".npy"), d3)
+            Image.fromarray(u8).save(os.path.join(save_root, view + ".JPG"))
+        else:
+            os.makedirs(os.path.join(save_root, view), exist_ok=True)
+            Image.fromarray(u8).save(os.path.join(save_root, view, "bust_hair_depth.png"))

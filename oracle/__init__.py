@@ -371,3 +371,20 @@ def randomly_generate_segments(vol, thr, jitter):
     """randomlyGenerateSegments (HairGrow.py:269-299): three rounds of voxel-seeded tracing."""
     flag = np.zeros((vol.Z, vol.H, vol.W), np.float32)
     return voxel_seed_rounds(vol, flag, thr, jitter, 3), flag
+
+
+def render_depth(cam_rec, verts, faces, H, W, pixel_center=0.5, channels=1):
+    """CPU statement of monohair_amd/csrc/raster.hip (oracle/raster_oracle.c) -> (depth [H,W(,channels)], covered)."""
+    verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+    faces = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1, 3)
+    rec = np.ascontiguousarray(cam_rec, dtype=np.float32)
+    out = np.empty((H, W, channels), np.float32)
+    L = lib()
+    L.ora_render_depth.restype = ctypes.c_long
+    L.ora_render_depth.argtypes = [c_f, c_f, ctypes.c_int, c_i, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_float, c_f, ctypes.c_int]
+    n = L.ora_render_depth(_p(rec), _p(verts), len(verts), _p(faces, c_i), len(faces), H, W, pixel_center, _p(out),
+                           channels)
+    if n < 0:
+        raise MemoryError("ora_render_depth")
+    return (out[..., 0] if channels == 1 else out), int(n)

@@ -1,0 +1,81 @@
+"""CPU: the depth-rasteriser specification (oracle/raster_oracle.c) against analytic answers.  The reference renders
+depth with an OpenGL driver (Utils/Render_utils.py:310-347), which cannot run here -> parity with it is unpinned; these
+tests pin the written specification: a finely tessellated sphere must reproduce the analytic ray-sphere depth of the
+synthetic scene, shared edges must be drawn exactly once, and depth ties go to the earlier primitive."""
+import math
+
+import numpy as np
+
+import oracle
+from monohair_amd import synth
+from monohair_amd.camera import camera_records, cameras_from_list
+
+
+def uv_sphere(radius, n_lat, n_lon):
+    vs, fs = [], []
+    for a in range(n_lat + 1):
+        th = math.pi * a / n_lat
+        for b in range(n_lon):
+            ph = 2 * math.pi * b / n_lon
+            vs.append((radius * math.sin(th) * math.cos(ph), radius * math.cos(th), radius * math.sin(th) * math.sin(ph)))
+    for a in range(n_lat):
+        for b in range(n_lon):
+            p00, p01 = a * n_lon + b, a * n_lon + (b + 1) % n_lon
+            p10, p11 = p00 + n_lon, p01 + n_lon
+            fs += [(p00, p10, p11), (p00, p11, p01)]
+    return np.array(vs, np.float32), np.array(fs, np.int32)
+
+
+def test_sphere_depth_matches_the_analytic_scene():
+    H, W = 240, 136
+    cams = synth.make_cameras(24, H, W, scale=1.7)
+    rec = camera_records(cameras_from_list(cams))
+    v, f = uv_sphere(synth.SPHERE_R, 192, 384)
+    for i in (0, 7):
+        want = synth.render_view(cams[i], i, H, W, seed=0, quantize=False)[0].numpy()      # analytic, centres at integers
+        got, covered = oracle.render_depth(rec[i], v, f, H, W, pixel_center=0.0)
+        hit_w, hit_g = want < 255, got < 255
+        assert covered == hit_g.sum() and abs(int(hit_g.sum()) - int(hit_w.sum())) <= 0.02 * hit_w.sum()
+        both = hit_w & hit_g
+        assert (hit_w != hit_g).sum() <= 0.03 * hit_w.sum()          # silhouette pixels only
+        assert np.abs(got[both] - want[both]).max() < 0.05 and np.median(np.abs(got[both] - want[both])) < 2e-3
+        # OpenGL's sample position (pixel centre +0.5) shifts the image by half a pixel: still the same sphere
+        gl, _ = oracle.render_depth(rec[i], v, f, H, W, pixel_center=0.5)
+        assert abs(int((gl < 255).sum()) - int(hit_w.sum())) <= 0.03 * hit_w.sum()
+
+
+def test_watertight_and_tie_rules():
+    H, W = 64, 64
+    cams = synth.make_cameras(20, H, W, scale=1.0)
+    rec = camera_records(cameras_from_list(cams))[0]
+    # a fan of triangles around a centre in a plane facing the camera: every covered pixel exactly once
+    rng = np.random.default_rng(1)
+    n = 17
+    ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+    ring = np.stack([0.1 * np.cos(ang), 0.1 * np.sin(ang), np.zeros(n)], 1)
+    verts = np.concatenate([[[0.003, -0.002, 0.0]], ring]).astype(np.float32)
+    faces = np.array([(0, 1 + k, 1 + (k + 1) % n) for k in range(n)], np.int32)
+    whole, cov = oracle.render_depth(rec, verts, faces, H, W)
+    per = [oracle.render_depth(rec, verts, faces[k:k + 1], H, W)[1] for k in range(n)]
+    assert cov == sum(per) and cov > 100                               # no pixel drawn twice, none lost on shared edges
+    # reversed winding and reversed draw order: same coverage (no culling, order-independent fill rule); the values
+    # only differ by the rounding of the barycentric sums
+    again, _ = oracle.render_depth(rec, verts, faces[::-1, ::-1], H, W)
+    assert np.array_equal(whole < 255, again < 255) and np.abs(whole - again).max() < 1e-4
+    # two coincident triangles with different colours cannot be told apart by depth -> the first drawn wins; a
+    # strictly nearer one replaces
+    tri = np.array([[-0.1, -0.1, 0], [0.1, -0.1, 0], [0, 0.1, 0]], np.float32)
+    near = tri + np.array([0, 0, 0.05], np.float32) * np.sign(np.array(cams[0]["pose"])[2, 3])
+    both = np.concatenate([tri, near]).astype(np.float32)
+    a, _ = oracle.render_depth(rec, both, np.array([[0, 1, 2], [3, 4, 5]], np.int32), H, W)
+    b, _ = oracle.render_depth(rec, both, np.array([[3, 4, 5], [0, 1, 2]], np.int32), H, W)
+    only_near, _ = oracle.render_depth(rec, near, np.array([[0, 1, 2]], np.int32), H, W)
+    assert np.array_equal(a, b)
+    m = only_near < 255
+    assert m.sum() > 50 and np.array_equal(a[m], only_near[m])
+    # behind the camera / degenerate / out-of-range indices are skipped, empty input gives the background
+    behind = tri + np.array([0, 0, 5.0], np.float32) * np.sign(np.array(cams[0]["pose"])[2, 3])
+    e, cov = oracle.render_depth(rec, behind, np.array([[0, 1, 2], [0, 0, 1], [0, 1, 7]], np.int32), H, W)
+    assert cov == 0 and (e == 255).all()
+    e, cov = oracle.render_depth(rec, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32), H, W, channels=3)
+    assert e.shape == (H, W, 3) and (e == 255).all()
