@@ -143,7 +143,7 @@ int mh_knn_grid(mh_ctx *ctx, const float *grid_origin_h, const int32_t *grid_dim
  * faces[Nf,3] int32 (several meshes: concatenate them, earlier primitives win depth ties as in GL draw order).
  * pixel_center: 0.5 = OpenGL's sample position, 0.0 = the integer positions PMVO.project_points rounds to.
  * out[H,W,channels] float32 (channels = 3 gives the reference's .npy layout).  scratch: mh_render_scratch_bytes. */
-size_t mh_render_scratch_bytes(int Nv, int H, int W);
+size_t mh_render_scratch_bytes(int Nv, int Nf, int H, int W);
 int mh_render_depth(mh_ctx *ctx, const float *cam_host, const float *verts, int Nv, const int32_t *faces, int Nf,
                     int H, int W, float pixel_center, void *scratch, size_t scratch_bytes, float *out, int channels,
                     void *stream);

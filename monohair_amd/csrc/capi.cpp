@@ -39,7 +39,7 @@ int mh_launch_pack_view(float4 *, float *, const float *, int, const float *, co
 int mh_launch_pack_view_u8(float4 *, float *, const float *, int, const uint8_t *, const uint8_t *, const uint8_t *,
                            const float4 *, size_t, hipStream_t);
 int mh_launch_render_depth(const float *, const float *, int, const int32_t *, int, int, int, int, void *,
-                           unsigned long long *, float *, int, hipStream_t);
+                           unsigned long long *, int32_t *, unsigned int *, float *, int, hipStream_t);
 int mh_launch_project_gather(MhViews, const float *, int, int, float *, float *, float *, float *, float *, float *,
                              float *, hipStream_t);
 int mh_launch_topk(const float *, const float *, int, int, int32_t *, float *, hipStream_t);
@@ -182,9 +182,12 @@ extern "C" int mh_ctx_set_view_u8(mh_ctx *ctx, int view, const float *cam_host, 
 
 static size_t render_vt_bytes(int Nv) { return (((size_t)(Nv > 0 ? Nv : 1) * 16) + 255) / 256 * 256; }
 
-extern "C" size_t mh_render_scratch_bytes(int Nv, int H, int W) {
-    if (Nv < 0 || H < 1 || W < 1) return 0;
-    return 256 + render_vt_bytes(Nv) + (size_t)H * W * sizeof(unsigned long long);
+static size_t render_q_bytes(int Nf) { return (((size_t)(Nf > 0 ? Nf : 1) * 4) + 255) / 256 * 256; }
+
+// scratch: [camera | queue counter] 512 B | vertices | z/primitive keys | queue of large triangles
+extern "C" size_t mh_render_scratch_bytes(int Nv, int Nf, int H, int W) {
+    if (Nv < 0 || Nf < 0 || H < 1 || W < 1) return 0;
+    return 512 + render_vt_bytes(Nv) + (size_t)H * W * sizeof(unsigned long long) + render_q_bytes(Nf);
 }
 
 extern "C" int mh_render_depth(mh_ctx *ctx, const float *cam_host, const float *verts, int Nv, const int32_t *faces,
@@ -194,18 +197,21 @@ extern "C" int mh_render_depth(mh_ctx *ctx, const float *cam_host, const float *
     if (!cam_host || !out || !scratch || H < 1 || W < 1 || Nv < 0 || Nf < 0 || channels < 1 ||
         ((Nv > 0 && Nf > 0) && (!verts || !faces)) || !(pixel_center >= 0.0f && pixel_center < 1.0f))
         return fail(MH_ERR_ARG, "mh_render_depth: bad arguments");
-    if (scratch_bytes < mh_render_scratch_bytes(Nv, H, W))
+    if (scratch_bytes < mh_render_scratch_bytes(Nv, Nf, H, W))
         return fail(MH_ERR_ARG, "mh_render_depth: scratch too small (%zu < %zu)", scratch_bytes,
-                    mh_render_scratch_bytes(Nv, H, W));
+                    mh_render_scratch_bytes(Nv, Nf, H, W));
     MH_HIP(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     char *base = (char *)scratch;
     float *cam = (float *)base;
     MH_HIP(hipMemcpyAsync(cam, cam_host, MH_CAM_STRIDE * sizeof(float), hipMemcpyHostToDevice, st));
-    void *vt = base + 256;
-    unsigned long long *zbuf = (unsigned long long *)(base + 256 + render_vt_bytes(Nv));
+    unsigned int *qcount = (unsigned int *)(base + 256);
+    void *vt = base + 512;
+    unsigned long long *zbuf = (unsigned long long *)(base + 512 + render_vt_bytes(Nv));
+    int32_t *queue = (int32_t *)((char *)zbuf + (size_t)H * W * sizeof(unsigned long long));
     const int off = (int)(pixel_center * 256.0f + 0.5f);
-    return launched(mh_launch_render_depth(cam, verts, Nv, faces, Nf, H, W, off, vt, zbuf, out, channels, st),
+    return launched(mh_launch_render_depth(cam, verts, Nv, faces, Nf, H, W, off, vt, zbuf, queue, qcount, out,
+                                           channels, st),
                     "mh_render_depth");
 }
 

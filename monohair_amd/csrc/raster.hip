@@ -103,24 +103,52 @@ __device__ __forceinline__ bool mh_cover(const MhRTri &t, int r, int c, int off,
     return true;
 }
 
-// One wave per triangle: the lanes sweep the bounding box (64 pixels per step, row-major inside the box).
-__global__ __launch_bounds__(256) void mh_raster_tri_kernel(const MhRVert *__restrict__ vt,
-                                                            const int32_t *__restrict__ faces, int Nf, int Nv,
-                                                            int H, int W, int off,
-                                                            unsigned long long *__restrict__ zbuf) {
-    const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ void mh_shade(const MhRTri &t, int f, int r, int c, int W, int off,
+                                         unsigned long long *__restrict__ zbuf) {
+    float l0, l1, l2;
+    if (!mh_cover(t, r, c, off, l0, l1, l2)) return;
+    const float zw = (l0 * t.za + l1 * t.zb) + l2 * t.zc;
+    if (!(zw >= 0.0f && zw <= 1.0f)) return;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(zw) << 32) | (unsigned)f;
+    atomicMin(&zbuf[(size_t)r * W + c], key);
+}
+
+// Pass 1, one lane per triangle: meshes of this pipeline are mostly triangles of a few pixels, which one lane
+// finishes by itself (<= MH_R_SMALL box pixels); bigger ones are queued for the wave-per-triangle pass.
+#define MH_R_SMALL 24
+__global__ __launch_bounds__(256) void mh_raster_small_kernel(const MhRVert *__restrict__ vt,
+                                                              const int32_t *__restrict__ faces, int Nf, int Nv,
+                                                              int H, int W, int off,
+                                                              unsigned long long *__restrict__ zbuf,
+                                                              int32_t *__restrict__ queue,
+                                                              unsigned int *__restrict__ qcount) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= Nf) return;
     MhRTri t;
     if (!mh_setup_tri(vt, faces, f, Nv, H, W, off, t)) return;
     const int bw = t.c1 - t.c0 + 1, n = bw * (t.r1 - t.r0 + 1);
-    for (int k = lane; k < n; k += MH_WAVE) {
-        const int r = t.r0 + k / bw, c = t.c0 + k % bw;
-        float l0, l1, l2;
-        if (!mh_cover(t, r, c, off, l0, l1, l2)) continue;
-        const float zw = (l0 * t.za + l1 * t.zb) + l2 * t.zc;
-        if (!(zw >= 0.0f && zw <= 1.0f)) continue;
-        const unsigned long long key = ((unsigned long long)__float_as_uint(zw) << 32) | (unsigned)f;
-        atomicMin(&zbuf[(size_t)r * W + c], key);
+    if (n > MH_R_SMALL) {
+        queue[atomicAdd(qcount, 1u)] = f;
+        return;
+    }
+    for (int r = t.r0; r <= t.r1; ++r)
+        for (int c = t.c0; c <= t.c1; ++c) mh_shade(t, f, r, c, W, off, zbuf);
+}
+
+// Pass 2, one wave per queued triangle (persistent waves): the lanes sweep the bounding box, 64 pixels per step.
+__global__ __launch_bounds__(256) void mh_raster_large_kernel(const MhRVert *__restrict__ vt,
+                                                              const int32_t *__restrict__ faces, int Nv, int H,
+                                                              int W, int off,
+                                                              unsigned long long *__restrict__ zbuf,
+                                                              const int32_t *__restrict__ queue,
+                                                              const unsigned int *__restrict__ qcount) {
+    const int lane = threadIdx.x & 63, nq = (int)*qcount;
+    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < nq; q += gridDim.x * 4) {
+        const int f = queue[q];
+        MhRTri t;
+        mh_setup_tri(vt, faces, f, Nv, H, W, off, t);
+        const int bw = t.c1 - t.c0 + 1, n = bw * (t.r1 - t.r0 + 1);
+        for (int k = lane; k < n; k += MH_WAVE) mh_shade(t, f, t.r0 + k / bw, t.c0 + k % bw, W, off, zbuf);
     }
 }
 
@@ -147,15 +175,20 @@ __global__ __launch_bounds__(256) void mh_raster_resolve_kernel(const MhRVert *_
 }
 
 extern "C" int mh_launch_render_depth(const float *cam, const float *verts, int Nv, const int32_t *faces, int Nf,
-                                      int H, int W, int off, MhRVert *vt, unsigned long long *zbuf, float *out,
-                                      int channels, hipStream_t st) {
+                                      int H, int W, int off, MhRVert *vt, unsigned long long *zbuf, int32_t *queue,
+                                      unsigned int *qcount, float *out, int channels, hipStream_t st) {
     hipError_t e = hipMemsetAsync(zbuf, 0xff, (size_t)H * W * sizeof(unsigned long long), st);
     if (e != hipSuccess) return (int)e;
     if (Nv > 0 && Nf > 0) {
+        e = hipMemsetAsync(qcount, 0, sizeof(unsigned int), st);
+        if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(mh_raster_vertex_kernel, dim3((Nv + 255) / 256), dim3(256), 0, st, cam, verts, Nv, (float)H,
                            (float)W, vt);
-        hipLaunchKernelGGL(mh_raster_tri_kernel, dim3((Nf + 3) / 4), dim3(256), 0, st, vt, faces, Nf, Nv, H, W, off,
-                           zbuf);
+        hipLaunchKernelGGL(mh_raster_small_kernel, dim3((Nf + 255) / 256), dim3(256), 0, st, vt, faces, Nf, Nv, H, W,
+                           off, zbuf, queue, qcount);
+        const int blocks = (Nf + 3) / 4 < 4096 ? (Nf + 3) / 4 : 4096;
+        hipLaunchKernelGGL(mh_raster_large_kernel, dim3(blocks), dim3(256), 0, st, vt, faces, Nv, H, W, off, zbuf,
+                           queue, qcount);
     }
     hipLaunchKernelGGL(mh_raster_resolve_kernel, dim3((unsigned)(((size_t)H * W + 255) / 256)), dim3(256), 0, st, vt,
                        faces, Nv, H, W, off, zbuf, out, channels);

@@ -44,7 +44,7 @@ class DepthRenderer:
         """One view -> float32 [H,W] (channels=1) or [H,W,channels] device tensor."""
         H, W = int(H), int(W)
         Nv, Nf = self.verts.shape[0], self.faces.shape[0]
-        need = int(self._L.mh_render_scratch_bytes(Nv, H, W))
+        need = int(self._L.mh_render_scratch_bytes(Nv, Nf, H, W))
         if self._scratch is None or self._scratch.numel() < need:
             self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
         if out is None:
