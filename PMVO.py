@@ -124,14 +124,15 @@ def main(argv=None):
         min_loss = np.load(args.save_root + "/min_loss.npy")
         filter_unvisible_points = np.load(args.save_root + "/filter_unvisible.npy")
         refine(select_points, select_ori, min_loss, pmvo, filter_unvisible_points, args, infer_inner=False,
-               threshold=args.PMVO.threshold, genrate_ori_only=False)
+               threshold=args.PMVO.threshold, genrate_ori_only=False, return_dense=False)
     else:
         select_points = np.load(args.save_root + "/select_p.npy")
         select_ori = np.load(args.save_root + "/select_o.npy")
         min_loss = np.load(args.save_root + "/min_loss.npy")
         filter_unvisible_points = np.load(args.save_root + "/filter_unvisible.npy")
         refine(select_points, select_ori, min_loss, pmvo, filter_unvisible_points, args,
-               infer_inner=args.PMVO.infer_inner, threshold=args.PMVO.threshold, genrate_ori_only=True)
+               infer_inner=args.PMVO.infer_inner, threshold=args.PMVO.threshold, genrate_ori_only=True,
+               return_dense=False)
 
 
 if __name__ == "__main__":

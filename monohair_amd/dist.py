@@ -106,9 +106,11 @@ def voxel_owner_mask(x, n_ranks, r, grid_x):
     return (x >= lo) & (x < hi)
 
 
-def voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size, grid_resolution, fit=None):
+def voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size, grid_resolution, fit=None,
+                      sparse=False):
     """Voxel fit with disjoint voxel ownership + the single reduce.  Returns dense (occ [X,Y,Z], ori [X,Y,Z,3])
-    float64 numpy arrays on rank 0 (zeros elsewhere)."""
+    float64 numpy arrays on rank 0 (zeros elsewhere); with sparse=True the occupied voxels instead:
+    (voxels [G,3] int64 (x,y,z) in ascending voxel order, ori [G,3] float32), empty off rank 0."""
     from . import pmvo_utils as U
 
     fit = U.voxel_fit if fit is None else fit
@@ -119,7 +121,9 @@ def voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size, 
     pts = np.array(select_points, copy=True)
     ori = np.array(select_ori, copy=True)
     if not d:
-        res = fit(pts, ori, device, voxel_min, voxel_size, g, dense=True)
+        res = fit(pts, ori, device, voxel_min, voxel_size, g, dense=not sparse)
+        if sparse:
+            return res["voxels"].cpu().numpy(), res["ori"].cpu().numpy()
         return res["occ"], res["ori_dense"]
     probe = pts.copy()
     x, _, _ = U.p2v(probe, np.asarray(voxel_min), voxel_size, g)
@@ -133,6 +137,12 @@ def voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size, 
     cdev = _comm_device(device)
     vol = vol.to(cdev)
     d.reduce(vol, dst=0, op=d.ReduceOp.SUM)          # the one collective of the data path
+    if sparse:
+        if r != 0:
+            return np.zeros((0, 3), np.int64), np.zeros((0, 3), np.float32)
+        vol = vol.to(device)
+        nz = torch.nonzero(vol[..., 0])                     # row-major order == ascending voxel key
+        return nz.cpu().numpy(), vol[nz[:, 0], nz[:, 1], nz[:, 2], 1:].cpu().numpy()
     if r != 0:
         return np.zeros(tuple(g)), np.zeros(tuple(g) + (3,))
     vol = vol.cpu().numpy()

@@ -448,9 +448,11 @@ def _knn(data_points, query_points, k, device, mode="device"):
 
 
 def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=True, threshold=0.001,
-           genrate_ori_only=False, voxel_min=None, voxel_size=None, grid_resolution=None):
+           genrate_ori_only=False, voxel_min=None, voxel_size=None, grid_resolution=None, return_dense=True):
     """PMVO.py:602-764: KNN-medoid smoothing (sequentially dependent 5000-point chunks, in place), threshold,
     orientations for the occluded shell points, voxel fit, Ori3D.mat / Occ3D.mat.
+    Returns the dense (occ [X,Y,Z], ori [X,Y,Z,3]) float64 arrays of the reference (it returns nothing itself);
+    return_dense=False skips building them (PMVO.py's command line does: the files are written from the voxel list).
     voxel_min/voxel_size/grid_resolution default to the reference's hard-coded 256x256x192 @ 2.5 mm grid.
     args.knn = "host" switches the neighbour queries back to scipy's KDTree (default: the device kernel)."""
     from . import dist as mdist
@@ -532,7 +534,9 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     select_points = np.concatenate([select_points, select_filter_unvisible_points], 0)
 
     # voxel fit (PMVO.py:695-726): every rank fits a disjoint slab of voxels; one reduce assembles the volume
-    occ, ori_vol = mdist.voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size, grid_resolution)
+    # The volume stays a list of occupied voxels; the dense float64 arrays of the reference exist only on request.
+    vox, vori = mdist.voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size, grid_resolution,
+                                        sparse=True)
 
     if is_root:
         if infer_inner:
@@ -546,10 +550,12 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
             un_visible_points = cpoints[unvisible_index]
             unvisible_ori = coarse_ori[unvisible_index]
             x, y, z = U.p2v(un_visible_points.copy(), voxel_min, voxel_size, grid_resolution)
-            occ[x, y, z] = 1
-            ori_vol[x, y, z] = unvisible_ori
+            vox = np.concatenate([vox, np.stack([x, y, z], 1).astype(np.int64)])      # later rows win (:746-747)
+            vori = np.concatenate([vori, unvisible_ori])
             np.save(os.path.join(args.save_path, "coarse.npy"), un_visible_points)
             np.save(os.path.join(args.save_path, "coarse_ori.npy"), unvisible_ori)
-        U.save_ori_occ_mat(args.save_path, occ, ori_vol)
+        U.save_ori_occ_mat_sparse(args.save_path, grid_resolution, vox, vori)
     mdist.barrier()
-    return occ, ori_vol
+    if not return_dense:
+        return None
+    return U.dense_from_sparse(grid_resolution, vox, vori)

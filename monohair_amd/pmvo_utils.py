@@ -383,6 +383,63 @@ def save_ori_occ_mat(path, occ, ori):
     scipy.io.savemat(os.path.join(path, "Occ3D.mat"), {"Occ": occ.transpose((1, 0, 2))})
 
 
+def _mat5_prefix(name, dims):
+    """Bytes of a MAT-v5 file up to the float64 payload of ONE real double array `name` of shape `dims` (the layout
+    scipy.io.savemat writes: 128-byte header, miMATRIX{array flags, dimensions, name, real part})."""
+    import struct
+    import time
+
+    nb = name.encode()
+    assert 1 <= len(nb) <= 4, "small-element name form"
+    ndata = 8 * int(np.prod(dims))
+    assert ndata < 2 ** 32 - 64, "MAT v5 elements are limited to 4 GiB"
+    text = ("MATLAB 5.0 MAT-file Platform: posix, Created on: %s" % time.asctime()).encode()
+    head = text.ljust(124, b"\x00") + struct.pack("<H", 0x0100) + b"IM"
+    flags = struct.pack("<IIII", 6, 8, 6, 0)                                   # miUINT32, mxDOUBLE_CLASS
+    d = struct.pack("<II", 5, 4 * len(dims)) + struct.pack("<%di" % len(dims), *[int(x) for x in dims])
+    d += b"\x00" * (-len(d) % 8)
+    nm = struct.pack("<HH", 1, len(nb)) + nb.ljust(4, b"\x00")                  # miINT8, small data element
+    real = struct.pack("<II", 9, ndata)                                        # miDOUBLE
+    body = flags + d + nm + real
+    return head + struct.pack("<II", 14, len(body) + ndata + (-ndata % 8)) + body, ndata
+
+
+def save_ori_occ_mat_sparse(path, grid_resolution, voxels, ori):
+    """Same two files as save_ori_occ_mat (PMVO.py:753-764) written from the occupied voxels only: `voxels` [G,3]
+    (x,y,z) and `ori` [G,3]; later rows win on duplicates, as the reference's fancy assignments do (:746-747).
+    The float64 payload (Ori [Y,X,3Z] with last index c*Z+z, Occ [Y,X,Z], column-major as MAT v5 stores it) is
+    created as a zero-filled file and only the pages holding occupied voxels are written."""
+    X, Y, Z = (int(v) for v in grid_resolution)
+    v = np.asarray(voxels, dtype=np.int64).reshape(-1, 3)
+    o = np.asarray(ori, dtype=np.float64).reshape(-1, 3)
+    lin = v[:, 1] + Y * (v[:, 0] + X * v[:, 2])                                # Occ[y,x,z], y fastest
+    for fname, name, dims, idx, val in (
+            ("Occ3D.mat", "Occ", (Y, X, Z), lin, np.ones(len(v))),
+            ("Ori3D.mat", "Ori", (Y, X, 3 * Z),
+             (lin[:, None] + (Y * X * Z) * np.arange(3)[None, :]).reshape(-1), o.reshape(-1))):
+        prefix, ndata = _mat5_prefix(name, dims)
+        full = os.path.join(path, fname)
+        with open(full, "wb") as f:
+            f.write(prefix)
+            f.truncate(len(prefix) + ndata)
+        if len(idx):
+            mm = np.memmap(full, dtype="<f8", mode="r+", offset=len(prefix), shape=(ndata // 8,))
+            order = np.argsort(idx, kind="stable")           # page order; duplicates keep their order -> last wins
+            mm[idx[order]] = val[order]
+            mm.flush()
+            del mm
+
+
+def dense_from_sparse(grid_resolution, voxels, ori):
+    """occ [X,Y,Z], ori [X,Y,Z,3] float64 as the reference holds them before saving (PMVO.py:698-726)."""
+    g = tuple(int(v) for v in grid_resolution)
+    occ, dense = np.zeros(g), np.zeros(g + (3,))
+    v = np.asarray(voxels, dtype=np.int64).reshape(-1, 3)
+    occ[v[:, 0], v[:, 1], v[:, 2]] = 1
+    dense[v[:, 0], v[:, 1], v[:, 2]] = np.asarray(ori, dtype=np.float64).reshape(-1, 3)
+    return occ, dense
+
+
 def get_ground_truth_3D_occ(d, flip=False):
     """PMVO_utils.py:86-95 -> [Z,Y,X,1] float32."""
     occ = scipy.io.loadmat(d, verify_compressed_data_integrity=False)["Occ"].astype(np.float32)

@@ -150,7 +150,14 @@ if r == 0:
     occ1, vol1 = oracle.voxel_fit(pts.copy(), ori.copy(), [-0.32, -0.32, -0.24], 0.01, g)
     assert np.array_equal(occ, occ1), "occupancy differs from the single-process fit"
     assert np.array_equal(vol.astype(np.float32), vol1.astype(np.float32)), "volume differs"
+vx, vo = mdist.voxel_fit_reduced(pts, ori, "cpu", [-0.32, -0.32, -0.24], 0.01, g, fit=fit, sparse=True)
+if r == 0:
+    from monohair_amd.pmvo_utils import dense_from_sparse
+    occ2, vol2 = dense_from_sparse(g, vx, vo)
+    assert np.array_equal(occ2, occ1) and np.array_equal(vol2.astype(np.float32), vol1.astype(np.float32)), "sparse"
     print("DIST_OK", int(occ.sum()))
+else:
+    assert len(vx) == 0
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -225,3 +232,30 @@ def test_maps_pack_roundtrip(tmp_path):
         mapspack.read_pack(str(bad))
     with pytest.raises(ValueError):
         mapspack.write_pack(path, views, o, c, m[:2], d)
+
+
+def test_sparse_mat_writer_equals_savemat(tmp_path):
+    """The MAT-v5 files written from the occupied voxels load to the same arrays as the reference's dense
+    scipy.io.savemat path (PMVO.py:753-764), duplicates resolved like its fancy assignments (last wins)."""
+    import scipy.io
+
+    from monohair_amd import pmvo_utils as U
+
+    rng = np.random.default_rng(0)
+    g = [40, 36, 28]
+    v = np.stack([rng.integers(0, g[i], 500) for i in range(3)], 1)
+    v[-5:] = v[:5]
+    o = rng.normal(size=(500, 3)).astype(np.float32)
+    a, b = tmp_path / "sparse", tmp_path / "dense"
+    a.mkdir(), b.mkdir()
+    U.save_ori_occ_mat_sparse(str(a), g, v, o)
+    occ, ori = U.dense_from_sparse(g, v, o)
+    assert occ.sum() == len(np.unique(v, axis=0)) and np.array_equal(ori[tuple(v[0])], o[-5].astype(np.float64))
+    U.save_ori_occ_mat(str(b), occ, ori)
+    for f, k in (("Ori3D.mat", "Ori"), ("Occ3D.mat", "Occ")):
+        x, y = scipy.io.loadmat(a / f)[k], scipy.io.loadmat(b / f)[k]
+        assert x.dtype == np.float64 and x.shape == y.shape and np.array_equal(x, y)
+        assert os.path.getsize(a / f) == os.path.getsize(b / f)
+    assert U.get_ground_truth_3D_ori(str(a / "Ori3D.mat")).shape == (28, 36, 40, 3)
+    U.save_ori_occ_mat_sparse(str(a), g, np.zeros((0, 3), int), np.zeros((0, 3)))          # empty volume
+    assert scipy.io.loadmat(a / "Occ3D.mat")["Occ"].sum() == 0
