@@ -38,8 +38,9 @@ __global__ __launch_bounds__(256) void mh_filter_kernel(MhViews vw, const float 
         float m = vw.mask[(size_t)v * H * W + (size_t)r * W + c];
         const float gap = (-z / 2.0f) * 255.0f - q.w;
         // raw (unclamped) patch confidences, zeroed when the point projects outside (PMVO.py:415-420)
+        // (only term 0 = visible * low_confidence uses it, so views that do not see the point skip the patch)
         float cmax = 0.0f;
-        if (surface_index || filter_index) {
+        if ((surface_index || filter_index) && !(oob || gap > 0.1f)) {
             // all PATCH*PATCH loads are issued before the first use (fully unrolled): the lane is latency bound
             float cv[PATCH * PATCH];
 #pragma unroll

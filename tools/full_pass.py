@@ -24,6 +24,7 @@ ap.add_argument("--width", type=int, default=1080)
 ap.add_argument("--volume", type=int, default=256)
 ap.add_argument("--patch", type=int, default=7)
 ap.add_argument("--quantize", action="store_true")
+ap.add_argument("--profile", action="store_true", help="cProfile the refine stage (host-side view)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 T = {}
@@ -56,10 +57,19 @@ tic("filter_s", t0)
 t0 = time.perf_counter()
 sp, so, ml, hc = optimize(s_pts, pm, args)
 tic("optimize_s", t0)
+if a.profile:
+    import cProfile
+    import pstats
+
+    pr = cProfile.Profile()
+    pr.enable()
 t0 = time.perf_counter()
 occ, ori = refine(sp.copy(), so.copy(), ml.copy(), pm, cand[:len(f_idx)][f_idx].astype(np.float32), args,
                   infer_inner=False, threshold=0.025)
 tic("refine+volume_s", t0)
+if a.profile:
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
 # --- strand tracing on the fitted volume (scalp roots + two voxel-seeded rounds)
 from monohair_amd.hairgrow import HairGrowing  # noqa: E402
 
