@@ -64,8 +64,8 @@ if a.profile:
     pr = cProfile.Profile()
     pr.enable()
 t0 = time.perf_counter()
-occ, ori = refine(sp.copy(), so.copy(), ml.copy(), pm, cand[:len(f_idx)][f_idx].astype(np.float32), args,
-                  infer_inner=False, threshold=0.025)
+refine(sp.copy(), so.copy(), ml.copy(), pm, cand[:len(f_idx)][f_idx].astype(np.float32), args, infer_inner=False,
+       threshold=0.025, return_dense=False)          # as PMVO.py does: Ori3D.mat / Occ3D.mat written from the voxel list
 tic("refine+volume_s", t0)
 if a.profile:
     pr.disable()
@@ -73,9 +73,15 @@ if a.profile:
 # --- strand tracing on the fitted volume (scalp roots + two voxel-seeded rounds)
 from monohair_amd.hairgrow import HairGrowing  # noqa: E402
 
+from monohair_amd.pmvo_utils import get_ground_truth_3D_occ, get_ground_truth_3D_ori  # noqa: E402
+
 t0 = time.perf_counter()
-hg = HairGrowing(None, None, device=str(dev), occ=occ.transpose(2, 1, 0)[..., None].astype(np.float32),
-                 ori=ori.transpose(2, 1, 0, 3).astype(np.float32))
+occ_zyx = get_ground_truth_3D_occ(args.save_path + "/Occ3D.mat")       # what HairGrow.py reads (HairGrow.py:816-824)
+ori_zyx = get_ground_truth_3D_ori(args.save_path + "/Ori3D.mat")
+T["voxels"] = int(occ_zyx.sum())
+tic("load_mat_s", t0)
+t0 = time.perf_counter()
+hg = HairGrowing(None, None, device=str(dev), occ=occ_zyx, ori=ori_zyx)
 rs = np.random.default_rng(2)
 nrm = rs.normal(size=(60000, 3))
 nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
@@ -84,10 +90,16 @@ nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
 centre = np.array([128.0, 128.0, 96.0])
 sp = torch.from_numpy((centre + nrm * 40.0).astype(np.float32))         # 10 cm scalp sphere in voxel units
 torch.manual_seed(0)
+if a.profile:
+    pr = cProfile.Profile()
+    pr.enable()
 strands, num_root = hg.GenerateGuideStrandFromScalp(sp, torch.from_numpy(nrm.astype(np.float32)), None, 0.85)
 tic("trace_strands_s", t0)
+if a.profile:
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
 T["strands"] = len(strands)
 T["strand_points"] = int(sum(s.shape[0] for s in strands))
 T["num_root"] = num_root
 print({"candidates": len(cand), "surface": int(s_idx.sum()), "shell": int(f_idx.sum()),
-       "iterations": len(s_pts) // 5000 + 1, "voxels": int(occ.sum()), **T})
+       "iterations": len(s_pts) // 5000 + 1, **T})
