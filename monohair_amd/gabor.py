@@ -187,10 +187,11 @@ def pmvo_maps_from_u8(k8, c8):
     return _FILE_LUT[0].to(k8.device)[k8.long()], _FILE_LUT[1].to(k8.device)[c8.long()]
 
 
-def orientation_maps_device(images, device=None, gabor=None):
+def orientation_maps_device(images, device=None, gabor=None, return_codes=False):
     """The Gabor stage for a list of gray uint8 images, device-resident, views dealt to the ranks of an initialised
     torch.distributed group (the image-wide confidence maximum is per view, so views are independent) and
-    all-gathered as 2 B/px uint8 planes.  Returns (ori [V,H,W,2], conf [V,H,W]) fp32 tensors on every rank."""
+    all-gathered as 2 B/px uint8 planes.  Returns (ori [V,H,W,2], conf [V,H,W]) fp32 tensors on every rank, or with
+    return_codes=True the 8-bit file codes themselves (best_ori [V,H,W], conf [V,H,W] uint8) for PMVO.from_u8."""
     from . import dist as mdist
 
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -206,6 +207,8 @@ def orientation_maps_device(images, device=None, gabor=None):
         _, _, k8, c8 = pmvo_maps_from_gabor(idx, conf)
         local.append(torch.stack([k8, c8], 0))
     planes = mdist.all_gather_views(local, V, (2, H, W), torch.uint8, device)      # [V,2,H,W]
+    if return_codes:
+        return planes[:, 0].contiguous(), planes[:, 1].contiguous()
     ori, conf = pmvo_maps_from_u8(planes[:, 0], planes[:, 1])
     return ori, conf
 

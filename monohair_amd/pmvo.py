@@ -82,7 +82,7 @@ class PMVO:
                 visible_threshold=1, conf_threshold=0.4, lut=None):
         """The constructor for maps kept as their 8-bit pixel codes (pmvo_utils.load_maps_u8 or a maps pack):
         dicts view -> uint8 [H,W] for orientation / confidence / mask (or [V,H,W] arrays in view order), depth
-        float32 [H,W] or [H,W,3].  Decoded on the GPU through the 256-entry table of the loaders
+        float32 [H,W] or [H,W,3]; numpy arrays or torch tensors (device tensors are used in place).  Decoded on the GPU through the 256-entry table of the loaders
         (pmvo_utils.map_code_lut), so the resident records equal those of PMVO(camera, <decoded float maps>)."""
         from .pmvo_utils import map_code_lut
 
@@ -103,6 +103,9 @@ class PMVO:
         self._alloc(len(keys), H, W)
         st = _lib.stream_ptr()
         def up(x, dtype=None):      # read-only memory maps are fine here: the tensor is only the source of a copy
+            if torch.is_tensor(x):  # already on a device (Gabor stage / depth rasteriser output): no host round trip
+                x = x.to(self.device)
+                return (x if dtype is None else x.to(torch.float32)).contiguous()
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore", UserWarning)
                 return torch.from_numpy(np.ascontiguousarray(x, dtype=dtype)).to(self.device)

@@ -83,3 +83,33 @@ def test_rendered_depth_feeds_pmvo():
     oa, ob = a.forward(pts[keep])[1], b.forward(pts[keep])[1]
     cosv = (oa * ob).sum(1).abs()
     assert (cosv > 0.999).float().mean() > 0.9
+
+
+def test_device_resident_hand_off_gabor_raster_pmvo():
+    """Images -> Gabor codes (device) + rasterised depth (device) -> PMVO.from_u8 on the device tensors: nothing goes
+    through the host or the disk, and the resident maps equal those built from host copies of the same arrays."""
+    from monohair_amd.gabor import orientation_maps_device
+    from monohair_amd.pmvo import PMVO
+    from monohair_amd.render import render_depth_planes
+
+    V, H, W = 20, 160, 120
+    cams = synth.make_cameras(V, H, W, scale=1.6)
+    camera = cameras_from_list(cams)
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:H, 0:W]
+    images = [np.clip(127 + 80 * np.cos(2 * np.pi * (xx * np.cos(0.1 * i) + yy * np.sin(0.1 * i)) / 4.0)
+                      + rng.normal(0, 5, (H, W)), 0, 255).astype(np.uint8) for i in range(V)]
+    k8, c8 = orientation_maps_device(images, DEV, return_codes=True)
+    assert k8.dtype == torch.uint8 and k8.shape == (V, H, W) and k8.is_cuda
+    v, f = uv_sphere(synth.SPHERE_R, 96, 192)
+    depth = render_depth_planes(camera, [(v, f)], [H, W], DEV, pixel_center=0.0)
+    m8 = (depth < 255).to(torch.uint8) * 255
+    kw = dict(device=DEV, image_size=[H, W], patch_size=3, conf_threshold=0.1)
+    a = PMVO.from_u8(camera, depth, k8, c8, m8, **kw)
+    b = PMVO.from_u8(camera, depth.cpu().numpy(), k8.cpu().numpy(), c8.cpu().numpy(), m8.cpu().numpy(), **kw)
+    pts = synth.candidate_points(res=32, seed=1)[:1500]
+    for pm in (a, b):
+        pm.Compute_Visible_and_Ori(pts)
+    for name in ("visible", "Ori", "Conf", "mask", "Ori_patch", "Conf_patch"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert (a.visible > -1).any() and float(a.Conf.max()) > 0.5
