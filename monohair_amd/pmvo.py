@@ -213,13 +213,17 @@ class PMVO:
         self._materialise_patches()
         return self._Conf_patch
 
-    def Find_max_conf_from_visible_view(self):
-        """PMVO.py:339-343 -> (base_view_index [20,N] int64, base_view_conf [20,N])."""
+    def _topk32(self):
         V, N = self.visible.shape
         idx = torch.empty((20, N), dtype=torch.int32, device=self.device)
         val = torch.empty((20, N), dtype=torch.float32, device=self.device)
         _lib.check(self._L.mh_topk_views(self._ctx, _lib.ptr(self.visible), _lib.ptr(self.Conf), N, _lib.ptr(idx),
                                          _lib.ptr(val), _lib.stream_ptr()), "mh_topk_views")
+        return idx, val
+
+    def Find_max_conf_from_visible_view(self):
+        """PMVO.py:339-343 -> (base_view_index [20,N] int64, base_view_conf [20,N])."""
+        idx, val = self._topk32()
         return idx.long(), val
 
     def _get_scratch(self, N):
@@ -262,15 +266,13 @@ class PMVO:
             N = points.shape[0]
             scratch, need = self._get_scratch(N)
         if base_view is None:
-            bidx, bval = self.Find_max_conf_from_visible_view()
+            bidx32, bval = self._topk32()          # int32 end to end: no int64 round trip on the hot path
         else:
-            bidx = torch.as_tensor(base_view[0]).to(self.device)
-            bval = torch.as_tensor(base_view[1]).to(self.device).type(torch.float)
-        bidx32 = bidx.to(torch.int32).contiguous()
-        bval = bval.contiguous()
+            bidx32 = torch.as_tensor(base_view[0]).to(self.device).to(torch.int32).contiguous()
+            bval = torch.as_tensor(base_view[1]).to(self.device).type(torch.float).contiguous()
         line_ori = torch.empty((N, 3), **f)
         min_loss = torch.empty((N,), **f)
-        hc = torch.empty((N,), dtype=torch.uint8, device=self.device)
+        hc = torch.empty((N,), dtype=torch.bool, device=self.device)      # the kernel writes 0/1 bytes
         bs = torch.empty((N, 3), **f) if extras else None
         br = torch.empty((N,), dtype=torch.int32, device=self.device) if extras else None
         bi = torch.empty((N,), dtype=torch.int32, device=self.device) if extras else None
@@ -287,9 +289,9 @@ class PMVO:
                 _lib.ptr(self._Ori_patch), _lib.ptr(self._Conf_patch), _lib.ptr(bidx32), _lib.ptr(bval),
                 _lib.ptr(scratch), need, _lib.ptr(line_ori), _lib.ptr(min_loss), _lib.ptr(hc), _lib.ptr(bs),
                 _lib.ptr(br), _lib.ptr(bi), _lib.stream_ptr()), "mh_search_forward")
-        out = (points, line_ori, min_loss, hc.bool())
+        out = (points, line_ori, min_loss, hc)
         if extras:
-            return out + (dict(best_sample=bs, best_rank=br, best_s=bi, base_idx=bidx, base_val=bval),)
+            return out + (dict(best_sample=bs, best_rank=br, best_s=bi, base_idx=bidx32.long(), base_val=bval),)
         return out
 
     __call__ = forward
