@@ -33,8 +33,8 @@ CHUNK = 5000                 # PMVO.py:566
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--views", type=int, default=60)
     ap.add_argument("--height", type=int, default=1920)
     ap.add_argument("--width", type=int, default=1080)
