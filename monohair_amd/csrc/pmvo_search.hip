@@ -8,8 +8,9 @@
 //                                                 sums over views in ATen's cascade order
 //   forward's best-so-far update (PMVO.py:57-70) -> LDS epilogue.
 // No [V,N,S] tensor ever exists.  The patch of (view, point) is the same for every lane of the
-// workgroup, so the tap list (pmvo_project.hip: mh_prep_taps_kernel) is read with scalar loads into
-// SGPRs and the inner loop is pure VALU: per (item, tap) 2 mul + add + (1-|x|) + cmp + 2 cndmask.
+// workgroup, so the tap list (pmvo_project.hip: mh_prep_taps_kernel) is read with wave-uniform loads (header
+// and first tap: scalar loads; the rest: broadcast vector loads, what the backend selects for the ping-pong
+// groups) and the inner loop is pure VALU: per (item, tap) 2 mul + add + (1-|x|) + cmp + 2 cndmask.
 // Views in which the point is not visible (vis == -1 => weight 0, PMVO.py:212) are skipped: adding
 // their exact zeros would not change any sum.
 #include "mh_device.h"
@@ -48,7 +49,7 @@ __device__ __forceinline__ float mh_one_minus_abs(float x) {
     return r;
 }
 
-template <int K, int T, bool FAST>
+template <int K, int T, int FAST>
 __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *__restrict__ offs, int S, int nrank,
                                                       int rank_step, const float *__restrict__ pts, int N, int P1,
                                                       float thr, const float *__restrict__ ori_c,
@@ -118,10 +119,12 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
                 ML[2 * jp + 1] = mh_one_minus_abs(cs.y);
                 BC[2 * jp] = BC[2 * jp + 1] = t0.z;
             }
-            // Tap records arrive through the scalar cache; a scalar load can only be waited for with lgkmcnt(0), so
-            // the loop is software-pipelined by hand in groups of GRP taps: wait for the group loaded during the
-            // previous trip, THEN issue the loads of the next group, then compute -- the ~200-cycle scalar latency
-            // hides behind GRP*19 VALU instructions even with a single wave on the SIMD.  (The list is padded: reading
+            // The tap loop is software-pipelined by hand in groups of GRP taps: the loads of the next group are issued
+            // before the current group is computed, so the load latency hides behind GRP*22 VALU instructions even
+            // with a single wave on the SIMD.  The records travel as wave-uniform VECTOR loads (every lane gets a
+            // copy): vmcnt lets the wave wait for one group while the next is in flight, whereas scalar loads can
+            // only be waited for all together (lgkmcnt(0)) -- measured 1155 vs 926 iterations/s.  The explicit
+            // s_waitcnt below is what keeps the backend from turning them into scalar loads.  (The list is padded: reading
             // up to 2*GRP records past `ntap` stays inside the scratch buffer and the values are never used.)
             constexpr int GRP = 4;
             auto process = [&](const float4 (&g)[GRP], int t) {
@@ -129,21 +132,59 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
                 for (int u = 0; u < GRP; ++u) {
                     if (t + u < ntap) {   // uniform
                         const float4 tp = g[u];
-                        const mh_v2f ox2 = mh_v2f{tp.x, tp.x}, oy2 = mh_v2f{tp.y, tp.y};
                         float l[K];
+                        if constexpr (FAST == 2 && K == 4) {
+                            // The tap record is wave-uniform and sits in a register pair {ox, oy}: v_pk_mul_f32
+                            // broadcasts one half of it (op_sel), no splat copies.  The four compares go to four SGPR
+                            // masks BEFORE the eight selects: gfx950 needs 2 wait states between a VALU write of an
+                            // SGPR/VCC and a VALU read of it, which the compiler's one-VCC-at-a-time code pays as an
+                            // s_nop after every compare.
+                            const unsigned long long xy =
+                                ((unsigned long long)__float_as_uint(tp.y) << 32) | __float_as_uint(tp.x);
 #pragma unroll
-                        for (int jp = 0; jp < K / 2; ++jp) {
-                            const mh_v2f cs = ox2 * DX[jp] + oy2 * DY[jp];
-                            l[2 * jp] = mh_one_minus_abs(cs.x);
-                            l[2 * jp + 1] = mh_one_minus_abs(cs.y);
-                        }
-                        // compare into an SGPR mask, two selects: measured 10 cycles per update against 12 for the
-                        // v_cmpx + v_pk_mov_b32 + EXEC-restore form (tools/ubench/valu.hip), and no SALU traffic
+                            for (int jp = 0; jp < 2; ++jp) {
+                                mh_v2f px, py;
+                                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(px) : "v"(xy), "v"(DX[jp]));
+                                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]"
+                                    : "=v"(py)
+                                    : "v"(xy), "v"(DY[jp]));
+                                const mh_v2f cs = px + py;
+                                l[2 * jp] = mh_one_minus_abs(cs.x);
+                                l[2 * jp + 1] = mh_one_minus_abs(cs.y);
+                            }
+                            unsigned long long m0, m1, m2, m3;
+                            asm("v_cmp_lt_f32_e64 %[m0], %[l0], %[a0]\n\t"
+                                "v_cmp_lt_f32_e64 %[m1], %[l1], %[a1]\n\t"
+                                "v_cmp_lt_f32_e64 %[m2], %[l2], %[a2]\n\t"
+                                "v_cmp_lt_f32_e64 %[m3], %[l3], %[a3]\n\t"
+                                "v_cndmask_b32_e64 %[a0], %[a0], %[l0], %[m0]\n\t"
+                                "v_cndmask_b32_e64 %[a1], %[a1], %[l1], %[m1]\n\t"
+                                "v_cndmask_b32_e64 %[a2], %[a2], %[l2], %[m2]\n\t"
+                                "v_cndmask_b32_e64 %[a3], %[a3], %[l3], %[m3]\n\t"
+                                "v_cndmask_b32_e64 %[b0], %[b0], %[cf], %[m0]\n\t"
+                                "v_cndmask_b32_e64 %[b1], %[b1], %[cf], %[m1]\n\t"
+                                "v_cndmask_b32_e64 %[b2], %[b2], %[cf], %[m2]\n\t"
+                                "v_cndmask_b32_e64 %[b3], %[b3], %[cf], %[m3]"
+                                : [a0] "+v"(ML[0]), [a1] "+v"(ML[1]), [a2] "+v"(ML[2]), [a3] "+v"(ML[3]),
+                                  [b0] "+v"(BC[0]), [b1] "+v"(BC[1]), [b2] "+v"(BC[2]), [b3] "+v"(BC[3]),
+                                  [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)
+                                : [l0] "v"(l[0]), [l1] "v"(l[1]), [l2] "v"(l[2]), [l3] "v"(l[3]), [cf] "v"(tp.z));
+                        } else {
+                            const mh_v2f ox2 = mh_v2f{tp.x, tp.x}, oy2 = mh_v2f{tp.y, tp.y};
 #pragma unroll
-                        for (int j = 0; j < K; ++j) {
-                            const bool upd = l[j] < ML[j];
-                            ML[j] = upd ? l[j] : ML[j];
-                            BC[j] = upd ? tp.z : BC[j];
+                            for (int jp = 0; jp < K / 2; ++jp) {
+                                const mh_v2f cs = ox2 * DX[jp] + oy2 * DY[jp];
+                                l[2 * jp] = mh_one_minus_abs(cs.x);
+                                l[2 * jp + 1] = mh_one_minus_abs(cs.y);
+                            }
+                            // compare into an SGPR mask, two selects: measured 10 cycles per update against 12 for
+                            // the v_cmpx + v_pk_mov_b32 + EXEC-restore form (tools/ubench/valu.hip)
+#pragma unroll
+                            for (int j = 0; j < K; ++j) {
+                                const bool upd = l[j] < ML[j];
+                                ML[j] = upd ? l[j] : ML[j];
+                                BC[j] = upd ? tp.z : BC[j];
+                            }
                         }
                     }
                 }
@@ -152,13 +193,13 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
 #pragma unroll
             for (int u = 0; u < GRP; ++u) ga[u] = rec[2 + u];
             for (int t = 1; t < ntap;) {
-                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): group A has landed
+                __builtin_amdgcn_s_waitcnt(0xc07f);   // (see above: keeps the record loads on the vector path)
 #pragma unroll
                 for (int u = 0; u < GRP; ++u) gb[u] = rec[1 + t + GRP + u];
                 process(ga, t);
                 t += GRP;
                 if (t >= ntap) break;
-                __builtin_amdgcn_s_waitcnt(0xc07f);   // group B has landed
+                __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
                 for (int u = 0; u < GRP; ++u) ga[u] = rec[1 + t + GRP + u];
                 process(gb, t);
@@ -373,7 +414,7 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
     hipLaunchKernelGGL((mh_search_kernel<KK, TT, FF>), dim3(N), dim3(TT), 0, st, vw, offs, S, nrank, rank_step, pts, N, \
                        P1, thr, ori_c, base_idx, base_val, taps, line_ori, min_loss, high_conf, best_sample,        \
                        best_rank, best_s)
-#define MH_SEARCH_LAUNCH(KK, TT) MH_SEARCH_LAUNCH_F(KK, TT, false)
+#define MH_SEARCH_LAUNCH(KK, TT) MH_SEARCH_LAUNCH_F(KK, TT, 0)
     // pick the smallest K*T that covers the items for the requested wave count
     if (variant == 0) variant = (nitems <= 64) ? 64 : (nitems <= 320 ? 320 : 256);
     if (variant == 64) {
@@ -387,11 +428,13 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
         if (nitems <= 960) MH_SEARCH_LAUNCH(5, 192);
         else MH_SEARCH_LAUNCH(6, 192);
     } else if (variant == 256) {
-        MH_SEARCH_LAUNCH_F(4, 256, true);
+        MH_SEARCH_LAUNCH_F(4, 256, 2);
+    } else if (variant == 2256) {   // compiler-scheduled tap body (pre hand-ordered compare/select block)
+        MH_SEARCH_LAUNCH_F(4, 256, 1);
     } else if (variant == 1256) {   // portable loop, for A/B and cross-checks
         MH_SEARCH_LAUNCH(4, 256);
     } else if (variant == 1128) {
-        MH_SEARCH_LAUNCH_F(8, 128, true);
+        MH_SEARCH_LAUNCH_F(8, 128, 1);
     } else if (variant == 320) {
         if (nitems <= 320) MH_SEARCH_LAUNCH(1, 320);
         else if (nitems <= 960) MH_SEARCH_LAUNCH(3, 320);

@@ -22,6 +22,7 @@ from monohair_amd.pmvo import PMVO, depth_offsets  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--minutes", type=float, default=3.0)
 ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--variant", type=int, default=0, help="search-kernel variant (0 = shipped default)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 DEV = "cuda:0"
@@ -54,6 +55,8 @@ while time.time() < t_end:
     rec = camera_records(cameras_from_list(scene["cams"]))
     pm = PMVO.from_planes(rec, scene["depth"].to(DEV), scene["ori"].to(DEV), scene["conf"].to(DEV),
                           scene["mask"].to(DEV), device=DEV, patch_size=patch, visible_threshold=1, conf_threshold=thr)
+    if a.variant:
+        pm.set_option("search_variant", a.variant)
     views = oracle.Views(rec, scene["depth"].numpy(), scene["ori"].numpy(), scene["conf"].numpy(), scene["mask"].numpy())
     N = int(rng.integers(1, 400))
     cand = synth.candidate_points(res=int(rng.choice([32, 64])), seed=seed % 1000)
