@@ -181,7 +181,11 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "synthetic sphere, %d views @ %dx%d, %d^3 volume, %d points/iteration, patch %d, S=90, "
-                        "10 base views (BASELINE.json configs[2])" % (V, H, W, a.volume, CHUNK, a.patch),
+                        "10 base views (%s)" % (V, H, W, a.volume, CHUNK, a.patch, {
+                            (60, 1920, 1080, 256): "BASELINE.json configs[2], the configuration the metric is quoted on",
+                            (30, 1920, 1080, 128): "BASELINE.json configs[1]",
+                            (120, 3840, 2160, 512): "BASELINE.json configs[4], one GPU's share"}.get(
+                                (V, H, W, a.volume), "custom size")),
             "views": V, "image": [H, W], "volume": a.volume, "points_per_iteration": CHUNK, "patch": a.patch,
             "conf_threshold": a.conf_threshold, "surface_points": int(len(pts)), "iterations_full_pass": nchunk,
             "parallelism": "points sharded over %d GPU(s), views replicated" % world,
