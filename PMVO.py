@@ -19,6 +19,7 @@ import numpy as np
 from monohair_amd import options
 from monohair_amd.camera import load_cam, parsing_camera
 from monohair_amd.pmvo import PMVO, filter_negative_points, optimize, refine  # noqa: F401  (re-exported)
+from monohair_amd.timing import stage
 from monohair_amd.pmvo_utils import (Load_Ori_And_Conf, load_bust, load_colmap_points, load_depth,  # noqa: F401
                                      load_depth_plane, load_maps_u8, load_mask, read_obj)
 
@@ -98,18 +99,21 @@ def main(argv=None):
 
     camera = parsing_camera(load_cam(args.image_camera_path), os.path.join(args.data.root, "capture_images"))
     print("num of view:", len(camera))
-    pmvo = load_views(camera, args)
+    with stage("load maps -> device", args.device):
+        pmvo = load_views(camera, args)
     pmvo.set_head(bust_tree, scalp_tree, scalp_max)
 
     if args.PMVO.optimize:
         print("load raw mesh...")
-        points = load_colmap_points(args.data.raw_points_path, args.bbox_min, args.bust_to_origin, 0.005 / 4,
-                                    [512, 512, 384], True, args.PMVO.num_sample_per_grid)
+        with stage("candidate points"):
+            points = load_colmap_points(args.data.raw_points_path, args.bbox_min, args.bust_to_origin, 0.005 / 4,
+                                        [512, 512, 384], True, args.PMVO.num_sample_per_grid)
         raw_points = points.copy()
         print("total points:", points.shape[0])
         print("filter low conf points...")
         if args.PMVO.filter_point:
-            surface_index, surface_points, filter_index = filter_negative_points(points, pmvo, args)
+            with stage("filter_negative_points", args.device):
+                surface_index, surface_points, filter_index = filter_negative_points(points, pmvo, args)
             points = surface_points
             if mdist.rank() == 0:
                 os.makedirs(args.save_root, exist_ok=True)
@@ -118,7 +122,8 @@ def main(argv=None):
                         raw_points[:len(filter_index)][filter_index])
             mdist.barrier()
         print("process points:", points.shape[0])
-        optimize(points, pmvo, args)
+        with stage("optimize", args.device):
+            optimize(points, pmvo, args)
         select_points = np.load(args.save_root + "/select_p.npy")
         select_ori = np.load(args.save_root + "/select_o.npy")
         min_loss = np.load(args.save_root + "/min_loss.npy")

@@ -15,6 +15,7 @@ import torch
 
 from . import _lib
 from .camera import CAM_STRIDE, camera_records
+from .timing import stage
 
 _GOLDEN_OFFSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "depth_offsets.npy")
 
@@ -474,8 +475,11 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         # cores), then the sequentially dependent smoothing loop (chunk k+1 reads the orientations chunk k wrote,
         # PMVO.py:614,640) runs entirely on the device, stream-ordered, without a host round trip per chunk.
         n_all = points.shape[0]
-        index_all = _knn(points, points, 100, device, getattr(args, "knn", "device"))
-        head_top_all = torch.from_numpy(pmvo.head_top_mask(points)).to(device)
+        with stage("refine: knn (surface)", device):
+            index_all = _knn(points, points, 100, device, getattr(args, "knn", "device"))
+        with stage("refine: head-top mask", device):
+            head_top_all = torch.from_numpy(pmvo.head_top_mask(points)).to(device)
+        T_loop = stage("refine: smoothing loop", device).__enter__()
         pts_dev = torch.from_numpy(points).to(device).type(torch.float)
         ori_dev = torch.from_numpy(ori).to(device).type(torch.float).contiguous()
         loss_dev = torch.from_numpy(loss).to(device).type(torch.float).contiguous()
@@ -491,6 +495,7 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
             loss_dev[lo:hi] = torch.where(update_loss == -1, torch.full_like(update_loss, 0.5), update_loss)
         ori[:] = ori_dev.cpu().numpy()
         loss[:] = loss_dev.cpu().numpy()
+        T_loop.__exit__()
         if is_root:
             os.makedirs(args.output_path + "/refine", exist_ok=True)
             np.save(args.output_path + "/refine/select_p.npy", points)
@@ -510,9 +515,11 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     step = filter_unvisible_points.shape[0] // sub_num + 1
     f_ori, f_pts = [], []
     print("compute points orientation near the surface... ")
+    T_shell = stage("refine: shell points", device).__enter__()
     if len(select_points) and len(filter_unvisible_points):
         fu = np.ascontiguousarray(filter_unvisible_points)
-        index_all = _knn(select_points, fu, 100, device, getattr(args, "knn", "device"))
+        with stage("refine: knn (shell)", device):
+            index_all = _knn(select_points, fu, 100, device, getattr(args, "knn", "device"))
         head_top_all = torch.from_numpy(pmvo.head_top_mask(fu.astype(np.float32))).to(device)
         fu_dev = torch.from_numpy(fu).type(torch.float).to(device)
         sel_ori_dev = torch.from_numpy(select_ori).to(device)
@@ -531,6 +538,7 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     else:
         filter_unvisible_ori = np.zeros((0, 3), np.float32)
         select_filter_unvisible_points = np.zeros((0, 3), np.float32)
+    T_shell.__exit__()
     if is_root:
         np.save(args.output_path + "/refine/filter_unvisible.npy", select_filter_unvisible_points)
         np.save(args.output_path + "/refine/filter_unvisible_ori.npy", filter_unvisible_ori)
@@ -540,8 +548,9 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
 
     # voxel fit (PMVO.py:695-726): every rank fits a disjoint slab of voxels; one reduce assembles the volume
     # The volume stays a list of occupied voxels; the dense float64 arrays of the reference exist only on request.
-    vox, vori = mdist.voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size, grid_resolution,
-                                        sparse=True)
+    with stage("refine: voxel fit + reduce", device):
+        vox, vori = mdist.voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size,
+                                            grid_resolution, sparse=True)
 
     if is_root:
         if infer_inner:
@@ -559,7 +568,8 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
             vori = np.concatenate([vori, unvisible_ori])
             np.save(os.path.join(args.save_path, "coarse.npy"), un_visible_points)
             np.save(os.path.join(args.save_path, "coarse_ori.npy"), unvisible_ori)
-        U.save_ori_occ_mat_sparse(args.save_path, grid_resolution, vox, vori)
+        with stage("refine: Ori3D/Occ3D.mat", device):
+            U.save_ori_occ_mat_sparse(args.save_path, grid_resolution, vox, vori)
     mdist.barrier()
     if not return_dense:
         return None
