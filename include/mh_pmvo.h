@@ -137,6 +137,21 @@ int mh_knn_grid(mh_ctx *ctx, const float *grid_origin_h, const int32_t *grid_dim
                 const int32_t *order, const int32_t *cell_start, const float *queries, int Q, int k,
                 int32_t *out_idx, int32_t *status, void *stream);
 
+/* The grid mh_knn_grid searches: points sorted by cell (x fastest) with their original indices and the first sorted
+ * position of every cell.  grid_origin_h (host): {ox, oy, oz, cell size}, grid_dims (host): {dx, dy, dz}.  Any of
+ * pts_sorted / cell_start [dx*dy*dz + 1] / n_occupied (device int32: number of non-empty cells) may be NULL; order[M]
+ * is always written.  (Replaces the torch sort / searchsorted / unique pipeline of the first implementation.) */
+size_t mh_grid_scratch_bytes(int M);
+int mh_grid_build(mh_ctx *ctx, const float *grid_origin_h, const int32_t *grid_dims, const float *points, int M,
+                  void *scratch, size_t scratch_bytes, float *pts_sorted, int32_t *order, int32_t *cell_start,
+                  int32_t *n_occupied, void *stream);
+
+/* Stable ascending sort of n 64-bit keys on their low end_bit bits -> keys_out[n], order[n] (original positions):
+ * the grouping of points by voxel of the volume fit, PMVO.py:705-715 (a dict of lists in point order). */
+size_t mh_sort_scratch_bytes(int n);
+int mh_sort_keys(mh_ctx *ctx, const unsigned long long *keys, int n, int end_bit, void *scratch, size_t scratch_bytes,
+                 unsigned long long *keys_out, int32_t *order, void *stream);
+
 /* ---- depth-map producer (the step before the path): Utils/Render_utils.py:310-347 render_bust_hair_depth with
  * the BustObj shader (:146-188) and Renderer.draw/ReadBuffer (:239-262) -- triangles drawn with a LESS depth test,
  * value (-z_camera / 2) * 255, background 255, top-left image origin.  verts[Nv,3] (world, bust offset applied),

@@ -40,6 +40,10 @@ _SIGS = {
     "mh_trace_scalp": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, cf, vp, vp, vp]),
     "mh_strands_accept": (ci, [ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, vp]),
     "mh_knn_grid": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp]),
+    "mh_grid_scratch_bytes": (csz, [ci]),
+    "mh_grid_build": (ci, [vp, vp, vp, vp, ci, vp, csz, vp, vp, vp, vp, vp]),
+    "mh_sort_scratch_bytes": (csz, [ci]),
+    "mh_sort_keys": (ci, [vp, vp, ci, ci, vp, csz, vp, vp, vp]),
     "mh_render_scratch_bytes": (csz, [ci, ci, ci, ci]),
     "mh_render_depth": (ci, [vp, vp, vp, ci, vp, ci, ci, ci, cf, vp, csz, vp, ci, vp]),
     "mh_gabor_bank": (ci, [vp, vp, ci, ci, vp, vp, vp, vp]),

@@ -40,6 +40,12 @@ int mh_launch_pack_view_u8(float4 *, float *, const float *, int, const uint8_t 
                            const float4 *, size_t, hipStream_t);
 int mh_launch_render_depth(const float *, const float *, int, const int32_t *, int, int, int, int, void *,
                            unsigned long long *, int32_t *, unsigned int *, float *, int, hipStream_t);
+size_t mh_grid_scratch_bytes_impl(int);
+size_t mh_sort_scratch_bytes_impl(int);
+int mh_launch_grid_build(const float *, int, float, float, float, float, int, int, int, void *, size_t, float *,
+                         int32_t *, int32_t *, int32_t *, hipStream_t);
+int mh_launch_sort_keys(const unsigned long long *, int, int, void *, size_t, unsigned long long *, int32_t *,
+                        hipStream_t);
 int mh_launch_project_gather(MhViews, const float *, int, int, float *, float *, float *, float *, float *, float *,
                              float *, hipStream_t);
 int mh_launch_topk(const float *, const float *, int, int, int32_t *, float *, hipStream_t);
@@ -391,6 +397,34 @@ extern "C" int mh_knn_grid(mh_ctx *ctx, const float *grid_origin_h /*host: ox,oy
                                   grid_dims[1], grid_dims[2], pts_sorted, order, cell_start, queries, Q, k, out_idx,
                                   status, (hipStream_t)stream),
                     "mh_knn_grid");
+}
+
+extern "C" size_t mh_grid_scratch_bytes(int M) { return M < 0 ? 0 : mh_grid_scratch_bytes_impl(M); }
+extern "C" size_t mh_sort_scratch_bytes(int n) { return n < 0 ? 0 : mh_sort_scratch_bytes_impl(n); }
+
+extern "C" int mh_grid_build(mh_ctx *ctx, const float *g, const int32_t *d, const float *points, int M, void *scratch,
+                             size_t scratch_bytes, float *pts_sorted, int32_t *order, int32_t *cell_start,
+                             int32_t *n_occupied, void *stream) {
+    if (M == 0) return MH_OK;
+    if (!ctx || !g || !d || !points || !scratch || !order || M < 0 || !(g[3] > 0.0f) || d[0] < 1 || d[1] < 1 ||
+        d[2] < 1 || (long long)d[0] * d[1] * d[2] > 0x7fffffffll)
+        return fail(MH_ERR_ARG, "mh_grid_build: bad arguments");
+    if (scratch_bytes < mh_grid_scratch_bytes_impl(M)) return fail(MH_ERR_ARG, "mh_grid_build: scratch too small");
+    MH_HIP(hipSetDevice(ctx->device));
+    return launched(mh_launch_grid_build(points, M, g[0], g[1], g[2], g[3], d[0], d[1], d[2], scratch, scratch_bytes,
+                                         pts_sorted, order, cell_start, n_occupied, (hipStream_t)stream),
+                    "mh_grid_build");
+}
+
+extern "C" int mh_sort_keys(mh_ctx *ctx, const unsigned long long *keys, int n, int end_bit, void *scratch,
+                            size_t scratch_bytes, unsigned long long *keys_out, int32_t *order, void *stream) {
+    if (n == 0) return MH_OK;
+    if (!ctx || !keys || !scratch || !keys_out || !order || n < 0 || end_bit < 1 || end_bit > 64)
+        return fail(MH_ERR_ARG, "mh_sort_keys: bad arguments");
+    if (scratch_bytes < mh_sort_scratch_bytes_impl(n)) return fail(MH_ERR_ARG, "mh_sort_keys: scratch too small");
+    MH_HIP(hipSetDevice(ctx->device));
+    return launched(mh_launch_sort_keys(keys, n, end_bit, scratch, scratch_bytes, keys_out, order, (hipStream_t)stream),
+                    "mh_sort_keys");
 }
 
 // ---- strand tracing on the fitted volume (HairGrow.py:59-299) ------------------------------------------------

@@ -235,17 +235,22 @@ class GridKNN:
 
     def __init__(self, points, k_hint=100, device="cuda:0"):
         self.device = torch.device(device)
-        pts = torch.from_numpy(np.ascontiguousarray(points).astype(np.float32)).to(self.device)
-        self._raw = pts
-        self.M = pts.shape[0]
-        lo, hi = pts.min(0).values, pts.max(0).values
-        self._lo, self._hi = lo, hi
-        ext = float((hi - lo).max().item()) + 1e-6
+        pts_np = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        self._raw = torch.from_numpy(pts_np).to(self.device)
+        self.M = pts_np.shape[0]
+        self._lo, self._hi = pts_np.min(0), pts_np.max(0)            # host: the points come from the host anyway
+        ext = float((self._hi - self._lo).max()) + 1e-6
+        self._ext = ext
+        self._grids = {}
+        self._scratch = torch.empty(int(_lib.lib().mh_grid_scratch_bytes(self.M)), dtype=torch.uint8,
+                                    device=self.device)
+        self._nocc = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._order_tmp = torch.empty(self.M, dtype=torch.int32, device=self.device)
 
-        def occupancy(h):
-            c = torch.floor((pts - lo) / h).long().clamp(min=0)
-            key = (c[:, 2] * 4096 + c[:, 1]) * 4096 + c[:, 0]
-            return self.M / float(torch.unique(key).numel())
+        def occupancy(h):       # mean number of points per non-empty cell at cell size h
+            grid, dims = self._geometry(h)
+            self._build(grid, dims, None, self._order_tmp, None, self._nocc)
+            return self.M / float(max(int(self._nocc.item()), 1))
 
         # local dimension and density from the mean occupancy at two scales -> radius of the k-ball -> cell size
         h0 = max(ext / 128.0, 1e-6)
@@ -253,28 +258,36 @@ class GridKNN:
         dim = min(3.0, max(1.0, math.log(max(c2 / c1, 1.01), 2)))
         ball = {1: 2.0, 2: math.pi, 3: 4.18879}[int(round(dim))]
         rk = h0 * (max(k_hint, 1) / (c1 * ball)) ** (1.0 / dim)
-        self._ext = ext
-        self._grids = {}
         self.h = max(rk / 1.5, ext / 480.0)
         self.last_retries = 0
 
+    def _geometry(self, h):
+        origin = self._lo.astype(np.float32)
+        dims = np.floor((self._hi.astype(np.float64) - origin) / h).astype(np.int64) + 1
+        return (np.array([origin[0], origin[1], origin[2], h], dtype=np.float32),
+                np.maximum(dims, 1).astype(np.int32))
+
+    def _build(self, grid, dims, pts_sorted, order, start, nocc):
+        import ctypes
+
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mh_grid_build(
+                _ctx_for(self.device), grid.ctypes.data_as(ctypes.c_void_p), dims.ctypes.data_as(ctypes.c_void_p),
+                _lib.ptr(self._raw), self.M, _lib.ptr(self._scratch), self._scratch.numel(), _lib.ptr(pts_sorted),
+                _lib.ptr(order), _lib.ptr(start), _lib.ptr(nocc), _lib.stream_ptr()), "mh_grid_build")
+
     def _grid(self, h):
-        """(origin+h [4] f32 host, dims [3] i32 host, points sorted by cell, original indices, cell_start)"""
+        """(origin+h [4] f32 host, dims [3] i32 host, points sorted by cell, original indices, cell_start) -- built by
+        mh_grid_build (csrc/sortgroup.hip): cell keys, stable radix sort, gather, first position of every cell."""
         h = float(np.float32(max(h, self._ext / 480.0)))
         if h not in self._grids:
-            pts, dev = self._raw, self.device
-            origin = self._lo.cpu().numpy().astype(np.float32)
-            dims = np.floor((self._hi.cpu().numpy().astype(np.float64) - origin) / h).astype(np.int64) + 1
-            dims = np.maximum(dims, 1).astype(np.int32)
-            c = torch.floor((pts - torch.from_numpy(origin).to(dev)) / torch.tensor(h, device=dev)).long()
-            for a in range(3):
-                c[:, a].clamp_(0, int(dims[a]) - 1)
-            cell = (c[:, 2] * int(dims[1]) + c[:, 1]) * int(dims[0]) + c[:, 0]
-            cs, order = torch.sort(cell, stable=True)
+            grid, dims = self._geometry(h)
             ncell = int(dims[0]) * int(dims[1]) * int(dims[2])
-            start = torch.searchsorted(cs, torch.arange(ncell + 1, device=dev)).to(torch.int32).contiguous()
-            self._grids[h] = (np.array([origin[0], origin[1], origin[2], h], dtype=np.float32), dims,
-                              pts[order].contiguous(), order.to(torch.int32).contiguous(), start)
+            pts = torch.empty((self.M, 3), dtype=torch.float32, device=self.device)
+            order = torch.empty(self.M, dtype=torch.int32, device=self.device)
+            start = torch.empty(ncell + 1, dtype=torch.int32, device=self.device)
+            self._build(grid, dims, pts, order, start, None)
+            self._grids[h] = (grid, dims, pts, order, start)
         return self._grids[h]
 
     def _run(self, h, q, k):
@@ -347,23 +360,37 @@ def voxel_fit(select_points, select_ori, device, voxel_min=VOXEL_MIN, voxel_size
     select_ori[up] *= -1
     x, y, z = p2v(select_points, np.asarray(voxel_min), voxel_size, g)
     dev = torch.device(device)
-    key = (torch.from_numpy(x.astype(np.int64)).to(dev) * int(g[1]) + torch.from_numpy(y.astype(np.int64)).to(dev)) \
-        * int(g[2]) + torch.from_numpy(z.astype(np.int64)).to(dev)
-    ks, order = torch.sort(key, stable=True)
-    first = torch.ones_like(ks, dtype=torch.bool)
-    first[1:] = ks[1:] != ks[:-1]
-    starts = torch.nonzero(first).flatten()
-    G = int(starts.numel())
-    seg = torch.cat([starts, torch.tensor([ks.numel()], device=dev)]).to(torch.int32).contiguous()
-    max_group = int((seg[1:] - seg[:-1]).max().item()) if G else 0
-    o = torch.from_numpy(np.ascontiguousarray(select_ori, dtype=np.float32)).to(dev)[order].contiguous()
+    key = (x.astype(np.int64) * int(g[1]) + y.astype(np.int64)) * int(g[2]) + z.astype(np.int64)
+    n = int(key.shape[0])
+    L = _lib.lib()
+    if n:
+        # stable sort of the voxel keys on the device (csrc/sortgroup.hip); the run boundaries are found on the host
+        kd = torch.from_numpy(np.ascontiguousarray(key)).to(dev)          # non-negative int64 == the same u64 bits
+        ks_d = torch.empty_like(kd)
+        order_d = torch.empty(n, dtype=torch.int32, device=dev)
+        scratch = torch.empty(int(L.mh_sort_scratch_bytes(n)), dtype=torch.uint8, device=dev)
+        end_bit = max(1, int(int(g[0]) * int(g[1]) * int(g[2]) - 1).bit_length())
+        with torch.cuda.device(dev):
+            _lib.check(L.mh_sort_keys(_ctx_for(dev), _lib.ptr(kd), n, end_bit, _lib.ptr(scratch), scratch.numel(),
+                                      _lib.ptr(ks_d), _lib.ptr(order_d), _lib.stream_ptr()), "mh_sort_keys")
+        ks = ks_d.cpu().numpy()
+        order = order_d.cpu().numpy()
+    else:
+        ks, order = key, np.zeros(0, np.int32)
+    starts = np.flatnonzero(np.concatenate([[True], ks[1:] != ks[:-1]])) if n else np.zeros(0, np.int64)
+    G = int(starts.size)
+    seg_h = np.concatenate([starts, [n]]).astype(np.int32)
+    max_group = int(np.diff(seg_h).max()) if G else 0
+    seg = torch.from_numpy(seg_h).to(dev)
+    o = torch.from_numpy(np.ascontiguousarray(np.asarray(select_ori, dtype=np.float32)[order])).to(dev)
     med = torch.empty((G, 3), dtype=torch.float32, device=dev)
     if G:
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().mh_medoid_segmented(_ctx_for(dev), _lib.ptr(o), _lib.ptr(seg), G, max_group,
-                                                      _lib.ptr(med), None, _lib.stream_ptr()), "mh_medoid_segmented")
-    kv = ks[starts]
-    vox = torch.stack([kv // (int(g[1]) * int(g[2])), (kv // int(g[2])) % int(g[1]), kv % int(g[2])], 1)
+            _lib.check(L.mh_medoid_segmented(_ctx_for(dev), _lib.ptr(o), _lib.ptr(seg), G, max_group,
+                                             _lib.ptr(med), None, _lib.stream_ptr()), "mh_medoid_segmented")
+    kv = ks[starts] if G else np.zeros(0, np.int64)
+    vox = torch.from_numpy(np.stack([kv // (int(g[1]) * int(g[2])), (kv // int(g[2])) % int(g[1]), kv % int(g[2])],
+                                    1).astype(np.int64).reshape(-1, 3))
     out = dict(voxels=vox, ori=med)
     if dense:
         occ = np.zeros(tuple(g))
