@@ -11,7 +11,6 @@ import os
 import struct
 
 import numpy as np
-import scipy.io
 import torch
 
 from . import _lib
@@ -406,6 +405,8 @@ def save_ori_occ_mat(path, occ, ori):
     """Layout + scipy.io.savemat of PMVO.py:753-764: Ori [Y,X,3*Z] (last index c*Z+z), Occ [Y,X,Z], float64."""
     g = occ.shape
     o = ori.transpose((0, 1, 3, 2)).reshape(g[0], g[1], g[2] * 3).transpose((1, 0, 2))
+    import scipy.io          # (lazy: 0.15 s of import time the command line does not need)
+
     scipy.io.savemat(os.path.join(path, "Ori3D.mat"), {"Ori": o})
     scipy.io.savemat(os.path.join(path, "Occ3D.mat"), {"Occ": occ.transpose((1, 0, 2))})
 
@@ -469,6 +470,8 @@ def dense_from_sparse(grid_resolution, voxels, ori):
 
 def get_ground_truth_3D_occ(d, flip=False):
     """PMVO_utils.py:86-95 -> [Z,Y,X,1] float32."""
+    import scipy.io
+
     occ = scipy.io.loadmat(d, verify_compressed_data_integrity=False)["Occ"].astype(np.float32)
     occ = np.expand_dims(np.transpose(occ, [2, 0, 1]), -1)
     if flip:
@@ -478,6 +481,8 @@ def get_ground_truth_3D_occ(d, flip=False):
 
 def get_ground_truth_3D_ori(d, flip=False, growInv=False):
     """PMVO_utils.py:98-113 -> [Z,Y,X,3] float32."""
+    import scipy.io
+
     ori = scipy.io.loadmat(d, verify_compressed_data_integrity=False)["Ori"].astype(np.float32)
     ori = np.reshape(ori, [ori.shape[0], ori.shape[1], 3, -1])
     ori = ori.transpose([0, 1, 3, 2]).transpose(2, 0, 1, 3)
