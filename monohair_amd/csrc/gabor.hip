@@ -114,6 +114,172 @@ __global__ __launch_bounds__(256) void mh_gabor_bank_kernel(const float *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split-bank variant (gabor_variant 2): the same v_pk_fma arithmetic with TWO pixels per lane and HALF of the
+// bank per wave.  Why: the coefficients reach the FMAs through SGPRs (scalar loads, out-of-order return, only
+// lgkmcnt(0) to wait on), ~96 SGPRs are all there is, and with one pixel per lane a loaded SGPR pair feeds one
+// v_pk_fma -- the ~200-cycle scalar latency is exposed twice per tap (PMC: VALU 57 % busy, profiles/
+// r01i_gabor_pmc.txt).  With two pixels per lane every SGPR pair feeds two FMAs, so the same SGPR budget covers
+// twice the cycles.  A pair of waves shares 16x8 pixels: wave A owns orientations 0..95, wave B 96..179.  The
+// exact epilogue survives the split because ATen's cascade sum adds 16-row block sums in order: A carries the
+// chain over blocks 0..5, B hands over its six block sums S6..S11 (each starts from 0, as in the chain), A
+// finishes ((chain + S6) + ... + S10) and adds the trailing partial block S11 last -- the same operations in
+// the same order as mh_gabor_bank_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int F0, int NF>
+__device__ __forceinline__ void mh_gabor_half(const float *__restrict__ bankT, const float *__restrict__ tile, int ty,
+                                              int tx, float (&ra)[NF], float (&rb)[NF]) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f aa[NF / 2], ab[NF / 2];
+#pragma unroll
+    for (int k = 0; k < NF / 2; ++k) aa[k] = ab[k] = v2f{0.0f, 0.0f};
+    for (int i = 0; i < MH_GB_KS; ++i) {
+        for (int j = 0; j < MH_GB_KS; ++j) {
+            const float xa = tile[(ty + i) * MH_GB_LDW + tx + j];
+            const float xb = tile[(ty + 4 + i) * MH_GB_LDW + tx + j];
+            const v2f xa2 = v2f{xa, xa}, xb2 = v2f{xb, xb};
+            const v2f *__restrict__ wt =
+                reinterpret_cast<const v2f *>(bankT + (i * MH_GB_KS + j) * MH_GB_KPAD + F0);
+#pragma unroll
+            for (int k = 0; k < NF / 2; ++k) {
+                aa[k] = __builtin_elementwise_fma(xa2, wt[k], aa[k]);
+                ab[k] = __builtin_elementwise_fma(xb2, wt[k], ab[k]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NF / 2; ++k) {
+        ra[2 * k] = __builtin_fabsf(aa[k].x);
+        ra[2 * k + 1] = __builtin_fabsf(aa[k].y);
+        rb[2 * k] = __builtin_fabsf(ab[k].x);
+        rb[2 * k + 1] = __builtin_fabsf(ab[k].y);
+    }
+}
+
+template <int F0, int NF>
+__device__ __forceinline__ void mh_gabor_argmax(const float (&r)[NF], float &M, int &b) {
+    M = r[0];
+    b = F0;
+#pragma unroll
+    for (int k = 1; k < NF; ++k)
+        if (r[k] > M) {
+            M = r[k];
+            b = F0 + k;
+        }
+}
+
+__device__ __forceinline__ float mh_gabor_term(float bh, int k, float r, float M) {
+    const float PI_F = 3.14159265358979323846f;
+    const float t1 = bh - mh_theta((float)k);
+    const float d = fminf(__builtin_fabsf(t1), fminf(__builtin_fabsf(t1 - PI_F), __builtin_fabsf(t1 + PI_F)));
+    const float rd = r - M;
+    return (d * rd) * rd;
+}
+
+#define MH_GS_SPLIT 96   // a multiple of the 16-row cascade block
+
+__global__ __launch_bounds__(256) void mh_gabor_split_kernel(const float *__restrict__ bankT,
+                                                             const float *__restrict__ img, int H, int W,
+                                                             int32_t *__restrict__ orient,
+                                                             float *__restrict__ var_out,
+                                                             unsigned int *__restrict__ maxbits) {
+    __shared__ float tile[MH_GB_LDW * MH_GB_LDW];
+    __shared__ float s_M[2][2][2][64];     // [pixel group][role][pixel a/b][lane]
+    __shared__ int s_b[2][2][2][64];
+    __shared__ float s_S[2][2][6][64];     // [pixel group][pixel a/b][block 6..11][lane]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int grp = wave >> 1, role = wave & 1;
+    const int ty = grp * 8 + (lane >> 4), tx = lane & 15;
+    const int y0 = blockIdx.y * MH_GB_TILE, x0 = blockIdx.x * MH_GB_TILE;
+    for (int q = tid; q < MH_GB_LDW * MH_GB_LDW; q += 256) {
+        const int ly = q / MH_GB_LDW, lx = q - ly * MH_GB_LDW;
+        const int gy = y0 + ly - 8, gx = x0 + lx - 8;
+        tile[q] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : 0.0f;
+    }
+    __syncthreads();
+    constexpr int NA = MH_GS_SPLIT, NB = MH_GB_NK - MH_GS_SPLIT;
+    float vmax = 0.0f;
+    if (role == 0) {
+        float ra[NA], rb[NA];
+        mh_gabor_half<0, NA>(bankT, tile, ty, tx, ra, rb);
+        float Ma, Mb;
+        int ba, bb;
+        mh_gabor_argmax<0, NA>(ra, Ma, ba);
+        mh_gabor_argmax<0, NA>(rb, Mb, bb);
+        s_M[grp][0][0][lane] = Ma, s_b[grp][0][0][lane] = ba;
+        s_M[grp][0][1][lane] = Mb, s_b[grp][0][1][lane] = bb;
+        __syncthreads();
+        // first maximum over all 180: the upper half only wins with a strictly larger response
+        const float Ua = s_M[grp][1][0][lane], Ub = s_M[grp][1][1][lane];
+        if (Ua > Ma) Ma = Ua, ba = s_b[grp][1][0][lane];
+        if (Ub > Mb) Mb = Ub, bb = s_b[grp][1][1][lane];
+        const float bha = mh_theta((float)ba), bhb = mh_theta((float)bb);
+        MhCasc ca = {0.f, 0.f}, cb = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            if (k > 0 && (k & 15) == 0) {
+                mh_casc_flush(ca);
+                mh_casc_flush(cb);
+            }
+            ca.a0 = ca.a0 + mh_gabor_term(bha, k, ra[k], Ma);
+            cb.a0 = cb.a0 + mh_gabor_term(bhb, k, rb[k], Mb);
+        }
+        mh_casc_flush(ca);   // k == 96 is a block boundary
+        mh_casc_flush(cb);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {   // S6..S10: flushed blocks, in order
+            ca.a1 = ca.a1 + s_S[grp][0][q][lane];
+            cb.a1 = cb.a1 + s_S[grp][1][q][lane];
+        }
+        const float va = __builtin_sqrtf(s_S[grp][0][5][lane] + ca.a1);   // a0 (= S11) + a1
+        const float vb = __builtin_sqrtf(s_S[grp][1][5][lane] + cb.a1);
+        const int x = x0 + tx, ya = y0 + ty, yb = y0 + ty + 4;
+        if (x < W && ya < H) {
+            var_out[(size_t)ya * W + x] = va;
+            orient[(size_t)ya * W + x] = (va > 0.0f) ? ba : 0;
+            vmax = va;
+        }
+        if (x < W && yb < H) {
+            var_out[(size_t)yb * W + x] = vb;
+            orient[(size_t)yb * W + x] = (vb > 0.0f) ? bb : 0;
+            vmax = fmaxf(vmax, vb);
+        }
+    } else {
+        float ra[NB], rb[NB];
+        mh_gabor_half<NA, NB>(bankT, tile, ty, tx, ra, rb);
+        float Ma, Mb;
+        int ba, bb;
+        mh_gabor_argmax<NA, NB>(ra, Ma, ba);
+        mh_gabor_argmax<NA, NB>(rb, Mb, bb);
+        s_M[grp][1][0][lane] = Ma, s_b[grp][1][0][lane] = ba;
+        s_M[grp][1][1][lane] = Mb, s_b[grp][1][1][lane] = bb;
+        __syncthreads();
+        const float La = s_M[grp][0][0][lane], Lb = s_M[grp][0][1][lane];
+        if (!(Ma > La)) Ma = La, ba = s_b[grp][0][0][lane];
+        if (!(Mb > Lb)) Mb = Lb, bb = s_b[grp][0][1][lane];
+        const float bha = mh_theta((float)ba), bhb = mh_theta((float)bb);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            float sa = 0.0f, sb = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int k = NA + q * 16 + u;
+                if (k < MH_GB_NK) {
+                    sa = sa + mh_gabor_term(bha, k, ra[k - NA], Ma);
+                    sb = sb + mh_gabor_term(bhb, k, rb[k - NA], Mb);
+                }
+            }
+            s_S[grp][0][q][lane] = sa;
+            s_S[grp][1][q][lane] = sb;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if (lane == 0 && role == 0) atomicMax(maxbits, __float_as_uint(vmax));
+}
+
+// ---------------------------------------------------------------------------------------------
 // FP32-MFMA variant: the bank as an im2col contraction  C[pixel, k] = sum_t A[pixel, t] * B[t, k]
 // (pixels x 289 taps x 180 orientations) on v_mfma_f32_32x32x2_f32.  The MFMA result is bit for bit a
 // k-ordered fp32 fma chain, i.e. exactly the tap-ordered chain of the VALU kernel above, so both variants (and
@@ -260,7 +426,10 @@ extern "C" int mh_launch_gabor_build(float *bankT, hipStream_t st) {
 extern "C" int mh_launch_gabor_bank(const float *bankT, const float *img, int H, int W, int32_t *orient, float *conf,
                                     float *var, unsigned int *maxbits, int variant, hipStream_t st) {
     (void)hipMemsetAsync(maxbits, 0, sizeof(unsigned int), st);
-    if (variant == 1) {
+    if (variant == 2) {
+        const dim3 grid((W + MH_GB_TILE - 1) / MH_GB_TILE, (H + MH_GB_TILE - 1) / MH_GB_TILE);
+        hipLaunchKernelGGL(mh_gabor_split_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);
+    } else if (variant == 1) {
         const dim3 grid((W + MH_GM_COLS - 1) / MH_GM_COLS, (H + MH_GM_ROWS - 1) / MH_GM_ROWS);
         const size_t lds = (size_t)(MH_GM_LDH * MH_GM_LDW + 4 * MH_GB_NK * MH_GM_RS) * sizeof(float);
         hipLaunchKernelGGL(mh_gabor_mfma_kernel, grid, dim3(256), lds, st, bankT, img, H, W, orient, var, maxbits);
