@@ -279,127 +279,6 @@ __global__ __launch_bounds__(256) void mh_gabor_split_kernel(const float *__rest
     if (lane == 0 && role == 0) atomicMax(maxbits, __float_as_uint(vmax));
 }
 
-// Four-way split (gabor_variant 3): one workgroup = 16x8 pixels, wave r owns orientations [48 r, 48 r + 48) (the last
-// one 36), two pixels per lane: ~100 accumulator registers per lane -> 4 waves per SIMD to hide the scalar-load
-// latency, and every coefficient SGPR pair still feeds two FMAs.  Same exact hand-over as above, generalised: every
-// wave writes the sums of its own 16-row cascade blocks, wave 0 adds the twelve of them in order.
-#define MH_G4_ROWS 8
-#define MH_G4_LDH (MH_G4_ROWS + MH_GB_KS - 1)   // 24
-
-template <int F0, int NF>
-__device__ __forceinline__ void mh_gabor_quarter(const float *__restrict__ bankT, const float *__restrict__ tile,
-                                                 int lane, float (*__restrict__ s_M)[2][64], int (*__restrict__ s_b)[2][64],
-                                                 float (*__restrict__ s_S)[2][64], int role, float &Ma, float &Mb,
-                                                 int &ba, int &bb) {
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    const int ty = lane >> 4, tx = lane & 15;
-    v2f aa[NF / 2], ab[NF / 2];
-#pragma unroll
-    for (int k = 0; k < NF / 2; ++k) aa[k] = ab[k] = v2f{0.0f, 0.0f};
-    for (int i = 0; i < MH_GB_KS; ++i) {
-        for (int j = 0; j < MH_GB_KS; ++j) {
-            const float xa = tile[(ty + i) * MH_GB_LDW + tx + j];
-            const float xb = tile[(ty + 4 + i) * MH_GB_LDW + tx + j];
-            const v2f xa2 = v2f{xa, xa}, xb2 = v2f{xb, xb};
-            const v2f *__restrict__ wt =
-                reinterpret_cast<const v2f *>(bankT + (i * MH_GB_KS + j) * MH_GB_KPAD + F0);
-#pragma unroll
-            for (int k = 0; k < NF / 2; ++k) {
-                aa[k] = __builtin_elementwise_fma(xa2, wt[k], aa[k]);
-                ab[k] = __builtin_elementwise_fma(xb2, wt[k], ab[k]);
-            }
-        }
-    }
-    float ra[NF], rb[NF];
-#pragma unroll
-    for (int k = 0; k < NF / 2; ++k) {
-        ra[2 * k] = __builtin_fabsf(aa[k].x);
-        ra[2 * k + 1] = __builtin_fabsf(aa[k].y);
-        rb[2 * k] = __builtin_fabsf(ab[k].x);
-        rb[2 * k + 1] = __builtin_fabsf(ab[k].y);
-    }
-    mh_gabor_argmax<F0, NF>(ra, Ma, ba);
-    mh_gabor_argmax<F0, NF>(rb, Mb, bb);
-    s_M[role][0][lane] = Ma, s_b[role][0][lane] = ba;
-    s_M[role][1][lane] = Mb, s_b[role][1][lane] = bb;
-    __syncthreads();
-    // first maximum over all 180: walk the quarters in index order, a later one only wins strictly
-    Ma = s_M[0][0][lane], ba = s_b[0][0][lane];
-    Mb = s_M[0][1][lane], bb = s_b[0][1][lane];
-#pragma unroll
-    for (int r = 1; r < 4; ++r) {
-        const float ua = s_M[r][0][lane], ub = s_M[r][1][lane];
-        if (ua > Ma) Ma = ua, ba = s_b[r][0][lane];
-        if (ub > Mb) Mb = ub, bb = s_b[r][1][lane];
-    }
-    const float bha = mh_theta((float)ba), bhb = mh_theta((float)bb);
-#pragma unroll
-    for (int q = 0; q < (NF + 15) / 16; ++q) {
-        float sa = 0.0f, sb = 0.0f;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int kk = q * 16 + u;
-            if (kk < NF) {
-                sa = sa + mh_gabor_term(bha, F0 + kk, ra[kk], Ma);
-                sb = sb + mh_gabor_term(bhb, F0 + kk, rb[kk], Mb);
-            }
-        }
-        s_S[F0 / 16 + q][0][lane] = sa;
-        s_S[F0 / 16 + q][1][lane] = sb;
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256, 3) void mh_gabor_split4_kernel(const float *__restrict__ bankT,
-                                                                 const float *__restrict__ img, int H, int W,
-                                                                 int32_t *__restrict__ orient,
-                                                                 float *__restrict__ var_out,
-                                                                 unsigned int *__restrict__ maxbits) {
-    __shared__ float tile[MH_G4_LDH * MH_GB_LDW];
-    __shared__ float s_M[4][2][64];
-    __shared__ int s_b[4][2][64];
-    __shared__ float s_S[12][2][64];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int y0 = blockIdx.y * MH_G4_ROWS, x0 = blockIdx.x * MH_GB_TILE;
-    for (int q = tid; q < MH_G4_LDH * MH_GB_LDW; q += 256) {
-        const int ly = q / MH_GB_LDW, lx = q - ly * MH_GB_LDW;
-        const int gy = y0 + ly - 8, gx = x0 + lx - 8;
-        tile[q] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : 0.0f;
-    }
-    __syncthreads();
-    float Ma, Mb;
-    int ba, bb;
-    if (wave == 0) mh_gabor_quarter<0, 48>(bankT, tile, lane, s_M, s_b, s_S, 0, Ma, Mb, ba, bb);
-    else if (wave == 1) mh_gabor_quarter<48, 48>(bankT, tile, lane, s_M, s_b, s_S, 1, Ma, Mb, ba, bb);
-    else if (wave == 2) mh_gabor_quarter<96, 48>(bankT, tile, lane, s_M, s_b, s_S, 2, Ma, Mb, ba, bb);
-    else mh_gabor_quarter<144, 36>(bankT, tile, lane, s_M, s_b, s_S, 3, Ma, Mb, ba, bb);
-    if (wave != 0) return;
-    float a1a = 0.0f, a1b = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 11; ++q) {   // the flushed blocks S0..S10, in order
-        a1a = a1a + s_S[q][0][lane];
-        a1b = a1b + s_S[q][1][lane];
-    }
-    const float va = __builtin_sqrtf(s_S[11][0][lane] + a1a);   // a0 (= S11, the trailing 4 rows) + a1
-    const float vb = __builtin_sqrtf(s_S[11][1][lane] + a1b);
-    const int ty = lane >> 4, tx = lane & 15;
-    const int x = x0 + tx, ya = y0 + ty, yb = y0 + ty + 4;
-    float vmax = 0.0f;
-    if (x < W && ya < H) {
-        var_out[(size_t)ya * W + x] = va;
-        orient[(size_t)ya * W + x] = (va > 0.0f) ? ba : 0;
-        vmax = va;
-    }
-    if (x < W && yb < H) {
-        var_out[(size_t)yb * W + x] = vb;
-        orient[(size_t)yb * W + x] = (vb > 0.0f) ? bb : 0;
-        vmax = fmaxf(vmax, vb);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if (lane == 0) atomicMax(maxbits, __float_as_uint(vmax));
-}
-
 // ---------------------------------------------------------------------------------------------
 // FP32-MFMA variant: the bank as an im2col contraction  C[pixel, k] = sum_t A[pixel, t] * B[t, k]
 // (pixels x 289 taps x 180 orientations) on v_mfma_f32_32x32x2_f32.  The MFMA result is bit for bit a
@@ -547,10 +426,7 @@ extern "C" int mh_launch_gabor_build(float *bankT, hipStream_t st) {
 extern "C" int mh_launch_gabor_bank(const float *bankT, const float *img, int H, int W, int32_t *orient, float *conf,
                                     float *var, unsigned int *maxbits, int variant, hipStream_t st) {
     (void)hipMemsetAsync(maxbits, 0, sizeof(unsigned int), st);
-    if (variant == 3) {
-        const dim3 grid((W + MH_GB_TILE - 1) / MH_GB_TILE, (H + MH_G4_ROWS - 1) / MH_G4_ROWS);
-        hipLaunchKernelGGL(mh_gabor_split4_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);
-    } else if (variant == 2) {
+    if (variant == 2) {
         const dim3 grid((W + MH_GB_TILE - 1) / MH_GB_TILE, (H + MH_GB_TILE - 1) / MH_GB_TILE);
         hipLaunchKernelGGL(mh_gabor_split_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);
     } else if (variant == 1) {
