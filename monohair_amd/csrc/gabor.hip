@@ -299,23 +299,38 @@ __device__ __forceinline__ void mh_gabor_quarter(const float *__restrict__ bankT
     for (int p = 0; p < MH_GQ_NP; ++p)
 #pragma unroll
         for (int k = 0; k < NF / 2; ++k) acc[p][k] = v2f{0.0f, 0.0f};
-    for (int i = 0; i < MH_GB_KS; ++i) {
-        for (int j = 0; j < MH_GB_KS; ++j) {
-            v2f x2[MH_GQ_NP];
+    // Software pipeline over the 289 taps: the coefficients of tap t+1 are requested right after the first FMA of
+    // tap t (whose operand wait -- s_waitcnt lgkmcnt(0), the only way to wait for scalar loads -- has just drained
+    // everything outstanding), so a scalar-cache miss (~700 cycles) overlaps the ~380 cycles of FMAs of tap t
+    // instead of stalling in front of them.  48 + 48 coefficient SGPRs fit; the sched_barriers keep the
+    // instruction scheduler from hoisting the loads back above the wait.
+    const v2f *__restrict__ wbase = reinterpret_cast<const v2f *>(bankT + F0);
+    v2f cur[NF / 2], nxt[NF / 2];
 #pragma unroll
-            for (int p = 0; p < MH_GQ_NP; ++p) {
-                const float x = tile[(ty + 4 * p + i) * MH_GB_LDW + tx + j];
-                x2[p] = v2f{x, x};
-            }
-            const v2f *__restrict__ wt =
-                reinterpret_cast<const v2f *>(bankT + (i * MH_GB_KS + j) * MH_GB_KPAD + F0);
+    for (int k = 0; k < NF / 2; ++k) cur[k] = wbase[k];
+    int ti = 0, tj = 0;
+    for (int t = 0; t < MH_GB_NT; ++t) {
+        v2f x2[MH_GQ_NP];
 #pragma unroll
-            for (int k = 0; k < NF / 2; ++k) {
-                const v2f w = wt[k];
-#pragma unroll
-                for (int p = 0; p < MH_GQ_NP; ++p) acc[p][k] = __builtin_elementwise_fma(x2[p], w, acc[p][k]);
-            }
+        for (int p = 0; p < MH_GQ_NP; ++p) {
+            const float x = tile[(ty + 4 * p + ti) * MH_GB_LDW + tx + tj];
+            x2[p] = v2f{x, x};
         }
+        acc[0][0] = __builtin_elementwise_fma(x2[0], cur[0], acc[0][0]);
+        __builtin_amdgcn_sched_barrier(0);
+        const v2f *__restrict__ wn = wbase + (size_t)(t + 1 < MH_GB_NT ? t + 1 : t) * (MH_GB_KPAD / 2);
+#pragma unroll
+        for (int k = 0; k < NF / 2; ++k) nxt[k] = wn[k];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NF / 2; ++k) {
+#pragma unroll
+            for (int p = 0; p < MH_GQ_NP; ++p)
+                if (k || p) acc[p][k] = __builtin_elementwise_fma(x2[p], cur[k], acc[p][k]);
+        }
+#pragma unroll
+        for (int k = 0; k < NF / 2; ++k) cur[k] = nxt[k];
+        if (++tj == MH_GB_KS) tj = 0, ++ti;
     }
     // |responses| in place; first maximum of this quarter
 #pragma unroll
