@@ -306,21 +306,25 @@ __device__ __forceinline__ void mh_gabor_quarter(const float *__restrict__ bankT
     // instruction scheduler from hoisting the loads back above the wait.
     const v2f *__restrict__ wbase = reinterpret_cast<const v2f *>(bankT + F0);
     v2f cur[NF / 2], nxt[NF / 2];
+    float xc[MH_GQ_NP], xn[MH_GQ_NP];
 #pragma unroll
     for (int k = 0; k < NF / 2; ++k) cur[k] = wbase[k];
+#pragma unroll
+    for (int p = 0; p < MH_GQ_NP; ++p) xc[p] = tile[(ty + 4 * p) * MH_GB_LDW + tx];
     int ti = 0, tj = 0;
     for (int t = 0; t < MH_GB_NT; ++t) {
         v2f x2[MH_GQ_NP];
 #pragma unroll
-        for (int p = 0; p < MH_GQ_NP; ++p) {
-            const float x = tile[(ty + 4 * p + ti) * MH_GB_LDW + tx + tj];
-            x2[p] = v2f{x, x};
-        }
+        for (int p = 0; p < MH_GQ_NP; ++p) x2[p] = v2f{xc[p], xc[p]};
         acc[0][0] = __builtin_elementwise_fma(x2[0], cur[0], acc[0][0]);
         __builtin_amdgcn_sched_barrier(0);
-        const v2f *__restrict__ wn = wbase + (size_t)(t + 1 < MH_GB_NT ? t + 1 : t) * (MH_GB_KPAD / 2);
+        if (++tj == MH_GB_KS) tj = 0, ++ti;
+        const bool more = t + 1 < MH_GB_NT;
+        const v2f *__restrict__ wn = wbase + (size_t)(more ? t + 1 : t) * (MH_GB_KPAD / 2);
 #pragma unroll
         for (int k = 0; k < NF / 2; ++k) nxt[k] = wn[k];
+#pragma unroll
+        for (int p = 0; p < MH_GQ_NP; ++p) xn[p] = tile[(ty + 4 * p + (more ? ti : 0)) * MH_GB_LDW + tx + (more ? tj : 0)];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < NF / 2; ++k) {
@@ -330,7 +334,8 @@ __device__ __forceinline__ void mh_gabor_quarter(const float *__restrict__ bankT
         }
 #pragma unroll
         for (int k = 0; k < NF / 2; ++k) cur[k] = nxt[k];
-        if (++tj == MH_GB_KS) tj = 0, ++ti;
+#pragma unroll
+        for (int p = 0; p < MH_GQ_NP; ++p) xc[p] = xn[p];
     }
     // |responses| in place; first maximum of this quarter
 #pragma unroll
