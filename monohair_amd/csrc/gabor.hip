@@ -279,154 +279,6 @@ __global__ __launch_bounds__(256) void mh_gabor_split_kernel(const float *__rest
     if (lane == 0 && role == 0) atomicMax(maxbits, __float_as_uint(vmax));
 }
 
-// Quarter-bank variant (gabor_variant 3): FOUR pixels per lane, a quarter of the bank per wave -- one workgroup =
-// 16x16 pixels, wave r owns orientations [48 r, 48 r + 48) (the last one 36).  Every coefficient SGPR pair now feeds
-// four FMAs, i.e. a quarter of the scalar traffic of the one-pixel kernel for the same arithmetic.  The hand-over is
-// the one of the split kernel, generalised: every wave writes the sums of its own 16-row cascade blocks, wave 0
-// adds the twelve of them in order.
-#define MH_GQ_NP 4
-
-template <int F0, int NF>
-__device__ __forceinline__ void mh_gabor_quarter(const float *__restrict__ bankT, const float *__restrict__ tile,
-                                                 int lane, float (*__restrict__ s_M)[MH_GQ_NP][64],
-                                                 int (*__restrict__ s_b)[MH_GQ_NP][64],
-                                                 float (*__restrict__ s_S)[MH_GQ_NP][64], int role,
-                                                 float (&M)[MH_GQ_NP], int (&b)[MH_GQ_NP]) {
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    const int ty = lane >> 4, tx = lane & 15;
-    v2f acc[MH_GQ_NP][NF / 2];
-#pragma unroll
-    for (int p = 0; p < MH_GQ_NP; ++p)
-#pragma unroll
-        for (int k = 0; k < NF / 2; ++k) acc[p][k] = v2f{0.0f, 0.0f};
-    // Software pipeline over the 289 taps: the coefficients of tap t+1 are requested right after the first FMA of
-    // tap t (whose operand wait -- s_waitcnt lgkmcnt(0), the only way to wait for scalar loads -- has just drained
-    // everything outstanding), so a scalar-cache miss (~700 cycles) overlaps the ~380 cycles of FMAs of tap t
-    // instead of stalling in front of them.  48 + 48 coefficient SGPRs fit; the sched_barriers keep the
-    // instruction scheduler from hoisting the loads back above the wait.
-    const v2f *__restrict__ wbase = reinterpret_cast<const v2f *>(bankT + F0);
-    v2f cur[NF / 2], nxt[NF / 2];
-    float xc[MH_GQ_NP], xn[MH_GQ_NP];
-#pragma unroll
-    for (int k = 0; k < NF / 2; ++k) cur[k] = wbase[k];
-#pragma unroll
-    for (int p = 0; p < MH_GQ_NP; ++p) xc[p] = tile[(ty + 4 * p) * MH_GB_LDW + tx];
-    int ti = 0, tj = 0;
-    for (int t = 0; t < MH_GB_NT; ++t) {
-        v2f x2[MH_GQ_NP];
-#pragma unroll
-        for (int p = 0; p < MH_GQ_NP; ++p) x2[p] = v2f{xc[p], xc[p]};
-        acc[0][0] = __builtin_elementwise_fma(x2[0], cur[0], acc[0][0]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (++tj == MH_GB_KS) tj = 0, ++ti;
-        const bool more = t + 1 < MH_GB_NT;
-        const v2f *__restrict__ wn = wbase + (size_t)(more ? t + 1 : t) * (MH_GB_KPAD / 2);
-#pragma unroll
-        for (int k = 0; k < NF / 2; ++k) nxt[k] = wn[k];
-#pragma unroll
-        for (int p = 0; p < MH_GQ_NP; ++p) xn[p] = tile[(ty + 4 * p + (more ? ti : 0)) * MH_GB_LDW + tx + (more ? tj : 0)];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < NF / 2; ++k) {
-#pragma unroll
-            for (int p = 0; p < MH_GQ_NP; ++p)
-                if (k || p) acc[p][k] = __builtin_elementwise_fma(x2[p], cur[k], acc[p][k]);
-        }
-#pragma unroll
-        for (int k = 0; k < NF / 2; ++k) cur[k] = nxt[k];
-#pragma unroll
-        for (int p = 0; p < MH_GQ_NP; ++p) xc[p] = xn[p];
-    }
-    // |responses| in place; first maximum of this quarter
-#pragma unroll
-    for (int p = 0; p < MH_GQ_NP; ++p) {
-#pragma unroll
-        for (int k = 0; k < NF / 2; ++k) acc[p][k] = v2f{__builtin_fabsf(acc[p][k].x), __builtin_fabsf(acc[p][k].y)};
-        float m = acc[p][0].x;
-        int bi = F0;
-#pragma unroll
-        for (int k = 1; k < NF; ++k) {
-            const float r = (k & 1) ? acc[p][k >> 1].y : acc[p][k >> 1].x;
-            if (r > m) {
-                m = r;
-                bi = F0 + k;
-            }
-        }
-        s_M[role][p][lane] = m;
-        s_b[role][p][lane] = bi;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < MH_GQ_NP; ++p) {
-        // first maximum over all 180: walk the quarters in index order, a later one only wins strictly
-        float m = s_M[0][p][lane];
-        int bi = s_b[0][p][lane];
-#pragma unroll
-        for (int r = 1; r < 4; ++r) {
-            const float u = s_M[r][p][lane];
-            if (u > m) m = u, bi = s_b[r][p][lane];
-        }
-        M[p] = m;
-        b[p] = bi;
-        const float bh = mh_theta((float)bi);
-#pragma unroll
-        for (int q = 0; q < (NF + 15) / 16; ++q) {
-            float sum = 0.0f;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int kk = q * 16 + u;
-                if (kk < NF) {
-                    const float r = (kk & 1) ? acc[p][kk >> 1].y : acc[p][kk >> 1].x;
-                    sum = sum + mh_gabor_term(bh, F0 + kk, r, m);
-                }
-            }
-            s_S[F0 / 16 + q][p][lane] = sum;
-        }
-    }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(256) void mh_gabor_quarter_kernel(const float *__restrict__ bankT,
-                                                               const float *__restrict__ img, int H, int W,
-                                                               int32_t *__restrict__ orient,
-                                                               float *__restrict__ var_out,
-                                                               unsigned int *__restrict__ maxbits) {
-    __shared__ float tile[MH_GB_LDW * MH_GB_LDW];
-    __shared__ float s_M[4][MH_GQ_NP][64];
-    __shared__ int s_b[4][MH_GQ_NP][64];
-    __shared__ float s_S[12][MH_GQ_NP][64];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int y0 = blockIdx.y * MH_GB_TILE, x0 = blockIdx.x * MH_GB_TILE;
-    for (int q = tid; q < MH_GB_LDW * MH_GB_LDW; q += 256) {
-        const int ly = q / MH_GB_LDW, lx = q - ly * MH_GB_LDW;
-        const int gy = y0 + ly - 8, gx = x0 + lx - 8;
-        tile[q] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : 0.0f;
-    }
-    __syncthreads();
-    float M[MH_GQ_NP];
-    int b[MH_GQ_NP];
-    if (wave == 0) mh_gabor_quarter<0, 48>(bankT, tile, lane, s_M, s_b, s_S, 0, M, b);
-    else if (wave == 1) mh_gabor_quarter<48, 48>(bankT, tile, lane, s_M, s_b, s_S, 1, M, b);
-    else if (wave == 2) mh_gabor_quarter<96, 48>(bankT, tile, lane, s_M, s_b, s_S, 2, M, b);
-    else mh_gabor_quarter<144, 36>(bankT, tile, lane, s_M, s_b, s_S, 3, M, b);
-    // the chain over the twelve block sums: wave p finishes pixel row-group p (all waves know M and b)
-    const int p = wave;
-    float a1 = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 11; ++q) a1 = a1 + s_S[q][p][lane];    // the flushed blocks S0..S10, in order
-    const float v = __builtin_sqrtf(s_S[11][p][lane] + a1);     // a0 (= S11, the trailing 4 rows) + a1
-    const int x = x0 + (lane & 15), y = y0 + (lane >> 4) + 4 * p;
-    float vmax = 0.0f;
-    if (x < W && y < H) {
-        var_out[(size_t)y * W + x] = v;
-        orient[(size_t)y * W + x] = (v > 0.0f) ? b[p] : 0;
-        vmax = v;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if (lane == 0) atomicMax(maxbits, __float_as_uint(vmax));
-}
-
 // ---------------------------------------------------------------------------------------------
 // FP32-MFMA variant: the bank as an im2col contraction  C[pixel, k] = sum_t A[pixel, t] * B[t, k]
 // (pixels x 289 taps x 180 orientations) on v_mfma_f32_32x32x2_f32.  The MFMA result is bit for bit a
@@ -574,10 +426,7 @@ extern "C" int mh_launch_gabor_build(float *bankT, hipStream_t st) {
 extern "C" int mh_launch_gabor_bank(const float *bankT, const float *img, int H, int W, int32_t *orient, float *conf,
                                     float *var, unsigned int *maxbits, int variant, hipStream_t st) {
     (void)hipMemsetAsync(maxbits, 0, sizeof(unsigned int), st);
-    if (variant == 3) {
-        const dim3 grid((W + MH_GB_TILE - 1) / MH_GB_TILE, (H + MH_GB_TILE - 1) / MH_GB_TILE);
-        hipLaunchKernelGGL(mh_gabor_quarter_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);
-    } else if (variant == 2) {
+    if (variant == 2) {
         const dim3 grid((W + MH_GB_TILE - 1) / MH_GB_TILE, (H + MH_GB_TILE - 1) / MH_GB_TILE);
         hipLaunchKernelGGL(mh_gabor_split_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);
     } else if (variant == 1) {

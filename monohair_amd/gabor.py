@@ -75,7 +75,7 @@ class calOrientationGabor:
     def set_variant(self, variant):
         """'valu': direct form on v_pk_fma_f32; 'mfma': im2col contraction on v_mfma_f32_32x32x2_f32.  Same bits."""
         self.variant = variant
-        _lib.check(_lib.lib().mh_ctx_set_option(self._ctx, b"gabor_variant", {"valu": 0, "mfma": 1, "split": 2, "quarter": 3}[variant]),
+        _lib.check(_lib.lib().mh_ctx_set_option(self._ctx, b"gabor_variant", {"valu": 0, "mfma": 1, "split": 2}[variant]),
                    "mh_ctx_set_option")
 
     def cuda(self):
