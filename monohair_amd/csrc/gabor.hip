@@ -299,14 +299,14 @@ __global__ __launch_bounds__(256) void mh_gabor_split_kernel(const float *__rest
 
 typedef float mh_f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256, 1) void mh_gabor_mfma_kernel(const float *__restrict__ bankT,
+__global__ __launch_bounds__(256, 2) void mh_gabor_mfma_kernel(const float *__restrict__ bankT,
                                                                const float *__restrict__ img, int H, int W,
                                                                int32_t *__restrict__ orient,
                                                                float *__restrict__ var_out,
                                                                unsigned int *__restrict__ maxbits) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *tile = smem;                                        // [25][48]
-    float *resp = smem + MH_GM_LDH * MH_GM_LDW;                // [4 waves][180][33]
+    __shared__ float tile[MH_GM_LDH * MH_GM_LDW];              // [25][48]
+    __shared__ float stage[4][2 * 32 * MH_GM_RS];              // per wave: [M-tile][orientation of the N-tile][33]
+    __shared__ float s_theta[MH_GB_KPAD];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int y0 = blockIdx.y * MH_GM_ROWS, x0 = blockIdx.x * MH_GM_COLS;
     for (int q = tid; q < MH_GM_LDH * MH_GM_LDW; q += 256) {
@@ -314,6 +314,7 @@ __global__ __launch_bounds__(256, 1) void mh_gabor_mfma_kernel(const float *__re
         const int gy = y0 + ly - 8, gx = x0 + lx - 8;
         tile[q] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : 0.0f;
     }
+    if (tid < MH_GB_KPAD) s_theta[tid] = mh_theta((float)tid);
     __syncthreads();
 
     mh_f32x16 acc[2][6];
@@ -330,13 +331,22 @@ __global__ __launch_bounds__(256, 1) void mh_gabor_mfma_kernel(const float *__re
     float bcur[6], bnxt[6];
 #pragma unroll
     for (int n = 0; n < 6; ++n) bcur[n] = brow[n * 32];
+    float a0 = tile[(2 * wave + ti) * MH_GM_LDW + pix + tj];
+    float a1 = tile[(2 * wave + 1 + ti) * MH_GM_LDW + pix + tj];
     constexpr int NSTEP = (MH_GB_NT + 1) / 2;                  // 145; tap 289 is a zero row of the bank
     for (int s = 0; s < NSTEP; ++s) {
+        // operands of the next K-step (bank fragments from global memory, pixel fragments from LDS) are requested
+        // before this step's 12 MFMAs are issued
         const float *__restrict__ bn = brow + (size_t)(2 * (s + 1 < NSTEP ? s + 1 : s)) * MH_GB_KPAD;
 #pragma unroll
         for (int n = 0; n < 6; ++n) bnxt[n] = bn[n * 32];
-        const float a0 = tile[(2 * wave + ti) * MH_GM_LDW + pix + tj];
-        const float a1 = tile[(2 * wave + 1 + ti) * MH_GM_LDW + pix + tj];
+        tj += 2;
+        if (tj >= MH_GB_KS) {
+            tj -= MH_GB_KS;
+            ++ti;
+        }
+        const float a0n = tile[(2 * wave + ti) * MH_GM_LDW + pix + tj];     // (the spare tile row keeps this in bounds)
+        const float a1n = tile[(2 * wave + 1 + ti) * MH_GM_LDW + pix + tj];
 #pragma unroll
         for (int n = 0; n < 6; ++n) {
             acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bcur[n], acc[0][n], 0, 0, 0);
@@ -344,61 +354,67 @@ __global__ __launch_bounds__(256, 1) void mh_gabor_mfma_kernel(const float *__re
         }
 #pragma unroll
         for (int n = 0; n < 6; ++n) bcur[n] = bnxt[n];
-        tj += 2;
-        if (tj >= MH_GB_KS) {
-            tj -= MH_GB_KS;
-            ++ti;
-        }
+        a0 = a0n;
+        a1 = a1n;
     }
 
-    float *__restrict__ rw = resp + wave * (MH_GB_NK * MH_GM_RS);
+    // Epilogue.  C layout of the 32x32 MFMA: column (orientation) = lane & 31, row (pixel) = (r&3) + 8*(r>>2) +
+    // 4*(lane>>5).  One N-tile (32 orientations x 2 x 32 pixels) at a time is transposed through LDS so that lane L
+    // owns pixel L&31 of M-tile L>>5 and walks the orientations in index order: pass 1 first-maximum argmax, pass 2
+    // the cascade-ordered variance -- the same operations in the same order as the VALU kernels.
+    float *__restrict__ st = stage[wave];
+    const int mt = lane >> 5;
     const float PI_F = 3.14159265358979323846f;
-    float vmax = 0.0f;
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        // C layout of the 32x32 MFMA: column (orientation) = lane&31, row (pixel) = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float M = 0.0f, bh = 0.0f;
+    int b = 0;
+    MhCasc sc = {0.f, 0.f};
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) bh = s_theta[b];
 #pragma unroll
         for (int n = 0; n < 6; ++n) {
-            const int k = n * 32 + pix;
-            if (k < MH_GB_NK) {
+            __builtin_amdgcn_sched_barrier(0);   // one N-tile at a time: do not hoist the 192 |acc| of all tiles
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-                    rw[k * MH_GM_RS + row] = __builtin_fabsf(acc[p][n][r]);
+                    st[(p * 32 + pix) * MH_GM_RS + row] = __builtin_fabsf(acc[p][n][r]);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int kmax = (n == 5) ? MH_GB_NK - 160 : 32;
+            if (pass == 0) {
+                for (int kl = 0; kl < kmax; ++kl) {
+                    const float r = st[(mt * 32 + kl) * MH_GM_RS + pix];
+                    if ((n | kl) == 0) {
+                        M = r;
+                    } else if (r > M) {
+                        M = r;
+                        b = n * 32 + kl;
+                    }
+                }
+            } else {
+                for (int kl = 0; kl < kmax; ++kl) {
+                    if (kl == 16 || (kl == 0 && n > 0)) mh_casc_flush(sc);
+                    const float t1 = bh - s_theta[n * 32 + kl];
+                    const float d =
+                        fminf(__builtin_fabsf(t1), fminf(__builtin_fabsf(t1 - PI_F), __builtin_fabsf(t1 + PI_F)));
+                    const float rd = st[(mt * 32 + kl) * MH_GM_RS + pix] - M;
+                    sc.a0 = sc.a0 + (d * rd) * rd;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 32) {
-            float M = rw[lane];
-            int b = 0;
-            for (int k = 1; k < MH_GB_NK; ++k) {
-                const float r = rw[k * MH_GM_RS + lane];
-                if (r > M) {
-                    M = r;
-                    b = k;
-                }
-            }
-            const float bh = mh_theta((float)b);
-            MhCasc sc = {0.f, 0.f};
-            for (int k = 0; k < MH_GB_NK; ++k) {
-                if (k > 0 && (k & 15) == 0) mh_casc_flush(sc);
-                const float t1 = bh - mh_theta((float)k);
-                const float d = fminf(__builtin_fabsf(t1), fminf(__builtin_fabsf(t1 - PI_F), __builtin_fabsf(t1 + PI_F)));
-                const float rd = rw[k * MH_GM_RS + lane] - M;
-                sc.a0 = sc.a0 + (d * rd) * rd;
-            }
-            const float var = __builtin_sqrtf(sc.a0 + sc.a1);
-            const int y = y0 + 2 * wave + p, x = x0 + lane;
-            if (y < H && x < W) {
-                var_out[(size_t)y * W + x] = var;
-                orient[(size_t)y * W + x] = (var > 0.0f) ? b : 0;
-                vmax = fmaxf(vmax, var);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    }
+    const float var = __builtin_sqrtf(sc.a0 + sc.a1);
+    const int y = y0 + 2 * wave + mt, x = x0 + pix;
+    float vmax = 0.0f;
+    if (y < H && x < W) {
+        var_out[(size_t)y * W + x] = var;
+        orient[(size_t)y * W + x] = (var > 0.0f) ? b : 0;
+        vmax = var;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
@@ -431,8 +447,7 @@ extern "C" int mh_launch_gabor_bank(const float *bankT, const float *img, int H,
         hipLaunchKernelGGL(mh_gabor_split_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);
     } else if (variant == 1) {
         const dim3 grid((W + MH_GM_COLS - 1) / MH_GM_COLS, (H + MH_GM_ROWS - 1) / MH_GM_ROWS);
-        const size_t lds = (size_t)(MH_GM_LDH * MH_GM_LDW + 4 * MH_GB_NK * MH_GM_RS) * sizeof(float);
-        hipLaunchKernelGGL(mh_gabor_mfma_kernel, grid, dim3(256), lds, st, bankT, img, H, W, orient, var, maxbits);
+        hipLaunchKernelGGL(mh_gabor_mfma_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);
     } else {
         const dim3 grid((W + MH_GB_TILE - 1) / MH_GB_TILE, (H + MH_GB_TILE - 1) / MH_GB_TILE);
         hipLaunchKernelGGL(mh_gabor_bank_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);
