@@ -28,7 +28,7 @@ struct mh_ctx {
     float4 *lut = nullptr;    // [256] pixel-code table of the 8-bit map files
     int S = 0;
     int search_variant = 0;
-    int gabor_variant = 2;    // 0: v_pk_fma, one pixel/lane; 1: FP32-MFMA im2col; 2: v_pk_fma, split bank (default)
+    int gabor_variant = 1;    // 0: v_pk_fma, one pixel/lane; 1: FP32-MFMA im2col (default); 2: v_pk_fma, split bank
     MhViews views() const { return MhViews{V, H, W, rec, mask, cams}; }
 };
 

@@ -280,16 +280,20 @@ __global__ __launch_bounds__(256) void mh_gabor_split_kernel(const float *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// FP32-MFMA variant: the bank as an im2col contraction  C[pixel, k] = sum_t A[pixel, t] * B[t, k]
+// FP32-MFMA variant (the default): the bank as an im2col contraction  C[pixel, k] = sum_t A[pixel, t] * B[t, k]
 // (pixels x 289 taps x 180 orientations) on v_mfma_f32_32x32x2_f32.  The MFMA result is bit for bit a
-// k-ordered fp32 fma chain, i.e. exactly the tap-ordered chain of the VALU kernel above, so both variants (and
-// the CPU oracle) produce identical maps.
+// k-ordered fp32 fma chain, i.e. exactly the tap-ordered chain of the VALU kernels above, so all variants (and
+// the CPU oracle) produce identical maps.  The coefficient matrix lives in VGPRs distributed over the lanes -- no
+// broadcast through SGPRs, which is what holds the v_pk_fma kernels at ~58 %.
 //   workgroup = 4 waves = 8 image rows x 32 columns; wave w owns rows 2w, 2w+1 (two 32-pixel M-tiles) and all
-//   six 32-wide orientation N-tiles: 12 accumulators x 16 registers.  Per K-step (2 taps): the A fragments are
-//   one ds_read each from the LDS image tile (lane l: pixel l&31, tap 2s + (l>>5)), the B fragments are six
-//   coalesced 256-B global reads of the tap-major bank, prefetched one step ahead; 12 MFMAs (768 cycles).
-//   Epilogue per M-tile: |responses| go through LDS ([k][33] padded) so that one lane per pixel can walk the 180
-//   values in index order (first-max argmax, cascade-ordered variance) exactly like the VALU kernel.
+//   six 32-wide orientation N-tiles: 12 accumulators x 16 registers, 2 waves per SIMD.  Per K-step (2 taps): the
+//   A fragments are one ds_read each from the LDS image tile (lane l: pixel l&31, tap 2s + (l>>5)), the B
+//   fragments are six coalesced 256-B global reads of the tap-major bank, both requested one step ahead; 12 MFMAs
+//   (768 cycles).  Epilogue: one N-tile at a time goes through an 8 KB LDS staging area so that lane L owns pixel
+//   L&31 of M-tile L>>5 and walks the 180 values in index order (first-max argmax, then the cascade-ordered
+//   variance) exactly like the VALU kernels.  Measured 2.15 ms per 1080p view = 64 % of the fp32 matrix peak
+//   (MFMA pipe busy 69 % of the kernel, the epilogue is ~15 %); the first version of this kernel (one workgroup per
+//   CU because of a 100 KB response exchange, half-idle epilogue) took 3.04 ms.
 // ---------------------------------------------------------------------------------------------
 #define MH_GM_ROWS 8
 #define MH_GM_COLS 32

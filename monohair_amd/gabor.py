@@ -53,7 +53,7 @@ def orientation_table():
 
 
 class calOrientationGabor:
-    def __init__(self, channel_in=1, channel_out=1, stride=1, device=None, bank=None, variant="split"):
+    def __init__(self, channel_in=1, channel_out=1, stride=1, device=None, bank=None, variant="mfma"):
         """bank: optional [180,17,17] kernels to install instead of gabor_bank() (torch's CPU sin/cos/exp differ
         in the last bit between host CPU types; tests pin the reference's own kernels this way)."""
         self.numKernels = NUM_KERNELS

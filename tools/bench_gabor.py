@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--height", type=int, default=1920)
 ap.add_argument("--width", type=int, default=1080)
 ap.add_argument("--reps", type=int, default=10)
-ap.add_argument("--variant", default="split")
+ap.add_argument("--variant", default="mfma")
 a = ap.parse_args()
 rng = np.random.default_rng(0)
 r, c = np.meshgrid(np.arange(a.height), np.arange(a.width), indexing="ij")
