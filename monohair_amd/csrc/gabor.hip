@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void mh_gabor_split_kernel(const float *__rest
 //   fragments are six coalesced 256-B global reads of the tap-major bank, both requested one step ahead; 12 MFMAs
 //   (768 cycles).  Epilogue: one N-tile at a time goes through an 8 KB LDS staging area so that lane L owns pixel
 //   L&31 of M-tile L>>5 and walks the 180 values in index order (first-max argmax, then the cascade-ordered
-//   variance) exactly like the VALU kernels.  Measured 2.15 ms per 1080p view = 64 % of the fp32 matrix peak
+//   variance) exactly like the VALU kernels.  Measured 2.11 ms per 1080p view = 65 % of the fp32 matrix peak
 //   (MFMA pipe busy 69 % of the kernel, the epilogue is ~15 %); the first version of this kernel (one workgroup per
 //   CU because of a 100 KB response exchange, half-idle epilogue) took 3.04 ms.
 // ---------------------------------------------------------------------------------------------
@@ -351,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void mh_gabor_mfma_kernel(const float *__re
         }
         const float a0n = tile[(2 * wave + ti) * MH_GM_LDW + pix + tj];     // (the spare tile row keeps this in bounds)
         const float a1n = tile[(2 * wave + 1 + ti) * MH_GM_LDW + pix + tj];
+        __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the MFMAs (the scheduler sinks them otherwise)
 #pragma unroll
         for (int n = 0; n < 6; ++n) {
             acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bcur[n], acc[0][n], 0, 0, 0);
