@@ -222,6 +222,11 @@ def main():
             out["secondary_8bit_maps"] = secondary_quantized(a, dev, recs, cams, dev_chunks)
         except Exception as e:   # the secondary number must never cost the headline line
             out["secondary_8bit_maps"] = {"error": repr(e)[:200]}
+    if not a.no_secondary and world == 1:
+        try:
+            out["secondary_gabor_bank"] = secondary_gabor(a, dev)
+        except Exception as e:
+            out["secondary_gabor_bank"] = {"error": repr(e)[:200]}
     print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
@@ -252,6 +257,35 @@ def secondary_quantized(a, dev, recs, cams, dev_chunks):
     dt = time.perf_counter() - t0
     return {"value": round(a.steps / dt, 3), "unit": "iterations/s", "ms_per_step": round(dt / a.steps * 1e3, 4),
             "maps": "quantized-8bit"}
+
+
+def secondary_gabor(a, dev):
+    """The other kernel family of the path: the per-view Gabor orientation bank on one
+    synthetic view of the benchmark's image size, FP32-MFMA im2col kernel, HIP events around 10 launches.
+    Compute bound: 2*180*289 FLOP per pixel against 12 B; peak = 157.3 TFLOP/s dense fp32 matrix."""
+    import numpy as np
+
+    from monohair_amd.gabor import calOrientationGabor
+
+    H, W = a.height, a.width
+    g = torch.Generator(device="cpu").manual_seed(0)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    img = (0.25 * torch.cos(2 * np.pi * (0.6 * xx + 0.8 * yy) / 4.0) + 0.02 * torch.randn((H, W), generator=g)).float().to(dev)
+    gab = calOrientationGabor(device=dev)
+    gab.filter_index(img)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        gab.filter_index(img)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    tf = 2.0 * 180 * 289 * H * W / ms / 1e9
+    return {"metric": "Gabor bank views/s", "value": round(1e3 / ms, 1), "unit": "views/s", "ms_per_view": round(ms, 3),
+            "image": [H, W], "kernel": "mh_gabor_mfma_kernel",
+            "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": round(tf / 157.3, 4), "traffic": None}}
 
 
 def pmc_traffic(kernel, V, H, W):
