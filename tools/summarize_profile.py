@@ -58,8 +58,8 @@ if (pg, "FETCH_SIZE") in pmc and (pg, "WRITE_SIZE") in pmc:
                "round": 1, "tag": tag, "workload": "60 views @ 1920x1080, 5000 points, patch 7",
                pg: {"fetch_bytes": int(fetch), "write_bytes": int(write), "traffic_bytes": int(fetch + write)}},
               open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-sk = "mh_search_kernel<4, 256, true>"
-if (sk, "SQ_INSTS_VALU") in pmc:
+sk = next((k for k, c in pmc if k.startswith("mh_search_kernel") and c == "SQ_INSTS_VALU"), None)
+if sk:
     g = lambda c: sum(pmc[(sk, c)]) / len(pmc[(sk, c)])   # noqa: E731
     lines += ["# %s: %.0f M VALU wave-instructions per launch, VALU-active %.0f M quad-cycles = %.2f cycles per "
               "instruction; waves resident %.0f M quad-cycles" % (sk, g("SQ_INSTS_VALU") / 1e6,
