@@ -224,6 +224,10 @@ def main():
             out["secondary_8bit_maps"] = {"error": repr(e)[:200]}
     if not a.no_secondary and world == 1:
         try:
+            out["secondary_full_pass"] = secondary_full_pass(dev, pm, cand)
+        except Exception as e:
+            out["secondary_full_pass"] = {"error": repr(e)[:200]}
+        try:
             out["secondary_gabor_bank"] = secondary_gabor(a, dev)
         except Exception as e:
             out["secondary_gabor_bank"] = {"error": repr(e)[:200]}
@@ -257,6 +261,49 @@ def secondary_quantized(a, dev, recs, cams, dev_chunks):
     dt = time.perf_counter() - t0
     return {"value": round(a.steps / dt, 3), "unit": "iterations/s", "ms_per_step": round(dt / a.steps * 1e3, 4),
             "maps": "quantized-8bit"}
+
+
+def secondary_full_pass(dev, pm, cand):
+    """Wall time of the whole exterior pass on this scene: filter_negative_points -> optimize ->
+    refine (smoothing, shell points, voxel fit, Ori3D.mat / Occ3D.mat written), one process, stages synchronised."""
+    import tempfile
+    import types
+
+    from scipy.spatial import KDTree
+
+    from monohair_amd.pmvo import filter_negative_points, optimize, refine
+
+    rng = np.random.default_rng(1)
+    b = rng.normal(size=(2000, 3))
+    b = b / np.linalg.norm(b, axis=1, keepdims=True) * 0.09          # stand-ins for the bust / scalp meshes
+    scalp = b[b[:, 1] > 0.03] * (0.1 / 0.09)
+    pm.set_head(KDTree(b), KDTree(scalp), scalp.max(0))
+    tmp = tempfile.mkdtemp(prefix="mhbench_")
+    args = types.SimpleNamespace(device=str(dev), output_path=tmp, save_root=tmp + "/optimize", save_path=tmp + "/refine",
+                                 PMVO=types.SimpleNamespace(visible_threshold=1), data=types.SimpleNamespace(root=tmp))
+    os.makedirs(args.save_path, exist_ok=True)
+    T = {}
+
+    def timed(name, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize()
+        T[name] = round(time.perf_counter() - t0, 3)
+        return r
+
+    import contextlib
+    import io
+
+    with contextlib.redirect_stdout(io.StringIO()):                   # the drivers print progress like the reference
+        s_idx, s_pts, f_idx = timed("filter_s", lambda: filter_negative_points(cand, pm, args))
+        sp, so, ml, _ = timed("optimize_s", lambda: optimize(s_pts, pm, args))
+        timed("refine_and_volume_s", lambda: refine(sp, so, ml, pm, cand[:len(f_idx)][f_idx].astype(np.float32), args,
+                                                   infer_inner=False, threshold=0.025, return_dense=False))
+    T["total_s"] = round(sum(T.values()), 3)
+    T.update(candidates=int(len(cand)), surface_points=int(s_idx.sum()), shell_points=int(f_idx.sum()),
+             iterations=int(len(s_pts) // CHUNK + 1), unit="s")
+    return T
 
 
 def secondary_gabor(a, dev):
