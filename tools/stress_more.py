@@ -1,0 +1,111 @@
+#!/usr/bin/env python
+"""Randomised sweeps of the other kernels against their checkers (GPU box):
+  k-NN grid search vs scipy.spatial.KDTree, depth rasteriser / Gabor bank (all variants) / medoid / voxel fit vs the
+  CPU oracle.  Every comparison is for exact equality.
+    python tools/stress_more.py --minutes 5 [--seed 0]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+from scipy.spatial import KDTree
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402  (this tool is a checker, like the tests)
+from monohair_amd import synth  # noqa: E402
+from monohair_amd.camera import camera_records, cameras_from_list  # noqa: E402
+from monohair_amd.gabor import calOrientationGabor, gabor_bank  # noqa: E402
+from monohair_amd.pmvo_utils import GridKNN, compute_points_similarity, voxel_fit  # noqa: E402
+from monohair_amd.render import DepthRenderer  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--minutes", type=float, default=3.0)
+ap.add_argument("--seed", type=int, default=0)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+DEV = "cuda:0"
+t_end = time.time() + a.minutes * 60
+count = {"knn": 0, "raster": 0, "gabor": 0, "medoid": 0, "voxel_fit": 0}
+bad = []
+gabs = {v: calOrientationGabor(device=DEV, variant=v) for v in ("valu", "mfma", "split")}
+bank = gabor_bank()
+
+
+def cloud(n):
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        return rng.random((n, 3))
+    if kind == 1:                                                     # shell (what refine sees)
+        p = rng.normal(size=(n, 3))
+        return p / np.linalg.norm(p, axis=1, keepdims=True) * (0.12 + rng.normal(0, 0.002, (n, 1)))
+    if kind == 2:                                                     # clusters of very different density
+        return np.concatenate([rng.normal(0, 0.005, (n // 2, 3)), rng.normal(0.5, 0.2, (n - n // 2, 3))])
+    return rng.normal(0, 1, (n, 3)) * np.array([1.0, 0.05, 0.3])      # anisotropic slab
+
+
+while time.time() < t_end:
+    # ---- k-NN
+    n = int(rng.integers(50, 60000))
+    pts = cloud(n).astype(np.float32)
+    k = int(rng.choice([1, 7, 32, 100]))
+    q = np.concatenate([pts[rng.choice(n, min(n, 300), replace=False)],
+                        (pts[:100] + rng.normal(0, 0.01, (min(n, 100), 3))).astype(np.float32)])
+    got = GridKNN(pts, k_hint=k, device=DEV).query(q, k).cpu().numpy()
+    kk = min(k, n)
+    d, ref = KDTree(data=pts).query(q, kk)
+    ref = np.asarray(ref).reshape(len(q), kk)
+    if not np.array_equal(got, ref):
+        dg = np.linalg.norm(pts[got].astype(np.float64) - q[:, None].astype(np.float64), axis=-1)
+        if not np.allclose(dg, np.asarray(d).reshape(len(q), kk), rtol=0, atol=0):    # only exact distance ties may differ
+            bad.append(("knn", n, k))
+    count["knn"] += 1
+    # ---- rasteriser
+    H, W = int(rng.integers(20, 300)), int(rng.integers(20, 300))
+    cams = synth.make_cameras(20, H, W, scale=float(rng.uniform(0.6, 2.5)), rings=int(rng.integers(1, 3)))
+    rec = camera_records(cameras_from_list(cams))[int(rng.integers(0, 20))]
+    nv = int(rng.integers(3, 3000))
+    verts = (rng.normal(0, 0.1, (nv, 3)) * rng.uniform(0.2, 3)).astype(np.float32)
+    faces = rng.integers(0, nv, (int(rng.integers(1, 6000)), 3)).astype(np.int32)
+    pc = float(rng.choice([0.0, 0.5, 0.25]))
+    want, _ = oracle.render_depth(rec, verts, faces, H, W, pc)
+    got = DepthRenderer([(verts, faces)], DEV).render(rec, H, W, pc).cpu().numpy()
+    if not np.array_equal(got, want):
+        bad.append(("raster", H, W, nv, len(faces), pc))
+    count["raster"] += 1
+    # ---- Gabor bank, three kernels
+    H, W = int(rng.integers(5, 90)), int(rng.integers(5, 120))
+    img = (rng.normal(size=(H, W)) * rng.uniform(0.01, 3)).astype(np.float32)
+    if rng.integers(0, 3) == 0:
+        img[:, : W // 2] = 0.0                                        # flat regions: zero responses, argmax ties
+    o_idx, o_conf, o_var = oracle.gabor_bank(bank, img)
+    for v, g in gabs.items():
+        idx, conf, var = g.filter_index(torch.from_numpy(img).to(DEV))
+        if not (np.array_equal(idx.cpu().numpy(), o_idx) and np.array_equal(conf.cpu().numpy(), o_conf, equal_nan=True)
+                and np.array_equal(var.cpu().numpy(), o_var)):
+            bad.append(("gabor", v, H, W))
+    count["gabor"] += 1
+    # ---- medoid
+    G, K = int(rng.integers(1, 400)), int(rng.integers(1, 130))
+    ori = rng.normal(size=(G, K, 3)).astype(np.float32)
+    if rng.integers(0, 3) == 0:
+        ori[:, K // 2:] = ori[:, : K - K // 2]                        # duplicates -> ties
+    got = compute_points_similarity(torch.from_numpy(ori).to(DEV)).cpu().numpy()
+    want, _ = oracle.medoid_dense(ori)
+    if not np.array_equal(got, want):
+        bad.append(("medoid", G, K))
+    count["medoid"] += 1
+    # ---- voxel fit
+    n = int(rng.integers(1, 20000))
+    p = cloud(n) * 0.2
+    o = rng.normal(size=(n, 3)).astype(np.float32)
+    res = voxel_fit(p.copy(), o.copy(), DEV)
+    occ, ori_d = oracle.voxel_fit(p.copy(), o.copy(), [-0.32, -0.32, -0.24], 0.005 / 2, [256, 256, 192])
+    if not (np.array_equal(res["occ"], occ) and np.array_equal(res["ori_dense"].astype(np.float32), ori_d.astype(np.float32))):
+        bad.append(("voxel_fit", n))
+    count["voxel_fit"] += 1
+print({"rounds": count, "mismatching_cases": len(bad), "first": bad[:6]})
+sys.exit(1 if bad else 0)
