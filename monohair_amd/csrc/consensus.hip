@@ -28,31 +28,60 @@ __global__ __launch_bounds__(256) void mh_medoid_kernel(const float *__restrict_
     const int K = seg_start ? (seg_start[g + 1] - begin) : K_dense;
     if (K <= 0) return;
     const float *__restrict__ o = ori + (size_t)begin * 3;
-    for (int k = tid; k < K; k += 256) {
+    auto unit_of = [&](int k, float &u0, float &u1, float &u2) {
         const float x0 = o[3 * k], x1 = o[3 * k + 1], x2 = o[3 * k + 2];
         float s = x0 * x0;
         s = mh_fma(x1, x1, s);
         s = mh_fma(x2, x2, s);
         float nrm = __builtin_sqrtf(s);
         nrm = (nrm < 1e-8f) ? 1e-8f : nrm;
-        s_u[3 * k] = x0 / nrm;
-        s_u[3 * k + 1] = x1 / nrm;
-        s_u[3 * k + 2] = x2 / nrm;
-    }
-    __syncthreads();
+        u0 = x0 / nrm;
+        u1 = x1 / nrm;
+        u2 = x2 / nrm;
+    };
     float bv = 0.0f;
     int bi = 0x7fffffff;
-    for (int k = tid; k < K; k += 256) {
-        const float a0 = s_u[3 * k], a1 = s_u[3 * k + 1], a2 = s_u[3 * k + 2];
-        float acc = 0.0f;
-        for (int j = 0; j < K; ++j) {
-            const float cs = (a0 * s_u[3 * j] + a1 * s_u[3 * j + 1]) + a2 * s_u[3 * j + 2];
-            acc = acc + __builtin_fabsf(cs);
+    if (K <= MH_MEDOID_MAXK) {
+        for (int k = tid; k < K; k += 256) unit_of(k, s_u[3 * k], s_u[3 * k + 1], s_u[3 * k + 2]);
+        __syncthreads();
+        for (int k = tid; k < K; k += 256) {
+            const float a0 = s_u[3 * k], a1 = s_u[3 * k + 1], a2 = s_u[3 * k + 2];
+            float acc = 0.0f;
+            for (int j = 0; j < K; ++j) {
+                const float cs = (a0 * s_u[3 * j] + a1 * s_u[3 * j + 1]) + a2 * s_u[3 * j + 2];
+                acc = acc + __builtin_fabsf(cs);
+            }
+            const float mean = acc / (float)K;
+            if (bi == 0x7fffffff || mh_arg_better(mean, k, bv, bi)) {
+                bv = mean;
+                bi = k;
+            }
         }
-        const float mean = acc / (float)K;
-        if (bi == 0x7fffffff || mh_arg_better(mean, k, bv, bi)) {
-            bv = mean;
-            bi = k;
+    } else {
+        // a group that does not fit in LDS (never the case for the 2.5 mm voxels of a real capture): the units are
+        // staged MH_MEDOID_MAXK at a time, every lane keeps the left-to-right sum of its current candidate
+        for (int kb = 0; kb < K; kb += 256) {
+            const int k = kb + tid;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, acc = 0.0f;
+            if (k < K) unit_of(k, a0, a1, a2);
+            for (int j0 = 0; j0 < K; j0 += MH_MEDOID_MAXK) {
+                const int nj = min(MH_MEDOID_MAXK, K - j0);
+                __syncthreads();
+                for (int j = tid; j < nj; j += 256) unit_of(j0 + j, s_u[3 * j], s_u[3 * j + 1], s_u[3 * j + 2]);
+                __syncthreads();
+                if (k < K)
+                    for (int j = 0; j < nj; ++j) {
+                        const float cs = (a0 * s_u[3 * j] + a1 * s_u[3 * j + 1]) + a2 * s_u[3 * j + 2];
+                        acc = acc + __builtin_fabsf(cs);
+                    }
+            }
+            if (k < K) {
+                const float mean = acc / (float)K;
+                if (bi == 0x7fffffff || mh_arg_better(mean, k, bv, bi)) {
+                    bv = mean;
+                    bi = k;
+                }
+            }
         }
     }
 #pragma unroll
@@ -123,16 +152,16 @@ extern "C" int mh_launch_replace_dissimilar(const float *center, float *ori, flo
 
 extern "C" int mh_launch_medoid_dense(const float *ori, int G, int K, float *out, int32_t *out_index,
                                       hipStream_t st) {
-    if (K > MH_MEDOID_MAXK) return -1;
-    hipLaunchKernelGGL(mh_medoid_kernel, dim3(G), dim3(256), (size_t)K * 3 * sizeof(float), st, ori, nullptr, K, out,
+    const int kl = K < MH_MEDOID_MAXK ? K : MH_MEDOID_MAXK;
+    hipLaunchKernelGGL(mh_medoid_kernel, dim3(G), dim3(256), (size_t)kl * 3 * sizeof(float), st, ori, nullptr, K, out,
                        out_index);
     return (int)hipGetLastError();
 }
 
 extern "C" int mh_launch_medoid_segmented(const float *ori, const int32_t *seg_start, int G, int max_group,
                                           float *out, int32_t *out_index, hipStream_t st) {
-    if (max_group > MH_MEDOID_MAXK) return -1;
-    hipLaunchKernelGGL(mh_medoid_kernel, dim3(G), dim3(256), (size_t)max_group * 3 * sizeof(float), st, ori,
-                       seg_start, 0, out, out_index);
+    const int kl = max_group < MH_MEDOID_MAXK ? max_group : MH_MEDOID_MAXK;
+    hipLaunchKernelGGL(mh_medoid_kernel, dim3(G), dim3(256), (size_t)kl * 3 * sizeof(float), st, ori, seg_start, 0, out,
+                       out_index);
     return (int)hipGetLastError();
 }

@@ -109,3 +109,22 @@ def test_bad_arguments_are_reported_not_crashed():
     pm.patch_size = 13                                    # larger than the instantiated kernels
     with pytest.raises(_lib.MhError):
         pm.Compute_Visible_and_Ori(synth.candidate_points(res=32, seed=6, limit=10))
+
+
+def test_medoid_groups_larger_than_lds():
+    """a voxel / neighbourhood with more members than the 4096 unit vectors the kernel keeps in LDS (never the case
+    for a real capture, but it must not fail): the staged path gives the oracle's medoid too"""
+    import oracle
+    from monohair_amd.pmvo_utils import compute_points_similarity, voxel_fit
+
+    rng = np.random.default_rng(0)
+    ori = rng.normal(size=(2, 4500, 3)).astype(np.float32)
+    got = compute_points_similarity(torch.from_numpy(ori).to(DEV)).cpu().numpy()
+    want, _ = oracle.medoid_dense(ori)
+    assert np.array_equal(got, want)
+    p = np.concatenate([rng.normal(0, 0.0002, (6000, 3)), rng.uniform(-0.1, 0.1, (500, 3))])   # 6000 points in one voxel
+    o = rng.normal(size=(6500, 3)).astype(np.float32)
+    res = voxel_fit(p.copy(), o.copy(), DEV)
+    occ, ori_d = oracle.voxel_fit(p.copy(), o.copy(), [-0.32, -0.32, -0.24], 0.005 / 2, [256, 256, 192])
+    assert np.array_equal(res["occ"], occ)
+    assert np.array_equal(res["ori_dense"].astype(np.float32), ori_d.astype(np.float32))
