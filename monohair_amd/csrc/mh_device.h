@@ -203,6 +203,24 @@ __device__ __forceinline__ float mh_soft_visible(float depth, float z255) {
 }
 
 // ATen cascade sum over the view axis (valid for V < 256): 16-view blocks, then the block sums.
+// ATen's cascade sum over the leading (view) dimension of a [V, ...] tensor (multi_row_sum, level_power 4): 16 rows
+// into level 0, level 0 into level 1 after every full block, level 1 into level 2 every 256 rows; the remainder
+// rows stay in level 0 and the levels are added in order at the end.  Exact for V < 4096.
+struct MhCascV {
+    float a0, a1, a2;
+};
+// call when v > 0 and v % 16 == 0, before adding row v
+__device__ __forceinline__ void mh_cascv_flush(MhCascV &c, int v) {
+    c.a1 = c.a1 + c.a0;
+    c.a0 = 0.0f;
+    if ((v & 0xF0) == 0) {
+        c.a2 = c.a2 + c.a1;
+        c.a1 = 0.0f;
+    }
+}
+__device__ __forceinline__ float mh_cascv_done(const MhCascV &c) { return (c.a0 + c.a1) + c.a2; }
+
+// two-level form for sums of fewer than 256 rows (the 180 orientations of the Gabor bank)
 struct MhCasc {
     float a0, a1;
 };

@@ -7,7 +7,7 @@
 // ATen's cascade order (mask values in (0, 0.2] stay fractional, PMVO.py:427, so order can matter).
 #include "mh_device.h"
 
-#define MH_FILTER_VMAX 128
+#define MH_FILTER_VMAX 512
 #define MH_NTERM 8
 
 template <int PATCH>
@@ -17,7 +17,8 @@ __global__ __launch_bounds__(256) void mh_filter_kernel(MhViews vw, const float 
                                                         uint8_t *__restrict__ unvisible_index,
                                                         uint8_t *__restrict__ head_filter) {
     constexpr int HP = PATCH / 2;
-    __shared__ float s_t[4][MH_NTERM][MH_FILTER_VMAX];
+    extern __shared__ float s_tbuf[];   // [4 waves][MH_NTERM][V]
+#define s_t(w, t, v) s_tbuf[((w) * MH_NTERM + (t)) * V + (v)]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + wave;
     if (n >= N) return;
@@ -62,31 +63,31 @@ __global__ __launch_bounds__(256) void mh_filter_kernel(MhViews vw, const float 
         const float lowc = (cmax < thr) ? 1.0f : 0.0f;
         m = (m > 0.2f) ? 1.0f : m;
         const float visb = 1.0f - unv, visb1 = 1.0f - unv1, visbh = 1.0f - unvh;
-        s_t[wave][0][v] = visb * lowc;    // visible with low confidence
-        s_t[wave][1][v] = visb;           // visibles
-        s_t[wave][2][v] = visb * m;       // visibles * masks
-        s_t[wave][3][v] = visb1;          // visibles1
-        s_t[wave][4][v] = visb1 * m;      // visibles1 * masks
-        s_t[wave][5][v] = 1.0f - unv9;    // compute_unvisible_points
-        s_t[wave][6][v] = visbh;          // filter_head_points visibles
-        s_t[wave][7][v] = visbh * m;      // filter_head_points indexs
+        s_t(wave, 0, v) = visb * lowc;    // visible with low confidence
+        s_t(wave, 1, v) = visb;           // visibles
+        s_t(wave, 2, v) = visb * m;       // visibles * masks
+        s_t(wave, 3, v) = visb1;          // visibles1
+        s_t(wave, 4, v) = visb1 * m;      // visibles1 * masks
+        s_t(wave, 5, v) = 1.0f - unv9;    // compute_unvisible_points
+        s_t(wave, 6, v) = visbh;          // filter_head_points visibles
+        s_t(wave, 7, v) = visbh * m;      // filter_head_points indexs
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane < MH_NTERM) {
-        MhCasc a = {0.f, 0.f};
+        MhCascV a = {0.f, 0.f, 0.f};
         for (int v = 0; v < V; ++v) {
-            if (v > 0 && (v & 15) == 0) mh_casc_flush(a);
-            a.a0 = a.a0 + s_t[wave][lane][v];
+            if (v > 0 && (v & 15) == 0) mh_cascv_flush(a, v);
+            a.a0 = a.a0 + s_t(wave, lane, v);
         }
-        s_t[wave][lane][0] = a.a0 + a.a1;
+        s_t(wave, lane, 0) = mh_cascv_done(a);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
-        const float s_idx = s_t[wave][0][0], s_vis = s_t[wave][1][0], s_vm = s_t[wave][2][0];
-        const float s_vis1 = s_t[wave][3][0], s_vm1 = s_t[wave][4][0], s_v9 = s_t[wave][5][0];
-        const float s_vh = s_t[wave][6][0], s_ih = s_t[wave][7][0];
+        const float s_idx = s_t(wave, 0, 0), s_vis = s_t(wave, 1, 0), s_vm = s_t(wave, 2, 0);
+        const float s_vis1 = s_t(wave, 3, 0), s_vm1 = s_t(wave, 4, 0), s_v9 = s_t(wave, 5, 0);
+        const float s_vh = s_t(wave, 6, 0), s_ih = s_t(wave, 7, 0);
         const bool low_conf = s_idx > 4.0f;
         const bool hair = (s_vis - s_vm) < (s_vis * 1.0f / 2.0f);
         const bool hair1 = (s_vis1 - s_vm1) < (s_vis1 * 1.0f / 2.0f);
@@ -104,9 +105,10 @@ extern "C" int mh_launch_filter_points(MhViews vw, const float *pts, int N, int 
                                        uint8_t *head_filter, hipStream_t st) {
     if (vw.V > MH_FILTER_VMAX) return -1;
     const dim3 grid((N + 3) / 4), block(256);
+    const size_t lds = (size_t)4 * MH_NTERM * vw.V * sizeof(float);
 #define MH_F_CASE(PS)                                                                                              \
     case PS:                                                                                                       \
-        hipLaunchKernelGGL(mh_filter_kernel<PS>, grid, block, 0, st, vw, pts, N, thr, vis_thr, surface_index,       \
+        hipLaunchKernelGGL(mh_filter_kernel<PS>, grid, block, lds, st, vw, pts, N, thr, vis_thr, surface_index,       \
                            filter_index, unvisible_index, head_filter);                                            \
         break;
     switch (patch) {

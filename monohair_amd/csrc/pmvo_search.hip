@@ -72,7 +72,7 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
     const float P0 = pts[3 * n], P1x = pts[3 * n + 1], P2 = pts[3 * n + 2];
 
     float X0[K], X1[K], X2[K];
-    MhCasc num[K], den[K];
+    MhCascV num[K], den[K];
     int cnt[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
         const int b = base_idx[(size_t)(r * rank_step) * N + n];
         const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
         mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[s], X0[j], X1[j], X2[j]);
-        num[j].a0 = num[j].a1 = den[j].a0 = den[j].a1 = 0.0f;
+        num[j] = den[j] = MhCascV{0.0f, 0.0f, 0.0f};
         cnt[j] = 0;
     }
 
@@ -90,8 +90,8 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
         if (v > 0 && (v & 15) == 0) {
 #pragma unroll
             for (int j = 0; j < K; ++j) {
-                mh_casc_flush(num[j]);
-                mh_casc_flush(den[j]);
+                mh_cascv_flush(num[j], v);
+                mh_cascv_flush(den[j], v);
             }
         }
         const float4 *__restrict__ rec = taps + ((size_t)v * N + n) * P1;
@@ -249,8 +249,8 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
     for (int j = 0; j < K; ++j) {
         const int it = j * T + tid;
         if (it < nitems) {
-            const float dn = den[j].a0 + den[j].a1;
-            const float nm = num[j].a0 + num[j].a1;
+            const float dn = mh_cascv_done(den[j]);
+            const float nm = mh_cascv_done(num[j]);
             const float ratio = dn / (float)cnt[j];
             s_pos[it] = (ratio > thr) ? 1 : 0;
             s_loss[it] = nm / dn;
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
 // num/den is returned, PMVO.py:199-204).  One wave per point, lane = view; the per-view terms go through
 // LDS so that lane 0 can add them in ATen's cascade order.  Patches are read raw ([V,N,P,..] layout).
 // ---------------------------------------------------------------------------------------------
-#define MH_REFINE_VMAX 256
+#define MH_REFINE_VMAX 512
 __global__ __launch_bounds__(256) void mh_refine_loss_kernel(MhViews vw, const float *__restrict__ pts,
                                                              const float *__restrict__ dir, float mul, float dv,
                                                              int N, int P, float thr, const float *__restrict__ vis,
@@ -384,20 +384,20 @@ __global__ __launch_bounds__(256) void mh_refine_loss_kernel(MhViews vw, const f
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
-        MhCasc nm = {0.f, 0.f}, dn = {0.f, 0.f};
+        MhCascV nm = {0.f, 0.f, 0.f}, dn = {0.f, 0.f, 0.f};
         int cnt = 0;
         for (int v = 0; v < V; ++v) {
             if (v > 0 && (v & 15) == 0) {
-                mh_casc_flush(nm);
-                mh_casc_flush(dn);
+                mh_cascv_flush(nm, v);
+                mh_cascv_flush(dn, v);
             }
             const float w = s_den[wave][v];
             nm.a0 = nm.a0 + s_num[wave][v];
             dn.a0 = dn.a0 + w;
             cnt += (w > 0.0f) ? 1 : 0;
         }
-        const float d = dn.a0 + dn.a1;
-        loss[n] = (nm.a0 + nm.a1) / d;
+        const float d = mh_cascv_done(dn);
+        loss[n] = mh_cascv_done(nm) / d;
         if (hcout) hcout[n] = (d / (float)cnt > thr) ? 1 : 0;
     }
 }

@@ -14,7 +14,8 @@
  *     products rounded separately, then added left to right (NO fma);
  *   - torch.sum(t, dim=0) on a contiguous [V,...] float tensor   = ATen "cascade sum":
  *     16-row blocks accumulated sequentially, block sums accumulated sequentially,
- *     remainder rows added, then the two levels added (valid for V < 256);
+ *     remainder rows added, then the levels added in order; a third level takes over the
+ *     second every 256 rows (ATen multi_row_sum with level_power 4; implemented for V < 4096);
  *   - torch.round = round-half-even; torch.min propagates NaN (first NaN index wins).
  * Compile with -ffp-contract=off so that the compiler adds no fma of its own.
  *
@@ -309,16 +310,20 @@ static inline float tap_loss(const float *oh, const float *dh) {
 
 /* ATen cascade sum over the leading (view) dimension, one column: see file header. */
 typedef struct {
-    float a0, a1;
+    float a0, a1, a2;
 } casc;
 static inline void casc_step(casc *c, int v, float x) {
-    if (v > 0 && (v & 15) == 0) {
+    if (v > 0 && (v & 15) == 0) {          /* a full 16-row block: level 0 -> level 1 */
         c->a1 = c->a1 + c->a0;
         c->a0 = 0.0f;
+        if ((v & 0xF0) == 0) {             /* 256 rows: level 1 -> level 2 (ATen: (i & (15 << 4)) == 0) */
+            c->a2 = c->a2 + c->a1;
+            c->a1 = 0.0f;
+        }
     }
     c->a0 = c->a0 + x;
 }
-static inline float casc_done(const casc *c) { return c->a0 + c->a1; }
+static inline float casc_done(const casc *c) { return (c->a0 + c->a1) + c->a2; }   /* V < 4096 */
 
 /*
  * PMVO.compute_prj_loss (PMVO.py:151-209) for ONE point.

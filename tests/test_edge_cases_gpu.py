@@ -52,11 +52,13 @@ def test_patch_sizes_beyond_one_wave(patch):
     assert np.array_equal(surf.cpu().numpy(), o_s) and np.array_equal(filt.cpu().numpy(), o_f)
 
 
-def test_many_views_cascade_blocks():
-    """V = 120 (BASELINE config 5): eight 16-view blocks in the cascade sum, two rounds of lanes-over-views"""
+@pytest.mark.parametrize("V", [120, 300])
+def test_many_views_cascade_blocks(V):
+    """V = 120 (BASELINE config 5): eight 16-view blocks in the cascade sum, two rounds of lanes-over-views;
+    V = 300 (an unstrided ~300-frame capture): the cascade's third level takes over at 256 rows"""
     from monohair_amd import synth
 
-    scene, pm, views = build(120, 96, 64, 3, rings=3)
+    scene, pm, views = build(V, 96, 64, 3, rings=3)
     pts = synth.candidate_points(res=32, seed=4, limit=120)
     check_forward(pm, views, pts, 3, 0.15)
     pm.Compute_Visible_and_Ori(pts)
@@ -64,6 +66,11 @@ def test_many_views_cascade_blocks():
     loss, _ = pm.prj_loss_of(pm._points, dirs)
     o_loss, _ = oracle.refine_loss(views, pts, np.tile([[0.0, -1.0, 0.0]], (len(pts), 1)), 3, 0.15)
     assert np.array_equal(loss.cpu().numpy(), o_loss, equal_nan=True)
+    surf, _, filt = pm.filter_points(pts)
+    unv = pm.compute_unvisible_points(pts)
+    o_s, o_f, o_u, _ = oracle.filter_votes(views, pts, 3, 0.15, 1.0)
+    assert np.array_equal(surf.cpu().numpy(), o_s) and np.array_equal(filt.cpu().numpy(), o_f)
+    assert np.array_equal(unv.cpu().numpy(), o_u)
 
 
 def test_fewer_than_twenty_views_fails_like_the_reference():

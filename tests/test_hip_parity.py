@@ -13,7 +13,7 @@ from conftest import golden_records, golden_scene, load_golden, scene_views
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["pmvo_small", "pmvo_mid", "pmvo_quant"]
+CASES = ["pmvo_small", "pmvo_mid", "pmvo_quant", "pmvo_views300"]
 
 
 def eq_nan(a, b):

@@ -6,7 +6,7 @@ import pytest
 import oracle
 from conftest import golden_records, golden_scene, load_golden, scene_views
 
-CASES = ["pmvo_small", "pmvo_mid", "pmvo_quant"]
+CASES = ["pmvo_small", "pmvo_mid", "pmvo_quant", "pmvo_views300"]
 
 
 def eq_nan(a, b):
@@ -84,7 +84,9 @@ def test_sample_reproject_loss(case, rank, depth_offsets):
     # Bit-exact except where the reference's matmul lands in another MKL kernel: a base view that owns a
     # single point of the batch goes through gemv instead of gemm (see oracle/pmvo_oracle.c, cam_unproject).
     exact = np.all(samples == ref_s, axis=(1, 2))
-    assert exact.mean() >= 0.97
+    shared = np.bincount(z["base_idx"][rank], minlength=z["visible"].shape[0])[z["base_idx"][rank]] >= 2
+    assert exact[shared].mean() >= 0.97          # (with 300 views and 64 points most base views own one point)
+    assert shared.mean() < 0.6 or exact.mean() >= 0.97
     assert np.allclose(samples, ref_s, rtol=0, atol=2e-7)
     D = oracle.reproject_ori(views, pts, samples)
     nd = meta["n_d"]
@@ -124,8 +126,9 @@ def test_forward(case, depth_offsets):
     match = (loss == z["fwd_loss"]) | (np.isnan(loss) & np.isnan(z["fwd_loss"]))
     match &= np.all((ori == z["fwd_ori"]) | (np.isnan(ori) & np.isnan(z["fwd_ori"])), axis=1)
     match &= hc == z["fwd_hc"]
-    # bit-exact on (nearly) every point; the exceptions are gemv-path points at ranks we did not store
-    assert match[body].mean() >= 0.98
+    # bit-exact on (nearly) every point; the exceptions are gemv-path points at ranks we did not store (with 300 views
+    # and 64 points nearly every base view owns a single point, so that fixture has more of them)
+    assert match[body].mean() >= (0.98 if z["visible"].shape[0] < 256 else 0.9)
     assert np.allclose(loss, z["fwd_loss"], rtol=0, atol=1e-6, equal_nan=True)
 
 
@@ -142,4 +145,5 @@ def test_forward_own_topk(case, depth_offsets):
     same_rank = np.all(ok, axis=0) & _comparable(z, depth_offsets, views, pts)
     assert same_rank.sum() >= 10
     match = (loss == z["fwd_loss"]) | (np.isnan(loss) & np.isnan(z["fwd_loss"]))
-    assert match[same_rank].mean() >= 0.98
+    assert match[same_rank].mean() >= (0.98 if z["visible"].shape[0] < 256 else 0.9)     # (see test_forward)
+    assert np.allclose(loss[same_rank], z["fwd_loss"][same_rank], rtol=0, atol=1e-6, equal_nan=True)

@@ -33,6 +33,10 @@ PMVO_CASES = {
                      thr=0.15, vis_thr=1.0, pt_seed=5, n_d=12),
     "pmvo_quant": dict(V=30, H=240, W=136, seed=7, scale=1.7, rings=1, quantize=True, res=64, N=200, patch=5,
                        thr=0.1, vis_thr=1.0, pt_seed=9, n_d=12),
+    # more than 256 views (a real capture of ~300 frames is used unstrided, Camera_utils.py:148-163): ATen's cascade
+    # sum moves to a third level every 256 rows
+    "pmvo_views300": dict(V=300, H=64, W=48, seed=2, scale=1.7, rings=3, quantize=False, res=32, N=64, patch=3,
+                          thr=0.15, vis_thr=1.0, pt_seed=13, n_d=8),
 }
 
 
