@@ -290,7 +290,7 @@ extern "C" int mh_search_forward(mh_ctx *ctx, const float *points, int N, int pa
     if (scratch_bytes < mh_search_scratch_bytes(ctx, N, patch))
         return fail(MH_ERR_ARG, "mh_search_forward: scratch too small (%zu < %zu)", scratch_bytes,
                     mh_search_scratch_bytes(ctx, N, patch));
-    if (ctx->V >= 256) return fail(MH_ERR_ARG, "mh_search_forward: V >= 256 needs a third cascade level");
+    if (ctx->V >= 4096) return fail(MH_ERR_ARG, "mh_search_forward: V >= 4096 needs a fourth cascade level");
     if (N == 0) return MH_OK;
     hipStream_t st = (hipStream_t)stream;
     const int P = patch * patch;
@@ -328,7 +328,7 @@ extern "C" int mh_search_prepared(mh_ctx *ctx, const float *points, int N, int p
     if (!points || !ori || !base_idx || !base_val || !scratch || !line_ori || !min_loss || !high_conf || N < 0 ||
         nrank < 1 || rank_step < 1 || (nrank - 1) * rank_step >= MH_TOPK)
         return fail(MH_ERR_ARG, "mh_search_prepared: bad arguments");
-    if (ctx->V >= 256) return fail(MH_ERR_ARG, "mh_search_prepared: V >= 256 needs a third cascade level");
+    if (ctx->V >= 4096) return fail(MH_ERR_ARG, "mh_search_prepared: V >= 4096 needs a fourth cascade level");
     return launched(mh_launch_search(ctx->views(), ctx->offs, ctx->S, nrank, rank_step, points, N,
                                      patch * patch + 1, conf_threshold, ori, base_idx, base_val,
                                      (const float4 *)scratch, line_ori, min_loss, high_conf, best_sample, best_rank,
