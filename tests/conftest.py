@@ -19,6 +19,8 @@ def pytest_configure(config):
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     meta = ast.literal_eval(str(z["meta"]))
+    if "scene_depth" in z.files:       # the fixture carries its own maps (see tools/gen_golden.py)
+        meta["_scene"] = {k: z["scene_" + k] for k in ("depth", "ori", "conf", "mask")}
     return meta, z
 
 
@@ -30,6 +32,13 @@ def golden_scene(meta):
     from monohair_amd import synth
 
     key = (meta["V"], meta["H"], meta["W"], meta["seed"], meta["scale"], meta["rings"], meta["quantize"])
+    if key not in _scene_cache and "_scene" in meta:
+        import torch
+
+        scene = {k: torch.from_numpy(np.array(v)) for k, v in meta["_scene"].items()}
+        scene["cams"] = synth.make_cameras(meta["V"], meta["H"], meta["W"], scale=meta["scale"], rings=meta["rings"])
+        scene["image_size"] = [meta["H"], meta["W"]]
+        _scene_cache[key] = scene
     if key not in _scene_cache:
         _scene_cache[key] = synth.make_scene(meta["V"], meta["H"], meta["W"], seed=meta["seed"], scale=meta["scale"],
                                              rings=meta["rings"], quantize=meta["quantize"])

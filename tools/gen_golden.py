@@ -35,8 +35,10 @@ PMVO_CASES = {
                        thr=0.1, vis_thr=1.0, pt_seed=9, n_d=12),
     # more than 256 views (a real capture of ~300 frames is used unstrided, Camera_utils.py:148-163): ATen's cascade
     # sum moves to a third level every 256 rows
-    "pmvo_views300": dict(V=300, H=64, W=48, seed=2, scale=1.7, rings=3, quantize=False, res=32, N=64, patch=3,
-                          thr=0.15, vis_thr=1.0, pt_seed=13, n_d=8),
+    # (this case stores its scene: with so many camera angles the host's libm shows up in the last bit of a few map
+    # values, and the GPU tests run on another CPU than the one the goldens come from)
+    "pmvo_views300": dict(V=300, H=40, W=32, seed=2, scale=1.7, rings=3, quantize=False, res=32, N=48, patch=3,
+                          thr=0.15, vis_thr=1.0, pt_seed=13, n_d=8, store_scene=True),
 }
 
 
@@ -68,6 +70,9 @@ def gen_pmvo(R, name, case):
     pts64 = pick_points(case)
     out = dict(points=pts64)
     out["scene_checksums"] = scene_checksums(scene)
+    if case.get("store_scene"):
+        for k in ("depth", "ori", "conf", "mask"):
+            out["scene_" + k] = scene[k].numpy()
     out["cam_pose"] = np.stack([c.pose.numpy() for c in pm.camera])
     out["cam_proj"] = np.stack([c.proj.numpy() for c in pm.camera])
     out["cam_rinv"] = np.stack([torch.linalg.inv(c.pose[:3, :3]).numpy() for c in pm.camera])
