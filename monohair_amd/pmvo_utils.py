@@ -169,10 +169,10 @@ def SamplePointsAroundmesh(colmap_points, bbox_min, vsize, num_per_grid=32, grid
     colmap_points[:, 1:] *= -1
     idx = np.round((colmap_points - bbox_min) / vsize).astype(np.int32)
     idx = np.clip(idx, 0, g - 1)
-    occ = np.zeros(tuple(g), dtype=bool)
-    occ[idx[:, 0], idx[:, 1], idx[:, 2]] = True
-    x, y, z = np.nonzero(occ)
-    indices = np.stack([x, y, z], 1)
+    # the occupied cells in np.nonzero order of the reference's dense grid (x, then y, then z ascending), without
+    # the 100 M-cell grid itself: the sorted unique linear indices
+    lin = np.unique((idx[:, 0].astype(np.int64) * g[1] + idx[:, 1]) * g[2] + idx[:, 2])
+    indices = np.stack([lin // (g[1] * g[2]), (lin // g[2]) % g[1], lin % g[2]], 1)
     base = np.concatenate([indices] * num_per_grid, 0)
     sample = (base + np.random.random(base.shape)) * vsize + bbox_min
     sample[:, 1:] *= -1
