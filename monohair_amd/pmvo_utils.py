@@ -115,20 +115,49 @@ def load_depth_plane(camera, path, threads=8):
 
 
 # ----------------------------------------------------------------------------------------- meshes / points
-def read_obj(path):
-    """Minimal Wavefront OBJ reader: (vertices [N,3] f64, faces [M,3] int) -- triangles / fan-triangulated polys."""
+def _read_obj_slow(lines):
     vs, fs = [], []
-    with open(path, "r") as f:
-        for line in f:
-            if line.startswith("v "):
-                p = line.split()
-                vs.append([float(p[1]), float(p[2]), float(p[3])])
-            elif line.startswith("f "):
-                idx = [int(t.split("/")[0]) for t in line.split()[1:]]
-                idx = [i - 1 if i > 0 else len(vs) + i for i in idx]
-                for k in range(1, len(idx) - 1):
-                    fs.append([idx[0], idx[k], idx[k + 1]])
+    for line in lines:
+        if line.startswith(b"v "):
+            p = line.split()
+            vs.append([float(p[1]), float(p[2]), float(p[3])])
+        elif line.startswith(b"f "):
+            idx = [int(t.split(b"/")[0]) for t in line.split()[1:]]
+            idx = [i - 1 if i > 0 else len(vs) + i for i in idx]
+            for k in range(1, len(idx) - 1):
+                fs.append([idx[0], idx[k], idx[k + 1]])
     return np.asarray(vs, dtype=np.float64).reshape(-1, 3), np.asarray(fs, dtype=np.int64).reshape(-1, 3)
+
+
+def read_obj(path):
+    """Minimal Wavefront OBJ reader: (vertices [N,3] f64, faces [M,3] int) -- triangles / fan-triangulated polys.
+    Meshes of the pipeline have 10^5..10^6 lines, so the regular case (every `v` line with the same number of
+    fields, every `f` line a triangle with positive indices) is parsed in bulk; anything else takes the line loop."""
+    import re
+
+    with open(path, "rb") as f:
+        lines = f.read().split(b"\n")
+    vl = [ln for ln in lines if ln.startswith(b"v ")]
+    fl = [ln for ln in lines if ln.startswith(b"f ")]
+    try:
+        nv = len(vl)
+        vt = np.fromstring(b" ".join(ln[2:] for ln in vl), dtype=np.float64, sep=" ")      # C text parser
+        if nv == 0 or vt.size % nv != 0 or vt.size // nv < 3:
+            raise ValueError
+        verts = np.ascontiguousarray(vt.reshape(nv, -1)[:, :3])
+        if fl:
+            ft = np.fromstring(re.sub(rb"/[^ \t\r]*", b"", b" ".join(ln[2:] for ln in fl)), dtype=np.int64, sep=" ")
+            if ft.size != 3 * len(fl):
+                raise ValueError                    # polygons: fan triangulation in the line loop
+            faces = ft.reshape(len(fl), 3)
+            if faces.min() < 1:
+                raise ValueError                    # relative (negative) indices
+            faces = faces - 1
+        else:
+            faces = np.zeros((0, 3), np.int64)
+        return verts, faces
+    except (ValueError, DeprecationWarning):
+        return _read_obj_slow(lines)
 
 
 def vertex_normals(vertices, faces):

@@ -117,6 +117,33 @@ def test_obj_reader_and_sampling(tmp_path):
     assert pts.shape == (8, 3)
 
 
+def test_obj_reader_bulk_path_equals_line_loop(tmp_path):
+    """read_obj parses regular files in bulk and falls back to the line loop for polygons / relative indices /
+    ragged vertex lines: same arrays either way, and 17-digit coordinates survive exactly."""
+    from monohair_amd.pmvo_utils import _read_obj_slow, read_obj
+
+    rng = np.random.default_rng(0)
+    v = rng.normal(size=(300, 3))
+    f = rng.integers(0, 300, (500, 3))
+    variants = {
+        "plain": ("v %.17g %.17g %.17g\n", "f %d %d %d\n"),
+        "crlf": ("v %.17g %.17g %.17g\r\n", "f %d %d %d\r\n"),
+        "colour": ("v %.17g %.17g %.17g 0.5 0.25 1\n", "f %d %d %d\n"),
+        "slashes": ("v %.17g %.17g %.17g\n", "f %d/1/1 %d//2 %d/3\n"),
+    }
+    for name, (vf, ff) in variants.items():
+        p = tmp_path / (name + ".obj")
+        p.write_text("# c\nmtllib m.mtl\n" + "".join(vf % tuple(x) for x in v) + "vn 0 0 1\n" +
+                     "".join(ff % tuple(t + 1) for t in f))
+        got_v, got_f = read_obj(str(p))
+        assert np.array_equal(got_v, v) and np.array_equal(got_f, f), name
+    quad = tmp_path / "quad.obj"
+    quad.write_text("".join("v %.17g %.17g %.17g\n" % tuple(x) for x in v) + "f 1 2 3 4\nf -1 -2 -3\n")
+    got_v, got_f = read_obj(str(quad))
+    ref_v, ref_f = _read_obj_slow(quad.read_bytes().split(b"\n"))
+    assert np.array_equal(got_v, ref_v) and got_f.tolist() == ref_f.tolist() == [[0, 1, 2], [0, 2, 3], [299, 298, 297]]
+
+
 _WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
