@@ -213,42 +213,66 @@ def orientation_maps_device(images, device=None, gabor=None, return_codes=False)
     return ori, conf
 
 
+def _orientation_arrays(image_u8, gabor, iter=1, threshold=0.0):
+    """gray uint8 image -> (deg uint8 [H,W], conf uint8 [H,W], viz uint8 [H,W,3]) as calculate_orientation writes
+    them; DoG and Gabor bank on the device (the device DoG reproduces scipy's float64 result bit for bit)."""
+    dog = difference_of_gaussians_device(image_u8, 0.4, 10, gabor.device).to(torch.float32)
+    two, best, confidence = gabor(dog[None, None], None, iter, threshold=threshold)
+    deg = torch.round(best[0, 0] / math.pi * 180).clamp(0, 255).to(torch.uint8).cpu().numpy()
+    c8 = (confidence[0, 0] * 255 + 0.5).clamp(0, 255).to(torch.uint8).cpu().numpy()
+    ori = ((two[0].permute(1, 2, 0) + 1) / 2).cpu().numpy()
+    H, W = ori.shape[:2]
+    viz = np.concatenate([np.ones((H, W, 1)), ori], axis=2) * 255          # RGB = (1, sin, cos) as cv2 BGR[::-1]
+    return deg, c8, np.clip(np.round(viz), 0, 255).astype(np.uint8)
+
+
+def _save_orientation_files(save_root, filename, deg, c8, viz):
+    from PIL import Image
+
+    kw = dict(quality=100) if filename.lower().endswith((".jpg", ".jpeg")) else {}
+    Image.fromarray(deg).save(os.path.join(save_root, "best_ori", filename), **kw)
+    Image.fromarray(np.repeat(c8[..., None], 3, axis=2)).save(os.path.join(save_root, "conf", filename))
+    Image.fromarray(viz).save(os.path.join(save_root, "Ori", filename), **kw)
+
+
 def calculate_orientation(image_dir, label_dir, save_root, filename=None, iter=1, threshold=0.0, gabor=None):
     """GaborFilter.py:164-224: gray image -> DoG -> Gabor bank -> best_ori/<file> (uint8 degrees),
     conf/<file> (uint8, x255+0.5, 3 channels), Ori/<file> (colour visualisation)."""
     from PIL import Image
 
-    paths = {}
     for sub in ("Ori", "conf", "best_ori"):
         os.makedirs(os.path.join(save_root, sub), exist_ok=True)
-        paths[sub] = os.path.join(save_root, sub, filename)
     gabor = gabor or calOrientationGabor()
     image = np.array(Image.open(image_dir).convert("L"))
-    image = difference_of_gaussians(image, 0.4, 10)
-    gray = torch.from_numpy(image).type(torch.float)[None, None]
-    two, best, confidence = gabor(gray, None, iter, threshold=threshold)
-    kw = dict(quality=100) if filename.lower().endswith((".jpg", ".jpeg")) else {}
-    deg = torch.round(best[0, 0] / math.pi * 180).clamp(0, 255).to(torch.uint8).cpu().numpy()
-    Image.fromarray(deg).save(paths["best_ori"], **kw)
-    c8 = (confidence[0, 0] * 255 + 0.5).clamp(0, 255).to(torch.uint8).cpu().numpy()
-    Image.fromarray(np.repeat(c8[..., None], 3, axis=2)).save(paths["conf"])
-    ori = ((two[0].permute(1, 2, 0) + 1) / 2).cpu().numpy()
-    H, W = ori.shape[:2]
-    viz = np.concatenate([np.ones((H, W, 1)), ori], axis=2) * 255          # RGB = (1, sin, cos) as cv2 BGR[::-1]
-    Image.fromarray(np.clip(np.round(viz), 0, 255).astype(np.uint8)).save(paths["Ori"], **kw)
+    deg, c8, viz = _orientation_arrays(image, gabor, iter, threshold)
+    _save_orientation_files(save_root, filename, deg, c8, viz)
     return deg, c8
 
 
-def batch_generate(root, image_folder):
+def batch_generate(root, image_folder, io_threads=8):
     """GaborFilter.py:231-237.  With torch.distributed initialised the views are dealt to the ranks (the global
-    maximum in the confidence is per image, so views are independent)."""
+    maximum in the confidence is per image, so views are independent).  Image decoding and the three encodes per
+    view (what the stage spends its time on once the filter takes 2 ms) run on a thread pool around the GPU work."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from PIL import Image
+
     from . import dist as mdist
 
     files = sorted(os.listdir(os.path.join(root, image_folder)))
+    mine = [f for i, f in enumerate(files) if mdist.owner(i) == mdist.rank()]
+    for sub in ("Ori", "conf", "best_ori"):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
     gabor = calOrientationGabor()
-    for i, file in enumerate(files):
-        if mdist.owner(i) != mdist.rank():
-            continue
-        calculate_orientation(os.path.join(root, image_folder, file), os.path.join(root, "hair_mask", file),
-                              save_root=root, filename=file, iter=1, threshold=0.0, gabor=gabor)
+
+    def load(f):
+        return np.array(Image.open(os.path.join(root, image_folder, f)).convert("L"))
+
+    with ThreadPoolExecutor(max(1, io_threads)) as pool:
+        pending = []
+        for f, image in zip(mine, pool.map(load, mine)):          # decoded ahead of the GPU, in order
+            deg, c8, viz = _orientation_arrays(image, gabor)
+            pending.append(pool.submit(_save_orientation_files, root, f, deg, c8, viz))
+        for p in pending:
+            p.result()
     mdist.barrier()
