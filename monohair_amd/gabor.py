@@ -249,7 +249,7 @@ def calculate_orientation(image_dir, label_dir, save_root, filename=None, iter=1
     return deg, c8
 
 
-def batch_generate(root, image_folder, io_threads=8):
+def batch_generate(root, image_folder, io_threads=None):
     """GaborFilter.py:231-237.  With torch.distributed initialised the views are dealt to the ranks (the global
     maximum in the confidence is per image, so views are independent).  Image decoding and the three encodes per
     view (what the stage spends its time on once the filter takes 2 ms) run on a thread pool around the GPU work."""
@@ -268,6 +268,7 @@ def batch_generate(root, image_folder, io_threads=8):
     def load(f):
         return np.array(Image.open(os.path.join(root, image_folder, f)).convert("L"))
 
+    io_threads = min(16, os.cpu_count() or 1) if io_threads is None else io_threads
     with ThreadPoolExecutor(max(1, io_threads)) as pool:
         pending = []
         for f, image in zip(mine, pool.map(load, mine)):          # decoded ahead of the GPU, in order
