@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void mh_gabor_bank_kernel(const float *__restr
 // bank per wave.  Why: the coefficients reach the FMAs through SGPRs (scalar loads, out-of-order return, only
 // lgkmcnt(0) to wait on), ~96 SGPRs are all there is, and with one pixel per lane a loaded SGPR pair feeds one
 // v_pk_fma -- the ~200-cycle scalar latency is exposed twice per tap (PMC: VALU 57 % busy, profiles/
-// r01i_gabor_pmc.txt).  With two pixels per lane every SGPR pair feeds two FMAs, so the same SGPR budget covers
+// r01i_gabor_valu_pmc.txt).  With two pixels per lane every SGPR pair feeds two FMAs, so the same SGPR budget covers
 // twice the cycles.  A pair of waves shares 16x8 pixels: wave A owns orientations 0..95, wave B 96..179.  The
 // exact epilogue survives the split because ATen's cascade sum adds 16-row block sums in order: A carries the
 // chain over blocks 0..5, B hands over its six block sums S6..S11 (each starts from 0, as in the chain), A
