@@ -99,6 +99,18 @@ def main():
     # consecutive iterations are independent chunks of `optimize` (PMVO.py:572-574); like the driver in
     # monohair_amd/pmvo.py they alternate between HIP streams so one chunk's tail overlaps the next one's head
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
+    # set-up, not steps: the per-stream tap-list scratch (1.2 GB each) and the allocator pools of the per-iteration
+    # outputs exist before anything is timed, whatever --warmup is
+    for st in streams:
+        with torch.cuda.stream(st):
+            pm._get_scratch(CHUNK)
+            hold = [torch.empty((V, CHUNK, 2), device=dev), torch.empty((V, CHUNK), device=dev),
+                    torch.empty((V, CHUNK), device=dev), torch.empty((V, CHUNK), device=dev),
+                    torch.empty((20, CHUNK), device=dev), torch.empty((20, CHUNK), device=dev, dtype=torch.int32),
+                    torch.empty((CHUNK, 3), device=dev), torch.empty((CHUNK,), device=dev),
+                    torch.empty((CHUNK,), device=dev, dtype=torch.bool)]
+            del hold
+    torch.cuda.synchronize()
 
     def step(i):
         with torch.cuda.stream(streams[i % len(streams)]):
