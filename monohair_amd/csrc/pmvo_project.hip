@@ -131,10 +131,9 @@ __global__ __launch_bounds__(256) void mh_project_gather_kernel(MhViews vw, cons
             if (idx < cnt) {
                 // streaming (non-temporal) stores: the 176 MB of patch output would otherwise wash the map lines
                 // that neighbouring points re-read out of the XCD's 4 MB L2
-                if (ori_patch) {
-                    __builtin_nontemporal_store(q[k].x, ori_patch + 2 * (obase + idx));
-                    __builtin_nontemporal_store(q[k].y, ori_patch + 2 * (obase + idx) + 1);
-                }
+                if (ori_patch)
+                    __builtin_nontemporal_store(mh_v2f{q[k].x, q[k].y},
+                                                reinterpret_cast<mh_v2f *>(ori_patch) + (obase + idx));
                 if (conf_patch) __builtin_nontemporal_store(mh_clampf(q[k].z, 1e-6f, 1.0f), conf_patch + obase + idx);
             }
         }
