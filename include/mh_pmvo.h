@@ -110,6 +110,19 @@ int mh_refine_loss(mh_ctx *ctx, const float *points, const float *dir /*[N,3]*/,
                    int N, int patch, float conf_threshold, const float *vis, const float *ori_patch,
                    const float *conf_patch, float *loss, uint8_t *high_conf, void *stream);
 
+/* The same loss evaluated straight from the resident maps (no patch tensors): what refine's smoothing loop needs per
+ * chunk (PMVO.py:619-623 calls PMVO.refine, i.e. Compute_Visible_and_Ori + this loss).  Bit-identical to
+ * mh_project_gather + mh_refine_loss. */
+int mh_refine_loss_maps(mh_ctx *ctx, const float *points, const float *dir, float step_mul, float step_div, int N,
+                        int patch, float conf_threshold, float *loss, uint8_t *high_conf, void *stream);
+
+/* The tail of one chunk of refine's smoothing loop (PMVO.py:91-92, 631-642), in place on slices of the global arrays:
+ * update = head_filter && !head_top ? -1 : loss_u;  ori <- center where |cos(center, ori)| < replace_threshold;
+ * loss_out = update == -1 ? 0.5 : update. */
+int mh_refine_combine(mh_ctx *ctx, const float *center, const float *loss_u, const unsigned char *head_filter,
+                      const unsigned char *head_top, float replace_threshold, float *ori /*[N,3] in/out*/,
+                      float *loss_out, int N, void *stream);
+
 /* ---- K13: per-view visibility / mask / confidence votes of PMVO.filter_points (PMVO.py:402-459),
  * PMVO.compute_unvisible_points (:461-480) and PMVO.filter_head_points (:110-137).
  * surface_index/filter_index/unvisible_index/head_filter: uint8 [N]; any may be NULL. */
@@ -119,7 +132,11 @@ int mh_filter_points(mh_ctx *ctx, const float *points, int N, int patch, float c
 
 /* ---- K11: compute_points_similarity (Utils/PMVO_utils.py:366-382): medoid orientation of each group.
  * Dense form: ori[G,K,3] -> out[G,3], out_index[G].  Segmented form (voxel fit, PMVO.py:717-726):
- * ori[M,3] sorted by group, seg_start[G+1] (device), max_group = largest group size (<= 4096). */
+ * ori[M,3] sorted by group, seg_start[G+1] (device), max_group = largest group size (groups beyond 4096 members take a staged path). */
+/* Indexed form: group g = rows index[g*K .. g*K+K) of ori_rows[M,3] (the neighbour lists of refine, PMVO.py:612-618,
+ * without materialising ori[index]). */
+int mh_medoid_indexed(mh_ctx *ctx, const float *ori_rows, const int32_t *index, int G, int K, float *out,
+                      int32_t *out_index, void *stream);
 int mh_medoid_dense(mh_ctx *ctx, const float *ori, int G, int K, float *out, int32_t *out_index, void *stream);
 int mh_medoid_segmented(mh_ctx *ctx, const float *ori, const int32_t *seg_start, int G, int max_group,
                         float *out, int32_t *out_index, void *stream);

@@ -32,6 +32,9 @@ _SIGS = {
     "mh_search_prepared": (ci, [vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mh_refine_loss": (ci, [vp, vp, vp, cf, cf, ci, ci, cf, vp, vp, vp, vp, vp, vp]),
     "mh_filter_points": (ci, [vp, vp, ci, ci, cf, cf, vp, vp, vp, vp, vp]),
+    "mh_medoid_indexed": (ci, [vp, vp, vp, ci, ci, vp, vp, vp]),
+    "mh_refine_loss_maps": (ci, [vp, vp, vp, cf, cf, ci, ci, cf, vp, vp, vp]),
+    "mh_refine_combine": (ci, [vp, vp, vp, vp, vp, cf, vp, vp, ci, vp]),
     "mh_medoid_dense": (ci, [vp, vp, ci, ci, vp, vp, vp]),
     "mh_medoid_segmented": (ci, [vp, vp, vp, ci, ci, vp, vp, vp]),
     "mh_replace_dissimilar": (ci, [vp, vp, vp, cf, ci, vp]),

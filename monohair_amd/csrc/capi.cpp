@@ -60,7 +60,11 @@ int mh_launch_refine_loss(MhViews, const float *, const float *, float, float, i
                           const float *, const float *, float *, uint8_t *, hipStream_t);
 int mh_launch_filter_points(MhViews, const float *, int, int, float, float, uint8_t *, uint8_t *, uint8_t *,
                             uint8_t *, hipStream_t);
-int mh_launch_medoid_dense(const float *, int, int, float *, int32_t *, hipStream_t);
+int mh_launch_medoid_dense(const float *, const int32_t *, int, int, float *, int32_t *, hipStream_t);
+int mh_launch_refine_loss_maps(MhViews, const float *, const float *, float, float, int, int, float, float *, uint8_t *,
+                               hipStream_t);
+int mh_launch_refine_combine(const float *, const float *, const uint8_t *, const uint8_t *, float, float *, float *,
+                             int, hipStream_t);
 int mh_launch_medoid_segmented(const float *, const int32_t *, int, int, float *, int32_t *, hipStream_t);
 int mh_launch_gabor_bank(const float *, const float *, int, int, int32_t *, float *, float *, unsigned int *, int,
                          hipStream_t);
@@ -366,7 +370,38 @@ extern "C" int mh_medoid_dense(mh_ctx *ctx, const float *ori, int G, int K, floa
                                void *stream) {
     if (!ctx || !ori || !out || G < 0 || K < 1) return fail(MH_ERR_ARG, "mh_medoid_dense: bad arguments");
     if (G == 0) return MH_OK;
-    return launched(mh_launch_medoid_dense(ori, G, K, out, out_index, (hipStream_t)stream), "mh_medoid_dense");
+    return launched(mh_launch_medoid_dense(ori, nullptr, G, K, out, out_index, (hipStream_t)stream), "mh_medoid_dense");
+}
+
+extern "C" int mh_medoid_indexed(mh_ctx *ctx, const float *ori_rows, const int32_t *index, int G, int K, float *out,
+                                 int32_t *out_index, void *stream) {
+    if (!ctx || !ori_rows || !index || !out || G < 0 || K < 1) return fail(MH_ERR_ARG, "mh_medoid_indexed: bad arguments");
+    if (G == 0) return MH_OK;
+    return launched(mh_launch_medoid_dense(ori_rows, index, G, K, out, out_index, (hipStream_t)stream),
+                    "mh_medoid_indexed");
+}
+
+extern "C" int mh_refine_loss_maps(mh_ctx *ctx, const float *points, const float *dir, float step_mul, float step_div,
+                                   int N, int patch, float conf_threshold, float *loss, uint8_t *high_conf,
+                                   void *stream) {
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_refine_loss_maps: views not set");
+    if (N == 0) return MH_OK;
+    if (!points || !dir || !loss || N < 0 || patch < 1 || !(patch & 1))
+        return fail(MH_ERR_ARG, "mh_refine_loss_maps: bad arguments");
+    return launched(mh_launch_refine_loss_maps(ctx->views(), points, dir, step_mul, step_div, N, patch, conf_threshold,
+                                               loss, high_conf, (hipStream_t)stream),
+                    "mh_refine_loss_maps");
+}
+
+extern "C" int mh_refine_combine(mh_ctx *ctx, const float *center, const float *loss_u, const uint8_t *head_filter,
+                                 const uint8_t *head_top, float replace_threshold, float *ori, float *loss_out, int N,
+                                 void *stream) {
+    if (N == 0) return MH_OK;
+    if (!ctx || !center || !loss_u || !head_filter || !head_top || !ori || !loss_out || N < 0)
+        return fail(MH_ERR_ARG, "mh_refine_combine: bad arguments");
+    return launched(mh_launch_refine_combine(center, loss_u, head_filter, head_top, replace_threshold, ori, loss_out, N,
+                                             (hipStream_t)stream),
+                    "mh_refine_combine");
 }
 
 extern "C" int mh_medoid_segmented(mh_ctx *ctx, const float *ori, const int32_t *seg_start, int G, int max_group,

@@ -19,7 +19,8 @@ __device__ __forceinline__ bool mh_arg_better(float av, int ai, float bv, int bi
 
 __global__ __launch_bounds__(256) void mh_medoid_kernel(const float *__restrict__ ori,
                                                         const int32_t *__restrict__ seg_start, int K_dense,
-                                                        float *__restrict__ out, int32_t *__restrict__ out_index) {
+                                                        float *__restrict__ out, int32_t *__restrict__ out_index,
+                                                        const int32_t *__restrict__ index) {
     extern __shared__ __attribute__((aligned(16))) float s_u[];   // [K][3] unit vectors (+ reduction scratch)
     __shared__ float s_bv[4];
     __shared__ int s_bi[4];
@@ -28,8 +29,13 @@ __global__ __launch_bounds__(256) void mh_medoid_kernel(const float *__restrict_
     const int K = seg_start ? (seg_start[g + 1] - begin) : K_dense;
     if (K <= 0) return;
     const float *__restrict__ o = ori + (size_t)begin * 3;
+    // dense groups may be given as K row indices into `ori` (the 100 nearest neighbours of refine, PMVO.py:612-618)
+    // instead of a materialised [G,K,3] gather
+    const int32_t *__restrict__ gidx = index ? index + (size_t)g * K_dense : nullptr;
+    auto row_of = [&](int k) -> const float * { return gidx ? ori + (size_t)gidx[k] * 3 : o + 3 * k; };
     auto unit_of = [&](int k, float &u0, float &u1, float &u2) {
-        const float x0 = o[3 * k], x1 = o[3 * k + 1], x2 = o[3 * k + 2];
+        const float *__restrict__ rw = row_of(k);
+        const float x0 = rw[0], x1 = rw[1], x2 = rw[2];
         float s = x0 * x0;
         s = mh_fma(x1, x1, s);
         s = mh_fma(x2, x2, s);
@@ -104,9 +110,10 @@ __global__ __launch_bounds__(256) void mh_medoid_kernel(const float *__restrict_
                 bv = s_bv[w];
                 bi = s_bi[w];
             }
-        out[3 * g] = o[3 * bi];
-        out[3 * g + 1] = o[3 * bi + 1];
-        out[3 * g + 2] = o[3 * bi + 2];
+        const float *__restrict__ rw = row_of(bi);
+        out[3 * g] = rw[0];
+        out[3 * g + 1] = rw[1];
+        out[3 * g + 2] = rw[2];
         if (out_index) out_index[g] = bi;
     }
 }
@@ -150,11 +157,11 @@ extern "C" int mh_launch_replace_dissimilar(const float *center, float *ori, flo
     return (int)hipGetLastError();
 }
 
-extern "C" int mh_launch_medoid_dense(const float *ori, int G, int K, float *out, int32_t *out_index,
+extern "C" int mh_launch_medoid_dense(const float *ori, const int32_t *index, int G, int K, float *out, int32_t *out_index,
                                       hipStream_t st) {
     const int kl = K < MH_MEDOID_MAXK ? K : MH_MEDOID_MAXK;
     hipLaunchKernelGGL(mh_medoid_kernel, dim3(G), dim3(256), (size_t)kl * 3 * sizeof(float), st, ori, nullptr, K, out,
-                       out_index);
+                       out_index, index);
     return (int)hipGetLastError();
 }
 
@@ -162,6 +169,6 @@ extern "C" int mh_launch_medoid_segmented(const float *ori, const int32_t *seg_s
                                           float *out, int32_t *out_index, hipStream_t st) {
     const int kl = max_group < MH_MEDOID_MAXK ? max_group : MH_MEDOID_MAXK;
     hipLaunchKernelGGL(mh_medoid_kernel, dim3(G), dim3(256), (size_t)kl * 3 * sizeof(float), st, ori, seg_start, 0, out,
-                       out_index);
+                       out_index, nullptr);
     return (int)hipGetLastError();
 }

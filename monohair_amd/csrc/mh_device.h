@@ -202,7 +202,6 @@ __device__ __forceinline__ float mh_soft_visible(float depth, float z255) {
     return mh_clampf(vis, -1.0f, 1.0f);
 }
 
-// ATen cascade sum over the view axis (valid for V < 256): 16-view blocks, then the block sums.
 // ATen's cascade sum over the leading (view) dimension of a [V, ...] tensor (multi_row_sum, level_power 4): 16 rows
 // into level 0, level 0 into level 1 after every full block, level 1 into level 2 every 256 rows; the remainder
 // rows stay in level 0 and the levels are added in order at the end.  Exact for V < 4096.

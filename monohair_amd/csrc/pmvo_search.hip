@@ -403,6 +403,134 @@ __global__ __launch_bounds__(256) void mh_refine_loss_kernel(MhViews vw, const f
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same loss straight from the maps (refine's smoothing loop, PMVO.py:602-650, calls PMVO.refine once per 5000-point
+// chunk): projection, visibility and the patch of every view that sees the point are evaluated in the kernel, the
+// [V,N,P,..] patch tensors (365 MB per chunk at the headline size) are never written.  Per (view, point) the
+// operations are those of mh_project_gather_kernel followed by mh_refine_loss_kernel, in the same order, so the
+// result is bit-identical to the two-kernel path; views that do not see the point have weight 0 (PMVO.py:212) and
+// are skipped, as in mh_search_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int PATCH>
+__global__ __launch_bounds__(256) void mh_refine_loss_maps_kernel(MhViews vw, const float *__restrict__ pts,
+                                                                  const float *__restrict__ dir, float mul, float dv,
+                                                                  int N, float thr, float *__restrict__ loss,
+                                                                  uint8_t *__restrict__ hcout) {
+    constexpr int P = PATCH * PATCH, HP = PATCH / 2;
+    __shared__ float s_num[4][MH_REFINE_VMAX], s_den[4][MH_REFINE_VMAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    const int V = vw.V, H = vw.H, W = vw.W;
+    const float Hf = (float)H, Wf = (float)W;
+    const float P0 = pts[3 * n], P1 = pts[3 * n + 1], P2 = pts[3 * n + 2];
+    const float Q0 = P0 + dir[3 * n] * mul / dv, Q1 = P1 + dir[3 * n + 1] * mul / dv,
+                Q2 = P2 + dir[3 * n + 2] * mul / dv;
+    for (int v = lane; v < V; v += MH_WAVE) {
+        const float *cam = vw.cams + v * MH_CAM_STRIDE;
+        float u, w, z, r0, c0;
+        mh_cam_project(cam, P0, P1, P2, u, w, z);
+        mh_ndc_to_pixel(u, w, Hf, Wf, r0, c0);
+        float cr = __builtin_rintf(c0), rr = __builtin_rintf(r0);
+        const bool oob = !(cr <= (float)(W - 1)) || (cr < 0.0f) || !(rr <= (float)(H - 1)) || (rr < 0.0f);
+        cr = fminf(fmaxf(cr, 0.0f), (float)(W - 1));
+        rr = fminf(fmaxf(rr, 0.0f), (float)(H - 1));
+        const int r = (int)rr, c = (int)cr;
+        const float4 *__restrict__ rec = vw.rec + (size_t)v * H * W;
+        const float4 q = rec[(size_t)r * W + c];
+        const float visv = oob ? -1.0f : mh_soft_visible(q.w, (-z / 2.0f) * 255.0f);
+        float numv = 0.0f, denv = 0.0f;
+        if (visv != -1.0f) {
+            float r1, c1, dx, dy;
+            mh_pixel_of(cam, Q0, Q1, Q2, Hf, Wf, r1, c1);
+            mh_unit2(r1 - r0, c1 - c0, dx, dy);
+            // pass 1: the patch maximum of the clamped confidences (PMVO.py:162); pass 2: the masked minimum
+            float cmax = 0.0f;
+#pragma unroll 1
+            for (int p = 0; p < P; ++p) {
+                const int i = p / PATCH - HP, j = p - (p / PATCH) * PATCH - HP;
+                const int r2 = min(max(r + i, 0), H - 1), c2 = min(max(c + j, 0), W - 1);
+                const float cf = mh_clampf(rec[(size_t)r2 * W + c2].z, 1e-6f, 1.0f);
+                cmax = (p == 0 || cf > cmax) ? cf : cmax;
+            }
+            const bool hc = cmax > thr;
+            float ml = 0.f, bc = 0.f;
+#pragma unroll 1
+            for (int p = 0; p < P; ++p) {
+                const int i = p / PATCH - HP, j = p - (p / PATCH) * PATCH - HP;
+                const int r2 = min(max(r + i, 0), H - 1), c2 = min(max(c + j, 0), W - 1);
+                const float4 t = rec[(size_t)r2 * W + c2];
+                float o0, o1;
+                mh_unit2(t.x, t.y, o0, o1);
+                const float cs = o0 * dx + o1 * dy;
+                const float l = 1.0f - __builtin_fabsf(cs);
+                const float cf = mh_clampf(t.z, 1e-6f, 1.0f);
+                const bool upd = (p == 0) || ((l < ml) && (hc ? (cf > thr) : true));
+                ml = upd ? l : ml;
+                bc = upd ? cf : bc;
+            }
+            numv = ml * bc;
+            denv = bc;
+        }
+        s_num[wave][v] = numv;
+        s_den[wave][v] = denv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        MhCascV nm = {0.f, 0.f, 0.f}, dn = {0.f, 0.f, 0.f};
+        int cnt = 0;
+        for (int v = 0; v < V; ++v) {
+            if (v > 0 && (v & 15) == 0) {
+                mh_cascv_flush(nm, v);
+                mh_cascv_flush(dn, v);
+            }
+            const float w = s_den[wave][v];
+            nm.a0 = nm.a0 + s_num[wave][v];
+            dn.a0 = dn.a0 + w;
+            cnt += (w > 0.0f) ? 1 : 0;
+        }
+        const float d = mh_cascv_done(dn);
+        loss[n] = mh_cascv_done(nm) / d;
+        if (hcout) hcout[n] = (d / (float)cnt > thr) ? 1 : 0;
+    }
+}
+
+// loss[n] <- -1 where the head filter fires (PMVO.py:91-92), the replacement rule of the smoothing loop on the
+// orientations in place (:631-636, as mh_replace_dissimilar_kernel), and loss -1 -> 0.5 (:641-642) into loss_out
+__global__ __launch_bounds__(256) void mh_refine_combine_kernel(const float *__restrict__ center,
+                                                                const float *__restrict__ loss_u,
+                                                                const uint8_t *__restrict__ head,
+                                                                const uint8_t *__restrict__ head_top, float thr,
+                                                                float *__restrict__ ori, float *__restrict__ loss_out,
+                                                                int N) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const bool filt = head[n] && !head_top[n];
+    const float ul = filt ? -1.0f : loss_u[n];
+    float c[3], o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        c[k] = center[3 * n + k];
+        o[k] = ori[3 * n + k];
+    }
+    float sc = c[0] * c[0];
+    sc = mh_fma(c[1], c[1], sc);
+    sc = mh_fma(c[2], c[2], sc);
+    float so = o[0] * o[0];
+    so = mh_fma(o[1], o[1], so);
+    so = mh_fma(o[2], o[2], so);
+    float nc = __builtin_sqrtf(sc), no = __builtin_sqrtf(so);
+    nc = (nc < 1e-8f) ? 1e-8f : nc;
+    no = (no < 1e-8f) ? 1e-8f : no;
+    const float cs = ((c[0] / nc) * (o[0] / no) + (c[1] / nc) * (o[1] / no)) + (c[2] / nc) * (o[2] / no);
+    if (__builtin_fabsf(cs) < thr) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) ori[3 * n + k] = c[k];
+    }
+    loss_out[n] = (ul == -1.0f) ? 0.5f : ul;
+}
+
+// ---------------------------------------------------------------------------------------------
 extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank, int rank_step, const float *pts,
                                 int N, int P1, float thr, const float *ori_c, const int32_t *base_idx,
                                 const float *base_val, const float4 *taps, float *line_ori, float *min_loss,
@@ -444,6 +572,36 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
     }
 #undef MH_SEARCH_LAUNCH
 #undef MH_SEARCH_LAUNCH_F
+    return (int)hipGetLastError();
+}
+
+extern "C" int mh_launch_refine_loss_maps(MhViews vw, const float *pts, const float *dir, float mul, float dv, int N,
+                                         int patch, float thr, float *loss, uint8_t *hc, hipStream_t st) {
+    if (vw.V > MH_REFINE_VMAX) return -1;
+    const dim3 grid((N + 3) / 4), block(256);
+#define MH_RM_CASE(PS)                                                                                               \
+    case PS:                                                                                                         \
+        hipLaunchKernelGGL(mh_refine_loss_maps_kernel<PS>, grid, block, 0, st, vw, pts, dir, mul, dv, N, thr, loss, hc); \
+        break;
+    switch (patch) {
+        MH_RM_CASE(1)
+        MH_RM_CASE(3)
+        MH_RM_CASE(5)
+        MH_RM_CASE(7)
+        MH_RM_CASE(9)
+        MH_RM_CASE(11)
+        default:
+            return -1;
+    }
+#undef MH_RM_CASE
+    return (int)hipGetLastError();
+}
+
+extern "C" int mh_launch_refine_combine(const float *center, const float *loss_u, const uint8_t *head,
+                                        const uint8_t *head_top, float thr, float *ori, float *loss_out, int N,
+                                        hipStream_t st) {
+    hipLaunchKernelGGL(mh_refine_combine_kernel, dim3((N + 255) / 256), dim3(256), 0, st, center, loss_u, head,
+                       head_top, thr, ori, loss_out, N);
     return (int)hipGetLastError();
 }
 

@@ -438,7 +438,7 @@ def optimize(points, pmvo, args):
     return select_points, select_ori, min_loss, high_conf_index
 
 
-def _knn(data_points, query_points, k, device, mode="device"):
+def _knn(data_points, query_points, k, device, mode="device", int32=False):
     """The `KDTree(data).query(queries, k)` of refine (PMVO.py:605,612,660,671) -> index [Q,k] int64 tensor on `device`.
     mode "device": exact grid k-NN kernel (csrc/knn.hip, scipy's result and order); "host": scipy on all cores.
     scipy returns index n for missing neighbours when k > n (the reference would raise on ori[index]); k is clamped."""
@@ -446,11 +446,12 @@ def _knn(data_points, query_points, k, device, mode="device"):
     if mode == "device":
         from .pmvo_utils import GridKNN
 
-        return GridKNN(data_points, k_hint=k, device=device).query(query_points, k)
+        return GridKNN(data_points, k_hint=k, device=device).query(query_points, k, int32=int32)
     from scipy.spatial import KDTree
 
     _, index = KDTree(data=data_points).query(query_points, k, workers=-1)
-    return torch.from_numpy(np.asarray(index).reshape(len(query_points), k)).to(device)
+    index = np.asarray(index).reshape(len(query_points), k)
+    return torch.from_numpy(index.astype(np.int32) if int32 else index).to(device)
 
 
 def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=True, threshold=0.001,
@@ -476,23 +477,39 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         # PMVO.py:614,640) runs entirely on the device, stream-ordered, without a host round trip per chunk.
         n_all = points.shape[0]
         with stage("refine: knn (surface)", device):
-            index_all = _knn(points, points, 100, device, getattr(args, "knn", "device"))
+            index_all = _knn(points, points, 100, device, getattr(args, "knn", "device"), int32=True).contiguous()
         with stage("refine: head-top mask", device):
-            head_top_all = torch.from_numpy(pmvo.head_top_mask(points)).to(device)
+            head_top_all = torch.from_numpy(pmvo.head_top_mask(points).astype(np.uint8)).to(device)
         T_loop = stage("refine: smoothing loop", device).__enter__()
-        pts_dev = torch.from_numpy(points).to(device).type(torch.float)
+        pts_dev = torch.from_numpy(points).to(device).type(torch.float).contiguous()
         ori_dev = torch.from_numpy(ori).to(device).type(torch.float).contiguous()
         loss_dev = torch.from_numpy(loss).to(device).type(torch.float).contiguous()
         sub_num = 5000
         step = n_all // sub_num + 1
+        # per chunk four launches and no tensor op: medoid over the neighbour rows, the loss of that direction straight
+        # from the maps, the head-filter votes, and the tail (-1 / replacement / 0.5) in place
+        K = index_all.shape[1]
+        center = torch.empty((sub_num, 3), dtype=torch.float32, device=device)
+        loss_u = torch.empty((sub_num,), dtype=torch.float32, device=device)
+        head = torch.empty((sub_num,), dtype=torch.uint8, device=device)
+        L, ctx, st = pmvo._L, pmvo._ctx, _lib.stream_ptr()
+        off = lambda t, row, width=1: ctypes.c_void_p(t.data_ptr() + row * width * t.element_size())   # noqa: E731
         for i in range(step):
             lo, hi = i * sub_num, min((i + 1) * sub_num, n_all)
-            if hi <= lo:
+            n = hi - lo
+            if n <= 0:
                 continue
-            center_ori = U.compute_points_similarity(ori_dev[index_all[lo:hi]])
-            update_loss = pmvo.refine(pts_dev[lo:hi], center_ori, head_top=head_top_all[lo:hi])
-            pmvo.replace_dissimilar(center_ori, ori_dev[lo:hi], 0.95)       # in place (a contiguous row slice)
-            loss_dev[lo:hi] = torch.where(update_loss == -1, torch.full_like(update_loss, 0.5), update_loss)
+            _lib.check(L.mh_medoid_indexed(ctx, _lib.ptr(ori_dev), off(index_all, lo, K), n, K, _lib.ptr(center), None,
+                                           st), "mh_medoid_indexed")
+            _lib.check(L.mh_refine_loss_maps(ctx, off(pts_dev, lo, 3), _lib.ptr(center), 0.005, 4.0, n,
+                                             pmvo.patch_size, float(pmvo.conf_threshold), _lib.ptr(loss_u), None, st),
+                       "mh_refine_loss_maps")
+            _lib.check(L.mh_filter_points(ctx, off(pts_dev, lo, 3), n, pmvo.patch_size, float(pmvo.conf_threshold),
+                                          float(pmvo.visible_threshold), None, None, None, _lib.ptr(head), st),
+                       "mh_filter_points")
+            _lib.check(L.mh_refine_combine(ctx, _lib.ptr(center), _lib.ptr(loss_u), _lib.ptr(head),
+                                           off(head_top_all, lo), 0.95, off(ori_dev, lo, 3), off(loss_dev, lo), n, st),
+                       "mh_refine_combine")
         ori[:] = ori_dev.cpu().numpy()
         loss[:] = loss_dev.cpu().numpy()
         T_loop.__exit__()
@@ -511,33 +528,30 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     select_points = points[index]
 
     # orientation of the occluded shell points from their 100 nearest kept neighbours (PMVO.py:662-686)
-    sub_num = 5000
-    step = filter_unvisible_points.shape[0] // sub_num + 1
-    f_ori, f_pts = [], []
     print("compute points orientation near the surface... ")
     T_shell = stage("refine: shell points", device).__enter__()
+    filter_unvisible_ori = np.zeros((0, 3), np.float32)
+    select_filter_unvisible_points = np.zeros((0, 3), np.float32)
     if len(select_points) and len(filter_unvisible_points):
         fu = np.ascontiguousarray(filter_unvisible_points)
         with stage("refine: knn (shell)", device):
-            index_all = _knn(select_points, fu, 100, device, getattr(args, "knn", "device"))
-        head_top_all = torch.from_numpy(pmvo.head_top_mask(fu.astype(np.float32))).to(device)
-        fu_dev = torch.from_numpy(fu).type(torch.float).to(device)
-        sel_ori_dev = torch.from_numpy(select_ori).to(device)
-        for i in range(step):
-            lo, hi = i * sub_num, min((i + 1) * sub_num, fu.shape[0])
-            if hi <= lo:
-                continue
-            filter_index = pmvo.filter_head_points(fu_dev[lo:hi], args.PMVO.visible_threshold,
-                                                   head_top=head_top_all[lo:hi])
-            center_ori = U.compute_points_similarity(sel_ori_dev[index_all[lo:hi]])
-            f_ori.append(center_ori[~filter_index])
-            f_pts.append(fu_dev[lo:hi][~filter_index])
-    if f_ori:
-        filter_unvisible_ori = torch.cat(f_ori, 0).cpu().numpy()
-        select_filter_unvisible_points = torch.cat(f_pts, 0).cpu().numpy()
-    else:
-        filter_unvisible_ori = np.zeros((0, 3), np.float32)
-        select_filter_unvisible_points = np.zeros((0, 3), np.float32)
+            index_all = _knn(select_points, fu, 100, device, getattr(args, "knn", "device"), int32=True).contiguous()
+        head_top = pmvo.head_top_mask(fu.astype(np.float32))
+        fu_dev = torch.from_numpy(fu).type(torch.float).to(device).contiguous()
+        sel_ori_dev = torch.from_numpy(select_ori).to(device).type(torch.float).contiguous()
+        F, K = index_all.shape
+        center = torch.empty((F, 3), dtype=torch.float32, device=device)
+        head = torch.empty((F,), dtype=torch.uint8, device=device)
+        # the points are independent here: one medoid launch and one vote launch for all of them (the reference's
+        # 5000-point chunks only bound its memory)
+        _lib.check(pmvo._L.mh_medoid_indexed(pmvo._ctx, _lib.ptr(sel_ori_dev), _lib.ptr(index_all), F, K,
+                                             _lib.ptr(center), None, _lib.stream_ptr()), "mh_medoid_indexed")
+        _lib.check(pmvo._L.mh_filter_points(pmvo._ctx, _lib.ptr(fu_dev), F, pmvo.patch_size,
+                                            float(pmvo.conf_threshold), float(args.PMVO.visible_threshold), None, None,
+                                            None, _lib.ptr(head), _lib.stream_ptr()), "mh_filter_points")
+        keep = ~np.logical_and(head.cpu().numpy().astype(bool), ~head_top)     # not filter_head_points
+        filter_unvisible_ori = center.cpu().numpy()[keep]
+        select_filter_unvisible_points = fu_dev.cpu().numpy()[keep]
     T_shell.__exit__()
     if is_root:
         np.save(args.output_path + "/refine/filter_unvisible.npy", select_filter_unvisible_points)

@@ -330,10 +330,11 @@ class GridKNN:
                                               dims.ctypes.data_as(ctypes.c_void_p), _lib.ptr(pts), _lib.ptr(order),
                                               _lib.ptr(start), _lib.ptr(q), Q, k, _lib.ptr(out), _lib.ptr(status),
                                               _lib.stream_ptr()), "mh_knn_grid")
-        return out.long(), status
+        return out, status
 
-    def query(self, queries, k):
-        """-> index [Q,k] int64 device tensor (k clamped to the number of points, like the drivers do)."""
+    def query(self, queries, k, int32=False):
+        """-> index [Q,k] device tensor, int64 (or int32 as the kernel writes it); k clamped to the number of points,
+        like the drivers do."""
         k = min(int(k), self.M)
         q = torch.from_numpy(np.ascontiguousarray(queries).astype(np.float32)).to(self.device).contiguous()
         out, status = self._run(self.h, q, k)
@@ -359,8 +360,8 @@ class GridKNN:
             for i in left.tolist():
                 d = p64 - q[i].to(torch.float64)
                 d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
-                out[i] = torch.sort(d2, stable=True).indices[:k]
-        return out
+                out[i] = torch.sort(d2, stable=True).indices[:k].to(torch.int32)
+        return out if int32 else out.long()
 
 
 def p2v(points, voxel_min, voxel_size, grid_resolution):
