@@ -259,3 +259,47 @@ def test_gabor_to_pmvo_device_handoff_equals_file_roundtrip(tmp_path):
         assert np.array_equal(ori[v].cpu().numpy(), Ori["v%d" % v].astype(np.float32))
         assert np.array_equal(conf[v].cpu().numpy(), Conf["v%d" % v].astype(np.float32))
     assert ori.shape == (V, H, W, 2) and float(conf.max()) == 1.0
+
+
+@pytest.mark.parametrize("patch", [1, 3, 7, 11])
+def test_refine_chunk_kernels_equal_the_unfused_path(patch):
+    """mh_refine_loss_maps == mh_project_gather + mh_refine_loss, mh_medoid_indexed == the medoid of the gathered
+    rows, mh_refine_combine == the tensor ops of the smoothing loop (PMVO.py:91-92, 631-642) -- bit for bit."""
+    import ctypes
+
+    from monohair_amd import _lib, synth
+    from monohair_amd.camera import camera_records, cameras_from_list
+    from monohair_amd.pmvo import PMVO
+    from monohair_amd.pmvo_utils import compute_points_similarity
+
+    V, H, W, N, K = 40, 150, 110, 700, 37
+    scene = synth.make_scene(V, H, W, seed=6, quantize=True, rings=2)
+    pm = PMVO.from_planes(camera_records(cameras_from_list(scene["cams"])), scene["depth"].to(DEV), scene["ori"].to(DEV),
+                          scene["conf"].to(DEV), scene["mask"].to(DEV), device=DEV, patch_size=patch, conf_threshold=0.15)
+    g = torch.Generator().manual_seed(patch)
+    pts = torch.from_numpy(synth.candidate_points(res=32, seed=patch)[:N]).float().to(DEV)
+    ori_all = torch.randn((N, 3), generator=g).to(DEV)
+    index = torch.randint(0, N, (N, K), generator=g, dtype=torch.int32).to(DEV)
+    L, st = pm._L, _lib.stream_ptr()
+    center = torch.empty((N, 3), device=DEV)
+    _lib.check(L.mh_medoid_indexed(pm._ctx, _lib.ptr(ori_all), _lib.ptr(index), N, K, _lib.ptr(center), None, st))
+    assert torch.equal(center, compute_points_similarity(ori_all[index.long()]))
+    loss_f = torch.empty((N,), device=DEV)
+    hc_f = torch.empty((N,), dtype=torch.uint8, device=DEV)
+    _lib.check(L.mh_refine_loss_maps(pm._ctx, _lib.ptr(pts), _lib.ptr(center), 0.005, 4.0, N, patch, 0.15,
+                                     _lib.ptr(loss_f), _lib.ptr(hc_f), st))
+    pm.Compute_Visible_and_Ori(pts)
+    loss_u, hc_u = pm.prj_loss_of(pm._points, center)
+    same = (loss_f == loss_u) | (torch.isnan(loss_f) & torch.isnan(loss_u))
+    assert bool(same.all()) and torch.equal(hc_f.bool(), hc_u) and bool(torch.isfinite(loss_u).any())
+    head = (torch.rand((N,), generator=g) < 0.3).to(torch.uint8).to(DEV)
+    head_top = (torch.rand((N,), generator=g) < 0.5).to(torch.uint8).to(DEV)
+    ori_new, loss_out = ori_all.clone(), torch.empty((N,), device=DEV)
+    _lib.check(L.mh_refine_combine(pm._ctx, _lib.ptr(center), _lib.ptr(loss_u), _lib.ptr(head), _lib.ptr(head_top), 0.95,
+                                   _lib.ptr(ori_new), _lib.ptr(loss_out), N, st))
+    upd = torch.where(head.bool() & ~head_top.bool(), torch.full_like(loss_u, -1.0), loss_u)
+    want_loss = torch.where(upd == -1, torch.full_like(upd, 0.5), upd)
+    want_ori = ori_all.clone()
+    pm.replace_dissimilar(center, want_ori, 0.95)
+    assert torch.equal(ori_new, want_ori)
+    assert bool(((loss_out == want_loss) | (torch.isnan(loss_out) & torch.isnan(want_loss))).all())
