@@ -98,7 +98,7 @@ def main():
 
     # consecutive iterations are independent chunks of `optimize` (PMVO.py:572-574); like the driver in
     # monohair_amd/pmvo.py they alternate between HIP streams so one chunk's tail overlaps the next one's head
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
+    streams = pm.side_streams(max(1, a.streams))
     # set-up, not steps: the per-stream tap-list scratch (1.2 GB each) and the allocator pools of the per-iteration
     # outputs exist before anything is timed, whatever --warmup is
     for st in streams:

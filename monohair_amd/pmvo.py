@@ -227,6 +227,12 @@ class PMVO:
         idx, val = self._topk32()
         return idx.long(), val
 
+    def side_streams(self, n=2):
+        """n HIP streams owned by this object (created once; the per-stream search scratch is keyed by them)."""
+        if len(getattr(self, "_side_streams", [])) < n:
+            self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(n)]
+        return self._side_streams[:n]
+
     def _get_scratch(self, N):
         """Tap-list scratch of the search, one buffer per launch stream (chunks of `optimize` are independent and
         may be in flight on different streams)."""
@@ -404,7 +410,7 @@ def optimize(points, pmvo, args):
 
     # consecutive chunks are independent: alternate two HIP streams so that the tail of one chunk's search
     # kernel (workgroups of points that see many views) overlaps the head of the next chunk
-    streams = [torch.cuda.Stream(device=pmvo.device) for _ in range(2)]
+    streams = pmvo.side_streams(2)     # kept on the object: their tap-list scratch (1.2 GB each) is reused
     counter = [0]
     main = torch.cuda.current_stream()
     for st in streams:
