@@ -1,3 +1,6 @@
+#!/usr/bin/env python
+"""Stage timers of refine() at the headline size (two passes in one process: the first includes every one-time cost,
+the second is steady state).  python tools/refine_stages.py"""
 import os, sys, tempfile, time, types
 os.environ["MH_TIMING"] = "1"
 import numpy as np, torch
