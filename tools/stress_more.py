@@ -29,7 +29,7 @@ a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 DEV = "cuda:0"
 t_end = time.time() + a.minutes * 60
-count = {"knn": 0, "raster": 0, "gabor": 0, "medoid": 0, "voxel_fit": 0}
+count = {"knn": 0, "raster": 0, "gabor": 0, "medoid": 0, "voxel_fit": 0, "trace": 0}
 bad = []
 gabs = {v: calOrientationGabor(device=DEV, variant=v) for v in ("valu", "mfma", "split")}
 bank = gabor_bank()
@@ -107,5 +107,38 @@ while time.time() < t_end:
     if not (np.array_equal(res["occ"], occ) and np.array_equal(res["ori_dense"].astype(np.float32), ori_d.astype(np.float32))):
         bad.append(("voxel_fit", n))
     count["voxel_fit"] += 1
+    # ---- strand tracing on a random smooth-ish volume
+    Z, Hh, Ww = int(rng.integers(8, 40)), int(rng.integers(8, 48)), int(rng.integers(8, 48))
+    occ = (rng.random((Z, Hh, Ww)) < rng.uniform(0.05, 0.6)).astype(np.float32)
+    base = rng.normal(size=3)
+    ori = (base + rng.normal(0, rng.uniform(0.05, 1.0), (Z, Hh, Ww, 3))).astype(np.float32)
+    ori /= np.maximum(np.linalg.norm(ori, axis=-1, keepdims=True), 1e-6)
+    ori *= occ[..., None]
+    from monohair_amd.hairgrow import HairGrowing
+
+    hg = HairGrowing(None, None, device=DEV, occ=occ[..., None], ori=ori)
+    vol = oracle.Volume(occ, ori)
+    nz = np.argwhere(vol.vox[..., 3] != 0)
+    if len(nz):
+        seeds = (nz[rng.choice(len(nz), min(len(nz), 400), replace=False)][:, ::-1] + rng.random((min(len(nz), 400), 3))).astype(np.float32)
+        thr = float(rng.choice([0.5, 0.8, 0.95]))
+        out, first, ln = hg._trace_seeds(torch.from_numpy(seeds).to(DEV), thr)
+        o_out, o_first, o_ln = oracle.trace_seeds(vol, seeds, thr)
+        ok = np.array_equal(first.cpu().numpy(), o_first) and np.array_equal(ln.cpu().numpy(), o_ln)
+        if ok:
+            out = out.cpu().numpy()
+            ok = all(np.array_equal(out[i, o_first[i]:o_first[i] + o_ln[i]], o_out[i, o_first[i]:o_first[i] + o_ln[i]])
+                     for i in range(len(seeds)))
+        nrm = rng.normal(size=seeds.shape).astype(np.float32)
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        sp, sl = hg._trace_scalp(torch.from_numpy(seeds).to(DEV), torch.from_numpy(nrm).to(DEV), thr)
+        o_sp, o_sl = oracle.trace_scalp(vol, seeds, nrm, thr)
+        ok = ok and np.array_equal(sl.cpu().numpy(), o_sl)
+        if ok:
+            sp = sp.cpu().numpy()
+            ok = all(np.array_equal(sp[i, :o_sl[i]], o_sp[i, :o_sl[i]]) for i in range(len(o_sl)))
+        if not ok:
+            bad.append(("trace", Z, Hh, Ww, thr))
+    count["trace"] += 1
 print({"rounds": count, "mismatching_cases": len(bad), "first": bad[:6]})
 sys.exit(1 if bad else 0)
