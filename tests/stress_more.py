@@ -2,7 +2,7 @@
 """Randomised sweeps of the other kernels against their checkers (GPU box):
   k-NN grid search vs scipy.spatial.KDTree, depth rasteriser / Gabor bank (all variants) / medoid / voxel fit vs the
   CPU oracle.  Every comparison is for exact equality.
-    python tools/stress_more.py --minutes 5 [--seed 0]
+    python tests/stress_more.py --minutes 5 [--seed 0]
 """
 import argparse
 import os

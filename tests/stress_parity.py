@@ -2,7 +2,7 @@
 """Randomised HIP-vs-oracle parity sweep (GPU box): many scenes with random camera counts / image sizes / patch sizes /
 thresholds / map quantisation / point sets, every result compared bit for bit with the CPU oracle.
 
-    python tools/stress_parity.py --minutes 5 [--seed 0]
+    python tests/stress_parity.py --minutes 5 [--seed 0]
 """
 import argparse
 import os
