@@ -50,3 +50,11 @@ def test_no_gpu_means_loud_failure():
         pytest.skip("GPU present")
     with pytest.raises(_lib.MhError):
         pmvo.PMVO({}, {}, {}, {}, {}, device="cuda:0", image_size=[8, 8])
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md maps each C entry point to the reference code it replaces: keep it complete."""
+    from monohair_amd import _lib
+
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert [n for n in _lib.EXPORTS if n not in doc] == []
