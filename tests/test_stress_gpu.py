@@ -1,0 +1,19 @@
+"""GPU: a short, fixed-seed run of the randomised sweeps (tests/stress_parity.py, tests/stress_more.py; run them for
+minutes with other seeds when kernels change)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("script,seed", [("stress_parity.py", 5), ("stress_more.py", 6)])
+def test_short_sweep(script, seed):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", script), "--minutes", "0.2", "--seed", str(seed)],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "'mismatching_cases': 0" in r.stdout
