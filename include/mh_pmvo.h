@@ -123,6 +123,30 @@ int mh_refine_combine(mh_ctx *ctx, const float *center, const float *loss_u, con
                       const unsigned char *head_top, float replace_threshold, float *ori /*[N,3] in/out*/,
                       float *loss_out, int N, void *stream);
 
+/* ---- the intermediate methods of the reference's class PMVO as stand-alone calls (the fused path above does not need
+ * them; they keep the class's method surface): project_points (PMVO.py:378-397) for resident view `view`: row_col
+ * int32 [N,2] rounded+clamped, z_half = -z/2, out_of_image flags, unrounded (row, col); any output may be NULL. */
+int mh_project_points(mh_ctx *ctx, int view, const float *points, int N, int32_t *row_col, float *z_half,
+                      unsigned char *out_of_image, float *pixel_unrounded, void *stream);
+/* get_depth / get_ori / get_conf / get_mask / get_ori_patch / get_c_patch (PMVO.py:482-523): the resident records
+ * {ori_row, ori_col, conf, depth} [N, size*size, 4] and mask [N, size*size] of view `view` at row_col (int64 [N,2]),
+ * taps clamped to the image one by one, row offset outer. */
+int mh_gather_pixels(mh_ctx *ctx, int view, const long long *row_col, int N, int size, float *records, float *mask,
+                     void *stream);
+/* compute_visible (PMVO.py:525-529), elementwise. */
+int mh_compute_visible(mh_ctx *ctx, const float *depth, const float *z, size_t n, float *out, void *stream);
+/* sample_next_3d_pos (PMVO.py:263-335): samples [N,S,3] for base_view [N]; ori = the [V,N,2] centre orientations of
+ * Compute_Visible_and_Ori; offsets [S] on the device. */
+int mh_sample_next(mh_ctx *ctx, const float *points, const int32_t *base_view, const float *ori, const float *offsets,
+                   int N, int S, float *samples, void *stream);
+/* compute_reproject_ori / compute_points_prj_ori (PMVO.py:219-260): D [V,N,S,2] = pixel(sample) - pixel(point). */
+int mh_reproject_ori(mh_ctx *ctx, const float *points, const float *samples, int N, int S, float *D, void *stream);
+/* compute_prj_loss (PMVO.py:151-209) on materialised tensors: loss [N], index int64 [N], high_conf [N];
+ * all_loss [N,S] (the per-sample losses after the positive / low-confidence rules) may be NULL. */
+int mh_prj_loss(mh_ctx *ctx, const float *D, const float *ori_patch, const float *conf_patch, const float *vis, int V,
+                int N, int S, int P, float conf_threshold, float *loss, long long *index, unsigned char *high_conf,
+                float *all_loss, void *stream);
+
 /* ---- K13: per-view visibility / mask / confidence votes of PMVO.filter_points (PMVO.py:402-459),
  * PMVO.compute_unvisible_points (:461-480) and PMVO.filter_head_points (:110-137).
  * surface_index/filter_index/unvisible_index/head_filter: uint8 [N]; any may be NULL. */

@@ -32,6 +32,12 @@ _SIGS = {
     "mh_search_prepared": (ci, [vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mh_refine_loss": (ci, [vp, vp, vp, cf, cf, ci, ci, cf, vp, vp, vp, vp, vp, vp]),
     "mh_filter_points": (ci, [vp, vp, ci, ci, cf, cf, vp, vp, vp, vp, vp]),
+    "mh_project_points": (ci, [vp, ci, vp, ci, vp, vp, vp, vp, vp]),
+    "mh_gather_pixels": (ci, [vp, ci, vp, ci, ci, vp, vp, vp]),
+    "mh_compute_visible": (ci, [vp, vp, vp, csz, vp, vp]),
+    "mh_sample_next": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp]),
+    "mh_reproject_ori": (ci, [vp, vp, vp, ci, ci, vp, vp]),
+    "mh_prj_loss": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp, vp, vp]),
     "mh_medoid_indexed": (ci, [vp, vp, vp, ci, ci, vp, vp, vp]),
     "mh_refine_loss_maps": (ci, [vp, vp, vp, cf, cf, ci, ci, cf, vp, vp, vp]),
     "mh_refine_combine": (ci, [vp, vp, vp, vp, vp, cf, vp, vp, ci, vp]),

@@ -46,6 +46,15 @@ int mh_launch_grid_build(const float *, int, float, float, float, float, int, in
                          int32_t *, int32_t *, int32_t *, hipStream_t);
 int mh_launch_sort_keys(const unsigned long long *, int, int, void *, size_t, unsigned long long *, int32_t *,
                         hipStream_t);
+int mh_launch_project_points(const float *, const float *, int, int, int, int32_t *, float *, uint8_t *, float *,
+                             hipStream_t);
+int mh_launch_gather(MhViews, int, const long long *, int, int, float4 *, float *, hipStream_t);
+int mh_launch_compute_visible(const float *, const float *, size_t, float *, hipStream_t);
+int mh_launch_sample_next(MhViews, const float *, const int32_t *, const float *, const float *, int, int, float *,
+                          hipStream_t);
+int mh_launch_reproject(MhViews, const float *, const float *, int, int, float *, hipStream_t);
+int mh_launch_prj_loss(const float *, const float *, const float *, const float *, int, int, int, int, float, float *,
+                       long long *, uint8_t *, float *, hipStream_t);
 int mh_launch_project_gather(MhViews, const float *, int, int, float *, float *, float *, float *, float *, float *,
                              float *, hipStream_t);
 int mh_launch_topk(const float *, const float *, int, int, int32_t *, float *, hipStream_t);
@@ -460,6 +469,63 @@ extern "C" int mh_sort_keys(mh_ctx *ctx, const unsigned long long *keys, int n, 
     MH_HIP(hipSetDevice(ctx->device));
     return launched(mh_launch_sort_keys(keys, n, end_bit, scratch, scratch_bytes, keys_out, order, (hipStream_t)stream),
                     "mh_sort_keys");
+}
+
+// ---- the intermediate methods of the reference's class, as stand-alone calls (csrc/pmvo_pieces.hip) ---------------
+extern "C" int mh_project_points(mh_ctx *ctx, int view, const float *points, int N, int32_t *row_col, float *z_half,
+                                 uint8_t *out_of_image, float *pixel_unrounded, void *stream) {
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_project_points: views not set");
+    if (N == 0) return MH_OK;
+    if (!points || N < 0 || view < 0 || view >= ctx->V) return fail(MH_ERR_ARG, "mh_project_points: bad arguments");
+    return launched(mh_launch_project_points(ctx->cams + (size_t)view * MH_CAM_STRIDE, points, N, ctx->H, ctx->W, row_col,
+                                             z_half, out_of_image, pixel_unrounded, (hipStream_t)stream),
+                    "mh_project_points");
+}
+
+extern "C" int mh_gather_pixels(mh_ctx *ctx, int view, const long long *row_col, int N, int size, float *records,
+                                float *mask, void *stream) {
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_gather_pixels: views not set");
+    if (N == 0) return MH_OK;
+    if (!row_col || N < 0 || view < 0 || view >= ctx->V || size < 1 || !(size & 1))
+        return fail(MH_ERR_ARG, "mh_gather_pixels: bad arguments");
+    return launched(mh_launch_gather(ctx->views(), view, row_col, N, size, (float4 *)records, mask, (hipStream_t)stream),
+                    "mh_gather_pixels");
+}
+
+extern "C" int mh_compute_visible(mh_ctx *ctx, const float *depth, const float *z, size_t n, float *out, void *stream) {
+    if (n == 0) return MH_OK;
+    if (!ctx || !depth || !z || !out) return fail(MH_ERR_ARG, "mh_compute_visible: bad arguments");
+    return launched(mh_launch_compute_visible(depth, z, n, out, (hipStream_t)stream), "mh_compute_visible");
+}
+
+extern "C" int mh_sample_next(mh_ctx *ctx, const float *points, const int32_t *base_view, const float *ori,
+                              const float *offsets, int N, int S, float *samples, void *stream) {
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_sample_next: views not set");
+    if (N == 0) return MH_OK;
+    if (!points || !base_view || !ori || !offsets || !samples || N < 0 || S < 1)
+        return fail(MH_ERR_ARG, "mh_sample_next: bad arguments");
+    return launched(mh_launch_sample_next(ctx->views(), points, base_view, ori, offsets, N, S, samples,
+                                          (hipStream_t)stream),
+                    "mh_sample_next");
+}
+
+extern "C" int mh_reproject_ori(mh_ctx *ctx, const float *points, const float *samples, int N, int S, float *D,
+                                void *stream) {
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_reproject_ori: views not set");
+    if (N == 0) return MH_OK;
+    if (!points || !samples || !D || N < 0 || S < 1) return fail(MH_ERR_ARG, "mh_reproject_ori: bad arguments");
+    return launched(mh_launch_reproject(ctx->views(), points, samples, N, S, D, (hipStream_t)stream), "mh_reproject_ori");
+}
+
+extern "C" int mh_prj_loss(mh_ctx *ctx, const float *D, const float *ori_patch, const float *conf_patch,
+                           const float *vis, int V, int N, int S, int P, float conf_threshold, float *loss,
+                           long long *index, uint8_t *high_conf, float *all_loss, void *stream) {
+    if (N == 0) return MH_OK;
+    if (!ctx || !D || !ori_patch || !conf_patch || !vis || !loss || V < 1 || V >= 4096 || N < 0 || S < 1 || P < 1)
+        return fail(MH_ERR_ARG, "mh_prj_loss: bad arguments");
+    return launched(mh_launch_prj_loss(D, ori_patch, conf_patch, vis, V, N, S, P, conf_threshold, loss, index, high_conf,
+                                       all_loss, (hipStream_t)stream),
+                    "mh_prj_loss");
 }
 
 // ---- strand tracing on the fitted volume (HairGrow.py:59-299) ------------------------------------------------

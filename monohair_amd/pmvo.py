@@ -227,6 +227,126 @@ class PMVO:
         idx, val = self._topk32()
         return idx.long(), val
 
+    # ------------------------------------------------------------------ the reference's intermediate methods
+    # (PMVO.forward above is fused and does not call them; same names, arguments and returns as PMVO.py)
+    def _view_index(self, view):
+        """camera key / Camera object / integer -> index of the resident view"""
+        if isinstance(view, (int, np.integer)):
+            return int(view)
+        if isinstance(view, str):
+            return self.camera_key.index(view)
+        for i, c in enumerate(self.camera or []):
+            if c is view:
+                return i
+        name = getattr(view, "id", None)
+        if name in self.camera_key:
+            return self.camera_key.index(name)
+        raise _lib.MhError("unknown view %r" % (view,))
+
+    def project_points(self, points, camera, image_size=None):
+        """PMVO.py:378-397 -> (uv [N,2] long as (row, col), z' = -z/2 [N], out-of-image flags [N]).  `camera`: one of
+        the resident cameras (object, key or index); image_size must be the resident one."""
+        pts = self._dev_points(points)
+        N = pts.shape[0]
+        if image_size is not None and [int(image_size[0]), int(image_size[1])] != self.image_size:
+            raise _lib.MhError("project_points: image_size differs from the resident maps")
+        rc = torch.empty((N, 2), dtype=torch.int32, device=self.device)
+        zp = torch.empty((N,), dtype=torch.float32, device=self.device)
+        oob = torch.empty((N,), dtype=torch.bool, device=self.device)
+        _lib.check(self._L.mh_project_points(self._ctx, self._view_index(camera), _lib.ptr(pts), N, _lib.ptr(rc),
+                                             _lib.ptr(zp), _lib.ptr(oob), None, _lib.stream_ptr()), "mh_project_points")
+        return rc.long(), zp, oob
+
+    def _gather(self, uv, view, size=1, want_mask=False):
+        uv = torch.as_tensor(uv).to(self.device).long().contiguous()
+        N, P = uv.shape[0], size * size
+        rec = torch.empty((N, P, 4), dtype=torch.float32, device=self.device)
+        mask = torch.empty((N, P), dtype=torch.float32, device=self.device) if want_mask else None
+        _lib.check(self._L.mh_gather_pixels(self._ctx, self._view_index(view), _lib.ptr(uv), N, size, _lib.ptr(rec),
+                                            _lib.ptr(mask), _lib.stream_ptr()), "mh_gather_pixels")
+        return rec, mask
+
+    def get_depth(self, uv, view):
+        """PMVO.py:482-485"""
+        return self._gather(uv, view)[0][:, 0, 3]
+
+    def get_ori(self, uv, view):
+        """PMVO.py:487-489"""
+        return self._gather(uv, view)[0][:, 0, 0:2]
+
+    def get_conf(self, uv, view):
+        """PMVO.py:517-519 (raw, unclamped)"""
+        return self._gather(uv, view)[0][:, 0, 2]
+
+    def get_mask(self, uv, view):
+        """PMVO.py:521-523"""
+        return self._gather(uv, view, want_mask=True)[1][:, 0]
+
+    def get_ori_patch(self, uv, view, size=1):
+        """PMVO.py:491-502 -> [N, size*size, 2]"""
+        return self._gather(uv, view, size)[0][..., 0:2].contiguous()
+
+    def get_c_patch(self, uv, view, size=1):
+        """PMVO.py:504-515 -> [N, size*size]"""
+        return self._gather(uv, view, size)[0][..., 2].contiguous()
+
+    def compute_visible(self, depth, z):
+        """PMVO.py:525-529 (z is already -z_cam/2*255)"""
+        depth = torch.as_tensor(depth).to(self.device).float().contiguous()
+        z = torch.as_tensor(z).to(self.device).float().contiguous().expand_as(depth).contiguous()
+        out = torch.empty_like(depth)
+        _lib.check(self._L.mh_compute_visible(self._ctx, _lib.ptr(depth), _lib.ptr(z), depth.numel(), _lib.ptr(out),
+                                              _lib.stream_ptr()), "mh_compute_visible")
+        return out
+
+    def compute_weight(self, visible, Conf, mask):
+        """PMVO.py:211-215: (visible != -1) * Conf; the mask `where` of the reference is an identity"""
+        return torch.where(visible == -1, torch.zeros_like(visible), torch.ones_like(visible)) * Conf
+
+    def sample_next_3d_pos(self, points, base_view_index, num_sample=90):
+        """PMVO.py:263-335 -> (sample_points [N,num_sample,3], surface_points [N,3]); needs Compute_Visible_and_Ori
+        on the same points.  (The reference's surface-point assignment at :333-334 writes into a temporary, so
+        surface_points is a copy of points there too.)"""
+        pts = self._dev_points(points)
+        N = pts.shape[0]
+        if getattr(self, "Ori", None) is None or self.Ori.shape[1] != N:
+            raise _lib.MhError("sample_next_3d_pos: call Compute_Visible_and_Ori(points) first")
+        base = torch.as_tensor(base_view_index).to(self.device).to(torch.int32).contiguous()
+        offs = torch.from_numpy(depth_offsets(num_sample)).to(self.device)
+        out = torch.empty((N, offs.shape[0], 3), dtype=torch.float32, device=self.device)
+        _lib.check(self._L.mh_sample_next(self._ctx, _lib.ptr(pts), _lib.ptr(base), _lib.ptr(self.Ori), _lib.ptr(offs), N,
+                                          offs.shape[0], _lib.ptr(out), _lib.stream_ptr()), "mh_sample_next")
+        return out, pts.clone()
+
+    def compute_reproject_ori(self, points, sample_next_points):
+        """PMVO.py:219-241 -> [V, N, num_sample, 2]"""
+        pts = self._dev_points(points)
+        smp = torch.as_tensor(sample_next_points).to(self.device).float().contiguous()
+        N, S = smp.shape[0], smp.shape[1]
+        D = torch.empty((self.num_view, N, S, 2), dtype=torch.float32, device=self.device)
+        _lib.check(self._L.mh_reproject_ori(self._ctx, _lib.ptr(pts), _lib.ptr(smp), N, S, _lib.ptr(D),
+                                            _lib.stream_ptr()), "mh_reproject_ori")
+        return D
+
+    def compute_points_prj_ori(self, points, next_points):
+        """PMVO.py:243-260 -> [V, N, 2]"""
+        nxt = torch.as_tensor(next_points).to(self.device).float()
+        return self.compute_reproject_ori(points, nxt[:, None, :])[:, :, 0, :].contiguous()
+
+    def compute_prj_loss(self, Prj_Ori_2D, Ori=None, weight=None):
+        """PMVO.py:151-209 -> (min_loss [N], min_index [N] long, high_conf_index [N] bool) on the patches of the last
+        Compute_Visible_and_Ori (the reference ignores its `Ori` and `weight` arguments too)."""
+        D = torch.as_tensor(Prj_Ori_2D).to(self.device).float().contiguous()
+        V, N, S, _ = D.shape
+        P = self.patch_size ** 2
+        loss = torch.empty((N,), dtype=torch.float32, device=self.device)
+        idx = torch.empty((N,), dtype=torch.int64, device=self.device)
+        hc = torch.empty((N,), dtype=torch.bool, device=self.device)
+        _lib.check(self._L.mh_prj_loss(self._ctx, _lib.ptr(D), _lib.ptr(self.Ori_patch), _lib.ptr(self.Conf_patch),
+                                       _lib.ptr(self.visible), V, N, S, P, float(self.conf_threshold), _lib.ptr(loss),
+                                       _lib.ptr(idx), _lib.ptr(hc), None, _lib.stream_ptr()), "mh_prj_loss")
+        return loss, idx, hc
+
     def side_streams(self, n=2):
         """n HIP streams owned by this object (created once; the per-stream search scratch is keyed by them)."""
         if len(getattr(self, "_side_streams", [])) < n:

@@ -164,3 +164,51 @@ def test_empty_and_ragged_batches(case, depth_offsets):
     assert eq_nan(loss.cpu().numpy(), o_loss) and eq_nan(ori.cpu().numpy(), o_ori)
     if meta["rings"] == 1:                     # a single ring of cameras: the far point is outside every frustum
         assert np.isnan(loss[-1].item())
+
+
+def test_intermediate_methods_vs_oracle_and_golden(case, depth_offsets):
+    """The reference's helper methods (project_points, get_*, compute_visible, sample_next_3d_pos,
+    compute_reproject_ori, compute_points_prj_ori, compute_prj_loss) as stand-alone calls: same results as the oracle's
+    restatements bit for bit, and the reference's own outputs where the goldens hold them."""
+    meta, z, scene, views, pm = case
+    pts = z["points"]
+    H, W, patch = meta["H"], meta["W"], meta["patch"]
+    # project_points + get_* on two views
+    for tag in ("a", "b"):
+        v = int(z["proj_%s_view" % tag])
+        uv, zp, oob = pm.project_points(pts, pm.camera_key[v] if pm.camera_key else v, [H, W])
+        o_rc, o_zp, o_oob, _ = oracle.project_points(views.cams[v], pts, H, W)
+        assert np.array_equal(uv.cpu().numpy(), o_rc) and np.array_equal(zp.cpu().numpy(), o_zp)
+        assert np.array_equal(oob.cpu().numpy(), o_oob)
+        assert np.array_equal(uv.cpu().numpy(), z["proj_%s_rc" % tag]) and np.array_equal(oob.cpu().numpy(), z["proj_%s_oob" % tag])
+        assert np.array_equal(zp.cpu().numpy(), z["proj_%s_z" % tag])
+        r, c = o_rc[:, 0], o_rc[:, 1]
+        assert np.array_equal(pm.get_depth(uv, v).cpu().numpy(), views.depth[v][r, c])
+        assert np.array_equal(pm.get_ori(uv, v).cpu().numpy(), views.ori[v][r, c])
+        assert np.array_equal(pm.get_conf(uv, v).cpu().numpy(), views.conf[v][r, c])
+        assert np.array_equal(pm.get_mask(uv, v).cpu().numpy(), views.mask[v][r, c])
+        hp = patch // 2
+        taps = [(np.clip(r + i, 0, H - 1), np.clip(c + j, 0, W - 1)) for i in range(-hp, hp + 1) for j in range(-hp, hp + 1)]
+        assert np.array_equal(pm.get_ori_patch(uv, v, patch).cpu().numpy(), np.stack([views.ori[v][a, b] for a, b in taps], 1))
+        assert np.array_equal(pm.get_c_patch(uv, v, patch).cpu().numpy(), np.stack([views.conf[v][a, b] for a, b in taps], 1))
+        vis = pm.compute_visible(pm.get_depth(uv, v), zp * 255)
+        assert np.array_equal(np.where(o_oob, -1.0, vis.cpu().numpy()).astype(np.float32), z["visible"][v])
+    # the search, step by step, against the fused forward's ingredients
+    pm.Compute_Visible_and_Ori(pts)
+    for rank in (0, 2):
+        base = z["base_idx"][rank]
+        samples, surface = pm.sample_next_3d_pos(pts, base)
+        o_s = oracle.sample_next(views, pts, base, z["Ori"], depth_offsets)
+        assert np.array_equal(samples.cpu().numpy(), o_s) and torch.equal(surface.cpu(), torch.from_numpy(pts).float())
+        D = pm.compute_reproject_ori(pts, samples)
+        o_D = oracle.reproject_ori(views, pts, o_s)
+        assert eq_nan(D.cpu().numpy(), o_D)
+        one = pm.compute_points_prj_ori(pts, samples[:, 7])
+        assert eq_nan(one.cpu().numpy(), o_D[:, :, 7])
+        loss, idx, hc = pm.compute_prj_loss(D, None, None)
+        o = oracle.visible_and_ori(views, pts, patch)
+        o_loss, o_idx, o_hc = oracle.prj_loss(o_D, o["Ori_patch"], o["Conf_patch"], o["visible"], meta["thr"])
+        assert eq_nan(loss.cpu().numpy(), o_loss) and np.array_equal(idx.cpu().numpy(), o_idx)
+        assert np.array_equal(hc.cpu().numpy(), o_hc)
+        w = pm.compute_weight(pm.visible, pm.Conf, pm.mask)
+        assert torch.equal(w, (pm.visible != -1).float() * pm.Conf)
