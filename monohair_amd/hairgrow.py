@@ -101,6 +101,26 @@ class HairGrowing:
         return list(torch.split(cat, [s.shape[0] for s in strands_np]))
 
     # ------------------------------------------------------------------ reference methods
+    def trace(self, seedPos, flag, thrDot, W=None, H=None, Z=None):
+        """HairGrow.py:59-149 for ONE seed (the drivers above trace all seeds in one launch instead): shifts seedPos in
+        place by 0.5 and by rand*0.5 like the reference, reads `flag` ([Z,H,W] tensor or array) at the seed only, and
+        returns the strand [L,3] (L >= 5) or False."""
+        seedPos += torch.tensor([0.5, 0.5, 0.5], dtype=torch.float, device=seedPos.device)
+        seedPos += torch.rand_like(seedPos) * 0.5
+        x, y, z = (min(max(int(v), 0), hi - 1) for v, hi in zip(seedPos.tolist(), (self.W, self.H, self.Z)))
+        if float(flag[z, y, x]) >= 3:
+            return False
+        out, first, ln = self._trace_seeds(seedPos.to(self.device).type(torch.float)[None].contiguous(), thrDot)
+        n, f = int(ln[0]), int(first[0])
+        return out[0, f:f + n].clone() if n >= 5 else False
+
+    def traceFromScalp(self, seedPos, seedNormal, thrDot, W=None, H=None, Z=None, pointsTree=None):
+        """HairGrow.py:154-223 for ONE root: the strand [L,3], or None when it grows into the head."""
+        out, ln = self._trace_scalp(seedPos.to(self.device).type(torch.float)[None].contiguous(),
+                                    seedNormal.to(self.device).type(torch.float)[None].contiguous(), thrDot)
+        n = int(ln[0])
+        return out[0, :n].clone() if n > 0 else None
+
     def GenerateGuideStrandFromScalp(self, scalp_points, scalp_normals, pointsTree=None, thrDot=0.8):
         """HairGrow.py:226-265 -> (strands: list of [L,3] device tensors in voxel space, num_root)."""
         flag = np.zeros((self.Z, self.H, self.W), np.float32)

@@ -70,3 +70,34 @@ def test_random_segments_match_reference_and_hair_file(setup, tmp_path):
     seg, pts = load_strand(p)
     assert seg == [int(x) for x in z["random_len"]]
     assert np.allclose(pts, np.concatenate(world))
+
+
+def test_per_seed_methods_equal_the_batched_drivers(setup):
+    """trace / traceFromScalp (one seed per call, the reference's signatures) give the strands of the batched kernels"""
+    z, hg, vol = setup
+    W, H, Z = hg.W, hg.H, hg.Z
+    sp, sn = torch.from_numpy(z["scalp_points"]), torch.from_numpy(z["scalp_normals"])
+    o_sp, o_sl = oracle.trace_scalp(vol, z["scalp_points"], z["scalp_normals"], 0.8)
+    for i in range(0, len(sp), max(1, len(sp) // 25)):
+        s = hg.traceFromScalp(sp[i].clone(), sn[i].clone(), 0.8, W, H, Z, None)
+        if o_sl[i] <= 0:
+            assert s is None
+        else:
+            assert np.array_equal(s.cpu().numpy(), o_sp[i, :o_sl[i]])
+    nz = np.argwhere(vol.vox[..., 3] != 0)[:, ::-1].astype(np.float32)
+    flag = np.zeros((Z, H, W), np.float32)
+    torch.manual_seed(5)
+    jit = torch.rand(len(nz[:40]), 3)
+    torch.manual_seed(5)
+    for i in range(40):
+        seed = torch.from_numpy(nz[i].copy())
+        want_seed = (nz[i] + 0.5 + jit[i].numpy() * 0.5).astype(np.float32)
+        got = hg.trace(seed, flag, 0.8, W, H, Z)
+        assert np.array_equal(seed.numpy(), want_seed)              # shifted in place, like the reference
+        o_out, o_first, o_ln = oracle.trace_seeds(vol, want_seed[None], 0.8)
+        if o_ln[0] >= 5:
+            assert np.array_equal(got.cpu().numpy(), o_out[0, o_first[0]:o_first[0] + o_ln[0]])
+        else:
+            assert got is False
+    flag[:] = 3
+    assert hg.trace(torch.from_numpy(nz[0].copy()), flag, 0.8, W, H, Z) is False
