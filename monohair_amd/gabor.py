@@ -93,17 +93,66 @@ class calOrientationGabor:
                                                 _lib.ptr(var), _lib.stream_ptr()), "mh_gabor_bank")
         return idx, conf, var
 
+    def gabor_fn(self, kernel_size, channel_in, channel_out, theta, sigma_x, sigma_y, Lambda, phase=0.):
+        """GaborFilter.py:115-145 with the reference's signature -> [channel_out, channel_in, k, k] on the device"""
+        th = torch.as_tensor(theta, dtype=torch.float32).reshape(-1).cpu()
+        ks = [gabor_fn(kernel_size, float(th[min(i, len(th) - 1)]), sigma_x, sigma_y, Lambda, phase)
+              for i in range(channel_out)]
+        return torch.stack(ks)[:, None].repeat(1, channel_in, 1, 1).to(self.device)
+
+    def _install_bank(self, sigma_x, sigma_y, Lambda):
+        key = (float(sigma_x), float(sigma_y), float(Lambda))
+        if getattr(self, "_bank_key", (1.8, 2.4, 4.0)) != key:
+            bank = torch.stack([gabor_fn(KSIZE, math.pi * k / NUM_KERNELS, *key) for k in range(NUM_KERNELS)]).numpy()
+            bank = np.ascontiguousarray(bank.reshape(NUM_KERNELS, KSIZE * KSIZE), dtype=np.float32)
+            _lib.check(_lib.lib().mh_gabor_set_bank(self._ctx, bank.ctypes.data_as(ctypes.c_void_p)), "mh_gabor_set_bank")
+            self._bank_key = key
+
+    def filter(self, image, label, threshold, variance_data, orient_data, max_resp_data, sigma_x=1.8, sigma_y=2.4,
+               Lambda=4, kernel_size=17):
+        """GaborFilter.py:29-94, one pass: the bank on image [1,1,H,W], then the reference's state update
+        (where variance > variance_data ...), both normalisations and the clamp.  Returns (confidence, variance_data,
+        orient_data), each [1,1,H,W].  (max_resp_data never reaches an output of the reference either.)"""
+        if int(kernel_size) != KSIZE:
+            raise NotImplementedError("the bank kernel is built for 17x17 filters (GaborFilter.py:105)")
+        self._install_bank(sigma_x, sigma_y, Lambda)
+        idx, _, var = self.filter_index(image[0, 0])
+        best = self._theta[idx.long()][None, None]
+        variance = var[None, None]
+        upd = variance > variance_data.to(self.device)
+        orient_data = torch.where(upd, best, orient_data.to(self.device))
+        variance_data = torch.where(upd, variance, variance_data.to(self.device))
+        variance_data = variance_data / torch.max(variance_data)                  # tensor divisor: IEEE division
+        span = torch.tensor(self.clamp_confidence_high - self.clamp_confidence_low, dtype=torch.float32,
+                            device=self.device)
+        conf = ((variance_data - self.clamp_confidence_low) / span).clamp(0, 1)
+        return conf, variance_data, orient_data
+
     def forward(self, image, label=None, iter=1, threshold=0.0):
         """GaborFilter.py:98-113.  image [1,1,H,W] -> (orientTwoChannel [1,2,H,W] = (sin,cos),
-        best_orient [1,1,H,W] radians, confidence [1,1,H,W]).  `label` is unused, as in the reference."""
-        if iter != 1:
-            raise NotImplementedError("the pipeline calls the Gabor bank with iter=1 only (GaborFilter.py:236)")
-        idx, conf, _ = self.filter_index(image[0, 0])
-        li = idx.long()
+        best_orient [1,1,H,W] radians, confidence [1,1,H,W]).  `label` is unused, as in the reference.  iter=1 (what
+        the pipeline uses, GaborFilter.py:236) is one fused launch; iter>1 re-filters the confidence map like the
+        reference, through filter()."""
+        if iter == 1:
+            self._install_bank(1.8, 2.4, 4.0)
+            idx, conf, _ = self.filter_index(image[0, 0])
+            li = idx.long()
+            conf = torch.where(conf < threshold, torch.zeros_like(conf), conf)
+            best = self._theta[li]
+            two = torch.stack([self._sin[li], self._cos[li]], 0)[None]
+            return two, best[None, None], conf[None, None]
+        H, W = image.shape[2:4]
+        z = lambda: torch.zeros((1, 1, H, W), dtype=torch.float32, device=self.device)   # noqa: E731
+        variance_data, orient_data, max_resp_data = z(), z(), z()
+        image = image.to(self.device).type(torch.float)
+        for _ in range(iter):
+            conf, variance_data, orient_data = self.filter(image, label, threshold, variance_data, orient_data,
+                                                           max_resp_data, sigma_x=1.8, sigma_y=2.4, Lambda=4,
+                                                           kernel_size=17)
+            image = conf
         conf = torch.where(conf < threshold, torch.zeros_like(conf), conf)
-        best = self._theta[li]
-        two = torch.stack([self._sin[li], self._cos[li]], 0)[None]
-        return two, best[None, None], conf[None, None]
+        oc = orient_data.cpu()             # sin/cos of the few distinct angles with the host's libm, as for iter=1
+        return torch.cat([torch.sin(oc), torch.cos(oc)], dim=1).to(self.device), orient_data, conf
 
     __call__ = forward
 

@@ -129,6 +129,20 @@ def test_gabor_vs_oracle_and_golden():
         assert np.allclose(conf[0, 0].cpu().numpy()[agree], ref_conf[agree], rtol=0, atol=1e-6)
         assert np.array_equal(two[0].cpu().numpy()[:, agree], ref_two[:, agree])
         assert two.shape == (1, 2) + img.shape and best.shape == (1, 1) + img.shape
+    # the iterated form with a confidence threshold (forward(..., iter=2, threshold=0.3)) and the class's own
+    # filter() / gabor_fn() with the reference's signatures
+    t = torch.from_numpy(z["mixed_img"])[None, None].to(DEV)
+    two, best, conf = gab(t, None, 2, threshold=0.3)
+    agree = best[0, 0].cpu().numpy() == z["mixed_iter2_best"]
+    assert agree.mean() >= 0.995, agree.mean()
+    assert np.allclose(conf[0, 0].cpu().numpy()[agree], z["mixed_iter2_conf"][agree], rtol=0, atol=1e-6)
+    assert np.allclose(two[0].cpu().numpy()[:, agree], z["mixed_iter2_two"][:, agree], rtol=0, atol=1e-7)
+    k7 = gab.gabor_fn(17, 1, 1, torch.ones(1) * (np.pi * 7 / 180), 1.8, 2.4, 4)
+    assert k7.shape == (1, 1, 17, 17) and np.allclose(k7[0, 0].cpu().numpy(), z["bank"][7], rtol=0, atol=2e-7)
+    zero = torch.zeros_like(t)
+    c1, v1, o1 = gab.filter(t, None, 0.0, zero, zero, zero, sigma_x=1.8, sigma_y=2.4, Lambda=4, kernel_size=17)
+    _, b1, cf1 = gab(t, None, 1, threshold=0.0)
+    assert torch.equal(o1, b1) and torch.equal(c1, cf1) and float(v1.max()) == 1.0
 
 
 @pytest.mark.parametrize("variant", ["valu", "mfma", "split"])

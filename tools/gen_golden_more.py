@@ -82,6 +82,12 @@ def gen_gabor(R):
         out[name + "_best"] = best[0, 0].numpy()
         out[name + "_conf"] = conf[0, 0].numpy()
         out[name + "_two"] = two[0].numpy()
+    # the iterated form (forward re-filters its own confidence map, GaborFilter.py:104-106) and a confidence threshold
+    t = torch.from_numpy(imgs["mixed"])[None, None]
+    two, best, conf = gab(t, torch.ones_like(t), 2, threshold=0.3)
+    out["mixed_iter2_best"] = best[0, 0].numpy()
+    out["mixed_iter2_conf"] = conf[0, 0].numpy()
+    out["mixed_iter2_two"] = two[0].numpy()
     np.savez_compressed(os.path.join(OUT, "gabor.npz"), **out)
     print("gabor written")
 
