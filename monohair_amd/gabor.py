@@ -157,6 +157,16 @@ class calOrientationGabor:
     __call__ = forward
 
 
+def normalize(x):
+    """GaborFilter.py:152-155"""
+    return x / np.maximum(np.linalg.norm(x, axis=-1)[..., None], 1e-8)
+
+
+def convert_numpy(tensor):
+    """GaborFilter.py:157-161: [1,C,H,W] tensor -> [H,W,C] numpy"""
+    return torch.squeeze(tensor, 0).permute(1, 2, 0).data.cpu().numpy()
+
+
 def difference_of_gaussians(image, low_sigma, high_sigma):
     """skimage.filters.difference_of_gaussians (scikit-image 0.23, the reference's pin): float image,
     gaussian(low) - gaussian(high), mode='nearest', truncate=4.0."""
