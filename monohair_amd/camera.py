@@ -22,8 +22,13 @@ ZNEAR = 0.1
 
 class Camera:
     def __init__(self, proj, pose, id, to_tensor=True):
-        fx, fy, cx, cy = [float(x) for x in proj]
-        mat = np.array(
+        self.id = id
+        self.proj = torch.from_numpy(self.get_projection_matrix(*[float(x) for x in proj])).type(torch.float)
+        self.pose = torch.from_numpy(np.asarray(pose, dtype=np.float64)).type(torch.float)
+
+    def get_projection_matrix(self, fx, fy, cx, cy):
+        """Camera_utils.py:19-36: GL-style projection, near 0.1, far 100, camera looking down -z"""
+        return np.array(
             [
                 [fx, 0, cx, 0],
                 [0, fy, cy, 0],
@@ -32,15 +37,72 @@ class Camera:
             ],
             dtype=np.float64,
         )
-        self.id = id
-        self.proj = torch.from_numpy(mat).type(torch.float)
-        self.pose = torch.from_numpy(np.asarray(pose, dtype=np.float64)).type(torch.float)
+
+    # ---- tensor utilities of the reference's class (Camera_utils.py:38-139), plain torch on whatever device the
+    # ---- argument lives on.  The PMVO kernels do NOT call these: they evaluate the same formulas from the records.
+    def projection(self, vertices, debug=False):
+        """[N,3] world points -> (uv [N,2] = (proj @ pose @ X)[:2] / z_cam, z_cam [N])  (Camera_utils.py:38-58)"""
+        self.proj, self.pose = self.proj.to(vertices.device), self.pose.to(vertices.device)
+        hom = torch.cat([vertices.permute(1, 0), torch.ones((1, vertices.size(0)), device=vertices.device)])
+        cam = torch.matmul(self.pose, hom)
+        z = cam[2:3, :]
+        uv = torch.matmul(self.proj, cam)
+        uv[:2] /= z
+        return uv.transpose(1, 0)[:, :2], z[0]
+
+    def uv2pixel(self, uv, image_size, device):
+        """ndc -> pixel as (row, col); like the reference it also rewrites its argument (Camera_utils.py:60-71)"""
+        uv[:, 0:1] = uv[:, 0:1] * -1
+        uv[:, :2] = (uv[:, :2] + 1) / 2
+        uv[:, :2] *= torch.tensor(image_size[::-1], device=device, dtype=torch.float)
+        return torch.flip(uv, dims=[1])
+
+    def pixel2uv(self, uv, image_size, device):
+        """(row, col) pixel -> ndc (Camera_utils.py:73-78)"""
+        uv = uv[:, [1, 0]]
+        uv /= torch.tensor(image_size[::-1], device=device, dtype=torch.float)
+        uv[:, :2] = uv * 2 - 1
+        uv[:, 0:1] = -uv[:, 0:1]
+        return uv
+
+    def reprojection(self, uv, z, to_world=False):
+        """ndc + camera depth -> camera-space homogeneous points [N,4], or world points [N,3] (Camera_utils.py:81-109)"""
+        self.proj, self.pose = self.proj.to(uv.device), self.pose.to(uv.device)
+        cam = torch.ones((4, uv.size(0)), dtype=uv.dtype, device=uv.device)
+        cam[0] = (uv[:, 0] - self.proj[0, 2]) / self.proj[0, 0] * z
+        cam[1] = (uv[:, 1] - self.proj[1, 2]) / self.proj[1, 1] * z
+        cam[2] = z
+        if not to_world:
+            return cam.permute(1, 0)
+        world = torch.matmul(torch.linalg.inv(self.pose[:3, :3]), cam[:3] - self.pose[:3, 3:4])
+        return world.permute(1, 0)
+
+    def camera2world(self, points):
+        """camera-space [N,3] -> world homogeneous [N,4] (Camera_utils.py:111-116)"""
+        self.pose = self.pose.to(points.device)
+        hom = torch.cat([points, torch.ones((points.size(0), 1), device=points.device)], 1).permute(1, 0)
+        return torch.matmul(torch.linalg.inv(self.pose), hom).permute(1, 0)
+
+    def render_img(self, vertices, image_size, device, save_path, color=None):
+        """splat the projected points into an image file (Camera_utils.py:121-139; PIL instead of cv2)"""
+        from PIL import Image
+
+        img = torch.ones((image_size[0], image_size[1], 3), device=device)
+        uv, z = self.projection(vertices)
+        uv[:, 0:1] = -uv[:, 0:1]
+        uv[:, :2] = (uv[:, :2] + 1) / 2
+        uv[:, :2] *= torch.tensor(image_size[::-1], device=device, dtype=torch.float)
+        uv = torch.round(uv).type(torch.long)
+        uv[:, 0] = torch.clamp(uv[:, 0], 0, image_size[1] - 1)
+        uv[:, 1] = torch.clamp(uv[:, 1], 0, image_size[0] - 1)
+        img[uv[:, 1], uv[:, 0]] *= color if color is not None else (-z / 2)[:, None]
+        Image.fromarray(np.clip(np.rint(img.cpu().numpy() * 255), 0, 255).astype(np.uint8)).save(save_path)
 
     def record(self):
         rec = np.zeros(CAM_STRIDE, dtype=np.float32)
-        rec[0:16] = self.pose.numpy().reshape(-1)
-        rec[16:32] = self.proj.numpy().reshape(-1)
-        rec[32:41] = torch.linalg.inv(self.pose[:3, :3]).numpy().reshape(-1)
+        rec[0:16] = self.pose.cpu().numpy().reshape(-1)
+        rec[16:32] = self.proj.cpu().numpy().reshape(-1)
+        rec[32:41] = torch.linalg.inv(self.pose[:3, :3].cpu()).numpy().reshape(-1)
         return rec
 
 

@@ -5,6 +5,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 from conftest import ROOT
 
@@ -286,3 +287,31 @@ def test_sparse_mat_writer_equals_savemat(tmp_path):
     assert U.get_ground_truth_3D_ori(str(a / "Ori3D.mat")).shape == (28, 36, 40, 3)
     U.save_ori_occ_mat_sparse(str(a), g, np.zeros((0, 3), int), np.zeros((0, 3)))          # empty volume
     assert scipy.io.loadmat(a / "Occ3D.mat")["Occ"].sum() == 0
+
+
+def test_camera_tensor_utilities_match_the_oracle():
+    """Camera.projection / uv2pixel / pixel2uv / reprojection / camera2world (the reference's torch utilities,
+    Camera_utils.py:38-116) on CPU tensors reproduce the oracle's restatement of the same formulas bit for bit."""
+    import oracle
+    from monohair_amd import synth
+    from monohair_amd.camera import camera_records, cameras_from_list
+
+    H, W = 120, 90
+    cams = cameras_from_list(synth.make_cameras(24, H, W, scale=1.5, rings=2))
+    recs = camera_records(cams)
+    rng = np.random.default_rng(0)
+    pts = rng.normal(0, 0.1, (200, 3)).astype(np.float32)
+    for i in (0, 5, 17):
+        cam = list(cams.values())[i]
+        uv, z = cam.projection(torch.from_numpy(pts))
+        assert uv.shape == (200, 2) and z.shape == (200,)
+        pix = cam.uv2pixel(uv.clone(), [H, W], "cpu")                      # (row, col), unrounded
+        _, zp, _, pixf = oracle.project_points(recs[i], pts, H, W)
+        assert np.array_equal(pix.numpy(), pixf) and np.array_equal((-z / 2).numpy(), zp)
+        back = cam.pixel2uv(pix.clone(), [H, W], "cpu")
+        assert np.allclose(back.numpy(), uv.numpy(), atol=1e-5)
+        world = cam.reprojection(uv, z, to_world=True)
+        assert np.allclose(world.numpy(), pts, atol=1e-5)
+        camv = cam.reprojection(uv, z, to_world=False)
+        assert camv.shape == (200, 4) and np.allclose(cam.camera2world(camv[:, :3]).numpy()[:, :3], pts, atol=1e-5)
+    assert list(cams.values())[0].get_projection_matrix(2.0, 3.0, 0.1, -0.2).shape == (4, 4)
