@@ -77,6 +77,25 @@ while time.time() < t_end:
     o_rl, _ = oracle.refine_loss(views, pts, dirs, patch, thr)
     if not eq(rl.cpu().numpy(), o_rl):
         bad.append(("refine_loss", V, H, W, patch, thr, quant, seed, N))
+    # the step-by-step methods of the class and the fused refine kernels on the same scene
+    base = oracle.topk_views(pm.visible.cpu().numpy(), pm.Conf.cpu().numpy(), 20)[0][0]
+    smp, _ = pm.sample_next_3d_pos(pts, base)
+    o_smp = oracle.sample_next(views, pts, base, pm.Ori.cpu().numpy(), offs)
+    D = pm.compute_reproject_ori(pts, smp)
+    o_D = oracle.reproject_ori(views, pts, o_smp)
+    l3, i3, h3 = pm.compute_prj_loss(D)
+    o = oracle.visible_and_ori(views, pts, patch)
+    o_l3, o_i3, o_h3 = oracle.prj_loss(o_D, o["Ori_patch"], o["Conf_patch"], o["visible"], thr)
+    if not (eq(smp.cpu().numpy(), o_smp) and eq(D.cpu().numpy(), o_D) and eq(l3.cpu().numpy(), o_l3)
+            and eq(i3.cpu().numpy(), o_i3) and eq(h3.cpu().numpy(), o_h3)):
+        bad.append(("pieces", V, H, W, patch, thr, quant, seed, N))
+    lf = torch.empty((N,), device=DEV)
+    from monohair_amd import _lib as L_
+
+    L_.check(pm._L.mh_refine_loss_maps(pm._ctx, L_.ptr(pm._points), L_.ptr(torch.from_numpy(dirs).to(DEV).contiguous()),
+                                       0.005, 4.0, N, patch, float(thr), L_.ptr(lf), None, L_.stream_ptr()))
+    if not eq(lf.cpu().numpy(), o_rl):
+        bad.append(("refine_loss_maps", V, H, W, patch, thr, quant, seed, N))
     n_scene += 1
     n_pts += N
 print({"scenes": n_scene, "points": n_pts, "mismatching_cases": len(bad), "first": bad[:5]})
