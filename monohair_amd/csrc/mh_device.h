@@ -182,10 +182,24 @@ __device__ __forceinline__ void mh_pixel_of_fast2(const float *__restrict__ cam,
     row = ((v + mh_splat(1.0f)) / mh_splat(2.0f)) * mh_splat(Hf);
 }
 
+// sqrt(x) for a value that is clamped from below at 1e-8 right afterwards: the correctly rounded result for
+// x >= 2^-96, something below 1e-8 (which the clamp replaces, exactly as it replaces the true root) for smaller x.
+// This is the compiler's own IEEE expansion of an f32 sqrt on gfx9 -- v_sqrt_f32 (1 ulp), the two neighbours, two
+// fma residuals, two selects -- minus its input pre-scaling for x < 2^-96 and its class fix-up, neither of which
+// can change the clamped value: 9 instructions instead of 16.  NaN and +inf pass through as in the full expansion.
+__device__ __forceinline__ float mh_sqrt_before_clamp(float x) {
+    float r = __builtin_amdgcn_sqrtf(x);
+    const float rd = __uint_as_float(__float_as_uint(r) - 1u), ru = __uint_as_float(__float_as_uint(r) + 1u);
+    const float ed = mh_fma(-rd, r, x), eu = mh_fma(-ru, r, x);
+    r = (0.0f >= ed) ? rd : r;
+    r = (0.0f < eu) ? ru : r;
+    return r;
+}
+
 __device__ __forceinline__ void mh_unit2_fast2(mh_v2f x0, mh_v2f x1, mh_v2f &o0, mh_v2f &o1) {
     mh_v2f s = x0 * x0;
     s = mh_fma2(x1, x1, s);
-    mh_v2f nrm = mh_v2f{__builtin_sqrtf(s.x), __builtin_sqrtf(s.y)};
+    mh_v2f nrm = mh_v2f{mh_sqrt_before_clamp(s.x), mh_sqrt_before_clamp(s.y)};
     nrm.x = (nrm.x < 1e-8f) ? 1e-8f : nrm.x;
     nrm.y = (nrm.y < 1e-8f) ? 1e-8f : nrm.y;
     mh_div2x2(x0, x1, nrm, o0, o1);
