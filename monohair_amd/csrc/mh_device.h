@@ -178,8 +178,9 @@ __device__ __forceinline__ void mh_pixel_of_fast2(const float *__restrict__ cam,
     const mh_v2f q1 = mh_fma2(mh_splat(cam[22]), c2, mh_splat(cam[21]) * c1);
     mh_v2f u, v;
     mh_div2x2(q0, q1, c2, u, v);
-    col = ((-u + mh_splat(1.0f)) / mh_splat(2.0f)) * mh_splat(Wf);   // /2 is exact: the compiler emits a multiply
-    row = ((v + mh_splat(1.0f)) / mh_splat(2.0f)) * mh_splat(Hf);
+    // ((1 - u) / 2) * W: halving is exact, so one rounding of (1 - u) * W / 2 either way -- multiply by W/2 directly
+    col = (-u + mh_splat(1.0f)) * mh_splat(Wf * 0.5f);
+    row = (v + mh_splat(1.0f)) * mh_splat(Hf * 0.5f);
 }
 
 // sqrt(x) for a value that is clamped from below at 1e-8 right afterwards: the correctly rounded result for
