@@ -279,10 +279,11 @@ def _orientation_arrays(image_u8, gabor, iter=1, threshold=0.0):
     two, best, confidence = gabor(dog[None, None], None, iter, threshold=threshold)
     deg = torch.round(best[0, 0] / math.pi * 180).clamp(0, 255).to(torch.uint8).cpu().numpy()
     c8 = (confidence[0, 0] * 255 + 0.5).clamp(0, 255).to(torch.uint8).cpu().numpy()
-    ori = ((two[0].permute(1, 2, 0) + 1) / 2).cpu().numpy()
-    H, W = ori.shape[:2]
-    viz = np.concatenate([np.ones((H, W, 1)), ori], axis=2) * 255          # RGB = (1, sin, cos) as cv2 BGR[::-1]
-    return deg, c8, np.clip(np.round(viz), 0, 255).astype(np.uint8)
+    # RGB = (1, sin, cos) as cv2 BGR[::-1]; (x+1)/2 in float32, then x255 and the rounding in float64 like the host
+    # formula it replaces, on the device
+    ori = ((two[0].permute(1, 2, 0) + 1) / 2).double()
+    viz = torch.cat([torch.ones_like(ori[..., :1]), ori], dim=2) * 255
+    return deg, c8, torch.round(viz).clamp(0, 255).to(torch.uint8).cpu().numpy()
 
 
 def _save_orientation_files(save_root, filename, deg, c8, viz):
