@@ -602,10 +602,16 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         # cores), then the sequentially dependent smoothing loop (chunk k+1 reads the orientations chunk k wrote,
         # PMVO.py:614,640) runs entirely on the device, stream-ordered, without a host round trip per chunk.
         n_all = points.shape[0]
-        with stage("refine: knn (surface)", device):
-            index_all = _knn(points, points, 100, device, getattr(args, "knn", "device"), int32=True).contiguous()
-        with stage("refine: head-top mask", device):
-            head_top_all = torch.from_numpy(pmvo.head_top_mask(points).astype(np.uint8)).to(device)
+        # the scalp query of filter_head_points is a host KDTree query (float64 scipy, kept for exactness): it runs
+        # on a worker thread while the GPU builds the grid and answers the neighbour queries
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(1) as pool:
+            head_job = pool.submit(pmvo.head_top_mask, points)
+            with stage("refine: knn (surface)", device):
+                index_all = _knn(points, points, 100, device, getattr(args, "knn", "device"), int32=True).contiguous()
+            with stage("refine: head-top mask", device):
+                head_top_all = torch.from_numpy(head_job.result().astype(np.uint8)).to(device)
         T_loop = stage("refine: smoothing loop", device).__enter__()
         pts_dev = torch.from_numpy(points).to(device).type(torch.float).contiguous()
         ori_dev = torch.from_numpy(ori).to(device).type(torch.float).contiguous()
@@ -660,9 +666,13 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     select_filter_unvisible_points = np.zeros((0, 3), np.float32)
     if len(select_points) and len(filter_unvisible_points):
         fu = np.ascontiguousarray(filter_unvisible_points)
-        with stage("refine: knn (shell)", device):
-            index_all = _knn(select_points, fu, 100, device, getattr(args, "knn", "device"), int32=True).contiguous()
-        head_top = pmvo.head_top_mask(fu.astype(np.float32))
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(1) as pool:
+            head_job = pool.submit(pmvo.head_top_mask, fu.astype(np.float32))
+            with stage("refine: knn (shell)", device):
+                index_all = _knn(select_points, fu, 100, device, getattr(args, "knn", "device"), int32=True).contiguous()
+            head_top = head_job.result()
         fu_dev = torch.from_numpy(fu).type(torch.float).to(device).contiguous()
         sel_ori_dev = torch.from_numpy(select_ori).to(device).type(torch.float).contiguous()
         F, K = index_all.shape
