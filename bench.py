@@ -225,11 +225,6 @@ def main():
             "gpair_per_s_nominal": round(pairs_nominal / (t_search * 1e-3) / 1e9, 1),
         },
     }
-    if not a.no_cpu and world == 1:      # the CPU leg runs on rank 0 at N=1 only
-        try:
-            out["cpu_baseline"] = cpu_baseline(a, scene, recs, my[0], ms)
-        except Exception as e:
-            out["cpu_baseline"] = {"error": repr(e)[:200]}
     if not a.quantize and not a.no_secondary and world == 1:
         try:
             out["secondary_8bit_maps"] = secondary_quantized(a, dev, recs, cams, dev_chunks)
@@ -244,6 +239,13 @@ def main():
             out["secondary_gabor_bank"] = secondary_gabor(a, dev)
         except Exception as e:
             out["secondary_gabor_bank"] = {"error": repr(e)[:200]}
+    # last: its 128 OpenMP workers keep spinning for a while after the parallel region and would slow the host side
+    # of the secondary legs
+    if not a.no_cpu and world == 1:      # the CPU leg runs on rank 0 at N=1 only
+        try:
+            out["cpu_baseline"] = cpu_baseline(a, scene, recs, my[0], ms)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)[:200]}
     print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
