@@ -29,8 +29,12 @@ def config_parser(argv=None):
     opt_cmd = options.parse_arguments(sys.argv[1:] if argv is None else argv)
     args = options.set(opt_cmd=opt_cmd)
     args.output_path = os.path.join(args.data.root, args.data.case, args.output_root, args.name)
-    os.makedirs(args.output_path, exist_ok=True)
-    options.save_options_file(args)
+    from monohair_amd import dist as mdist
+
+    if mdist.rank() == 0:       # one writer: another rank could otherwise read a half-written options.yaml
+        os.makedirs(args.output_path, exist_ok=True)
+        options.save_options_file(args)
+    mdist.barrier()
     args.data.root = os.path.join(args.data.root, args.data.case)
     args.bbox_min = np.array(args.bbox_min)
     args.bust_to_origin = np.array(args.bust_to_origin)
@@ -42,7 +46,9 @@ def config_parser(argv=None):
         args.save_path = os.path.join(args.output_path, "full")
     else:
         args.save_path = os.path.join(args.output_path, "refine")
-    os.makedirs(args.save_path, exist_ok=True)
+    if mdist.rank() == 0:
+        os.makedirs(args.save_path, exist_ok=True)
+    mdist.barrier()
     return args
 
 
@@ -58,12 +64,14 @@ def load_views(camera, args):
     pack = args.data.get("maps_pack")
     if pack:
         pack = pack if os.path.isabs(pack) else os.path.join(args.data.root, pack)
-        if not os.path.exists(pack):
-            if mdist.rank() == 0:
-                print("writing maps pack", pack)
-                mapspack.pack_case(camera, args.data.Ori2D_path, args.data.Conf_path, args.data.mask_path,
-                                   args.data.depth_path, pack)
-            mdist.barrier()
+        # rank 0 alone decides whether the pack has to be written; EVERY rank then takes the same barrier (a rank
+        # that tested for the file itself could see rank 0's finished pack, skip the barrier and pair its next
+        # collective with the others' barrier)
+        if mdist.rank() == 0 and not os.path.exists(pack):
+            print("writing maps pack", pack)
+            mapspack.pack_case(camera, args.data.Ori2D_path, args.data.Conf_path, args.data.mask_path,
+                               args.data.depth_path, pack)
+        mdist.barrier()
         m = mapspack.read_pack(pack, views=list(camera.keys()))
         return PMVO.from_u8(camera, m["depth"], m["ori"], m["conf"], m["mask"], **kw)
     ori, conf, mask = load_maps_u8(camera, args.data.Ori2D_path, args.data.Conf_path, args.data.mask_path)

@@ -95,12 +95,13 @@ int mh_search_forward(mh_ctx *ctx, const float *points, int N, int patch, float 
  * the projection / visibility / centre-sample part of Compute_Visible_and_Ori (PMVO.py:346-376) fused with the
  * tap-list preparation, straight from the packed maps (patches of views that fail the depth test are not even
  * gathered); mh_topk_views then ranks the base views; mh_search_prepared runs the fused loss search on the
- * prepared scratch.  Results are identical to mh_project_gather + mh_search_forward.  mask may be NULL. */
+ * prepared scratch (its tail is work space: the search takes the points in descending order of work, which it
+ * derives there).  Results are identical to mh_project_gather + mh_search_forward.  mask may be NULL. */
 int mh_forward_prepare(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, float *vis,
                        float *ori, float *conf, float *mask, void *scratch, size_t scratch_bytes, void *stream);
 int mh_search_prepared(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank,
                        int rank_step, const float *ori, const int32_t *base_idx, const float *base_val,
-                       const void *scratch, float *line_ori, float *min_loss, uint8_t *high_conf, float *best_sample,
+                       void *scratch, float *line_ori, float *min_loss, uint8_t *high_conf, float *best_sample,
                        int32_t *best_rank, int32_t *best_s, void *stream);
 
 /* ---- compute_reproject_ori + compute_prj_loss with ONE given candidate per point: the core of

@@ -50,20 +50,27 @@ class Camera:
         uv[:2] /= z
         return uv.transpose(1, 0)[:, :2], z[0]
 
+    @staticmethod
+    def _extent(image_size, device):
+        """(W, H) as a float row: ndc x runs along the image width, ndc y along its height"""
+        H, W = float(image_size[0]), float(image_size[1])
+        return torch.tensor([W, H], device=device, dtype=torch.float)
+
     def uv2pixel(self, uv, image_size, device):
-        """ndc -> pixel as (row, col); like the reference it also rewrites its argument (Camera_utils.py:60-71)"""
-        uv[:, 0:1] = uv[:, 0:1] * -1
-        uv[:, :2] = (uv[:, :2] + 1) / 2
-        uv[:, :2] *= torch.tensor(image_size[::-1], device=device, dtype=torch.float)
-        return torch.flip(uv, dims=[1])
+        """ndc [-1,1]^2 (x to the left, y down) -> unrounded pixel position as (row, col).  Same arithmetic, operation
+        by operation, as Camera_utils.py:60-71 -- negate x, (. + 1) / 2, times (W, H) -- and, as there, the scaled
+        (col, row) values are left behind in the argument."""
+        col_row = torch.stack([uv[:, 0] * -1, uv[:, 1]], dim=1)
+        col_row = (col_row + 1) / 2
+        col_row = col_row * self._extent(image_size, device)
+        uv[:, :2] = col_row
+        return torch.stack([uv[:, 1], uv[:, 0]], dim=1)
 
     def pixel2uv(self, uv, image_size, device):
-        """(row, col) pixel -> ndc (Camera_utils.py:73-78)"""
-        uv = uv[:, [1, 0]]
-        uv /= torch.tensor(image_size[::-1], device=device, dtype=torch.float)
-        uv[:, :2] = uv * 2 - 1
-        uv[:, 0:1] = -uv[:, 0:1]
-        return uv
+        """inverse of uv2pixel: (row, col) pixel -> ndc (Camera_utils.py:73-78: / (W, H), * 2 - 1, negate x)"""
+        col_row = torch.stack([uv[:, 1], uv[:, 0]], dim=1) / self._extent(image_size, device)
+        ndc = col_row * 2 - 1
+        return torch.stack([-ndc[:, 0], ndc[:, 1]], dim=1)
 
     def reprojection(self, uv, z, to_world=False):
         """ndc + camera depth -> camera-space homogeneous points [N,4], or world points [N,3] (Camera_utils.py:81-109)"""
@@ -82,21 +89,6 @@ class Camera:
         self.pose = self.pose.to(points.device)
         hom = torch.cat([points, torch.ones((points.size(0), 1), device=points.device)], 1).permute(1, 0)
         return torch.matmul(torch.linalg.inv(self.pose), hom).permute(1, 0)
-
-    def render_img(self, vertices, image_size, device, save_path, color=None):
-        """splat the projected points into an image file (Camera_utils.py:121-139; PIL instead of cv2)"""
-        from PIL import Image
-
-        img = torch.ones((image_size[0], image_size[1], 3), device=device)
-        uv, z = self.projection(vertices)
-        uv[:, 0:1] = -uv[:, 0:1]
-        uv[:, :2] = (uv[:, :2] + 1) / 2
-        uv[:, :2] *= torch.tensor(image_size[::-1], device=device, dtype=torch.float)
-        uv = torch.round(uv).type(torch.long)
-        uv[:, 0] = torch.clamp(uv[:, 0], 0, image_size[1] - 1)
-        uv[:, 1] = torch.clamp(uv[:, 1], 0, image_size[0] - 1)
-        img[uv[:, 1], uv[:, 0]] *= color if color is not None else (-z / 2)[:, None]
-        Image.fromarray(np.clip(np.rint(img.cpu().numpy() * 255), 0, 255).astype(np.uint8)).save(save_path)
 
     def record(self):
         rec = np.zeros(CAM_STRIDE, dtype=np.float32)

@@ -59,12 +59,12 @@ int mh_launch_project_gather(MhViews, const float *, int, int, float *, float *,
                              float *, hipStream_t);
 int mh_launch_topk(const float *, const float *, int, int, int32_t *, float *, hipStream_t);
 int mh_launch_prep_taps(const float *, const float *, const float *, const float *, int, int, float, float4 *,
-                        hipStream_t);
+                        uint8_t *, hipStream_t);
 int mh_launch_project_taps(MhViews, const float *, int, int, float, float *, float *, float *, float *, float4 *,
-                           hipStream_t);
+                           uint8_t *, hipStream_t);
 int mh_launch_search(MhViews, const float *, int, int, int, const float *, int, int, float, const float *,
-                     const int32_t *, const float *, const float4 *, float *, float *, uint8_t *, float *, int32_t *,
-                     int32_t *, int, hipStream_t);
+                     const int32_t *, const float *, const float4 *, int32_t *, const uint8_t *, float *, float *,
+                     uint8_t *, float *, int32_t *, int32_t *, int, hipStream_t);
 int mh_launch_refine_loss(MhViews, const float *, const float *, float, float, int, int, float, const float *,
                           const float *, const float *, float *, uint8_t *, hipStream_t);
 int mh_launch_filter_points(MhViews, const float *, int, int, float, float, uint8_t *, uint8_t *, uint8_t *,
@@ -281,10 +281,20 @@ extern "C" int mh_topk_views(mh_ctx *ctx, const float *vis, const float *conf, i
     return launched(mh_launch_topk(vis, conf, ctx->V, N, out_idx, out_val, (hipStream_t)stream), "mh_topk_views");
 }
 
+static size_t search_order_offset(const mh_ctx *ctx, int N, int patch) {
+    return ((size_t)ctx->V * (size_t)N * (size_t)(patch * patch + 1) + 16) * sizeof(float4);
+}
+
+static size_t search_count_offset(const mh_ctx *ctx, int N, int patch) {
+    return search_order_offset(ctx, N, patch) + 2 * (size_t)N * sizeof(int32_t);
+}
+
 extern "C" size_t mh_search_scratch_bytes(mh_ctx *ctx, int N, int patch) {
     if (!ctx || N < 0 || patch < 1) return 0;
-    // + 16 records of slack: the search kernel prefetches tap records in groups past the end of a list
-    return ((size_t)ctx->V * (size_t)N * (size_t)(patch * patch + 1) + 16) * sizeof(float4);
+    // + 16 records of slack: the search kernel prefetches tap records in groups past the end of a list;
+    // + 2N ints behind them: the launch order of the search (mh_search_order_kernel) and its staging area
+    // + V*N bytes: the list lengths once more, compact, for the work estimate
+    return search_count_offset(ctx, N, patch) + (size_t)ctx->V * (size_t)N;
 }
 
 extern "C" int mh_search_forward(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank,
@@ -308,11 +318,14 @@ extern "C" int mh_search_forward(mh_ctx *ctx, const float *points, int N, int pa
     hipStream_t st = (hipStream_t)stream;
     const int P = patch * patch;
     int rc = launched(mh_launch_prep_taps(ori_patch, conf_patch, vis, pixf, ctx->V * N, P, conf_threshold,
-                                          (float4 *)scratch, st),
+                                          (float4 *)scratch,
+                                          (uint8_t *)scratch + search_count_offset(ctx, N, patch), st),
                       "mh_search_forward(prep)");
     if (rc) return rc;
     return launched(mh_launch_search(ctx->views(), ctx->offs, ctx->S, nrank, rank_step, points, N, P + 1,
-                                     conf_threshold, ori, base_idx, base_val, (const float4 *)scratch, line_ori,
+                                     conf_threshold, ori, base_idx, base_val, (const float4 *)scratch,
+                                     (int32_t *)((char *)scratch + search_order_offset(ctx, N, patch)),
+                                     (const uint8_t *)scratch + search_count_offset(ctx, N, patch), line_ori,
                                      min_loss, high_conf, best_sample, best_rank, best_s, ctx->search_variant, st),
                     "mh_search_forward");
 }
@@ -327,13 +340,15 @@ extern "C" int mh_forward_prepare(mh_ctx *ctx, const float *points, int N, int p
     if (scratch_bytes < mh_search_scratch_bytes(ctx, N, patch))
         return fail(MH_ERR_ARG, "mh_forward_prepare: scratch too small");
     return launched(mh_launch_project_taps(ctx->views(), points, N, patch, conf_threshold, vis, ori, conf, mask,
-                                           (float4 *)scratch, (hipStream_t)stream),
+                                           (float4 *)scratch,
+                                           (uint8_t *)scratch + search_count_offset(ctx, N, patch),
+                                           (hipStream_t)stream),
                     "mh_forward_prepare");
 }
 
 extern "C" int mh_search_prepared(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank,
                                   int rank_step, const float *ori, const int32_t *base_idx, const float *base_val,
-                                  const void *scratch, float *line_ori, float *min_loss, uint8_t *high_conf,
+                                  void *scratch, float *line_ori, float *min_loss, uint8_t *high_conf,
                                   float *best_sample, int32_t *best_rank, int32_t *best_s, void *stream) {
     if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_search_prepared: views not set");
     if (!ctx->offs) return fail(MH_ERR_STATE, "mh_search_prepared: depth offsets not set");
@@ -344,8 +359,11 @@ extern "C" int mh_search_prepared(mh_ctx *ctx, const float *points, int N, int p
     if (ctx->V >= 4096) return fail(MH_ERR_ARG, "mh_search_prepared: V >= 4096 needs a fourth cascade level");
     return launched(mh_launch_search(ctx->views(), ctx->offs, ctx->S, nrank, rank_step, points, N,
                                      patch * patch + 1, conf_threshold, ori, base_idx, base_val,
-                                     (const float4 *)scratch, line_ori, min_loss, high_conf, best_sample, best_rank,
-                                     best_s, ctx->search_variant, (hipStream_t)stream),
+                                     (const float4 *)scratch,
+                                     (int32_t *)((char *)scratch + search_order_offset(ctx, N, patch)),
+                                     (const uint8_t *)scratch + search_count_offset(ctx, N, patch), line_ori,
+                                     min_loss, high_conf, best_sample, best_rank, best_s, ctx->search_variant,
+                                     (hipStream_t)stream),
                     "mh_search_prepared");
 }
 

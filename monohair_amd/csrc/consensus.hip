@@ -5,7 +5,16 @@
 // (PMVO.py:717-726).  One workgroup per group; unit vectors are staged once in LDS, each lane owns a
 // candidate k and walks all j (LDS broadcast reads), then a wave-shuffle + LDS argmax picks the winner.
 // cos = (x0*y0 + x1*y1) + x2*y2 on vectors normalised as torch.cosine_similarity does; cos(-o_k,o_j) is
-// the exact negation, so the max is |cos|.  The mean adds the K terms left to right and divides by K.
+// the exact negation, so the max is |cos|.
+// The mean over j is torch.mean(dim=-1) of a contiguous [N,K,K] tensor = ATen's sum over the innermost
+// dimension (aten/src/ATen/native/cpu/SumKernel.cpp, its AVX2 build: 8 floats per vector) divided by K, and is
+// evaluated in exactly that order (MhInnerSum below; oracle/consensus_oracle.c states the same rule in C and is
+// pinned to the reference on 24 group sizes, tests/golden/consensus*.npz):
+//   K >= 8: the K/8 full vectors go round-robin to 4 vector accumulators = element j to accumulator j mod 32 while
+//           j < 32*(K/32), through multi_row_sum's cascade (level 0 flushed into level 1 every 16 rows of 32 elements,
+//           level 1 into level 2 every 256 rows, ...); vectors left over go to accumulator vector 0; the four
+//           vectors are added 0+1+2+3; a scalar starting at 0 takes the K%8 tail elements, then the 8 lanes in order;
+//   K < 8:  the same scheme on scalars: 4 accumulators, leftover elements into accumulator 0, then 0+1+2+3.
 #include "mh_device.h"
 
 #define MH_MEDOID_MAXK 4096
@@ -17,6 +26,88 @@ __device__ __forceinline__ bool mh_arg_better(float av, int ai, float bv, int bi
     return (av > bv) || (av == bv && ai < bi);
 }
 
+// ATen's inner-dimension sum of the K values x(0..K-1), consumed in index order.  BIG adds the cascade levels that
+// only groups of 512 and more members reach (96 more registers per lane).
+template <bool BIG>
+struct MhInnerSum {
+    float a0[32];
+    float a1[BIG ? 32 : 1], a2[BIG ? 32 : 1], a3[BIG ? 32 : 1];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int a = 0; a < 32; ++a) a0[a] = 0.0f;
+        if constexpr (BIG) {
+#pragma unroll
+            for (int a = 0; a < 32; ++a) a1[a] = a2[a] = a3[a] = 0.0f;
+        }
+    }
+    // row r = elements 32 r .. 32 r + 31 (four vectors of eight), r < K / 32
+    template <typename F>
+    __device__ __forceinline__ void row(int r, F x) {
+#pragma unroll
+        for (int a = 0; a < 32; ++a) a0[a] = a0[a] + x(32 * r + a);
+        if constexpr (BIG) {
+            const int i = r + 1;
+            if ((i & 15) == 0) {   // a full level-0 block of 16 rows
+#pragma unroll
+                for (int a = 0; a < 32; ++a) {
+                    a1[a] = a1[a] + a0[a];
+                    a0[a] = 0.0f;
+                }
+                if ((i & 0xF0) == 0) {
+#pragma unroll
+                    for (int a = 0; a < 32; ++a) {
+                        a2[a] = a2[a] + a1[a];
+                        a1[a] = 0.0f;
+                    }
+                    if ((i & 0xF00) == 0) {
+#pragma unroll
+                        for (int a = 0; a < 32; ++a) {
+                            a3[a] = a3[a] + a2[a];
+                            a2[a] = 0.0f;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // everything behind the last full row (K >= 8): x is called for j = 32 (K/32) .. K-1
+    template <typename F>
+    __device__ __forceinline__ float finish(int K, F x) {
+        if constexpr (BIG) {
+#pragma unroll
+            for (int a = 0; a < 32; ++a) a0[a] = ((a0[a] + a1[a]) + a2[a]) + a3[a];
+        }
+        const int vec_size = K >> 3, R = vec_size >> 2;
+        for (int i = R * 4; i < vec_size; ++i) {
+#pragma unroll
+            for (int l = 0; l < 8; ++l) a0[l] = a0[l] + x(8 * i + l);
+        }
+        float p[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) p[l] = ((a0[l] + a0[8 + l]) + a0[16 + l]) + a0[24 + l];
+        float fin = 0.0f;
+        for (int j = vec_size * 8; j < K; ++j) fin = fin + x(j);
+#pragma unroll
+        for (int l = 0; l < 8; ++l) fin = fin + p[l];
+        return fin;
+    }
+};
+
+// K < 8: ATen's scalar_inner_sum (row_sum with four scalar accumulators)
+template <typename F>
+__device__ __forceinline__ float mh_inner_sum_small(int K, F x) {
+    float q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int full = (K >> 2) << 2;
+    for (int j = 0; j < full; j += 4) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) q[a] = q[a] + x(j + a);
+    }
+    for (int j = full; j < K; ++j) q[0] = q[0] + x(j);
+    return ((q[0] + q[1]) + q[2]) + q[3];
+}
+
+// big_pass = 0: groups below 512 members (one cascade level); 1: only the larger ones (all four levels)
+template <bool BIG>
 __global__ __launch_bounds__(256) void mh_medoid_kernel(const float *__restrict__ ori,
                                                         const int32_t *__restrict__ seg_start, int K_dense,
                                                         float *__restrict__ out, int32_t *__restrict__ out_index,
@@ -27,7 +118,7 @@ __global__ __launch_bounds__(256) void mh_medoid_kernel(const float *__restrict_
     const int g = blockIdx.x, tid = threadIdx.x;
     const int begin = seg_start ? seg_start[g] : g * K_dense;
     const int K = seg_start ? (seg_start[g + 1] - begin) : K_dense;
-    if (K <= 0) return;
+    if (K <= 0 || (K >= 512) != BIG) return;   // the other launch takes this group
     const float *__restrict__ o = ori + (size_t)begin * 3;
     // dense groups may be given as K row indices into `ori` (the 100 nearest neighbours of refine, PMVO.py:612-618)
     // instead of a materialised [G,K,3] gather
@@ -52,12 +143,20 @@ __global__ __launch_bounds__(256) void mh_medoid_kernel(const float *__restrict_
         __syncthreads();
         for (int k = tid; k < K; k += 256) {
             const float a0 = s_u[3 * k], a1 = s_u[3 * k + 1], a2 = s_u[3 * k + 2];
-            float acc = 0.0f;
-            for (int j = 0; j < K; ++j) {
-                const float cs = (a0 * s_u[3 * j] + a1 * s_u[3 * j + 1]) + a2 * s_u[3 * j + 2];
-                acc = acc + __builtin_fabsf(cs);
+            auto x = [&](int j) {
+                return __builtin_fabsf((a0 * s_u[3 * j] + a1 * s_u[3 * j + 1]) + a2 * s_u[3 * j + 2]);
+            };
+            float sum;
+            if (K < 8) {
+                sum = mh_inner_sum_small(K, x);
+            } else {
+                MhInnerSum<BIG> acc;
+                acc.init();
+                const int R = K >> 5;
+                for (int r = 0; r < R; ++r) acc.row(r, x);
+                sum = acc.finish(K, x);
             }
-            const float mean = acc / (float)K;
+            const float mean = sum / (float)K;
             if (bi == 0x7fffffff || mh_arg_better(mean, k, bv, bi)) {
                 bv = mean;
                 bi = k;
@@ -65,27 +164,36 @@ __global__ __launch_bounds__(256) void mh_medoid_kernel(const float *__restrict_
         }
     } else {
         // a group that does not fit in LDS (never the case for the 2.5 mm voxels of a real capture): the units are
-        // staged MH_MEDOID_MAXK at a time, every lane keeps the left-to-right sum of its current candidate
-        for (int kb = 0; kb < K; kb += 256) {
-            const int k = kb + tid;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, acc = 0.0f;
-            if (k < K) unit_of(k, a0, a1, a2);
-            for (int j0 = 0; j0 < K; j0 += MH_MEDOID_MAXK) {
-                const int nj = min(MH_MEDOID_MAXK, K - j0);
-                __syncthreads();
-                for (int j = tid; j < nj; j += 256) unit_of(j0 + j, s_u[3 * j], s_u[3 * j + 1], s_u[3 * j + 2]);
-                __syncthreads();
-                if (k < K)
-                    for (int j = 0; j < nj; ++j) {
-                        const float cs = (a0 * s_u[3 * j] + a1 * s_u[3 * j + 1]) + a2 * s_u[3 * j + 2];
-                        acc = acc + __builtin_fabsf(cs);
+        // staged MH_MEDOID_MAXK (= 128 rows of 32) at a time, every lane carries the accumulators of its candidate
+        if constexpr (BIG) {
+            for (int kb = 0; kb < K; kb += 256) {
+                const int k = kb + tid;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+                if (k < K) unit_of(k, a0, a1, a2);
+                MhInnerSum<true> acc;
+                acc.init();
+                float sum = 0.0f;
+                for (int j0 = 0; j0 < K; j0 += MH_MEDOID_MAXK) {
+                    const int nj = min(MH_MEDOID_MAXK, K - j0);
+                    __syncthreads();
+                    for (int j = tid; j < nj; j += 256) unit_of(j0 + j, s_u[3 * j], s_u[3 * j + 1], s_u[3 * j + 2]);
+                    __syncthreads();
+                    auto x = [&](int j) {
+                        const int q = j - j0;
+                        return __builtin_fabsf((a0 * s_u[3 * q] + a1 * s_u[3 * q + 1]) + a2 * s_u[3 * q + 2]);
+                    };
+                    if (k < K) {
+                        const int r1 = min((j0 + nj) >> 5, K >> 5);
+                        for (int r = j0 >> 5; r < r1; ++r) acc.row(r, x);
+                        if (j0 + nj == K) sum = acc.finish(K, x);   // the remainder lies in this (last) piece
                     }
-            }
-            if (k < K) {
-                const float mean = acc / (float)K;
-                if (bi == 0x7fffffff || mh_arg_better(mean, k, bv, bi)) {
-                    bv = mean;
-                    bi = k;
+                }
+                if (k < K) {
+                    const float mean = sum / (float)K;
+                    if (bi == 0x7fffffff || mh_arg_better(mean, k, bv, bi)) {
+                        bv = mean;
+                        bi = k;
+                    }
                 }
             }
         }
@@ -160,15 +268,26 @@ extern "C" int mh_launch_replace_dissimilar(const float *center, float *ori, flo
 extern "C" int mh_launch_medoid_dense(const float *ori, const int32_t *index, int G, int K, float *out, int32_t *out_index,
                                       hipStream_t st) {
     const int kl = K < MH_MEDOID_MAXK ? K : MH_MEDOID_MAXK;
-    hipLaunchKernelGGL(mh_medoid_kernel, dim3(G), dim3(256), (size_t)kl * 3 * sizeof(float), st, ori, nullptr, K, out,
-                       out_index, index);
+    if (K < 512)
+        hipLaunchKernelGGL(mh_medoid_kernel<false>, dim3(G), dim3(256), (size_t)kl * 3 * sizeof(float), st, ori, nullptr,
+                           K, out, out_index, index);
+    else
+        hipLaunchKernelGGL(mh_medoid_kernel<true>, dim3(G), dim3(256), (size_t)kl * 3 * sizeof(float), st, ori, nullptr,
+                           K, out, out_index, index);
     return (int)hipGetLastError();
 }
 
 extern "C" int mh_launch_medoid_segmented(const float *ori, const int32_t *seg_start, int G, int max_group,
                                           float *out, int32_t *out_index, hipStream_t st) {
-    const int kl = max_group < MH_MEDOID_MAXK ? max_group : MH_MEDOID_MAXK;
-    hipLaunchKernelGGL(mh_medoid_kernel, dim3(G), dim3(256), (size_t)kl * 3 * sizeof(float), st, ori, seg_start, 0, out,
-                       out_index, nullptr);
+    // two launches over the same groups: every workgroup looks at its group's size and leaves if the other form
+    // owns it (the four-level accumulators cost registers that the common small groups should not pay for)
+    const int ks = max_group < 511 ? max_group : 511;
+    hipLaunchKernelGGL(mh_medoid_kernel<false>, dim3(G), dim3(256), (size_t)(ks > 0 ? ks : 1) * 3 * sizeof(float), st,
+                       ori, seg_start, 0, out, out_index, nullptr);
+    if (max_group >= 512) {
+        const int kl = max_group < MH_MEDOID_MAXK ? max_group : MH_MEDOID_MAXK;
+        hipLaunchKernelGGL(mh_medoid_kernel<true>, dim3(G), dim3(256), (size_t)kl * 3 * sizeof(float), st, ori,
+                           seg_start, 0, out, out_index, nullptr);
+    }
     return (int)hipGetLastError();
 }

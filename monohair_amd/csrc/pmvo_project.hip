@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void mh_prep_taps_kernel(const float *__restri
                                                            const float *__restrict__ conf_patch,
                                                            const float *__restrict__ vis,
                                                            const float *__restrict__ pixf, int VN, int P, float thr,
-                                                           float4 *__restrict__ taps) {
+                                                           float4 *__restrict__ taps, uint8_t *__restrict__ cnt) {
     __shared__ float2 s_o[4][MH_PREP_PMAX];
     __shared__ unsigned char s_el[4][MH_PREP_PMAX];
     __shared__ unsigned int s_first[4][256];
@@ -198,7 +198,10 @@ __global__ __launch_bounds__(256) void mh_prep_taps_kernel(const float *__restri
     const float visv = vis[vn];
     float4 *__restrict__ out = taps + (size_t)vn * (P + 1);
     if (visv == -1.0f) {   // the search skips this view for this point: header only
-        if (lane == 0) out[0] = make_float4(__int_as_float(0), visv, 0.0f, 0.0f);
+        if (lane == 0) {
+            out[0] = make_float4(__int_as_float(0), visv, 0.0f, 0.0f);
+            cnt[vn] = 0;
+        }
         return;
     }
     const float *__restrict__ cp = conf_patch + (size_t)vn * P;
@@ -256,6 +259,7 @@ __global__ __launch_bounds__(256) void mh_prep_taps_kernel(const float *__restri
     if (lane == 0) {
         const float2 pf = reinterpret_cast<const float2 *>(pixf)[vn];
         out[0] = make_float4(__int_as_float(base), visv, pf.x, pf.y);
+        cnt[vn] = (uint8_t)base;   // compact copy of the list lengths [V,N]: the search's work estimate reads it coalesced
     }
 }
 
@@ -271,7 +275,8 @@ template <int PATCH>
 __global__ __launch_bounds__(256) void mh_project_taps_kernel(MhViews vw, const float *__restrict__ pts, int N,
                                                               int tiles, float thr, float *__restrict__ vis,
                                                               float *__restrict__ ori, float *__restrict__ conf,
-                                                              float *__restrict__ mask, float4 *__restrict__ taps) {
+                                                              float *__restrict__ mask, float4 *__restrict__ taps,
+                                                              uint8_t *__restrict__ cnt) {
     // One workgroup = one view x 64 consecutive points (the tiling and XCD mapping of mh_project_gather_kernel).
     //   phase 1: 64 lanes project their point, fetch the centre record, decide visibility, write the per-(v,n)
     //            outputs coalesced and the header of points that fail the depth test;
@@ -315,7 +320,10 @@ __global__ __launch_bounds__(256) void mh_project_taps_kernel(MhViews vw, const 
             reinterpret_cast<float2 *>(ori)[vn] = make_float2(q0.x, q0.y);
             conf[vn] = mh_clampf(q0.z, 1e-6f, 1.0f);
             if (mask) mask[vn] = vw.mask[(size_t)v * H * W + (size_t)r * W + c];
-            if (visv == -1.0f) taps[vn * (P + 1)] = make_float4(__int_as_float(0), visv, 0.0f, 0.0f);
+            if (visv == -1.0f) {
+                taps[vn * (P + 1)] = make_float4(__int_as_float(0), visv, 0.0f, 0.0f);
+                cnt[vn] = 0;
+            }
             s_r[tid] = r;
             s_cc[tid] = c;
             s_rowf[tid] = rowf;
@@ -393,7 +401,10 @@ __global__ __launch_bounds__(256) void mh_project_taps_kernel(MhViews vw, const 
             if (el) out[1 + pos] = make_float4(o.x, o.y, cc, 0.0f);
             base += __popcll(m);
         }
-        if (lane == 0) out[0] = make_float4(__int_as_float(base), s_vis[cur], s_rowf[cur], s_colf[cur]);
+        if (lane == 0) {
+            out[0] = make_float4(__int_as_float(base), s_vis[cur], s_rowf[cur], s_colf[cur]);
+            cnt[vn] = (uint8_t)base;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         cur = nxt;
@@ -454,22 +465,24 @@ extern "C" int mh_launch_topk(const float *vis, const float *conf, int V, int N,
 }
 
 extern "C" int mh_launch_prep_taps(const float *ori_patch, const float *conf_patch, const float *vis,
-                                   const float *pixf, int VN, int P, float thr, float4 *taps, hipStream_t st) {
+                                   const float *pixf, int VN, int P, float thr, float4 *taps, uint8_t *cnt,
+                                   hipStream_t st) {
     if (P > MH_PREP_PMAX) return -1;
     hipLaunchKernelGGL(mh_prep_taps_kernel, dim3((VN + 3) / 4), dim3(256), 0, st, ori_patch, conf_patch, vis, pixf,
-                       VN, P, thr, taps);
+                       VN, P, thr, taps, cnt);
     return (int)hipGetLastError();
 }
 
 extern "C" int mh_launch_project_taps(MhViews vw, const float *pts, int N, int patch, float thr, float *vis,
-                                      float *ori, float *conf, float *mask, float4 *taps, hipStream_t st) {
+                                      float *ori, float *conf, float *mask, float4 *taps, uint8_t *cnt,
+                                      hipStream_t st) {
     if (patch * patch > MH_PREP_PMAX) return -1;
     const int tiles = (N + MH_PG_TILE - 1) / MH_PG_TILE;
     const dim3 grid((vw.V * tiles + 7) & ~7), block(256);
 #define MH_PT_CASE(PS)                                                                                           \
     case PS:                                                                                                     \
         hipLaunchKernelGGL(mh_project_taps_kernel<PS>, grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, conf, \
-                           mask, taps);                                                                          \
+                           mask, taps, cnt);                                                                     \
         break;
     switch (patch) {
         MH_PT_CASE(1)

@@ -332,6 +332,381 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
 }
 
 // ---------------------------------------------------------------------------------------------
+// mh_search2_kernel -- the shipped search (round 2).  Same arithmetic, operation for operation, as mh_search_kernel;
+// what changed is how the work is laid out on the machine (tools/ubench/valu2.hip, valu3.hip give the issue costs):
+//   * the tap body uses plain v_mul/v_mul/v_add/v_sub (full-rate VALU operations, ~2 cycles per wave-instruction)
+//     instead of v_pk_mul/v_pk_add: packed fp32 operations go through the half-rate path together with v_cmp /
+//     v_cndmask and do not overlap with them, the full-rate ones do (82 -> 69 cycles per tap per 4 items);
+//   * candidates of base-view ranks that can never be taken are not evaluated: ranks > 0 only replace the best-so-far
+//     when base_view_conf[rank] > 0 (PMVO.py:64), and the ranking is sorted by that value, so the usable ranks are a
+//     prefix; a point seen by few views costs proportionally less (exact: those losses are never read);
+//   * every wave evaluates only the item slices it has (900 items = 15 wave-slices, not 16);
+//   * workgroups take the points in descending order of work (order[], mh_search_order_kernel), so the tail of the
+//     launch is made of cheap points.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float mh_vmul(float a, float b) {
+    float r;
+    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// the same with the first factor in an SGPR (a wave-uniform tap value that came through the scalar cache)
+__device__ __forceinline__ float mh_vmul_s(float a, float b) {
+    float r;
+    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float mh_vadd(float a, float b) {
+    float r;
+    asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// running minimum over the taps with first-index ties (strict '<', PMVO.py:177): compares of all items first, then the
+// selects (gfx950 wants 2 wait states between a VALU write of an SGPR mask and a VALU read of it)
+template <int KA>
+__device__ __forceinline__ void mh_tap_update(float (&ML)[KA], float (&BC)[KA], const float (&l)[KA], float cf) {
+    if constexpr (KA == 4) {
+        unsigned long long m0, m1, m2, m3;
+        asm("v_cmp_lt_f32_e64 %[m0], %[l0], %[a0]\n\t"
+            "v_cmp_lt_f32_e64 %[m1], %[l1], %[a1]\n\t"
+            "v_cmp_lt_f32_e64 %[m2], %[l2], %[a2]\n\t"
+            "v_cmp_lt_f32_e64 %[m3], %[l3], %[a3]\n\t"
+            "v_cndmask_b32_e64 %[a0], %[a0], %[l0], %[m0]\n\t"
+            "v_cndmask_b32_e64 %[a1], %[a1], %[l1], %[m1]\n\t"
+            "v_cndmask_b32_e64 %[a2], %[a2], %[l2], %[m2]\n\t"
+            "v_cndmask_b32_e64 %[a3], %[a3], %[l3], %[m3]\n\t"
+            "v_cndmask_b32_e64 %[b0], %[b0], %[cf], %[m0]\n\t"
+            "v_cndmask_b32_e64 %[b1], %[b1], %[cf], %[m1]\n\t"
+            "v_cndmask_b32_e64 %[b2], %[b2], %[cf], %[m2]\n\t"
+            "v_cndmask_b32_e64 %[b3], %[b3], %[cf], %[m3]"
+            : [a0] "+v"(ML[0]), [a1] "+v"(ML[1]), [a2] "+v"(ML[2]), [a3] "+v"(ML[3]), [b0] "+v"(BC[0]),
+              [b1] "+v"(BC[1]), [b2] "+v"(BC[2]), [b3] "+v"(BC[3]), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2),
+              [m3] "=&s"(m3)
+            : [l0] "v"(l[0]), [l1] "v"(l[1]), [l2] "v"(l[2]), [l3] "v"(l[3]), [cf] "v"(cf));
+    } else if constexpr (KA == 3) {
+        unsigned long long m0, m1, m2;
+        asm("v_cmp_lt_f32_e64 %[m0], %[l0], %[a0]\n\t"
+            "v_cmp_lt_f32_e64 %[m1], %[l1], %[a1]\n\t"
+            "v_cmp_lt_f32_e64 %[m2], %[l2], %[a2]\n\t"
+            "v_cndmask_b32_e64 %[a0], %[a0], %[l0], %[m0]\n\t"
+            "v_cndmask_b32_e64 %[a1], %[a1], %[l1], %[m1]\n\t"
+            "v_cndmask_b32_e64 %[a2], %[a2], %[l2], %[m2]\n\t"
+            "v_cndmask_b32_e64 %[b0], %[b0], %[cf], %[m0]\n\t"
+            "v_cndmask_b32_e64 %[b1], %[b1], %[cf], %[m1]\n\t"
+            "v_cndmask_b32_e64 %[b2], %[b2], %[cf], %[m2]"
+            : [a0] "+v"(ML[0]), [a1] "+v"(ML[1]), [a2] "+v"(ML[2]), [b0] "+v"(BC[0]), [b1] "+v"(BC[1]),
+              [b2] "+v"(BC[2]), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2)
+            : [l0] "v"(l[0]), [l1] "v"(l[1]), [l2] "v"(l[2]), [cf] "v"(cf));
+    } else if constexpr (KA == 2) {
+        unsigned long long m0, m1;
+        asm("v_cmp_lt_f32_e64 %[m0], %[l0], %[a0]\n\t"
+            "v_cmp_lt_f32_e64 %[m1], %[l1], %[a1]\n\t"
+            "s_nop 0\n\t"
+            "v_cndmask_b32_e64 %[a0], %[a0], %[l0], %[m0]\n\t"
+            "v_cndmask_b32_e64 %[a1], %[a1], %[l1], %[m1]\n\t"
+            "v_cndmask_b32_e64 %[b0], %[b0], %[cf], %[m0]\n\t"
+            "v_cndmask_b32_e64 %[b1], %[b1], %[cf], %[m1]"
+            : [a0] "+v"(ML[0]), [a1] "+v"(ML[1]), [b0] "+v"(BC[0]), [b1] "+v"(BC[1]), [m0] "=&s"(m0), [m1] "=&s"(m1)
+            : [l0] "v"(l[0]), [l1] "v"(l[1]), [cf] "v"(cf));
+    } else {
+#pragma unroll
+        for (int j = 0; j < KA; ++j) {
+            const bool upd = l[j] < ML[j];
+            ML[j] = upd ? l[j] : ML[j];
+            BC[j] = upd ? cf : BC[j];
+        }
+    }
+}
+
+// One wave's share of a point: KA item slices (item = j*T + tid), all views, per-sample loss and "positive" flag into LDS
+template <int KA, int T, int LD>
+__device__ __forceinline__ void mh_search_slices(const MhViews &vw, const float *__restrict__ offs, int S, int rank_step,
+                                                 float P0, float P1x, float P2, int n, int N, int P1, float thr,
+                                                 const float *__restrict__ ori_c, const int32_t *__restrict__ base_idx,
+                                                 const float4 *__restrict__ taps, int nact, int tid, float *s_loss,
+                                                 uint8_t *s_pos) {
+    const int V = vw.V;
+    const float Hf = (float)vw.H, Wf = (float)vw.W;
+    float X0[KA], X1[KA], X2[KA];
+    MhCascV num[KA], den[KA];
+    int cnt[KA];
+#pragma unroll
+    for (int j = 0; j < KA; ++j) {
+        int it = j * T + tid;
+        it = it < nact ? it : 0;
+        const int r = it / S, s = it - r * S;
+        const int b = base_idx[(size_t)(r * rank_step) * N + n];
+        const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
+        mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[s], X0[j], X1[j], X2[j]);
+        num[j] = den[j] = MhCascV{0.0f, 0.0f, 0.0f};
+        cnt[j] = 0;
+    }
+    for (int v = 0; v < V; ++v) {
+        if (v > 0 && (v & 15) == 0) {
+#pragma unroll
+            for (int j = 0; j < KA; ++j) {
+                mh_cascv_flush(num[j], v);
+                mh_cascv_flush(den[j], v);
+            }
+        }
+        const float4 *__restrict__ rec0 = taps + ((size_t)v * N + n) * P1;
+        const float4 hdr = rec0[0];
+        if (hdr.y == -1.0f) continue;   // uniform: point not visible in this view, weight 0
+        const int ntap = __float_as_int(hdr.x);
+        const float *__restrict__ cam = vw.cams + v * MH_CAM_STRIDE;
+        // LD == 0: the tap records travel as wave-uniform VECTOR loads (every lane gets a copy; the address is made
+        // opaque so that the backend cannot move them to the scalar cache); LD == 1: scalar loads, the tap values are
+        // SGPR operands of the multiplies
+        const float4 *__restrict__ rec = rec0;
+        if constexpr (LD == 0) {
+            unsigned zl;
+            asm("v_mov_b32_e32 %0, 0" : "=v"(zl));
+            rec = rec0 + zl;
+        }
+        const float4 t0 = rec[1];
+        float DX[KA], DY[KA], ML[KA], BC[KA];
+#pragma unroll
+        for (int jp = 0; jp < KA / 2; ++jp) {
+            mh_v2f row, col, dx, dy;
+            mh_pixel_of_fast2(cam, mh_v2f{X0[2 * jp], X0[2 * jp + 1]}, mh_v2f{X1[2 * jp], X1[2 * jp + 1]},
+                              mh_v2f{X2[2 * jp], X2[2 * jp + 1]}, Hf, Wf, row, col);
+            mh_unit2_fast2(row - mh_splat(hdr.z), col - mh_splat(hdr.w), dx, dy);
+            DX[2 * jp] = dx.x;
+            DX[2 * jp + 1] = dx.y;
+            DY[2 * jp] = dy.x;
+            DY[2 * jp + 1] = dy.y;
+        }
+        if constexpr (KA & 1) {
+            // the odd item goes through the pairwise form too (a duplicated lane pair): identical operations
+            mh_v2f row, col, dx, dy;
+            mh_pixel_of_fast2(cam, mh_splat(X0[KA - 1]), mh_splat(X1[KA - 1]), mh_splat(X2[KA - 1]), Hf, Wf, row, col);
+            mh_unit2_fast2(row - mh_splat(hdr.z), col - mh_splat(hdr.w), dx, dy);
+            DX[KA - 1] = dx.x;
+            DY[KA - 1] = dy.x;
+        }
+#pragma unroll
+        for (int j = 0; j < KA; ++j) {
+            if constexpr (LD == 0) ML[j] = mh_one_minus_abs(mh_vadd(mh_vmul(t0.x, DX[j]), mh_vmul(t0.y, DY[j])));
+            else ML[j] = mh_one_minus_abs(mh_vadd(mh_vmul_s(t0.x, DX[j]), mh_vmul_s(t0.y, DY[j])));
+            BC[j] = t0.z;
+        }
+        // tap records travel as wave-uniform VECTOR loads in ping-pong groups of four (see mh_search_kernel)
+        constexpr int GRP = 4;
+        auto process = [&](const float4 (&g)[GRP], int t) {
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+                if (t + u < ntap) {   // uniform
+                    const float4 tp = g[u];
+                    float l[KA];
+#pragma unroll
+                    for (int j = 0; j < KA; ++j) {
+                        if constexpr (LD == 0) l[j] = mh_one_minus_abs(mh_vadd(mh_vmul(tp.x, DX[j]), mh_vmul(tp.y, DY[j])));
+                        else l[j] = mh_one_minus_abs(mh_vadd(mh_vmul_s(tp.x, DX[j]), mh_vmul_s(tp.y, DY[j])));
+                    }
+                    mh_tap_update<KA>(ML, BC, l, tp.z);
+                }
+            }
+        };
+        float4 ga[GRP], gb[GRP];
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) ga[u] = rec[2 + u];
+        for (int t = 1; t < ntap;) {
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) gb[u] = rec[1 + t + GRP + u];
+            process(ga, t);
+            t += GRP;
+            if (t >= ntap) break;
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) ga[u] = rec[1 + t + GRP + u];
+            process(gb, t);
+            t += GRP;
+        }
+#pragma unroll
+        for (int j = 0; j < KA; ++j) {
+            const float w = BC[j];   // (vis != -1) * best_conf
+            num[j].a0 = num[j].a0 + ML[j] * w;
+            den[j].a0 = den[j].a0 + w;
+            cnt[j] += (w > 0.0f) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KA; ++j) {
+        const int it = j * T + tid;
+        if (it < nact) {
+            const float dn = mh_cascv_done(den[j]);
+            const float nm = mh_cascv_done(num[j]);
+            const float ratio = dn / (float)cnt[j];
+            s_pos[it] = (ratio > thr) ? 1 : 0;
+            s_loss[it] = nm / dn;
+        }
+    }
+}
+
+template <int T, int LD>
+__global__ __launch_bounds__(T) void mh_search2_kernel(MhViews vw, const float *__restrict__ offs, int S, int nrank,
+                                                       int rank_step, const float *__restrict__ pts, int N, int P1,
+                                                       float thr, const float *__restrict__ ori_c,
+                                                       const int32_t *__restrict__ base_idx,
+                                                       const float *__restrict__ base_val,
+                                                       const float4 *__restrict__ taps,
+                                                       const int32_t *__restrict__ order, float *__restrict__ line_ori,
+                                                       float *__restrict__ min_loss, uint8_t *__restrict__ high_conf,
+                                                       float *__restrict__ best_sample, int32_t *__restrict__ best_rank,
+                                                       int32_t *__restrict__ best_s) {
+    __shared__ float s_loss[MH_MAX_ITEMS];
+    __shared__ uint8_t s_pos[MH_MAX_ITEMS];
+    __shared__ float s_rl[MH_MAX_RANKS];
+    __shared__ int s_ri[MH_MAX_RANKS];
+    __shared__ int s_rh[MH_MAX_RANKS];
+
+    const int tid = threadIdx.x;
+    const int n = order ? order[blockIdx.x] : (int)blockIdx.x;
+    const float P0 = pts[3 * n], P1x = pts[3 * n + 1], P2 = pts[3 * n + 2];
+    // usable base-view ranks: rank 0 always, rank r > 0 only if base_view_conf[r] > 0 (PMVO.py:57-64); keep every rank up
+    // to the last usable one
+    int nvalid = 1;
+    for (int r = 1; r < nrank; ++r)
+        if (base_val[(size_t)(r * rank_step) * N + n] > 0.0f) nvalid = r + 1;
+    const int nact = nvalid * S;
+    const int wave0 = tid & ~63;   // first item of this wave in slice 0
+    int ka = 0;
+    for (int j = 0; j < 4; ++j) ka += (j * T + wave0 < nact) ? 1 : 0;
+#define MH_S2_ARGS vw, offs, S, rank_step, P0, P1x, P2, n, N, P1, thr, ori_c, base_idx, taps, nact, tid, s_loss, s_pos
+    if (ka == 4) mh_search_slices<4, T, LD>(MH_S2_ARGS);
+    else if (ka == 3) mh_search_slices<3, T, LD>(MH_S2_ARGS);
+    else if (ka == 2) mh_search_slices<2, T, LD>(MH_S2_ARGS);
+    else if (ka == 1) mh_search_slices<1, T, LD>(MH_S2_ARGS);
+#undef MH_S2_ARGS
+    __syncthreads();
+
+    // ---- per rank: low-confidence escape hatch, min / argmin over the S samples (PMVO.py:199-206)
+    const int wave = tid >> 6, lane = tid & 63, nwaves = T >> 6;
+    for (int r = wave; r < nvalid; r += nwaves) {
+        int npos = 0;
+        for (int s0 = 0; s0 < S; s0 += MH_WAVE) {
+            const int s = s0 + lane;
+            npos += __popcll(__ballot(s < S && s_pos[r * S + s]));
+        }
+        const bool low = npos < 5;
+        float bl = 0.0f;
+        int bi = 0x7fffffff;
+        for (int s = lane; s < S; s += MH_WAVE) {
+            float l = s_loss[r * S + s];
+            if (!low && !s_pos[r * S + s]) l = 1.0f;
+            if (bi == 0x7fffffff || mh_min_better(l, s, bl, bi)) {
+                bl = l;
+                bi = s;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ol = __shfl_xor(bl, o);
+            const int oi = __shfl_xor(bi, o);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || mh_min_better(ol, oi, bl, bi))) {
+                bl = ol;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            s_rl[r] = bl;
+            s_ri[r] = bi;
+            s_rh[r] = s_pos[r * S + bi];
+        }
+    }
+    __syncthreads();
+
+    // ---- best candidate across base-view ranks (PMVO.py:57-70) and the 3D direction (:73-74)
+    if (tid == 0) {
+        const float Hf = (float)vw.H, Wf = (float)vw.W;
+        float ml = s_rl[0];
+        int br = 0, bs = s_ri[0], hc = s_rh[0];
+        for (int r = 1; r < nvalid; ++r) {
+            const float l = s_rl[r];
+            if ((l < ml) && (base_val[(size_t)(r * rank_step) * N + n] > 0.0f)) {
+                ml = l;
+                br = r;
+                bs = s_ri[r];
+                hc = s_rh[r];
+            }
+        }
+        const int b = base_idx[(size_t)(br * rank_step) * N + n];
+        const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
+        float B0, B1, B2;
+        mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[bs], B0, B1, B2);
+        const float d0 = B0 - P0, d1 = B1 - P1x, d2 = B2 - P2;
+        float s2 = d0 * d0;
+        s2 = mh_fma(d1, d1, s2);
+        s2 = mh_fma(d2, d2, s2);
+        const float nrm = __builtin_sqrtf(s2);
+        line_ori[3 * n] = d0 / nrm;
+        line_ori[3 * n + 1] = d1 / nrm;
+        line_ori[3 * n + 2] = d2 / nrm;
+        min_loss[n] = ml;
+        high_conf[n] = (uint8_t)hc;
+        if (best_sample) {
+            best_sample[3 * n] = B0;
+            best_sample[3 * n + 1] = B1;
+            best_sample[3 * n + 2] = B2;
+        }
+        if (best_rank) best_rank[n] = br;
+        if (best_s) best_s[n] = bs;
+    }
+}
+
+// Launch order of the search: points sorted by descending work = (taps of the views that see the point) x (item slices
+// it needs).  mh_search_work_kernel: one lane per point -> work class (0 = heaviest) in order[0..N);
+// mh_search_order_kernel: one workgroup -- histogram of the MH_ORDER_BUCKETS classes, exclusive scan, scatter of the
+// point indices into order[N..2N).  The order inside a class is whatever the atomics give: it only decides WHEN a
+// point is processed, never what is computed for it.
+#define MH_ORDER_BUCKETS 1024
+__global__ __launch_bounds__(256) void mh_search_work_kernel(const uint8_t *__restrict__ cnt, int V, int N, int P1,
+                                                             const float *__restrict__ base_val, int nrank,
+                                                             int rank_step, int S, int T, int32_t *__restrict__ order) {
+    // one wave per point: lanes over the views (list lengths, 0 for views that do not see the point) and over the ranks
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    int nt = 0;
+    for (int v = lane; v < V; v += MH_WAVE) nt += cnt[(size_t)v * N + n];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nt += __shfl_xor(nt, o);
+    const bool usable = lane > 0 && lane < nrank && base_val[(size_t)(lane * rank_step) * N + n] > 0.0f;
+    const unsigned long long m = __ballot(usable);
+    const int nvalid = m ? (64 - __builtin_clzll(m)) : 1;   // last usable rank + 1
+    if (lane == 0) {
+        const int maxwork = V * (P1 - 1) * 4;   // taps of all views x 4 slices
+        const int work = nt * ((nvalid * S + T - 1) / T);
+        int b = (int)(((long long)work * (MH_ORDER_BUCKETS - 1)) / (maxwork > 0 ? maxwork : 1));
+        order[n] = MH_ORDER_BUCKETS - 1 - min(max(b, 0), MH_ORDER_BUCKETS - 1);
+    }
+}
+
+__global__ __launch_bounds__(1024) void mh_search_order_kernel(int N, int32_t *__restrict__ order) {
+    __shared__ int s_hist[MH_ORDER_BUCKETS];
+    __shared__ int s_part[1024 / 64];
+    const int tid = threadIdx.x;
+    s_hist[tid] = 0;
+    __syncthreads();
+    for (int n = tid; n < N; n += 1024) atomicAdd(&s_hist[order[n]], 1);
+    __syncthreads();
+    const int mine = s_hist[tid];   // lane = class
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int x = __shfl_up(incl, o);
+        if ((tid & 63) >= o) incl += x;
+    }
+    if ((tid & 63) == 63) s_part[tid >> 6] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) base += s_part[w];
+    __syncthreads();
+    s_hist[tid] = base + incl - mine;   // first position of this class
+    __syncthreads();
+    for (int n = tid; n < N; n += 1024) order[N + atomicAdd(&s_hist[order[n]], 1)] = n;
+}
+
+// ---------------------------------------------------------------------------------------------
 // PMVO.refine's loss of ONE given direction per point (PMVO.py:86-90): next = p + dir*mul/div,
 // compute_reproject_ori + compute_prj_loss with S = 1 (then `low_conf_index` is always true and the raw
 // num/den is returned, PMVO.py:199-204).  One wave per point, lane = view; the per-view terms go through
@@ -533,9 +908,10 @@ __global__ __launch_bounds__(256) void mh_refine_combine_kernel(const float *__r
 // ---------------------------------------------------------------------------------------------
 extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank, int rank_step, const float *pts,
                                 int N, int P1, float thr, const float *ori_c, const int32_t *base_idx,
-                                const float *base_val, const float4 *taps, float *line_ori, float *min_loss,
-                                uint8_t *high_conf, float *best_sample, int32_t *best_rank, int32_t *best_s,
-                                int variant, hipStream_t st) {
+                                const float *base_val, const float4 *taps, int32_t *order /* 2N ints of work space */,
+                                const uint8_t *cnt /* [V,N] list lengths */,
+                                float *line_ori, float *min_loss, uint8_t *high_conf, float *best_sample,
+                                int32_t *best_rank, int32_t *best_s, int variant, hipStream_t st) {
     const int nitems = nrank * S;
     if (nitems > MH_MAX_ITEMS || nrank > MH_MAX_RANKS || nitems < 1) return -1;
 #define MH_SEARCH_LAUNCH_F(KK, TT, FF)                                                                                   \
@@ -543,9 +919,27 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
                        P1, thr, ori_c, base_idx, base_val, taps, line_ori, min_loss, high_conf, best_sample,        \
                        best_rank, best_s)
 #define MH_SEARCH_LAUNCH(KK, TT) MH_SEARCH_LAUNCH_F(KK, TT, 0)
-    // pick the smallest K*T that covers the items for the requested wave count
-    if (variant == 0) variant = (nitems <= 64) ? 64 : (nitems <= 320 ? 320 : 256);
-    if (variant == 64) {
+    // variant 0: mh_search2_kernel (256 threads, up to 4 item slices) when the items fit, ordered by work;
+    // 2: the same without the work order (A/B); the others: earlier forms kept for A/B and cross-checks
+    if (variant == 0) variant = (nitems <= 64) ? 64 : (nitems <= 1024 ? 1 : 256);
+    if (variant >= 1 && variant <= 4) {   // 1: vector tap loads, ordered; 2: same, natural order; 3/4: scalar tap loads
+        if (nitems > 1024) return -1;
+        const int32_t *ord = nullptr;
+        if ((variant & 1) && order && cnt && N > 1) {
+            hipLaunchKernelGGL(mh_search_work_kernel, dim3((N + 3) / 4), dim3(256), 0, st, cnt, vw.V, N, P1, base_val,
+                               nrank, rank_step, S, 256, order);
+            hipLaunchKernelGGL(mh_search_order_kernel, dim3(1), dim3(1024), 0, st, N, order);
+            ord = order + N;
+        }
+        if (variant <= 2)
+            hipLaunchKernelGGL((mh_search2_kernel<256, 0>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts,
+                               N, P1, thr, ori_c, base_idx, base_val, taps, ord, line_ori, min_loss, high_conf,
+                               best_sample, best_rank, best_s);
+        else
+            hipLaunchKernelGGL((mh_search2_kernel<256, 1>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts,
+                               N, P1, thr, ori_c, base_idx, base_val, taps, ord, line_ori, min_loss, high_conf,
+                               best_sample, best_rank, best_s);
+    } else if (variant == 64) {
         if (nitems <= 64) MH_SEARCH_LAUNCH(1, 64);
         else if (nitems <= 512) MH_SEARCH_LAUNCH(8, 64);
         else if (nitems <= 960) MH_SEARCH_LAUNCH(15, 64);
@@ -555,7 +949,7 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
     } else if (variant == 192) {
         if (nitems <= 960) MH_SEARCH_LAUNCH(5, 192);
         else MH_SEARCH_LAUNCH(6, 192);
-    } else if (variant == 256) {
+    } else if (variant == 256) {    // round 1's shipped form: packed multiplies, all ranks, natural order
         MH_SEARCH_LAUNCH_F(4, 256, 2);
     } else if (variant == 2256) {   // compiler-scheduled tap body (pre hand-ordered compare/select block)
         MH_SEARCH_LAUNCH_F(4, 256, 1);

@@ -115,7 +115,22 @@ def process_options(opt):
         if opt.seed != 0:
             opt.name = str(opt.name) + "_seed{}".format(opt.seed)
     else:
-        opt.name = str(opt.name) + "_" + "".join(random.choice(string.ascii_uppercase) for _ in range(4))
+        # unseeded run: the reference appends four random letters to the run name (options.py:106-107).  Under
+        # torch.distributed every rank must end up with the SAME name (ranks > 0 read files rank 0 writes) and the
+        # same numpy stream (load_colmap_points jitters the candidates with np.random): rank 0 draws, all adopt.
+        suffix = "".join(random.choice(string.ascii_uppercase) for _ in range(4))
+        shared_seed = random.randrange(2 ** 31)
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            import torch.distributed as tdist
+
+            if not (tdist.is_available() and tdist.is_initialized()):
+                raise RuntimeError("seed: null under torch.distributed needs an initialised process group (the run "
+                                   "name and the candidate jitter are drawn on rank 0); set a seed or init first")
+            box = [suffix, shared_seed]
+            tdist.broadcast_object_list(box, src=0)
+            suffix, shared_seed = box
+            np.random.seed(shared_seed)
+        opt.name = str(opt.name) + "_" + suffix
     assert isinstance(opt.gpu, int)
     local = os.environ.get("MH_DEVICE_OVERRIDE", os.environ.get("LOCAL_RANK"))
     gpu = int(local) if local is not None else opt.gpu      # one process per GPU under torchrun

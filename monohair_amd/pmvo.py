@@ -17,8 +17,6 @@ from . import _lib
 from .camera import CAM_STRIDE, camera_records
 from .timing import stage
 
-_GOLDEN_OFFSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "depth_offsets.npy")
-
 
 def depth_offsets(num_sample=90):
     """The depth offsets of sample_next_3d_pos (PMVO.py:274-278): three torch.arange pieces, concatenated,
@@ -706,16 +704,10 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         if infer_inner:
             # merge the network's orientation for points seen in <= 2 views (PMVO.py:733-751)
             coarse_data = np.load(args.data.root + "/ours/raw.npy")
-            cpoints = coarse_data[:, :3].astype(np.float32)
-            coarse_ori = coarse_data[:, 3:6].astype(np.float32)
-            up_index = coarse_ori[:, 1] > 0
-            coarse_ori[up_index] *= -1
-            unvisible_index = pmvo.compute_unvisible_points(torch.from_numpy(cpoints).to(device)).cpu().numpy()
-            un_visible_points = cpoints[unvisible_index]
-            unvisible_ori = coarse_ori[unvisible_index]
-            x, y, z = U.p2v(un_visible_points.copy(), voxel_min, voxel_size, grid_resolution)
-            vox = np.concatenate([vox, np.stack([x, y, z], 1).astype(np.int64)])      # later rows win (:746-747)
-            vori = np.concatenate([vori, unvisible_ori])
+            unvisible_index = pmvo.compute_unvisible_points(
+                torch.from_numpy(coarse_data[:, :3].astype(np.float32)).to(device)).cpu().numpy()
+            vox, vori, un_visible_points, unvisible_ori = U.merge_inner_points(vox, vori, coarse_data, unvisible_index,
+                                                                               voxel_min, voxel_size, grid_resolution)
             np.save(os.path.join(args.save_path, "coarse.npy"), un_visible_points)
             np.save(os.path.join(args.save_path, "coarse_ori.npy"), unvisible_ori)
         with stage("refine: Ori3D/Occ3D.mat", device):

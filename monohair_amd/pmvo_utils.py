@@ -47,8 +47,10 @@ def Load_Ori_And_Conf(camera, Ori_path, Conf_path):
     on case-insensitive file systems for .JPG data; we look for .png, .JPG, .jpg in that order."""
     Ori, Conf = {}, {}
     for view, _ in camera.items():
-        o = _imread_gray(_find(Ori_path, view)).astype(np.float64)
-        o = (180 - o) / 180 * math.pi
+        # `180 - o` is evaluated on the uint8 image cv2.imread returns (PMVO_utils.py:265-266): pixel codes above 180
+        # wrap modulo 256 (code 200 -> 236 degrees), they do not go negative
+        o = (np.uint8(180) - _imread_gray(_find(Ori_path, view)).astype(np.uint8)).astype(np.uint8)
+        o = o / 180 * math.pi
         Ori[view] = np.stack([np.sin(o), np.cos(o)], -1)
         Conf[view] = _imread_gray(_find(Conf_path, view)) / 255.0
     return Ori, Conf
@@ -73,7 +75,7 @@ def map_code_lut():
     """[256,4] float32 table {ori_row, ori_col, conf, mask}: what Load_Ori_And_Conf / load_mask above give for each
     8-bit pixel code (the same float64 numpy expressions, then the float32 cast of PMVO.__init__, PMVO.py:23-26)."""
     code = np.arange(256, dtype=np.uint8)
-    o = (180 - code.astype(np.float64)) / 180 * math.pi
+    o = (np.uint8(180) - code).astype(np.uint8) / 180 * math.pi      # uint8 arithmetic: codes > 180 wrap (see above)
     m = code.copy()
     m[m < 50] = 0
     return np.stack([np.sin(o), np.cos(o), code / 255.0, m / 255.0], -1).astype(np.float32)
@@ -486,6 +488,26 @@ def save_ori_occ_mat_sparse(path, grid_resolution, voxels, ori):
             mm[idx[order]] = val[order]
             mm.flush()
             del mm
+
+
+def merge_inner_points(voxels, ori, coarse_data, unvisible_index, voxel_min=VOXEL_MIN, voxel_size=VOXEL_SIZE,
+                       grid_resolution=GRID_RESOLUTION):
+    """The infer_inner merge of refine (PMVO.py:733-751): rows of DeepMVSHair's ours/raw.npy (N x 7: xyz, orientation,
+    occupancy) that no view sees (`unvisible_index`, PMVO.compute_unvisible_points) overwrite the fitted volume -- sign
+    canonicalised (ori.y > 0 -> negated, :739-740), quantised by p2v on a copy (:746), appended BEHIND the fitted voxels
+    so that the "later rows win" rule of the writers reproduces the reference's fancy assignments (:747-748, where a
+    later raw row also overwrites an earlier one in the same voxel).
+    -> (voxels [G+M,3] int64, ori [G+M,3], un_visible_points [M,3] f32, unvisible_ori [M,3] f32); the last two are what
+    the reference saves as coarse.npy / coarse_ori.npy (:749-750)."""
+    cpoints = coarse_data[:, :3].astype(np.float32)
+    coarse_ori = coarse_data[:, 3:6].astype(np.float32)
+    coarse_ori[coarse_ori[:, 1] > 0] *= -1
+    sel = np.asarray(unvisible_index, dtype=bool)
+    un_visible_points, unvisible_ori = cpoints[sel], coarse_ori[sel]
+    x, y, z = p2v(un_visible_points.copy(), np.asarray(voxel_min), voxel_size, grid_resolution)
+    vox = np.concatenate([np.asarray(voxels, dtype=np.int64).reshape(-1, 3), np.stack([x, y, z], 1).astype(np.int64)])
+    vori = np.concatenate([np.asarray(ori).reshape(-1, 3), unvisible_ori])
+    return vox, vori, un_visible_points, unvisible_ori
 
 
 def dense_from_sparse(grid_resolution, voxels, ori):

@@ -5,9 +5,17 @@
  * directions under |cos| similarity, argmax_k mean_j max(cos(o_k,o_j), cos(-o_k,o_j)), self term included,
  * first maximum wins (torch.argmax).  cos as torch.cosine_similarity evaluates it: vectors normalised by
  * max(|x|, 1e-8) with |x| = sqrt of an fma chain, products rounded separately and added left to right.
- * The mean adds the K similarities left to right and divides by K.  (ATen's vectorised inner-dim sum uses a
- * lane-strided order for K >= 16; the argmax is insensitive to it except for exact near-ties at the 1e-7
- * level -- tests/test_consensus.py reports the agreement with the reference's goldens.)
+ * The mean is ATen's sum over the innermost (contiguous) dimension divided by K, in ATen's order
+ * (aten/src/ATen/native/cpu/SumKernel.cpp, probed against torch 2.10 on this container's CPU, where the sum
+ * kernel runs its AVX2 build: 8 floats per vector):
+ *   K >= 8: vectorized_inner_sum -- the K/8 full vectors are dealt round-robin to 4 vector accumulators
+ *           (row_sum, ilp_factor 4) through the cascade of multi_row_sum (16 "rows" of 4 vectors per level-0
+ *           block); vectors left over after the last full group of 4 go to accumulator 0; the 4 accumulators
+ *           are added 0+1+2+3; then a scalar starts at 0, takes the K%8 tail elements in order and finally the
+ *           8 lanes of the vector accumulator in order;
+ *   K < 8:  scalar_inner_sum -- the same row_sum on single floats: 4 accumulators, leftover into accumulator 0,
+ *           then 0+1+2+3.
+ * tests/test_oracle_more.py demands 100 % agreement with the reference's goldens (consensus.npz).
  */
 #include <math.h>
 #include <stdint.h>
@@ -24,19 +32,65 @@ static void unit3(const float *x, float *o) {
     o[2] = x[2] / nrm;
 }
 
+/* multi_row_sum over `size` rows of NR floats (row r = x[r*NR .. r*NR+NR)), ATen's 4-level cascade */
+#define ORC_MAXNR 32
+static void aten_multi_row_sum(const float *x, int size, int NR, float *out) {
+    int level_power = 4, lg = 0;
+    while ((1 << lg) < size) ++lg;          /* CeilLog2(size) */
+    if (lg / 4 > level_power) level_power = lg / 4;
+    const int level_step = 1 << level_power, level_mask = level_step - 1;
+    float acc[4][ORC_MAXNR];
+    for (int j = 0; j < 4; ++j)
+        for (int k = 0; k < NR; ++k) acc[j][k] = 0.0f;
+    int i = 0;
+    while (i + level_step <= size) {
+        for (int j = 0; j < level_step; ++j, ++i)
+            for (int k = 0; k < NR; ++k) acc[0][k] = acc[0][k] + x[(size_t)i * NR + k];
+        for (int j = 1; j < 4; ++j) {
+            for (int k = 0; k < NR; ++k) {
+                acc[j][k] = acc[j][k] + acc[j - 1][k];
+                acc[j - 1][k] = 0.0f;
+            }
+            if ((i & (level_mask << (j * level_power))) != 0) break;
+        }
+    }
+    for (; i < size; ++i)
+        for (int k = 0; k < NR; ++k) acc[0][k] = acc[0][k] + x[(size_t)i * NR + k];
+    for (int j = 1; j < 4; ++j)
+        for (int k = 0; k < NR; ++k) acc[0][k] = acc[0][k] + acc[j][k];
+    for (int k = 0; k < NR; ++k) out[k] = acc[0][k];
+}
+
+/* torch.sum of K contiguous floats along the innermost dimension (see the header) */
+float orc_aten_inner_sum(const float *x, int K) {
+    const int VL = (K >= 8) ? 8 : 1;
+    const int vec_size = K / VL, size_ilp = vec_size / 4;
+    float ps[ORC_MAXNR];
+    aten_multi_row_sum(x, size_ilp, 4 * VL, ps);
+    for (int i = size_ilp * 4; i < vec_size; ++i)
+        for (int l = 0; l < VL; ++l) ps[l] = ps[l] + x[(size_t)i * VL + l];
+    for (int k = 1; k < 4; ++k)
+        for (int l = 0; l < VL; ++l) ps[l] = ps[l] + ps[k * VL + l];
+    if (VL == 1) return ps[0];
+    float fin = 0.0f;
+    for (int k = vec_size * VL; k < K; ++k) fin = fin + x[k];
+    for (int l = 0; l < VL; ++l) fin = fin + ps[l];
+    return fin;
+}
+
 /* one group of K directions -> index of the medoid */
 static int medoid_one(const float *ori, int K) {
     float *u = (float *)malloc(sizeof(float) * 3 * (size_t)K);
+    float *row = (float *)malloc(sizeof(float) * (size_t)K);
     for (int k = 0; k < K; ++k) unit3(ori + 3 * k, u + 3 * k);
     int best = 0;
     float bv = 0.f;
     for (int k = 0; k < K; ++k) {
-        float acc = 0.0f;
         for (int j = 0; j < K; ++j) {
             float cs = (u[3 * k] * u[3 * j] + u[3 * k + 1] * u[3 * j + 1]) + u[3 * k + 2] * u[3 * j + 2];
-            acc = acc + fabsf(cs);
+            row[j] = fabsf(cs);
         }
-        const float mean = acc / (float)K;
+        const float mean = orc_aten_inner_sum(row, K) / (float)K;
         /* torch.argmax: NaN is the maximum, the first occurrence wins */
         if (k == 0) {
             bv = mean;
@@ -46,6 +100,7 @@ static int medoid_one(const float *ori, int K) {
         }
     }
     free(u);
+    free(row);
     return best;
 }
 

@@ -69,20 +69,42 @@ def test_refine_method_vs_oracle_and_golden(case):
 
 
 def test_consensus_vs_oracle_and_golden():
+    """mh_medoid_dense == oracle == the reference (100 %): the mean runs in ATen's inner-dimension summation order
+    (consensus.hip MhInnerSum); consensus_more.npz walks through every branch of that order, including groups of
+    512+ members (second cascade level, the four-level kernel form)."""
     from monohair_amd.pmvo_utils import compute_points_similarity
 
-    z = load_npz("consensus")
-    total = same = 0
-    for k in ("a", "b", "c", "d1", "d2", "d3"):
-        got, idx = compute_points_similarity(torch.from_numpy(z[k + "_in"]).to(DEV), return_index=True)
-        o_out, o_idx = oracle.medoid_dense(z[k + "_in"])
-        assert np.array_equal(idx.cpu().numpy(), o_idx), k
-        assert np.array_equal(got.cpu().numpy(), o_out, equal_nan=True), k
-        ref = z[k + "_out"]
-        ok = np.all((got.cpu().numpy() == ref) | (np.isnan(ref) & np.isnan(got.cpu().numpy())), axis=1)
-        total += len(ok)
-        same += ok.sum()
-    assert same / total >= 0.99
+    for name in ("consensus", "consensus_more"):
+        z = load_npz(name)
+        for k in sorted(f[:-3] for f in z.files if f.endswith("_in")):
+            got, idx = compute_points_similarity(torch.from_numpy(z[k + "_in"]).to(DEV), return_index=True)
+            o_out, o_idx = oracle.medoid_dense(z[k + "_in"])
+            assert np.array_equal(idx.cpu().numpy(), o_idx), (name, k)
+            assert np.array_equal(got.cpu().numpy(), o_out, equal_nan=True), (name, k)
+            ref = z[k + "_out"]
+            ok = np.all((got.cpu().numpy() == ref) | (np.isnan(ref) & np.isnan(got.cpu().numpy())), axis=1)
+            assert ok.all(), (name, k, float(ok.mean()))
+
+
+def test_segmented_medoid_mixes_small_and_large_groups():
+    """one segmented call over groups of 1 .. 1300 members (both kernel forms of mh_medoid_segmented) == per-group oracle"""
+    import ctypes
+
+    from monohair_amd import _lib
+    from monohair_amd.pmvo_utils import _ctx_for
+
+    rng = np.random.default_rng(12)
+    sizes = [1, 2, 5, 7, 8, 9, 31, 33, 100, 511, 512, 513, 640, 1300, 3, 64]
+    seg = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    base = rng.normal(size=(len(sizes), 3))
+    ori = np.concatenate([b + 0.1 * rng.normal(size=(n, 3)) for b, n in zip(base, sizes)]).astype(np.float32)
+    o = torch.from_numpy(ori).to(DEV)
+    out = torch.empty((len(sizes), 3), device=DEV)
+    idx = torch.empty((len(sizes),), dtype=torch.int32, device=DEV)
+    _lib.check(_lib.lib().mh_medoid_segmented(_ctx_for(DEV), _lib.ptr(o), _lib.ptr(torch.from_numpy(seg).to(DEV)),
+                                              len(sizes), max(sizes), _lib.ptr(out), _lib.ptr(idx), _lib.stream_ptr()))
+    want, widx = oracle.medoid_segmented(ori, seg)
+    assert np.array_equal(idx.cpu().numpy(), widx) and np.array_equal(out.cpu().numpy(), want)
 
 
 def test_voxel_fit_vs_oracle_and_golden():
@@ -212,14 +234,14 @@ def test_drivers_end_to_end_vs_reference(tmp_path):
     assert np.array_equal(r["select_p"], z["ref_select_p"])
     lm = (r["min_loss"] == z["ref_min_loss"]) | (np.isnan(r["min_loss"]) & np.isnan(z["ref_min_loss"]))
     om = np.all((r["select_o"] == z["ref_select_o"]) | (np.isnan(r["select_o"]) & np.isnan(z["ref_select_o"])), 1)
-    assert lm.mean() >= 0.98 and om.mean() >= 0.98, (lm.mean(), om.mean())
-    # a medoid that differs on a near-tie (ATen's lane-strided mean vs our left-to-right mean) changes that
-    # point's loss; everything else agrees to the last bits
+    # the medoid is bit-faithful to the reference (ATen's summation order), so the smoothing loop is too; what is left are
+    # the trailing N mod 64 columns of the reference's [V,N,1] sums (one ulp on those points, see the oracle tests)
+    assert lm.mean() >= 0.999 and om.mean() >= 0.999, (lm.mean(), om.mean())
     close = np.isclose(r["min_loss"], z["ref_min_loss"], rtol=0, atol=1e-6, equal_nan=True)
-    assert close.mean() >= 0.98, close.mean()
+    assert close.mean() >= 0.999, close.mean()
     assert np.array_equal(r["filter_unvisible"], z["ref_filter_unvisible"])
     fm = np.all(r["filter_unvisible_ori"] == z["ref_filter_unvisible_ori"], axis=1)
-    assert fm.mean() >= 0.98
+    assert fm.mean() >= 0.999
 
     Ori3 = scipy.io.loadmat(os.path.join(args.save_path, "Ori3D.mat"))["Ori"]
     Occ3 = scipy.io.loadmat(os.path.join(args.save_path, "Occ3D.mat"))["Occ"]
@@ -229,14 +251,50 @@ def test_drivers_end_to_end_vs_reference(tmp_path):
     ref_nz = z["mat_occ_nz"]
     a = set(map(tuple, nz.tolist()))
     b = set(map(tuple, ref_nz.tolist()))
-    assert len(a ^ b) <= 0.01 * len(b), (len(a), len(b), len(a ^ b))         # same occupied voxels
+    assert len(a ^ b) <= 0.001 * len(b), (len(a), len(b), len(a ^ b))        # same occupied voxels
     Z = Occ3.shape[2]
     got_o = np.stack([Ori3[ref_nz[:, 0], ref_nz[:, 1], c * Z + ref_nz[:, 2]] for c in range(3)], 1)
     vm = np.all(got_o == z["mat_ori_at_nz"], axis=1)
-    assert vm.mean() >= 0.98, vm.mean()
+    assert vm.mean() >= 0.999, vm.mean()
     # the consumer's readers (HairGrow.py:41-55) see the documented shapes
     assert get_ground_truth_3D_occ(os.path.join(args.save_path, "Occ3D.mat")).shape == (192, 256, 256, 1)
     assert get_ground_truth_3D_ori(os.path.join(args.save_path, "Ori3D.mat")).shape == (192, 256, 256, 3)
+
+
+def test_infer_inner_second_pass_vs_reference(tmp_path):
+    """`PMVO.py --PMVO.infer_inner --PMVO.optimize=` (PMVO.py:874-880 -> refine(genrate_ori_only=True, infer_inner=True),
+    :653-764): resumed from the exterior pass's checkpoint files, with a synthetic ours/raw.npy, against the reference's
+    own run of that pass (tests/golden/e2e_inner.npz): coarse.npy / coarse_ori.npy (compute_unvisible_points + the sign
+    flip), the occluded-shell orientations, and every voxel of full/Ori3D.mat / Occ3D.mat."""
+    import scipy.io
+
+    from monohair_amd.pmvo import refine
+
+    z, meta, pm, args = _e2e_setup(tmp_path)
+    inn = load_npz("e2e_inner")
+    args.save_path = str(tmp_path / "full")
+    os.makedirs(args.save_path)
+    os.makedirs(tmp_path / "ours")
+    os.makedirs(tmp_path / "refine", exist_ok=True)
+    for k in ("select_p", "select_o", "min_loss"):
+        np.save(tmp_path / "refine" / (k + ".npy"), z["ref_" + k])
+    np.save(tmp_path / "ours" / "raw.npy", inn["raw"])
+    refine(z["opt_select_p"].copy(), z["opt_select_o"].copy(), z["opt_min_loss"].copy(), pm, inn["filter_unvisible_in"],
+           args, infer_inner=True, threshold=meta["threshold"], genrate_ori_only=True, return_dense=False)
+    unv = pm.compute_unvisible_points(torch.from_numpy(inn["raw"][:, :3].astype(np.float32)).to(DEV)).cpu().numpy()
+    assert np.array_equal(unv, inn["unvisible_index"])
+    assert np.array_equal(np.load(tmp_path / "full" / "coarse.npy"), inn["coarse"])
+    assert np.array_equal(np.load(tmp_path / "full" / "coarse_ori.npy"), inn["coarse_ori"])
+    assert np.array_equal(np.load(tmp_path / "refine" / "filter_unvisible.npy"), inn["ref_filter_unvisible"])
+    assert np.array_equal(np.load(tmp_path / "refine" / "filter_unvisible_ori.npy"), inn["ref_filter_unvisible_ori"])
+    Ori3 = scipy.io.loadmat(tmp_path / "full" / "Ori3D.mat")["Ori"]
+    Occ3 = scipy.io.loadmat(tmp_path / "full" / "Occ3D.mat")["Occ"]
+    assert Ori3.shape == tuple(inn["mat_ori_shape"]) and Occ3.shape == tuple(inn["mat_occ_shape"])
+    nz = np.argwhere(Occ3 != 0).astype(np.int32)
+    assert np.array_equal(nz, inn["mat_occ_nz"])
+    Z = Occ3.shape[2]
+    got = np.stack([Ori3[nz[:, 0], nz[:, 1], c * Z + nz[:, 2]] for c in range(3)], 1)
+    assert np.array_equal(got, inn["mat_ori_at_nz"])
 
 
 def test_gabor_to_pmvo_device_handoff_equals_file_roundtrip(tmp_path):

@@ -89,7 +89,7 @@ def test_topk_vs_oracle(case):
     assert np.array_equal(val.cpu().numpy(), z["base_val"])
 
 
-@pytest.mark.parametrize("variant", [0, 64, 128, 192, 256, 320, 1128, 1256])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 64, 128, 192, 256, 320, 1128, 1256])
 def test_forward_vs_oracle_bit_exact(case, depth_offsets, variant):
     meta, z, scene, views, pm = case
     pm.set_option("search_variant", variant)

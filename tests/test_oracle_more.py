@@ -52,17 +52,34 @@ def test_refine_method_loss(case):
 
 
 def test_consensus_medoid():
-    z = load_npz("consensus")
-    total = same = 0
-    for k in ("a", "b", "c", "d1", "d2", "d3"):
-        out, idx = oracle.medoid_dense(z[k + "_in"])
-        ref = z[k + "_out"]
-        ok = np.all((out == ref) | (np.isnan(out) & np.isnan(ref)), axis=1)
-        total += len(ok)
-        same += ok.sum()
-        if k in ("c", "d1", "d2", "d3"):
-            assert ok.all(), k          # exact ties / degenerate groups: first index must win
-    assert same / total >= 0.99, (same, total)
+    """The oracle's medoid (mean in ATen's inner-dimension summation order) against the reference on every golden
+    group: 100 % -- exact ties, degenerate groups, group sizes on both sides of every branch of ATen's sum (scalar
+    path below 8, leftover vectors, tail elements, the second cascade level from 512 members on) and tight clusters."""
+    for name in ("consensus", "consensus_more"):
+        z = load_npz(name)
+        for k in sorted(f[:-3] for f in z.files if f.endswith("_in")):
+            out, idx = oracle.medoid_dense(z[k + "_in"])
+            ref = z[k + "_out"]
+            ok = np.all((out == ref) | (np.isnan(out) & np.isnan(ref)), axis=1)
+            assert ok.all(), (name, k, float(ok.mean()))
+
+
+def test_aten_inner_sum_order_matches_torch():
+    """orc_aten_inner_sum == torch.sum over the last dimension of a contiguous float32 tensor, bit for bit (the claim the
+    medoid's parity rests on; torch is the very library the reference calls)."""
+    import ctypes
+
+    import torch
+
+    L = oracle.lib()
+    L.orc_aten_inner_sum.restype = ctypes.c_float
+    L.orc_aten_inner_sum.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    rng = np.random.default_rng(9)
+    for K in list(range(1, 70)) + [100, 127, 128, 129, 255, 256, 300, 511, 512, 513, 1000, 4097, 9000]:
+        x = np.ascontiguousarray(rng.random((3, K)).astype(np.float32) - 0.3)
+        want = torch.from_numpy(x).sum(dim=-1).numpy()
+        got = np.array([L.orc_aten_inner_sum(x[r].ctypes.data_as(ctypes.c_void_p), K) for r in range(3)], np.float32)
+        assert np.array_equal(got, want), K
 
 
 def load_npz(name):
@@ -88,8 +105,42 @@ def test_voxel_fit_and_mat_layout():
     Z = occ_l.shape[2]
     got = np.stack([ori_l[nz[:, 0], nz[:, 1], c * Z + nz[:, 2]] for c in range(3)], 1)
     same = np.all(got == z["mat_ori_at_nz"], axis=1)
-    assert same.mean() >= 0.995, same.mean()
+    assert same.all(), same.mean()            # per-voxel medoid in ATen's summation order: every voxel, bit for bit
     assert int(z["mat_ori_nnz"][0]) == np.count_nonzero(ori_l)
+
+
+def test_infer_inner_merge_and_mat_files(tmp_path):
+    """PMVO.py:733-751 -- the DeepMVSHair points no view sees overwrite the fitted volume ("later rows win", also among
+    themselves), y > 0 orientations flipped first, coarse.npy / coarse_ori.npy -- against the reference's own second
+    pass (tests/golden/e2e_inner.npz: exterior voxels of e2e_small + a synthetic ours/raw.npy).  Host logic only:
+    merge_inner_points + the sparse MAT-v5 writer, read back with scipy."""
+    import scipy.io
+
+    from monohair_amd import pmvo_utils as U
+
+    ext, inn = load_npz("e2e_small"), load_npz("e2e_inner")
+    nz = ext["mat_occ_nz"].astype(np.int64)                    # Occ[Y,X,Z] indices of the exterior pass
+    vox = nz[:, [1, 0, 2]]
+    vori = ext["mat_ori_at_nz"]
+    vox, vori, coarse, coarse_ori = U.merge_inner_points(vox, vori, inn["raw"], inn["unvisible_index"])
+    assert coarse.dtype == np.float32 and np.array_equal(coarse, inn["coarse"])
+    assert coarse_ori.dtype == np.float32 and np.array_equal(coarse_ori, inn["coarse_ori"])
+    assert 0 < inn["unvisible_index"].sum() < len(inn["raw"]) and (inn["coarse_ori"][:, 1] <= 0).all()
+    U.save_ori_occ_mat_sparse(str(tmp_path), U.GRID_RESOLUTION, vox, vori)
+    Ori3 = scipy.io.loadmat(str(tmp_path / "Ori3D.mat"))["Ori"]
+    Occ3 = scipy.io.loadmat(str(tmp_path / "Occ3D.mat"))["Occ"]
+    assert Ori3.shape == tuple(inn["mat_ori_shape"]) and Occ3.shape == tuple(inn["mat_occ_shape"])
+    got_nz = np.argwhere(Occ3 != 0).astype(np.int32)
+    assert np.array_equal(got_nz, inn["mat_occ_nz"])
+    Z = Occ3.shape[2]
+    got = np.stack([Ori3[got_nz[:, 0], got_nz[:, 1], c * Z + got_nz[:, 2]] for c in range(3)], 1)
+    assert np.array_equal(got, inn["mat_ori_at_nz"])
+    assert int(inn["mat_ori_nnz"][0]) == np.count_nonzero(Ori3)
+    # the fixture really exercises the overwrite rules: raw rows colliding with fitted voxels and with each other
+    x, y, z = U.p2v(inn["coarse"].copy(), U.VOXEL_MIN, U.VOXEL_SIZE, U.GRID_RESOLUTION)
+    keys = (x.astype(np.int64) * 256 + y) * 192 + z
+    assert len(np.unique(keys)) < len(keys)
+    assert len(set(map(tuple, nz[:, [1, 0, 2]].tolist())) & set(zip(x.tolist(), y.tolist(), z.tolist()))) > 0
 
 
 def test_gabor_bank_vs_reference():
