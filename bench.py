@@ -2,32 +2,35 @@
 """bench.py -- PMVO iterations/sec on the synthetic 60-view 1080p / 256^3 workload (BASELINE.json).
 
 One step = one PMVO iteration = one `PMVO.forward()` over a chunk of 5000 candidate points against all
-V views (one step of the trange at /root/reference/PMVO.py:572-574): project-and-gather, base-view
-ranking, tap preparation and the fused loss search, maps resident in HBM, no file IO.
+V views (one step of the trange at /root/reference/PMVO.py:572-574): the H2D upload of the chunk, project /
+visibility / tap lists (mh_project_taps_kernel), base-view ranking (mh_topk_kernel) and the fused loss search
+(mh_search2_kernel), maps resident in HBM, no file IO.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
 
-Points shard across ranks (every GPU holds all views; no collective inside an iteration -- SURVEY.md §8e),
-so per-GPU work is fixed as N grows: "scaling": "weak".  Rank 0 prints ONE JSON line.
+N > 1: one process per GPU over RCCL.  Under `python -m torch.distributed.run ... bench.py --gpus N` the ranks are
+already there (RANK / LOCAL_RANK / WORLD_SIZE); started plainly, `python bench.py --gpus N` launches the N ranks
+itself (it re-executes under torch.distributed.run on 127.0.0.1).  Points shard across ranks (every GPU holds all
+views; no collective inside an iteration -- SURVEY.md §8e), so per-GPU work is fixed as N grows: "scaling": "weak".
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from monohair_amd import synth  # noqa: E402
-from monohair_amd.camera import camera_records, cameras_from_list  # noqa: E402
-from monohair_amd.pmvo import PMVO, depth_offsets  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TF = 157.3         # same guide: peak fp32 vector (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
+FLOP_PER_PAIR = 8            # SURVEY.md §8d: one (candidate, view, tap) evaluation
 CHUNK = 5000                 # PMVO.py:566
+XGMI_LINK_GBS = 153.0        # SURVEY.md §5: per-link xGMI bandwidth, 7 links per GPU
 
 
 def parse():
@@ -44,34 +47,93 @@ def parse():
     ap.add_argument("--quantize", action="store_true", help="8-bit orientation/confidence maps (file hand-off)")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the extra 8-bit-maps measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the independent iterations alternate on (as monohair_amd.pmvo.optimize does)")
     return ap.parse_args()
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, RCCL)."""
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < a.gpus and os.environ.get("MH_DEVICE_OVERRIDE") is None:     # (test hook: ranks share one GPU over gloo)
+        sys.stderr.write("bench.py: --gpus %d asked for but this node shows %d GPU(s); refusing to report a %d-GPU "
+                         "number from fewer devices\n" % (a.gpus, have, a.gpus))
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               MH_BENCH_SPAWNED="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+class Emitter:
+    """exactly one JSON line, whoever gets there first (the main path or the watchdog of the collective legs)"""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.done = False
+
+    def emit(self, out):
+        with self.lock:
+            if self.done:
+                return
+            self.done = True
+            print(json.dumps(out), flush=True)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a)
+
+    import numpy as np
+    import torch
+
+    from monohair_amd import synth
+    from monohair_amd.camera import camera_records, cameras_from_list
+    from monohair_amd.pmvo import PMVO
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # test hooks: MH_DEVICE_OVERRIDE pins every rank to one GPU and MH_DIST_BACKEND=gloo replaces RCCL, so that the
     # world_size > 1 code path can be exercised on a single-GPU box (RCCL refuses two ranks on one device)
-    if os.environ.get("MH_DEVICE_OVERRIDE") is not None:
+    shared_gpu = os.environ.get("MH_DEVICE_OVERRIDE") is not None
+    if shared_gpu:
         local = int(os.environ["MH_DEVICE_OVERRIDE"])
     backend = os.environ.get("MH_DIST_BACKEND", "nccl")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    dist = None
+    ranks_seen, devices_seen = 1, [local]
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-    n_gpus = max(a.gpus, world) if world > 1 else 1
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+        # every rank really is there and sits on its own GPU
+        ident = [None] * world
+        prop = torch.cuda.get_device_properties(dev)
+        dist.all_gather_object(ident, (socket.gethostname(), torch.cuda.current_device(),
+                                       str(getattr(prop, "uuid", "")), os.getpid()))
+        ranks_seen = dist.get_world_size()
+        devices_seen = [i[1] for i in ident]
+        assert ranks_seen == world, (ranks_seen, world)
+        if not shared_gpu:
+            assert len({(i[0], i[1]) for i in ident}) == world, "two ranks share a GPU: %r" % (ident,)
+    if a.gpus > 1:
+        assert world == a.gpus, "--gpus %d but %d rank(s) were launched" % (a.gpus, world)
+    n_gpus = world
 
     V, H, W, P = a.views, a.height, a.width, a.patch * a.patch
     scene = synth.make_scene(V, H, W, device=dev, seed=0, quantize=a.quantize)
@@ -93,8 +155,7 @@ def main():
     pts = cand[surf]
     nchunk = max(1, len(pts) // CHUNK)
     chunks = [pts[i * CHUNK:(i + 1) * CHUNK] for i in range(nchunk)]
-    my = [chunks[i] for i in range(rank, nchunk, world)] or chunks[:1]
-    dev_chunks = [torch.from_numpy(c).to(dev).float() for c in my]
+    my = [chunks[i] for i in range(rank, nchunk, world)] or chunks[:1]      # HOST arrays, as optimize() gets them
 
     # consecutive iterations are independent chunks of `optimize` (PMVO.py:572-574); like the driver in
     # monohair_amd/pmvo.py they alternate between HIP streams so one chunk's tail overlaps the next one's head
@@ -110,20 +171,20 @@ def main():
                     torch.empty((CHUNK, 3), device=dev), torch.empty((CHUNK,), device=dev),
                     torch.empty((CHUNK,), device=dev, dtype=torch.bool)]
             del hold
-            pm.forward(dev_chunks[0][:1])       # one point: loads the kernels' code objects (not a workload step)
+            pm.forward(my[0][:1])       # one point: loads the kernels' code objects (not a workload step)
     torch.cuda.synchronize()
 
     def step(i):
+        # the whole forward() of the reference (PMVO.py:39-78): host numpy chunk in (the H2D copy is part of the step,
+        # PMVO.py:40), four device tensors out
         with torch.cuda.stream(streams[i % len(streams)]):
-            return pm.forward(dev_chunks[i % len(dev_chunks)])
+            return pm.forward(my[i % len(my)])
 
     for i in range(a.warmup):
         step(i)
 
     def barrier():
-        if world > 1:
-            import torch.distributed as dist
-
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -134,56 +195,20 @@ def main():
         step(a.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-
+    if dist is not None:
         t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # --- per-kernel durations on the same chunks, outside the timed region: HIP events on the launch stream,
-    # REP back-to-back launches per measurement so that launch gaps do not count as kernel time
-    def timed(fn, rep):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        fn()
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(rep):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / rep
-
-    t_pg = t_tk = t_sr = nvis = 0.0
-    reps = max(2, min(len(dev_chunks), 6))
-    for i in range(reps):
-        c = dev_chunks[i % len(dev_chunks)]
-        t_pg += timed(lambda: pm.Compute_Visible_and_Ori(c), 10)
-        t_tk += timed(lambda: pm.Find_max_conf_from_visible_view(), 10)
-        nvis += float((pm.visible != -1).float().mean().item())
-        t_sr += timed(lambda: pm.forward(c), 5)
-    t_pg, t_tk, t_sr, nvis = t_pg / reps, t_tk / reps, t_sr / reps, nvis / reps
-    t_search = max(t_sr - t_tk, 1e-6)     # forward = fused front end + top-k + search
-
-    if rank != 0:
-        if world > 1:
-            import torch.distributed as dist
-
-            dist.barrier()
-            dist.destroy_process_group()
-        return
     ms = dt / a.steps * 1e3
     value = a.steps * world / dt
-    # algorithmic bytes of project-and-gather per iteration: V*N*(12P+20) gathered + the same
-    # written + 12N of points, fp32 reference layout
-    pg_bytes = 2 * V * CHUNK * (12 * P + 20) + 12 * CHUNK
-    achieved = pg_bytes / (t_pg * 1e-3) / 1e9
-    pairs_nominal = 10 * V * CHUNK * 90 * P
     out = {
         "metric": "PMVO iterations/sec (60x1080p views, 256^3 volume)",
         "value": round(value, 3),
         "unit": "iterations/s",
         "n_gpus": n_gpus,
+        "ranks_seen": ranks_seen,
+        "backend": ("nccl" if backend == "nccl" else backend) if world > 1 else None,
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": round(ms, 4),
@@ -201,38 +226,56 @@ def main():
                                 (V, H, W, a.volume), "custom size")),
             "views": V, "image": [H, W], "volume": a.volume, "points_per_iteration": CHUNK, "patch": a.patch,
             "conf_threshold": a.conf_threshold, "surface_points": int(len(pts)), "iterations_full_pass": nchunk,
-            "parallelism": "points sharded over %d GPU(s), views replicated" % world,
+            "parallelism": "points sharded over %d GPU(s) (one process each), views replicated; no collective inside "
+                           "an iteration" % world,
+            "devices": devices_seen,
             "maps": "quantized-8bit" if a.quantize else "continuous",
             "streams": len(streams),
-        },
-        "roofline": {
-            "kernel": "mh_project_gather_kernel<%d>" % a.patch,
-            "bound": "hbm",
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": pmc_traffic("mh_project_gather_kernel<%d>" % a.patch, V, H, W),
-            "algorithmic_bytes_per_launch": pg_bytes,
-            "launch_ms": round(t_pg, 4),
-        },
-        "kernels_ms": {"forward_total_single_stream": round(t_sr, 4), "topk": round(t_tk, 4),
-                       "project_taps+search": round(t_search, 4),
-                       "project_gather_api_kernel": round(t_pg, 4)},
-        "search": {
-            "pair_evals_nominal": pairs_nominal,
-            "visible_view_fraction": round(nvis, 4),
-            "gpair_per_s_nominal": round(pairs_nominal / (t_search * 1e-3) / 1e9, 1),
+            "step_input": "host numpy chunk [5000,3] float64, uploaded inside the step (PMVO.py:40); maps resident in HBM",
         },
     }
-    if not a.quantize and not a.no_secondary and world == 1:
+    em = Emitter()
+
+    # --- legs that need every rank: the RCCL volume reduce and the sharded full pass (N > 1).  A watchdog prints the
+    # line with whatever has been measured if a collective does not come back.
+    if world > 1 and not a.no_secondary:
+        def give_up():
+            if rank == 0:
+                out.setdefault("secondary_error", "collective legs timed out")
+                em.emit(out)
+            os._exit(0)
+
+        wd = threading.Timer(240.0 if rank == 0 else 250.0, give_up)
+        wd.daemon = True
+        wd.start()
         try:
-            out["secondary_8bit_maps"] = secondary_quantized(a, dev, recs, cams, dev_chunks)
-        except Exception as e:   # the secondary number must never cost the headline line
-            out["secondary_8bit_maps"] = {"error": repr(e)[:200]}
+            out["secondary_volume_reduce"] = secondary_volume_reduce(dev, backend)
+        except Exception as e:
+            out["secondary_volume_reduce"] = {"error": repr(e)[:300]}
+        try:
+            out["secondary_full_pass"] = secondary_full_pass(dev, pm, cand, dist)
+        except Exception as e:
+            out["secondary_full_pass"] = {"error": repr(e)[:300]}
+        wd.cancel()
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    # --- the kernels of the timed loop, one by one (rank 0, outside the timed region): HIP events on the launch
+    # stream around launches that ROTATE over the chunks, so that no launch finds its read set in the Infinity Cache
+    try:
+        out.update(kernel_rooflines(a, pm, my, dev, V, H, W, P))
+    except Exception as e:
+        out["roofline"] = {"error": repr(e)[:300]}
     if not a.no_secondary and world == 1:
+        if not a.quantize:
+            try:
+                out["secondary_8bit_maps"] = secondary_quantized(a, dev, recs, cams, my)
+            except Exception as e:   # a secondary number must never cost the headline line
+                out["secondary_8bit_maps"] = {"error": repr(e)[:200]}
         try:
-            out["secondary_full_pass"] = secondary_full_pass(dev, pm, cand)
+            out["secondary_full_pass"] = secondary_full_pass(dev, pm, cand, None)
         except Exception as e:
             out["secondary_full_pass"] = {"error": repr(e)[:200]}
         try:
@@ -246,17 +289,212 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a, scene, recs, my[0], ms)
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)[:200]}
-    print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.barrier()
+    em.emit(out)
+    if dist is not None:
         dist.destroy_process_group()
 
 
-def secondary_quantized(a, dev, recs, cams, dev_chunks):
+def kernel_rooflines(a, pm, my, dev, V, H, W, P):
+    """Per-kernel durations of one iteration with HIP events on the launch stream, each launch on a different chunk,
+    and the roofline of each kernel from what it actually executed.
+      mh_search2_kernel  (dominant, fp32 VALU bound): executed (candidate, view, tap) evaluations x 8 FLOP
+      mh_project_taps_kernel (HBM): bytes it has to move for what it produces
+      mh_project_gather_kernel (HBM; the API form of Compute_Visible_and_Ori): SURVEY §8d's 2*V*N*(12P+20)+12N"""
+    import torch
+
+    from monohair_amd import _lib
+
+    L, ctx = pm._L, pm._ctx
+    N = len(my[0])
+    f = dict(dtype=torch.float32, device=dev)
+    same = [c for c in my if len(c) == N]
+    reps = max(2, min(len(same), 8))
+    dchunks = [torch.from_numpy(same[i % len(same)]).to(dev).float().contiguous() for i in range(reps)]
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    vis, ori, conf, mask = (torch.empty((V, N), **f), torch.empty((V, N, 2), **f), torch.empty((V, N), **f),
+                            torch.empty((V, N), **f))
+    bidx = torch.empty((20, N), dtype=torch.int32, device=dev)
+    bval = torch.empty((20, N), **f)
+    lo, ml = torch.empty((N, 3), **f), torch.empty((N,), **f)
+    hc = torch.empty((N,), dtype=torch.bool, device=dev)
+    scratch, need = pm._get_scratch(N)
+    st = _lib.stream_ptr()
+    ranks = list(pm.RANKS)
+
+    def prepare(p):
+        _lib.check(L.mh_forward_prepare(ctx, _lib.ptr(p), N, pm.patch_size, float(pm.conf_threshold), _lib.ptr(vis),
+                                        _lib.ptr(ori), _lib.ptr(conf), _lib.ptr(mask), _lib.ptr(scratch), need, st))
+
+    def topk():
+        _lib.check(L.mh_topk_views(ctx, _lib.ptr(vis), _lib.ptr(conf), N, _lib.ptr(bidx), _lib.ptr(bval), st))
+
+    def search(p):
+        _lib.check(L.mh_search_prepared(ctx, _lib.ptr(p), N, pm.patch_size, float(pm.conf_threshold), len(ranks),
+                                        ranks[1] - ranks[0], _lib.ptr(ori), _lib.ptr(bidx), _lib.ptr(bval),
+                                        _lib.ptr(scratch), _lib.ptr(lo), _lib.ptr(ml), _lib.ptr(hc), None, None, None,
+                                        st))
+
+    prepare(dchunks[0]); topk(); search(dchunks[0])     # noqa: E702  (warm)
+    torch.cuda.synchronize()
+    # tap preparation: `reps` launches back to back, every one on another chunk
+    e[0].record()
+    for p in dchunks:
+        prepare(p)
+    e[1].record()
+    torch.cuda.synchronize()
+    t_taps = e[0].elapsed_time(e[1]) / reps
+    t_topk = t_search = 0.0
+    pairs = taps_vis = nvis = list_rec = 0
+    for p in dchunks:
+        prepare(p)
+        e[0].record(); topk(); e[1].record()            # noqa: E702
+        torch.cuda.synchronize()
+        t_topk += e[0].elapsed_time(e[1])
+        e[0].record(); search(p); e[1].record()         # noqa: E702  (order kernels + mh_search2_kernel)
+        torch.cuda.synchronize()
+        t_search += e[0].elapsed_time(e[1])
+        cnt, nvalid = pm.search_work(N, bval)
+        pairs += int((cnt.sum(0) * nvalid * pm.NUM_SAMPLE).sum().item())
+        taps_vis += int(cnt.sum().item())
+        nvis += int((vis != -1).sum().item())
+    t_topk, t_search = t_topk / reps, t_search / reps
+    pairs, taps_vis, nvis = pairs / reps, taps_vis / reps, nvis / reps
+    # API form with materialised patches, rotating chunks as well
+    pm.Compute_Visible_and_Ori(dchunks[0])
+    torch.cuda.synchronize()
+    e[0].record()
+    for p in dchunks:
+        pm.Compute_Visible_and_Ori(p)
+    e[1].record()
+    torch.cuda.synchronize()
+    t_pg = e[0].elapsed_time(e[1]) / reps
+
+    nominal = 10 * V * N * 90 * P
+    tf = pairs * FLOP_PER_PAIR / (t_search * 1e-3) / 1e12
+    # bytes mh_project_taps_kernel has to move (per launch): points + centre record and mask sample of every (view, point)
+    # + the patch of every visible pair in; vis/ori/conf/mask + one header per pair + the tap lists + list lengths out
+    taps_in = 12 * N + V * N * (16 + 4) + nvis * P * 16
+    taps_out = V * N * (4 + 8 + 4 + 4) + V * N * 16 + taps_vis * 16 + V * N
+    pg_bytes = 2 * V * N * (12 * P + 20) + 12 * N
+    prof = load_profile_facts(V, H, W)
+    return {
+        "roofline": {
+            "kernel": "mh_search2_kernel<256,0>", "bound": "valu",
+            "achieved": round(tf, 2), "peak": VALU_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TF, 4),
+            "traffic": None,
+            "launch_ms": round(t_search, 4),
+            "pair_evals_executed": int(pairs), "flop_per_pair_eval": FLOP_PER_PAIR,
+            "gpair_per_s_executed": round(pairs / (t_search * 1e-3) / 1e9, 1),
+            "pair_evals_nominal": nominal, "executed_fraction_of_nominal": round(pairs / nominal, 4),
+            "visible_view_fraction": round(nvis / (V * N), 4),
+            "note": "executed = sum over points of (taps of the views that see the point) x (usable base-view ranks) x 90 "
+                    "samples, read back from the launch's own work arrays; launch_ms includes the two small ordering "
+                    "kernels in front of the search",
+            "valu_issue": prof.get("search_valu_issue"),
+        },
+        "roofline_kernels": [
+            {"kernel": "mh_project_taps_kernel<%d>" % a.patch, "bound": "hbm", "launch_ms": round(t_taps, 4),
+             "algorithmic_bytes_per_launch": int(taps_in + taps_out),
+             "achieved": round((taps_in + taps_out) / (t_taps * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round((taps_in + taps_out) / (t_taps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+             "traffic": prof.get("traffic", {}).get("mh_project_taps_kernel<%d>" % a.patch),
+             "bytes_model": "in: 12N + V*N*20 + visible*P*16; out: V*N*20 + V*N*16 + taps*16 + V*N",
+             "visible_pairs": int(nvis), "taps_written": int(taps_vis)},
+            {"kernel": "mh_project_gather_kernel<%d>" % a.patch, "bound": "hbm", "launch_ms": round(t_pg, 4),
+             "algorithmic_bytes_per_launch": pg_bytes,
+             "achieved": round(pg_bytes / (t_pg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": round(pg_bytes / (t_pg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+             "traffic": prof.get("traffic", {}).get("mh_project_gather_kernel<%d>" % a.patch),
+             "note": "the API form of Compute_Visible_and_Ori (patch tensors materialised, SURVEY.md §8d byte count); "
+                     "forward() uses mh_project_taps_kernel instead; launches rotate over %d chunks" % reps},
+        ],
+        "kernels_ms": {"project_taps": round(t_taps, 4), "topk": round(t_topk, 4),
+                       "order+search": round(t_search, 4), "project_gather_api_kernel": round(t_pg, 4)},
+    }
+
+
+def load_profile_facts(V, H, W):
+    """Facts that cannot be measured from inside this process (rocprofv3 PMC passes of this same command), from the
+    committed profiles/traffic.json: HBM bytes per launch and the search kernel's VALU issue figures."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if not t.get("workload", "").startswith("%d views @ %dx%d" % (V, H, W)):
+            return {}
+        return {"traffic": {k: v.get("traffic_bytes") for k, v in t.items() if isinstance(v, dict) and "traffic_bytes" in v},
+                "search_valu_issue": t.get("search_valu_issue")}
+    except Exception:
+        return {}
+
+
+def secondary_volume_reduce(dev, backend):
+    """The one exchange of the data path: the 256 x 256 x 192 x 4 fp32 orientation/occupancy volume of
+    the voxel fit, every rank owning an x-slab, assembled on rank 0 over xGMI.  Three forms, each timed with a barrier
+    on both sides, max over ranks: the shipped one (mh_volume_reduce mode 0: slab gather, direct to root), the dense
+    ncclReduce through the same C entry point (mode 1), and torch.distributed.reduce."""
+    import torch
+    import torch.distributed as dist
+
+    from monohair_amd import dist as mdist
+
+    w, r = dist.get_world_size(), dist.get_rank()
+    X, Y, Z, C = 256, 256, 192, 4
+    nbytes = X * Y * Z * C * 4
+    b = mdist.slab_bounds(X, w)
+    res = {"volume": [X, Y, Z, C], "bytes_dense": nbytes, "unit": "ms", "ranks": w}
+    if backend != "nccl":
+        res["note"] = "gloo test backend: RCCL legs skipped"
+        return res
+    base = torch.zeros((X, Y, Z, C), device=dev)
+    base[b[r]:b[r + 1]] = float(r + 1)
+
+    def timed(fn, reps=5):
+        vol = base.clone()
+        fn(vol)                                     # warm (communicator set-up, first-use buffers)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            vol.copy_(base)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn(vol)
+            torch.cuda.synchronize()
+            t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ts.append(float(t.item()))
+        ok = True
+        if r == 0:
+            want = torch.cat([torch.full((int(b[k + 1] - b[k]),), float(k + 1)) for k in range(w)]).to(dev)
+            ok = bool(torch.equal(vol[:, 0, 0, 0], want) and torch.equal(vol[:, -1, -1, -1], want))
+        return min(ts) * 1e3, ok
+
+    moved = nbytes * (w - 1) / w
+    for name, fn in (("slab_gather_c_abi", lambda v: mdist.volume_reduce(v, dev, mode=0)),
+                     ("dense_reduce_c_abi", lambda v: mdist.volume_reduce(v, dev, mode=1)),
+                     ("dense_reduce_torch", lambda v: dist.reduce(v, dst=0, op=dist.ReduceOp.SUM))):
+        try:
+            ms, ok = timed(fn)
+            res[name + "_ms"] = round(ms, 3)
+            res[name + "_correct"] = ok
+        except Exception as e:
+            res[name + "_error"] = repr(e)[:200]
+    if "slab_gather_c_abi_ms" in res:
+        res["slab_gather_GBps_into_root"] = round(moved / (res["slab_gather_c_abi_ms"] * 1e-3) / 1e9, 1)
+        res["xgmi_expectation"] = ("%d peers x %.0f GB/s links into the root: %.2f ms for %.0f MB"
+                                   % (w - 1, XGMI_LINK_GBS, moved / ((w - 1) * XGMI_LINK_GBS * 1e9) * 1e3, moved / 1e6))
+    if "dense_reduce_c_abi_ms" in res:
+        res["dense_reduce_GBps_volume"] = round(nbytes / (res["dense_reduce_c_abi_ms"] * 1e-3) / 1e9, 1)
+    return res
+
+
+def secondary_quantized(a, dev, recs, cams, my):
     """The same iteration on maps pushed through the reference's 8-bit file hand-off (integer degrees, conf/255 --
     what a real capture delivers): duplicate tap orientations are dropped exactly."""
+    import torch
+
+    from monohair_amd import synth
+    from monohair_amd.pmvo import PMVO
+
     scene_q = synth.make_scene(a.views, a.height, a.width, device=dev, seed=0, quantize=True)
     pm = PMVO.from_planes(recs, scene_q["depth"], scene_q["ori"], scene_q["conf"], scene_q["mask"], device=dev,
                           patch_size=a.patch, visible_threshold=1, conf_threshold=a.conf_threshold, camera=cams)
@@ -264,7 +502,7 @@ def secondary_quantized(a, dev, recs, cams, dev_chunks):
 
     def step(i):
         with torch.cuda.stream(streams[i % len(streams)]):
-            return pm.forward(dev_chunks[i % len(dev_chunks)])
+            return pm.forward(my[i % len(my)])
 
     for i in range(a.warmup):
         step(i)
@@ -278,12 +516,19 @@ def secondary_quantized(a, dev, recs, cams, dev_chunks):
             "maps": "quantized-8bit"}
 
 
-def secondary_full_pass(dev, pm, cand):
+def secondary_full_pass(dev, pm, cand, dist):
     """Wall time of the whole exterior pass on this scene: filter_negative_points -> optimize ->
-    refine (smoothing, shell points, voxel fit, Ori3D.mat / Occ3D.mat written), one process, stages synchronised."""
+    refine (smoothing, shell points, voxel fit, Ori3D.mat / Occ3D.mat written), stages synchronised.  With N ranks the
+    drivers shard the independent chunks over the GPUs and assemble the volume with mh_volume_reduce (monohair_amd/dist.py);
+    the times are the maximum over the ranks."""
+    import contextlib
+    import io
+    import shutil
     import tempfile
     import types
 
+    import numpy as np
+    import torch
     from scipy.spatial import KDTree
 
     from monohair_amd.pmvo import filter_negative_points, optimize, refine
@@ -293,22 +538,31 @@ def secondary_full_pass(dev, pm, cand):
     b = b / np.linalg.norm(b, axis=1, keepdims=True) * 0.09          # stand-ins for the bust / scalp meshes
     scalp = b[b[:, 1] > 0.03] * (0.1 / 0.09)
     pm.set_head(KDTree(b), KDTree(scalp), scalp.max(0))
-    tmp = tempfile.mkdtemp(prefix="mhbench_")
+    if dist is not None:
+        box = [tempfile.mkdtemp(prefix="mhbench_") if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        tmp = box[0]
+    else:
+        tmp = tempfile.mkdtemp(prefix="mhbench_")
     args = types.SimpleNamespace(device=str(dev), output_path=tmp, save_root=tmp + "/optimize", save_path=tmp + "/refine",
                                  PMVO=types.SimpleNamespace(visible_threshold=1), data=types.SimpleNamespace(root=tmp))
     os.makedirs(args.save_path, exist_ok=True)
     T = {}
 
     def timed(name, fn):
+        if dist is not None:
+            dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         r = fn()
         torch.cuda.synchronize()
-        T[name] = round(time.perf_counter() - t0, 3)
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        T[name] = round(dt, 3)
         return r
-
-    import contextlib
-    import io
 
     with contextlib.redirect_stdout(io.StringIO()):                   # the drivers print progress like the reference
         s_idx, s_pts, f_idx = timed("filter_s", lambda: filter_negative_points(cand, pm, args))
@@ -317,7 +571,9 @@ def secondary_full_pass(dev, pm, cand):
                                                    infer_inner=False, threshold=0.025, return_dense=False))
     T["total_s"] = round(sum(T.values()), 3)
     T.update(candidates=int(len(cand)), surface_points=int(s_idx.sum()), shell_points=int(f_idx.sum()),
-             iterations=int(len(s_pts) // CHUNK + 1), unit="s")
+             iterations=int(len(s_pts) // CHUNK + 1), unit="s", ranks=1 if dist is None else dist.get_world_size())
+    if dist is None or dist.get_rank() == 0:
+        shutil.rmtree(tmp, ignore_errors=True)
     return T
 
 
@@ -326,6 +582,7 @@ def secondary_gabor(a, dev):
     synthetic view of the benchmark's image size, FP32-MFMA im2col kernel, HIP events around 10 launches.
     Compute bound: 2*180*289 FLOP per pixel against 12 B; peak = 157.3 TFLOP/s dense fp32 matrix."""
     import numpy as np
+    import torch
 
     from monohair_amd.gabor import calOrientationGabor
 
@@ -350,22 +607,11 @@ def secondary_gabor(a, dev):
                          "frac": round(tf / 157.3, 4), "traffic": None}}
 
 
-def pmc_traffic(kernel, V, H, W):
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC pass (profiles/traffic.json;
-    counters cannot be read from inside this process).  None when no pass exists for this workload."""
-    try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if t.get("workload", "").startswith("%d views @ %dx%d" % (V, H, W)):
-            return t[kernel]["traffic_bytes"]
-    except Exception:
-        pass
-    return None
-
-
 def cpu_baseline(a, scene, recs, chunk, gpu_ms):
     """The CPU oracle (oracle/pmvo_oracle.c, OpenMP over points) timed on this host on a bounded sample of the
     same iteration: the first n points of the chunk against all views."""
     import oracle
+    from monohair_amd.pmvo import depth_offsets
 
     views = oracle.Views(recs, scene["depth"].cpu().numpy(), scene["ori"].cpu().numpy(),
                          scene["conf"].cpu().numpy(), scene["mask"].cpu().numpy())
@@ -387,7 +633,9 @@ def cpu_baseline(a, scene, recs, chunk, gpu_ms):
         "cores": cores,
         "kind": "port",
         "sample": "%d x %d points of one %d-point iteration, all %d views, C oracle (oracle/pmvo_oracle.c) with "
-                  "OpenMP on %d threads, %.1f s of wall time" % (reps, n, CHUNK, a.views, cores, t),
+                  "OpenMP on %d threads, %.1f s of wall time; the unmodified reference (torch-CPU, 8 vCPU Xeon, "
+                  "BASELINE.md §2) needs 250-500 s per iteration = 0.002-0.004 iterations/s" % (reps, n, CHUNK, a.views,
+                                                                                              cores, t),
     }
 
 

@@ -79,6 +79,10 @@ int mh_topk_views(mh_ctx *ctx, const float *vis, const float *conf, int N, int32
 
 /* bytes of scratch mh_search_forward / mh_refine_loss need for N points and this patch size */
 size_t mh_search_scratch_bytes(mh_ctx *ctx, int N, int patch);
+/* byte offset, inside that scratch, of the [V,N] uint8 array of tap-list lengths the preparation kernels leave there
+ * (0 for views that do not see the point): what the search orders its workgroups by, and what a caller can read to
+ * count the (candidate, view, tap) evaluations a launch actually executes */
+size_t mh_search_counts_offset(mh_ctx *ctx, int N, int patch);
 
 /* ---- K7-K10 fused: the body of PMVO.forward (PMVO.py:50-78): for base-view ranks 0,rank_step,...
  * sample_next_3d_pos (:263-335), compute_reproject_ori (:219-241), compute_prj_loss (:151-209) and the
@@ -205,6 +209,20 @@ int mh_render_depth(mh_ctx *ctx, const float *cam_host, const float *verts, int 
                     int H, int W, float pixel_center, void *scratch, size_t scratch_bytes, float *out, int channels,
                     void *stream);
 
+/* ---- the caller on the other side of the path: Utils/Render_utils.py:269-307 render_data -- the
+ * strand segments traced from the exterior volume drawn as GL_LINES of width 3 (StrandsObj, :8-127) over the bust mesh
+ * (BustObj, :130-203) with a shared depth test, one of four fragment colourings; the images DeepMVSHair reads
+ * (infer_inner.py:60-73).  line_pts / line_tan [2*Nseg,3]: the reference's `Lines` / `tangent` vertex buffers (two
+ * vertices per segment).  color_option 0 depth/2, 1 direction, 2 undirected direction (2 theta), 3 white, < 0: strands
+ * not drawn; depth_option (mesh fragments) 0 depth/2, 1 black, 2 white; clear: background value of all three channels.
+ * out [H,W,3] float32 in the shader's range, top-left origin.  A specified rasteriser (header of csrc/raster.hip);
+ * parity with an OpenGL driver is unpinned. */
+size_t mh_render_strands_scratch_bytes(int Nv, int Nf, int Nseg, int H, int W);
+int mh_render_strands(mh_ctx *ctx, const float *cam_host, const float *verts, int Nv, const int32_t *faces, int Nf,
+                      const float *line_pts, const float *line_tan, int Nseg, int H, int W, float pixel_center,
+                      int line_width, int color_option, int depth_option, float clear, void *scratch,
+                      size_t scratch_bytes, float *out, void *stream);
+
 /* ---- K1+K2: calOrientationGabor.forward with iter=1 (preprocess_capture_data/GaborFilter.py:29-145):
  * 180 real Gabor kernels 17x17 (sigma 1.8/2.4, lambda 4), |response| argmax -> orientation index,
  * response-curve variance -> confidence normalised by the image maximum.
@@ -231,6 +249,23 @@ int mh_trace_scalp(mh_ctx *ctx, const void *vox, int W, int H, int Z, const floa
                    float thr_dot, float *out, int32_t *len, void *stream);
 int mh_strands_accept(int W, int H, int Z, float *flag, const float *pts, const int32_t *first, const int32_t *len,
                       int stride, const float *seeds, int n, int mode, uint8_t *accepted);
+
+/* ---- the one exchange of the data path, RCCL over xGMI.  The reference has no multi-GPU path
+ * (options.py:112 asserts a single GPU); the voxel fit of refine (PMVO.py:695-726) is sharded here by x-slabs of
+ * the volume, every rank fitting the voxels of its slab into a zero-initialised dense [X,Y,Z,C] fp32 volume (C = 4:
+ * occupancy + orientation), and rank `root` assembles the shared volume:
+ *   mode 0: slab gather -- ownership is disjoint, so every peer ncclSend's its slab straight to the root, which
+ *           ncclRecv's it in place ((nranks-1)/nranks of the volume crosses xGMI, one slab per link);
+ *   mode 1: dense ncclReduce(sum) of the whole volume (x + 0 is exact: the same result; kept for comparison).
+ * slab_host (host, nranks+1 ints): rank r owns x in [slab_host[r], slab_host[r+1]).  `comm` is an ncclComm_t:
+ * mh_comm_init makes one from a 128-byte ncclUniqueId that rank 0 obtains with mh_comm_unique_id and hands to the
+ * other ranks by any means (torch.distributed broadcast, a file, MPI); any ncclComm_t of the caller works as well.
+ * librccl.so.1 is bound at run time; a process that never calls these does not load it. */
+int mh_comm_unique_id(void *id_out_host /*128 bytes*/);
+int mh_comm_init(mh_ctx *ctx, const void *id_host /*128 bytes*/, int nranks, int rank, void **comm_out);
+int mh_comm_destroy(void *comm);
+int mh_volume_reduce(mh_ctx *ctx, void *comm, int rank, int nranks, int root, float *volume /*[X,Y,Z,C] in place*/,
+                     int X, int Y, int Z, int C, const int32_t *slab_host, int mode, void *stream);
 
 /* Tuning knobs (e.g. "search_variant": threads per point in the search kernel; 0 = default). */
 int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value);

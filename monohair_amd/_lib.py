@@ -26,6 +26,7 @@ _SIGS = {
     "mh_project_gather": (ci, [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mh_topk_views": (ci, [vp, vp, vp, ci, vp, vp, vp]),
     "mh_search_scratch_bytes": (csz, [vp, ci, ci]),
+    "mh_search_counts_offset": (csz, [vp, ci, ci]),
     "mh_search_forward": (ci, [vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, csz, vp, vp, vp, vp, vp,
                                vp, vp]),
     "mh_forward_prepare": (ci, [vp, vp, ci, ci, cf, vp, vp, vp, vp, vp, csz, vp]),
@@ -55,6 +56,12 @@ _SIGS = {
     "mh_sort_keys": (ci, [vp, vp, ci, ci, vp, csz, vp, vp, vp]),
     "mh_render_scratch_bytes": (csz, [ci, ci, ci, ci]),
     "mh_render_depth": (ci, [vp, vp, vp, ci, vp, ci, ci, ci, cf, vp, csz, vp, ci, vp]),
+    "mh_comm_unique_id": (ci, [vp]),
+    "mh_comm_init": (ci, [vp, vp, ci, ci, ctypes.POINTER(vp)]),
+    "mh_comm_destroy": (ci, [vp]),
+    "mh_volume_reduce": (ci, [vp, vp, ci, ci, ci, vp, ci, ci, ci, ci, vp, ci, vp]),
+    "mh_render_strands_scratch_bytes": (csz, [ci, ci, ci, ci, ci]),
+    "mh_render_strands": (ci, [vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, cf, ci, ci, ci, cf, vp, csz, vp, vp]),
     "mh_gabor_bank": (ci, [vp, vp, ci, ci, vp, vp, vp, vp]),
     "mh_gabor_set_bank": (ci, [vp, vp]),
 }

@@ -46,6 +46,9 @@ int mh_launch_grid_build(const float *, int, float, float, float, float, int, in
                          int32_t *, int32_t *, int32_t *, hipStream_t);
 int mh_launch_sort_keys(const unsigned long long *, int, int, void *, size_t, unsigned long long *, int32_t *,
                         hipStream_t);
+int mh_launch_render_strands(const float *, const float *, int, const int32_t *, int, const float *, const float *, int,
+                             int, int, int, int, int, int, float, void *, void *, unsigned long long *, int32_t *,
+                             unsigned int *, float *, hipStream_t);
 int mh_launch_project_points(const float *, const float *, int, int, int, int32_t *, float *, uint8_t *, float *,
                              hipStream_t);
 int mh_launch_gather(MhViews, int, const long long *, int, int, float4 *, float *, hipStream_t);
@@ -234,6 +237,40 @@ extern "C" int mh_render_depth(mh_ctx *ctx, const float *cam_host, const float *
                     "mh_render_depth");
 }
 
+extern "C" size_t mh_render_strands_scratch_bytes(int Nv, int Nf, int Nseg, int H, int W) {
+    if (Nv < 0 || Nf < 0 || Nseg < 0 || H < 1 || W < 1) return 0;
+    return mh_render_scratch_bytes(Nv, Nf, H, W) + 64 + (size_t)2 * Nseg * 32;
+}
+
+extern "C" int mh_render_strands(mh_ctx *ctx, const float *cam_host, const float *verts, int Nv, const int32_t *faces,
+                                 int Nf, const float *line_pts, const float *line_tan, int Nseg, int H, int W,
+                                 float pixel_center, int line_width, int color_option, int depth_option, float clear,
+                                 void *scratch, size_t scratch_bytes, float *out, void *stream) {
+    if (!ctx) return fail(MH_ERR_ARG, "mh_render_strands: no context");
+    if (!cam_host || !out || !scratch || H < 1 || W < 1 || Nv < 0 || Nf < 0 || Nseg < 0 || line_width < 1 ||
+        line_width > 64 || color_option > 3 || depth_option < 0 || depth_option > 2 ||
+        ((Nv > 0 && Nf > 0) && (!verts || !faces)) || (Nseg > 0 && color_option >= 0 && (!line_pts || !line_tan)) ||
+        !(pixel_center >= 0.0f && pixel_center < 1.0f))
+        return fail(MH_ERR_ARG, "mh_render_strands: bad arguments");
+    if (scratch_bytes < mh_render_strands_scratch_bytes(Nv, Nf, Nseg, H, W))
+        return fail(MH_ERR_ARG, "mh_render_strands: scratch too small (%zu < %zu)", scratch_bytes,
+                    mh_render_strands_scratch_bytes(Nv, Nf, Nseg, H, W));
+    MH_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    char *base = (char *)scratch;
+    float *cam = (float *)base;
+    MH_HIP(hipMemcpyAsync(cam, cam_host, MH_CAM_STRIDE * sizeof(float), hipMemcpyHostToDevice, st));
+    unsigned int *qcount = (unsigned int *)(base + 256);
+    void *vt = base + 512;
+    unsigned long long *zbuf = (unsigned long long *)(base + 512 + render_vt_bytes(Nv));
+    int32_t *queue = (int32_t *)((char *)zbuf + (size_t)H * W * sizeof(unsigned long long));
+    char *lv = base + ((mh_render_scratch_bytes(Nv, Nf, H, W) + 63) / 64) * 64;
+    const int off = (int)(pixel_center * 256.0f + 0.5f);
+    return launched(mh_launch_render_strands(cam, verts, Nv, faces, Nf, line_pts, line_tan, Nseg, H, W, off, line_width,
+                                             color_option, depth_option, clear, vt, lv, zbuf, queue, qcount, out, st),
+                    "mh_render_strands");
+}
+
 extern "C" int mh_ctx_set_depth_offsets(mh_ctx *ctx, const float *offsets_host, int S) {
     if (!ctx || !offsets_host || S < 1 || S > 256) return fail(MH_ERR_ARG, "mh_ctx_set_depth_offsets: bad arguments");
     MH_HIP(hipSetDevice(ctx->device));
@@ -287,6 +324,11 @@ static size_t search_order_offset(const mh_ctx *ctx, int N, int patch) {
 
 static size_t search_count_offset(const mh_ctx *ctx, int N, int patch) {
     return search_order_offset(ctx, N, patch) + 2 * (size_t)N * sizeof(int32_t);
+}
+
+extern "C" size_t mh_search_counts_offset(mh_ctx *ctx, int N, int patch) {
+    if (!ctx || N < 0 || patch < 1) return 0;
+    return search_count_offset(ctx, N, patch);
 }
 
 extern "C" size_t mh_search_scratch_bytes(mh_ctx *ctx, int N, int patch) {
@@ -649,4 +691,125 @@ extern "C" int mh_gabor_bank(mh_ctx *ctx, const float *image, int H, int W, int3
     return launched(mh_launch_gabor_bank(ctx->gabor, image, H, W, orient_index, conf, variance, ctx->gabor_max,
                                          ctx->gabor_variant, st),
                     "mh_gabor_bank");
+}
+
+// ---------------------------------------------------------------------------------------------
+// RCCL through the C ABI: the ONE exchange of the data path -- every rank has fitted a disjoint
+// slab of the orientation/occupancy volume, rank `root` ends up with all of it.  librccl is bound at run time
+// (dlopen by its soname: in a torch process that is the copy torch already loaded, so both share one RCCL), so the
+// single-GPU path does not depend on it.
+// ---------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+
+namespace {
+struct MhNcclId {
+    char internal[128];   // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES)
+};
+typedef void *MhNcclComm;
+struct MhRccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(MhNcclId *) = nullptr;
+    int (*CommInitRank)(MhNcclComm *, int, MhNcclId, int) = nullptr;
+    int (*CommDestroy)(MhNcclComm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, MhNcclComm, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, MhNcclComm, hipStream_t) = nullptr;
+    int (*Reduce)(const void *, void *, size_t, int, int, int, MhNcclComm, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+MhRccl g_rccl;
+const int MH_NCCL_FLOAT32 = 7, MH_NCCL_SUM = 0;   // rccl.h: ncclFloat32, ncclSum
+
+int rccl_load() {
+    if (g_rccl.h) return MH_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return fail(MH_ERR_STATE, "librccl.so.1 not found: %s", dlerror());
+    MhRccl r;
+    r.h = h;
+#define MH_SYM(field, name)                                                               \
+    *(void **)(&r.field) = dlsym(h, name);                                                \
+    if (!r.field) return fail(MH_ERR_STATE, "librccl: symbol %s missing", name)
+    MH_SYM(GetUniqueId, "ncclGetUniqueId");
+    MH_SYM(CommInitRank, "ncclCommInitRank");
+    MH_SYM(CommDestroy, "ncclCommDestroy");
+    MH_SYM(GroupStart, "ncclGroupStart");
+    MH_SYM(GroupEnd, "ncclGroupEnd");
+    MH_SYM(Send, "ncclSend");
+    MH_SYM(Recv, "ncclRecv");
+    MH_SYM(Reduce, "ncclReduce");
+    MH_SYM(GetErrorString, "ncclGetErrorString");
+#undef MH_SYM
+    g_rccl = r;
+    return MH_OK;
+}
+}   // namespace
+
+#define MH_NCCL(call)                                                                                   \
+    do {                                                                                                \
+        int e_ = (call);                                                                                \
+        if (e_ != 0) return fail(MH_ERR_HIP, "%s: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(e_) : "?"); \
+    } while (0)
+
+extern "C" int mh_comm_unique_id(void *id_out_host) {
+    if (!id_out_host) return fail(MH_ERR_ARG, "mh_comm_unique_id: NULL");
+    if (int rc = rccl_load()) return rc;
+    MH_NCCL(g_rccl.GetUniqueId((MhNcclId *)id_out_host));
+    return MH_OK;
+}
+
+extern "C" int mh_comm_init(mh_ctx *ctx, const void *id_host, int nranks, int rank, void **comm_out) {
+    if (!ctx || !id_host || !comm_out || nranks < 1 || rank < 0 || rank >= nranks)
+        return fail(MH_ERR_ARG, "mh_comm_init: bad arguments");
+    if (int rc = rccl_load()) return rc;
+    MH_HIP(hipSetDevice(ctx->device));
+    MhNcclId id;
+    memcpy(&id, id_host, sizeof(id));
+    MhNcclComm c = nullptr;
+    MH_NCCL(g_rccl.CommInitRank(&c, nranks, id, rank));
+    *comm_out = c;
+    return MH_OK;
+}
+
+extern "C" int mh_comm_destroy(void *comm) {
+    if (!comm) return MH_OK;
+    if (int rc = rccl_load()) return rc;
+    MH_NCCL(g_rccl.CommDestroy((MhNcclComm)comm));
+    return MH_OK;
+}
+
+extern "C" int mh_volume_reduce(mh_ctx *ctx, void *comm, int rank, int nranks, int root, float *volume, int X, int Y,
+                                int Z, int C, const int32_t *slab_host, int mode, void *stream) {
+    if (!ctx || !comm || !volume || !slab_host || nranks < 1 || rank < 0 || rank >= nranks || root < 0 ||
+        root >= nranks || X < 1 || Y < 1 || Z < 1 || C < 1 || (mode != 0 && mode != 1))
+        return fail(MH_ERR_ARG, "mh_volume_reduce: bad arguments");
+    if (slab_host[0] != 0 || slab_host[nranks] != X) return fail(MH_ERR_ARG, "mh_volume_reduce: slabs must cover [0, X)");
+    for (int r = 0; r < nranks; ++r)
+        if (slab_host[r] > slab_host[r + 1]) return fail(MH_ERR_ARG, "mh_volume_reduce: slabs must be ascending");
+    if (int rc = rccl_load()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t plane = (size_t)Y * Z * C;   // floats per x index: a slab is one contiguous block
+    if (mode == 1) {   // dense sum into root (x + 0 is exact, so this is the same volume; C*X*Y*Z floats over every link)
+        MH_NCCL(g_rccl.Reduce(volume, volume, plane * X, MH_NCCL_FLOAT32, MH_NCCL_SUM, root, (MhNcclComm)comm, st));
+        return MH_OK;
+    }
+    // mode 0: slab ownership is disjoint, so nothing has to be added: every peer sends its own slab straight to the
+    // root over its own xGMI link and the root receives it in place -- (nranks-1)/nranks of the volume in total, each
+    // link carrying one slab
+    MH_NCCL(g_rccl.GroupStart());
+    if (rank == root) {
+        for (int r = 0; r < nranks; ++r) {
+            const size_t cnt = (size_t)(slab_host[r + 1] - slab_host[r]) * plane;
+            if (r == root || cnt == 0) continue;
+            MH_NCCL(g_rccl.Recv(volume + (size_t)slab_host[r] * plane, cnt, MH_NCCL_FLOAT32, r, (MhNcclComm)comm, st));
+        }
+    } else {
+        const size_t cnt = (size_t)(slab_host[rank + 1] - slab_host[rank]) * plane;
+        if (cnt) MH_NCCL(g_rccl.Send(volume + (size_t)slab_host[rank] * plane, cnt, MH_NCCL_FLOAT32, root, (MhNcclComm)comm, st));
+    }
+    MH_NCCL(g_rccl.GroupEnd());
+    return MH_OK;
 }

@@ -194,3 +194,208 @@ extern "C" int mh_launch_render_depth(const float *cam, const float *verts, int 
                        faces, Nv, H, W, off, zbuf, out, channels);
     return (int)hipGetLastError();
 }
+
+// =============================================================================================
+// Strand-segment renderer: the moderngl pass of Utils/Render_utils.py:269-307 (render_data) with
+// the StrandsObj line shader (:8-127) drawn over the BustObj mesh (:130-203) -- what infer_inner.py:60-73 feeds to
+// DeepMVSHair.  As for the depth maps, OpenGL leaves line rasterisation details to the driver, so this is a
+// SPECIFIED rasteriser (oracle/raster_oracle.c restates it in C; parity with a GL driver is unpinned):
+//   * line vertices: window position / window z / 1/w exactly as the mesh vertices above; per vertex the shader's
+//     `Tangent_2d` = ndc(p + normalize(T) * 0.01) - ndc(p) in GL's clip convention (ndc_gl = -(u, v) of
+//     Camera.projection) and `depth` = -z_camera (:57-68);
+//   * a segment is x-major if |dx| >= |dy| (1/256 pixel units), else y-major; it produces one fragment column per
+//     sample position m = i*256 + off of the major axis inside the half-open interval [min, max) of its end points
+//     (the interval form of GL's diamond-exit rule); t = (m - A) / (B - A); the minor coordinate is interpolated
+//     linearly, the centre fragment is the pixel whose sample is nearest, and `width` fragments (ctx.line_width = 3,
+//     :30) are stacked around it in the minor direction (GL's wide-line rule);
+//   * window z linear in t, depth test LESS against the mesh and the other segments (same 64-bit key buffer; ties to
+//     the earlier primitive: mesh before strands, segments in buffer order);
+//   * attributes perspective-correct in t: a = ((1-t) a0/w0 + t a1/w1) / ((1-t)/w0 + t/w1);
+//   * fragment colours (:80-104): 0 depth/2 grey; 1 ((cos th, sin th, 0) + (1,1,0))/2 with th = atan(T2d.y, T2d.x);
+//     2 the same with 2 th; 3 white -- evaluated algebraically (cos th = x/r, cos 2th = (x^2-y^2)/r^2, ...) so that
+//     the kernel and its C statement agree to the bit; mesh fragments (:171-183): 0 depth/2, 1 black, 2 white.
+// Output: float32 [H,W,3] in the shader's range (the reference multiplies by 255 when it writes the PNGs).
+// =============================================================================================
+struct MhRLVert {
+    int x, y;
+    float zw, iw;
+    float tx, ty, depth;
+    int pad;
+};
+
+__global__ __launch_bounds__(256) void mh_raster_linevert_kernel(const float *__restrict__ cam,
+                                                                 const float *__restrict__ pts,
+                                                                 const float *__restrict__ tans, int Nlv, float Hf,
+                                                                 float Wf, MhRLVert *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nlv) return;
+    const float p0 = pts[3 * i], p1 = pts[3 * i + 1], p2 = pts[3 * i + 2];
+    const float t0 = tans[3 * i], t1 = tans[3 * i + 1], t2 = tans[3 * i + 2];
+    float u, v, z, rowf, colf;
+    mh_cam_project(cam, p0, p1, p2, u, v, z);
+    mh_ndc_to_pixel(u, v, Hf, Wf, rowf, colf);
+    MhRLVert r;
+    const float w = -z;
+    const float zc = mh_fma(cam[27], 1.0f, cam[26] * z);
+    r.zw = (zc / w) * 0.5f + 0.5f;
+    r.iw = 1.0f / w;
+    const bool ok = (w > 0.0f) && (__builtin_fabsf(colf) < 1.0e5f) && (__builtin_fabsf(rowf) < 1.0e5f);
+    r.x = ok ? (int)__builtin_rintf(colf * (float)MH_R_SUB) : MH_R_BAD;
+    r.y = ok ? (int)__builtin_rintf(rowf * (float)MH_R_SUB) : MH_R_BAD;
+    float s = t0 * t0;
+    s = mh_fma(t1, t1, s);
+    s = mh_fma(t2, t2, s);
+    const float nrm = __builtin_sqrtf(s);
+    const float n0 = nrm > 0.0f ? t0 / nrm : 0.0f, n1 = nrm > 0.0f ? t1 / nrm : 0.0f, n2 = nrm > 0.0f ? t2 / nrm : 0.0f;
+    float u2, v2, z2;
+    mh_cam_project(cam, p0 + n0 * 0.01f, p1 + n1 * 0.01f, p2 + n2 * 0.01f, u2, v2, z2);
+    r.tx = u - u2;   // ndc_gl = -(u, v)
+    r.ty = v - v2;
+    r.depth = w;
+    r.pad = 0;
+    out[i] = r;
+}
+
+struct MhRSeg {
+    int A, B, ma, mb;   // major / minor coordinates of the two ends (1/256 pixel)
+    int xmaj;
+    int i0, i1;         // fragment columns along the major axis
+};
+
+__device__ __forceinline__ bool mh_setup_seg(const MhRLVert &a, const MhRLVert &b, int H, int W, int off, MhRSeg &g) {
+    if (a.x == MH_R_BAD || b.x == MH_R_BAD) return false;
+    const int dx = b.x - a.x, dy = b.y - a.y;
+    g.xmaj = (abs(dx) >= abs(dy)) ? 1 : 0;
+    g.A = g.xmaj ? a.x : a.y;
+    g.B = g.xmaj ? b.x : b.y;
+    g.ma = g.xmaj ? a.y : a.x;
+    g.mb = g.xmaj ? b.y : b.x;
+    if (g.A == g.B) return false;
+    const int lo = min(g.A, g.B), hi = max(g.A, g.B);
+    g.i0 = max(-mh_floor_div(-(lo - off), MH_R_SUB), 0);                       // first sample >= lo
+    g.i1 = min(-mh_floor_div(-(hi - off), MH_R_SUB) - 1, (g.xmaj ? W : H) - 1);   // last sample < hi
+    return g.i0 <= g.i1;
+}
+__device__ __forceinline__ float mh_seg_t(const MhRSeg &g, int i, int off) {
+    return (float)(i * MH_R_SUB + off - g.A) / (float)(g.B - g.A);
+}
+// first of the `width` stacked fragments in the minor direction for major index i
+__device__ __forceinline__ int mh_seg_minor0(const MhRSeg &g, float t, int off, int width) {
+    const float minor = (float)g.ma + t * (float)(g.mb - g.ma);
+    const float jf = (minor - (float)off) / (float)MH_R_SUB;
+    const int jc = (int)__builtin_floorf(jf + 0.5f);
+    return jc - (width - 1) / 2;
+}
+
+__global__ __launch_bounds__(256) void mh_raster_lines_kernel(const MhRLVert *__restrict__ lv, int Ns, int H, int W,
+                                                              int off, int width, unsigned prim_base,
+                                                              unsigned long long *__restrict__ zbuf) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= Ns) return;
+    const MhRLVert a = lv[2 * s], b = lv[2 * s + 1];
+    MhRSeg g;
+    if (!mh_setup_seg(a, b, H, W, off, g)) return;
+    const int nminor = g.xmaj ? H : W;
+    for (int i = g.i0; i <= g.i1; ++i) {
+        const float t = mh_seg_t(g, i, off);
+        const float zw = a.zw + t * (b.zw - a.zw);
+        if (!(zw >= 0.0f && zw <= 1.0f)) continue;
+        const unsigned long long key = ((unsigned long long)__float_as_uint(zw) << 32) | (prim_base + (unsigned)s);
+        const int j0 = mh_seg_minor0(g, t, off, width);
+        for (int k = 0; k < width; ++k) {
+            const int j = j0 + k;
+            if (j < 0 || j >= nminor) continue;
+            const size_t pix = g.xmaj ? ((size_t)j * W + i) : ((size_t)i * W + j);
+            atomicMin(&zbuf[pix], key);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mh_raster_resolve_color_kernel(
+    const MhRVert *__restrict__ vt, const int32_t *__restrict__ faces, int Nv, int Nf, const MhRLVert *__restrict__ lv,
+    int H, int W, int off, int color_option, int depth_option, float clear,
+    const unsigned long long *__restrict__ zbuf, float *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)H * W) return;
+    const unsigned long long key = zbuf[i];
+    float c0 = clear, c1 = clear, c2 = clear;
+    if (key != ~0ull) {
+        const int r = (int)(i / W), c = (int)(i % W);
+        const unsigned prim = (unsigned)(key & 0xffffffffu);
+        if (prim < (unsigned)Nf) {
+            float g = 0.0f;
+            if (depth_option == 0) {
+                MhRTri t;
+                float l0, l1, l2;
+                mh_setup_tri(vt, faces, (int)prim, Nv, H, W, off, t);
+                mh_cover(t, r, c, off, l0, l1, l2);
+                const float s = (l0 * t.ia + l1 * t.ib) + l2 * t.ic;
+                g = (1.0f / s) / 2.0f;
+            } else if (depth_option == 2) {
+                g = 1.0f;
+            }
+            c0 = c1 = c2 = g;
+        } else {
+            const int s = (int)(prim - (unsigned)Nf);
+            const MhRLVert a = lv[2 * s], b = lv[2 * s + 1];
+            MhRSeg g;
+            mh_setup_seg(a, b, H, W, off, g);
+            const float t = mh_seg_t(g, g.xmaj ? c : r, off);
+            const float wa = (1.0f - t) * a.iw, wb = t * b.iw;
+            const float den = wa + wb;
+            const float depth = (wa * a.depth + wb * b.depth) / den;
+            const float tx = (wa * a.tx + wb * b.tx) / den;
+            const float ty = (wa * a.ty + wb * b.ty) / den;
+            if (color_option == 0) {
+                c0 = c1 = c2 = depth / 2.0f;
+            } else if (color_option == 1) {
+                const float rr = __builtin_sqrtf(tx * tx + ty * ty);
+                const float cs = rr > 0.0f ? tx / rr : 1.0f, sn = rr > 0.0f ? ty / rr : 0.0f;
+                c0 = (cs + 1.0f) * 0.5f;
+                c1 = (sn + 1.0f) * 0.5f;
+                c2 = 0.0f;
+            } else if (color_option == 2) {
+                const float xx = tx * tx, yy = ty * ty, s2 = xx + yy;
+                const float cs = s2 > 0.0f ? (xx - yy) / s2 : 1.0f, sn = s2 > 0.0f ? (2.0f * tx * ty) / s2 : 0.0f;
+                c0 = (cs + 1.0f) * 0.5f;
+                c1 = (sn + 1.0f) * 0.5f;
+                c2 = 0.0f;
+            } else {
+                c0 = c1 = c2 = 1.0f;
+            }
+        }
+    }
+    out[i * 3] = c0;
+    out[i * 3 + 1] = c1;
+    out[i * 3 + 2] = c2;
+}
+
+extern "C" int mh_launch_render_strands(const float *cam, const float *verts, int Nv, const int32_t *faces, int Nf,
+                                        const float *lpts, const float *ltan, int Ns, int H, int W, int off, int width,
+                                        int color_option, int depth_option, float clear, MhRVert *vt, MhRLVert *lv,
+                                        unsigned long long *zbuf, int32_t *queue, unsigned int *qcount, float *out,
+                                        hipStream_t st) {
+    hipError_t e = hipMemsetAsync(zbuf, 0xff, (size_t)H * W * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return (int)e;
+    if (Nv > 0 && Nf > 0) {
+        e = hipMemsetAsync(qcount, 0, sizeof(unsigned int), st);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(mh_raster_vertex_kernel, dim3((Nv + 255) / 256), dim3(256), 0, st, cam, verts, Nv, (float)H,
+                           (float)W, vt);
+        hipLaunchKernelGGL(mh_raster_small_kernel, dim3((Nf + 255) / 256), dim3(256), 0, st, vt, faces, Nf, Nv, H, W,
+                           off, zbuf, queue, qcount);
+        const int blocks = (Nf + 3) / 4 < 4096 ? (Nf + 3) / 4 : 4096;
+        hipLaunchKernelGGL(mh_raster_large_kernel, dim3(blocks), dim3(256), 0, st, vt, faces, Nv, H, W, off, zbuf,
+                           queue, qcount);
+    }
+    if (Ns > 0 && color_option >= 0) {
+        hipLaunchKernelGGL(mh_raster_linevert_kernel, dim3((2 * Ns + 255) / 256), dim3(256), 0, st, cam, lpts, ltan,
+                           2 * Ns, (float)H, (float)W, lv);
+        hipLaunchKernelGGL(mh_raster_lines_kernel, dim3((Ns + 255) / 256), dim3(256), 0, st, lv, Ns, H, W, off, width,
+                           (unsigned)(Nf > 0 && Nv > 0 ? Nf : 0), zbuf);
+    }
+    hipLaunchKernelGGL(mh_raster_resolve_color_kernel, dim3((unsigned)(((size_t)H * W + 255) / 256)), dim3(256), 0, st,
+                       vt, faces, Nv, (Nf > 0 && Nv > 0) ? Nf : 0, lv, H, W, off, color_option, depth_option, clear, zbuf,
+                       out);
+    return (int)hipGetLastError();
+}

@@ -5,9 +5,11 @@ The path shards by POINTS, not by views: a point's result needs every view but n
 holds all packed views (2.5 GB at 60 x 1080p, nothing against 288 GB), so an iteration has no collective at
 all and results are bit-identical to the single-GPU run.  Exactly two kinds of exchange exist:
   * map_chunks: independent chunks dealt round-robin, one all_gather of the per-chunk results at the end;
-  * voxel_fit_reduced: every rank fits a disjoint set of voxels and writes them into a zero volume; ONE
-    reduce(SUM) over xGMI assembles the shared 3D orientation/occupancy volume on rank 0 (x + 0 is exact,
-    so the reduced volume equals the single-GPU one bit for bit).
+  * voxel_fit_reduced: every rank fits a disjoint x-slab of voxels and writes them into a zero volume; ONE
+    exchange over xGMI assembles the shared 3D orientation/occupancy volume on rank 0: mh_volume_reduce (RCCL
+    through the C ABI) -- because ownership is disjoint, every peer sends its slab straight to the root
+    (ncclSend/ncclRecv), 1/N of the bytes of a dense reduce per link; the dense ncclReduce(sum) is kept as mode 1
+    (x + 0 is exact, so both give the single-GPU volume bit for bit).
 """
 import numpy as np
 import torch
@@ -99,6 +101,64 @@ def all_gather_views(local, n_views, shape, dtype, device):
     return out
 
 
+_COMMS = {}
+
+
+def rccl_comm(device):
+    """The ncclComm_t of this job created through the C ABI (mh_comm_init): rank 0 draws the 128-byte unique id
+    (mh_comm_unique_id), torch.distributed carries it to the other ranks, every rank joins.  Cached per device.
+    -> (ctx, comm) handles for mh_volume_reduce."""
+    import ctypes
+
+    from . import _lib
+    from .pmvo_utils import _ctx_for
+
+    d = _dist()
+    dev = torch.device(device)
+    key = (dev.index or 0, world(), rank())
+    if key not in _COMMS:
+        L = _lib.lib()
+        ctx = _ctx_for(dev)
+        raw = (ctypes.c_ubyte * 128)()
+        if rank() == 0:
+            _lib.check(L.mh_comm_unique_id(ctypes.cast(raw, ctypes.c_void_p)), "mh_comm_unique_id")
+        if d and world() > 1:
+            cdev = _comm_device(dev)
+            t = torch.tensor(list(raw), dtype=torch.uint8, device=cdev)
+            d.broadcast(t, src=0)
+            raw = (ctypes.c_ubyte * 128)(*t.cpu().tolist())
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(L.mh_comm_init(ctx, ctypes.cast(raw, ctypes.c_void_p), world(), rank(), ctypes.byref(comm)),
+                       "mh_comm_init")
+        _COMMS[key] = (ctx, comm)
+    return _COMMS[key]
+
+
+def slab_bounds(grid_x, n_ranks):
+    """x-slab ownership of the volume: rank r owns x in [b[r], b[r+1])"""
+    return np.array([(int(grid_x) * r) // n_ranks for r in range(n_ranks + 1)], dtype=np.int32)
+
+
+def volume_reduce(vol, device, mode=0, root=0):
+    """mh_volume_reduce on a dense [X,Y,Z,C] fp32 device tensor whose x-slabs were filled by their owners: after the
+    call (stream-ordered on the current stream) rank `root` holds the whole volume.  mode 0: slab gather
+    (ncclSend/ncclRecv, direct to the root); mode 1: dense ncclReduce(sum)."""
+    import ctypes
+
+    from . import _lib
+
+    assert vol.is_cuda and vol.dtype == torch.float32 and vol.is_contiguous() and vol.dim() == 4
+    ctx, comm = rccl_comm(device)
+    X, Y, Z, C = (int(v) for v in vol.shape)
+    slabs = slab_bounds(X, world())
+    with torch.cuda.device(vol.device):
+        _lib.check(_lib.lib().mh_volume_reduce(ctx, comm, rank(), world(), root, _lib.ptr(vol), X, Y, Z, C,
+                                               slabs.ctypes.data_as(ctypes.c_void_p), int(mode), _lib.stream_ptr()),
+                   "mh_volume_reduce")
+    return vol
+
+
 def voxel_owner_mask(x, n_ranks, r, grid_x):
     """Spatial partition of the volume into n_ranks slabs along x: rank r owns x in [r*G/n, (r+1)*G/n)."""
     lo = (grid_x * r) // n_ranks
@@ -134,9 +194,13 @@ def voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size, 
         v = res["voxels"].to(device)
         vol[v[:, 0], v[:, 1], v[:, 2], 0] = 1.0
         vol[v[:, 0], v[:, 1], v[:, 2], 1:] = res["ori"].to(device)
-    cdev = _comm_device(device)
-    vol = vol.to(cdev)
-    d.reduce(vol, dst=0, op=d.ReduceOp.SUM)          # the one collective of the data path
+    # the one exchange of the data path: RCCL through the C ABI (slab gather over xGMI, direct to rank 0); under the
+    # gloo backend of the CPU / single-GPU multi-rank tests the same volume is summed by torch.distributed on the host
+    if d.get_backend() == "nccl":
+        volume_reduce(vol, device, mode=0, root=0)
+    else:
+        vol = vol.to("cpu")
+        d.reduce(vol, dst=0, op=d.ReduceOp.SUM)
     if sparse:
         if r != 0:
             return np.zeros((0, 3), np.int64), np.zeros((0, 3), np.float32)

@@ -364,6 +364,21 @@ class PMVO:
             self._scratch[key] = buf
         return buf, need
 
+    def search_work(self, N, base_val=None):
+        """What the last forward() on the current stream executed: (list lengths [V,N] int64, usable ranks [N] or None).
+        The preparation kernels leave the per-(view, point) tap-list lengths in the scratch (0 = the view does not see
+        the point); with base_val [20,N] the number of base-view ranks the search evaluated per point (rank 0 always,
+        later ranks up to the last one with base_view_conf > 0, PMVO.py:64)."""
+        buf, _ = self._get_scratch(N)
+        off = int(self._L.mh_search_counts_offset(self._ctx, N, self.patch_size))
+        cnt = buf[off:off + self.num_view * N].view(self.num_view, N).to(torch.int64)
+        nvalid = None
+        if base_val is not None:
+            pos = base_val[list(self.RANKS)] > 0                      # [10, N]
+            last = (pos * torch.arange(1, pos.shape[0] + 1, device=pos.device)[:, None]).amax(0)
+            nvalid = torch.clamp(last, min=1)
+        return cnt, nvalid
+
     def forward(self, points, base_view=None, extras=False, fused=True):
         """PMVO.py:39-78.  points: numpy [N,3].  Returns (points, line_ori [N,3], min_loss [N],
         high_conf [N] bool) on the device.  base_view=(idx [20,N], val [20,N]) injects a base-view ranking

@@ -1,0 +1,56 @@
+"""bench.py's contract on the GPU box: one JSON line; the roofline block describes the kernels of the timed loop;
+`python bench.py --gpus 2` starts its two ranks itself (here they share the one GPU over gloo -- RCCL refuses two
+ranks on one device -- which still runs the whole multi-rank code path: rank discovery, sharded steps, the sharded
+full pass)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+SMALL = ["--steps", "3", "--warmup", "1", "--views", "24", "--height", "240", "--width", "136", "--volume", "48",
+         "--patch", "3", "--no-cpu"]
+
+
+def run_bench(args, env=None):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT,
+                       env=dict(os.environ, PYTHONPATH=ROOT, **(env or {})), stdin=subprocess.DEVNULL, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_and_rooflines_of_the_timed_kernels():
+    d = run_bench(SMALL)
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["steps"] == 3 and d["unit"] == "iterations/s"
+    rf = d["roofline"]
+    assert rf["kernel"].startswith("mh_search2_kernel") and rf["bound"] == "valu" and rf["peak"] == 157.3
+    assert 0 < rf["pair_evals_executed"] <= rf["pair_evals_nominal"]
+    # frac must be recomputable from the line itself
+    assert abs(rf["pair_evals_executed"] * rf["flop_per_pair_eval"] / (rf["launch_ms"] * 1e-3) / 1e12 - rf["achieved"]) < 0.05
+    names = [k["kernel"] for k in d["roofline_kernels"]]
+    assert any(n.startswith("mh_project_taps_kernel") for n in names) and any(n.startswith("mh_project_gather") for n in names)
+    for k in d["roofline_kernels"]:
+        assert abs(k["algorithmic_bytes_per_launch"] / (k["launch_ms"] * 1e-3) / 1e9 - k["achieved"]) < 1.0
+    assert "refine_and_volume_s" in d["secondary_full_pass"]
+
+
+def test_gpus_2_spawns_two_ranks_itself():
+    d = run_bench(["--gpus", "2"] + SMALL, env={"MH_DIST_BACKEND": "gloo", "MH_DEVICE_OVERRIDE": "0"})
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo"
+    assert d["secondary_full_pass"]["ranks"] == 2 and "total_s" in d["secondary_full_pass"]
+
+
+def test_gpus_more_than_present_is_refused():
+    import torch
+
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + SMALL, cwd=ROOT,
+                       env=dict(os.environ, PYTHONPATH=ROOT), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "refusing" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

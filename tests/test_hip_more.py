@@ -234,11 +234,12 @@ def test_drivers_end_to_end_vs_reference(tmp_path):
     assert np.array_equal(r["select_p"], z["ref_select_p"])
     lm = (r["min_loss"] == z["ref_min_loss"]) | (np.isnan(r["min_loss"]) & np.isnan(z["ref_min_loss"]))
     om = np.all((r["select_o"] == z["ref_select_o"]) | (np.isnan(r["select_o"]) & np.isnan(z["ref_select_o"])), 1)
-    # the medoid is bit-faithful to the reference (ATen's summation order), so the smoothing loop is too; what is left are
-    # the trailing N mod 64 columns of the reference's [V,N,1] sums (one ulp on those points, see the oracle tests)
-    assert lm.mean() >= 0.999 and om.mean() >= 0.999, (lm.mean(), om.mean())
-    close = np.isclose(r["min_loss"], z["ref_min_loss"], rtol=0, atol=1e-6, equal_nan=True)
-    assert close.mean() >= 0.999, close.mean()
+    # the medoid is bit-faithful to the reference (ATen's summation order), so the smoothing loop is too: every
+    # orientation, and every loss except the trailing N mod 64 points of a chunk, whose [V,N,1] sums ATen adds in another
+    # order (one ulp, see the oracle tests; this pass is one chunk of N < 5000 points)
+    tail = len(lm) - len(lm) % 64
+    assert om.all() and lm[:tail].all(), (lm[:tail].mean(), om.mean())
+    assert np.allclose(r["min_loss"], z["ref_min_loss"], rtol=0, atol=2e-7, equal_nan=True)
     assert np.array_equal(r["filter_unvisible"], z["ref_filter_unvisible"])
     fm = np.all(r["filter_unvisible_ori"] == z["ref_filter_unvisible_ori"], axis=1)
     assert fm.mean() >= 0.999
