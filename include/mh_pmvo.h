@@ -180,8 +180,18 @@ int mh_replace_dissimilar(mh_ctx *ctx, const float *center, float *ori /*in/out 
  * grid_origin_h (host): {ox, oy, oz, cell size}, grid_dims (host): {dx, dy, dz}.  out_idx[Q,k] sorted by (fp64 distance,
  * index); status[Q] != 0 marks queries the kernel could not finish (candidate buffer / ring limit): redo on the host. */
 int mh_knn_grid(mh_ctx *ctx, const float *grid_origin_h, const int32_t *grid_dims, const float *pts_sorted,
-                const int32_t *order, const int32_t *cell_start, const float *queries, int Q, int k,
+                const int32_t *order, const int32_t *cell_start, const void *queries /*[Q,3] float32, or float64 if
+                query_f64*/, int query_f64, int Q, int k, int first_ring /*cells around the query's cell looked at first
+                (>= 1)*/, const int32_t *query_order /*optional [Q]: order in which the queries are taken (locality)*/,
+                const unsigned char *valid /*optional [M], by original index: only these points count as neighbours*/,
                 int32_t *out_idx, int32_t *status, void *stream);
+
+/* Distance (float64) from each of N float32 points to the nearest of M float64 reference points, exhaustive: the
+ * `scalp_tree.query(points, k=1)` of PMVO.filter_head_points (PMVO.py:100-101) -- d = sqrt(min_j ((dx*dx + dy*dy) + dz*dz))
+ * evaluated in float64 as scipy's KDTree does.  out_mask (optional, uint8 [N]) = dist < max_dist && z < z_limit in
+ * float64: the `head_top_index` of PMVO.py:102-106 (4 cm from the scalp, 1 cm below its top).  out_dist may be NULL. */
+int mh_nearest_distance(mh_ctx *ctx, const float *points, int N, const double *ref_points, int M, double *out_dist,
+                        double max_dist, double z_limit, unsigned char *out_mask, void *stream);
 
 /* The grid mh_knn_grid searches: points sorted by cell (x fastest) with their original indices and the first sorted
  * position of every cell.  grid_origin_h (host): {ox, oy, oz, cell size}, grid_dims (host): {dx, dy, dz}.  Any of
@@ -266,6 +276,14 @@ int mh_comm_init(mh_ctx *ctx, const void *id_host /*128 bytes*/, int nranks, int
 int mh_comm_destroy(void *comm);
 int mh_volume_reduce(mh_ctx *ctx, void *comm, int rank, int nranks, int root, float *volume /*[X,Y,Z,C] in place*/,
                      int X, int Y, int Z, int C, const int32_t *slab_host, int mode, void *stream);
+
+/* ---- host-side IO of the volume files: scipy.io.savemat of PMVO.py:753-764 writes dense float64 arrays that are zero
+ * except at the occupied voxels.  Creates `path` = prefix (the MAT-v5 header + array tags, built by the caller) + a
+ * zero-filled payload of payload_bytes, then stores values[i] at payload element elem_index[i] (float64 elements; later
+ * entries win on duplicates).  The file is sparse on disk; the scatter runs on `threads` host threads split by
+ * destination range.  Host pointers only; no GPU involved. */
+int mh_mat_write_sparse(const char *path, const void *prefix, size_t prefix_bytes, size_t payload_bytes,
+                        const long long *elem_index, const double *values, size_t n, int threads);
 
 /* Tuning knobs (e.g. "search_variant": threads per point in the search kernel; 0 = default). */
 int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value);

@@ -49,7 +49,8 @@ _SIGS = {
     "mh_trace_seeds": (ci, [vp, vp, ci, ci, ci, vp, ci, cf, vp, vp, vp, vp]),
     "mh_trace_scalp": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, cf, vp, vp, vp]),
     "mh_strands_accept": (ci, [ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, vp]),
-    "mh_knn_grid": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp, vp]),
+    "mh_knn_grid": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]),
+    "mh_nearest_distance": (ci, [vp, vp, ci, vp, ci, vp, ctypes.c_double, ctypes.c_double, vp, vp]),
     "mh_grid_scratch_bytes": (csz, [ci]),
     "mh_grid_build": (ci, [vp, vp, vp, vp, ci, vp, csz, vp, vp, vp, vp, vp]),
     "mh_sort_scratch_bytes": (csz, [ci]),
@@ -62,6 +63,7 @@ _SIGS = {
     "mh_volume_reduce": (ci, [vp, vp, ci, ci, ci, vp, ci, ci, ci, ci, vp, ci, vp]),
     "mh_render_strands_scratch_bytes": (csz, [ci, ci, ci, ci, ci]),
     "mh_render_strands": (ci, [vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, cf, ci, ci, ci, cf, vp, csz, vp, vp]),
+    "mh_mat_write_sparse": (ci, [ctypes.c_char_p, vp, csz, csz, vp, vp, csz, ci]),
     "mh_gabor_bank": (ci, [vp, vp, ci, ci, vp, vp, vp, vp]),
     "mh_gabor_set_bank": (ci, [vp, vp]),
 }

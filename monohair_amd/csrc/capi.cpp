@@ -83,7 +83,8 @@ int mh_launch_gabor_bank(const float *, const float *, int, int, int32_t *, floa
 int mh_launch_gabor_build(float *, hipStream_t);
 int mh_launch_replace_dissimilar(const float *, float *, float, int, hipStream_t);
 int mh_launch_knn(float, float, float, float, int, int, int, const float *, const int32_t *, const int32_t *,
-                  const float *, int, int, int32_t *, int32_t *, hipStream_t);
+                  const void *, int, int, int, int, const int32_t *, const uint8_t *, int32_t *, int32_t *, hipStream_t);
+int mh_launch_nearest_dist(const float *, int, const double *, int, double *, double, double, uint8_t *, hipStream_t);
 int mh_launch_pack_volume(const float *, const float *, size_t, float4 *, hipStream_t);
 int mh_launch_trace_seeds(const float4 *, int, int, int, const float *, int, float, float *, int32_t *, int32_t *,
                           hipStream_t);
@@ -492,15 +493,27 @@ extern "C" int mh_replace_dissimilar(mh_ctx *ctx, const float *center, float *or
 
 extern "C" int mh_knn_grid(mh_ctx *ctx, const float *grid_origin_h /*host: ox,oy,oz,h*/, const int32_t *grid_dims /*host*/,
                            const float *pts_sorted, const int32_t *order, const int32_t *cell_start,
-                           const float *queries, int Q, int k, int32_t *out_idx, int32_t *status, void *stream) {
+                           const void *queries, int query_f64, int Q, int k, int first_ring, const int32_t *query_order,
+                           const unsigned char *valid, int32_t *out_idx, int32_t *status, void *stream) {
     if (Q == 0) return MH_OK;
     if (!ctx || !grid_origin_h || !grid_dims || !pts_sorted || !order || !cell_start || !queries || !out_idx ||
         !status || Q < 0)
         return fail(MH_ERR_ARG, "mh_knn_grid: bad arguments");
     return launched(mh_launch_knn(grid_origin_h[0], grid_origin_h[1], grid_origin_h[2], grid_origin_h[3], grid_dims[0],
-                                  grid_dims[1], grid_dims[2], pts_sorted, order, cell_start, queries, Q, k, out_idx,
-                                  status, (hipStream_t)stream),
+                                  grid_dims[1], grid_dims[2], pts_sorted, order, cell_start, queries, query_f64 ? 1 : 0, Q,
+                                  k, first_ring, query_order, valid, out_idx, status, (hipStream_t)stream),
                     "mh_knn_grid");
+}
+
+extern "C" int mh_nearest_distance(mh_ctx *ctx, const float *points, int N, const double *ref_points, int M,
+                                   double *out_dist, double max_dist, double z_limit, unsigned char *out_mask,
+                                   void *stream) {
+    if (N == 0) return MH_OK;
+    if (!ctx || !points || !ref_points || (!out_dist && !out_mask) || N < 0 || M < 1)
+        return fail(MH_ERR_ARG, "mh_nearest_distance: bad arguments");
+    return launched(mh_launch_nearest_dist(points, N, ref_points, M, out_dist, max_dist, z_limit, out_mask,
+                                           (hipStream_t)stream),
+                    "mh_nearest_distance");
 }
 
 extern "C" size_t mh_grid_scratch_bytes(int M) { return M < 0 ? 0 : mh_grid_scratch_bytes_impl(M); }
@@ -811,5 +824,63 @@ extern "C" int mh_volume_reduce(mh_ctx *ctx, void *comm, int rank, int nranks, i
         if (cnt) MH_NCCL(g_rccl.Send(volume + (size_t)slab_host[rank] * plane, cnt, MH_NCCL_FLOAT32, root, (MhNcclComm)comm, st));
     }
     MH_NCCL(g_rccl.GroupEnd());
+    return MH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host-side IO of the volume files (PMVO.py:753-764 scipy.io.savemat of the dense float64 arrays): the MAT-v5 payload is
+// a zero-filled array of which only the occupied voxels are non-zero, so the file is created sparse and the occupied
+// elements are scattered into a shared mapping.  What costs time is the first touch of each 4 KB page (allocation +
+// zero fill in the page cache); the scatter is therefore split over threads by DESTINATION range, which keeps every
+// page with one thread and preserves "later rows win" for duplicate elements (each thread walks the list in order).
+// ---------------------------------------------------------------------------------------------
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <thread>
+#include <vector>
+
+extern "C" int mh_mat_write_sparse(const char *path, const void *prefix, size_t prefix_bytes, size_t payload_bytes,
+                                   const long long *elem_index, const double *values, size_t n, int threads) {
+    if (!path || (!prefix && prefix_bytes) || (payload_bytes & 7) || (n && (!elem_index || !values)))
+        return fail(MH_ERR_ARG, "mh_mat_write_sparse: bad arguments");
+    const size_t nelem = payload_bytes / 8;
+    for (size_t i = 0; i < n; ++i)
+        if (elem_index[i] < 0 || (size_t)elem_index[i] >= nelem)
+            return fail(MH_ERR_ARG, "mh_mat_write_sparse: element %zu out of range", i);
+    const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return fail(MH_ERR_STATE, "mh_mat_write_sparse: cannot create %s", path);
+    const size_t total = prefix_bytes + payload_bytes;
+    bool ok = (size_t)write(fd, prefix, prefix_bytes) == prefix_bytes && ftruncate(fd, (off_t)total) == 0;
+    if (ok && n) {
+        void *m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m == MAP_FAILED) {
+            ok = false;
+        } else {
+            char *payload = (char *)m + prefix_bytes;      // (8-byte elements at an 8-byte aligned prefix: MAT v5 pads)
+            int T = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+            if (n < 4096) T = 1;
+            const size_t span = (nelem + T - 1) / T;
+            auto work = [&](int t) {
+                const size_t lo = (size_t)t * span, hi = lo + span;
+                for (size_t i = 0; i < n; ++i) {
+                    const size_t e = (size_t)elem_index[i];
+                    if (e >= lo && e < hi) memcpy(payload + e * 8, &values[i], 8);
+                }
+            };
+            if (T == 1) {
+                work(0);
+            } else {
+                std::vector<std::thread> pool;
+                for (int t = 0; t < T; ++t) pool.emplace_back(work, t);
+                for (auto &th : pool) th.join();
+            }
+            munmap(m, total);
+        }
+    }
+    close(fd);
+    if (!ok) return fail(MH_ERR_STATE, "mh_mat_write_sparse: writing %s failed", path);
     return MH_OK;
 }

@@ -4,10 +4,15 @@
 // neighbours come back sorted by (distance, index), i.e. scipy's order whenever distances are distinct.
 //
 // Points are pre-sorted by cell (x fastest), so a row of cells is ONE contiguous range.  One wave per query: for
-// ring = 1, 2, ... gather every point of the (2 ring + 1)^3 cell block into LDS (ballot-prefix append), bitonic-sort
-// the candidates by (d2, index) and stop as soon as the k-th distance is <= ring * h -- nothing outside the block can
-// be closer than that.  Queries that overflow the candidate buffer (status 2) or reach the ring limit (status 1)
-// are flagged; the host wrapper re-runs just those on a finer / coarser grid (still on the GPU).
+// ring = ring0, ring0+1, ... look at every point of the (2 ring + 1)^3 cell block and keep, in LDS (ballot-prefix
+// append), the ones within reach = ring * h of the query -- every point that close lies inside the block, so as soon
+// as k of them are there the k nearest neighbours are among them: bitonic-sort just those by (d2, index) and stop.
+// (Sorting only the points within reach instead of the whole block makes the sort 2-4x smaller.)  Queries that
+// overflow the candidate buffer (status 2) or reach the ring limit (status 1) are flagged; the host wrapper re-runs
+// just those on a finer / coarser grid (still on the GPU).  qperm (optional): the order in which the waves take the
+// queries -- for a self-query the cell-sorted order, so that neighbouring waves read the same cells.  valid (optional,
+// one byte per original point index): only those points are neighbours -- the k-NN of a SUBSET on the grid that was built
+// for all points (refine queries the points kept by the loss threshold right after querying all of them).
 #include "mh_device.h"
 
 #define MH_KNN_CAP 2048
@@ -25,23 +30,41 @@ __device__ __forceinline__ bool mh_knn_less(double da, int ia, double db, int ib
 __global__ __launch_bounds__(128) void mh_knn_kernel(MhGrid g, const float *__restrict__ pts,
                                                      const int32_t *__restrict__ order,
                                                      const int32_t *__restrict__ cell_start,
-                                                     const float *__restrict__ queries, int Q, int k,
+                                                     const void *__restrict__ queries, int q64, int Q, int k,
+                                                     int ring0, const int32_t *__restrict__ qperm,
+                                                     const uint8_t *__restrict__ valid,
                                                      int32_t *__restrict__ out_idx, int32_t *__restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double *s_d = reinterpret_cast<double *>(smem) + (size_t)wave * MH_KNN_CAP;
     int *s_i = reinterpret_cast<int *>(smem + 2 * MH_KNN_CAP * sizeof(double)) + (size_t)wave * MH_KNN_CAP;
-    const int qi = blockIdx.x * 2 + wave;
-    if (qi >= Q) return;
-    const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
+    const int qw = blockIdx.x * 2 + wave;
+    if (qw >= Q) return;
+    const int qi = qperm ? qperm[qw] : qw;
+    // queries are float32 or float64 (the reference hands float64 shell points to KDTree.query, PMVO.py:671); distances
+    // use the exact coordinates, the cell of the query only has to be near enough (see the reach margin below)
+    double dqx, dqy, dqz;
+    if (q64) {
+        const double *__restrict__ q = reinterpret_cast<const double *>(queries);
+        dqx = q[3 * qi], dqy = q[3 * qi + 1], dqz = q[3 * qi + 2];
+    } else {
+        const float *__restrict__ q = reinterpret_cast<const float *>(queries);
+        dqx = (double)q[3 * qi], dqy = (double)q[3 * qi + 1], dqz = (double)q[3 * qi + 2];
+    }
+    const float qx = (float)dqx, qy = (float)dqy, qz = (float)dqz;
     const int cx = min(max((int)floorf((qx - g.ox) / g.h), 0), g.dx - 1);
     const int cy = min(max((int)floorf((qy - g.oy) / g.h), 0), g.dy - 1);
     const int cz = min(max((int)floorf((qz - g.oz) / g.h), 0), g.dz - 1);
-    const double dqx = (double)qx, dqy = (double)qy, dqz = (double)qz;
     int st = 1;   // 1: ring limit reached (cells too small for this query), 2: candidate buffer overflow (too large)
-    for (int ring = 1; ring <= MH_KNN_MAXRING; ++ring) {
+    for (int ring = max(ring0, 1); ring <= MH_KNN_MAXRING; ++ring) {
         int cnt = 0;
         bool overflow = false;
+        const bool whole_grid = (cx - ring <= 0) && (cy - ring <= 0) && (cz - ring <= 0) && (cx + ring >= g.dx - 1) &&
+                                (cy + ring >= g.dy - 1) && (cz + ring >= g.dz - 1);
+        // the block reaches at least `ring` cells beyond the query's cell; 1e-3 of a cell absorbs the float rounding of
+        // the cell indices of the query and of the points (coordinates / h < 2^10, i.e. errors below 1e-4 cells)
+        const double reach = ((double)ring - 1.0e-3) * (double)g.h;
+        const double reach2 = whole_grid ? __builtin_inf() : reach * reach;
         const int x0 = max(cx - ring, 0), x1 = min(cx + ring, g.dx - 1);
         for (int z = max(cz - ring, 0); z <= min(cz + ring, g.dz - 1); ++z)
             for (int y = max(cy - ring, 0); y <= min(cy + ring, g.dy - 1); ++y) {
@@ -58,9 +81,11 @@ __global__ __launch_bounds__(128) void mh_knn_kernel(MhGrid g, const float *__re
                         d2 = (ax * ax + ay * ay) + az * az;
                         id = order[p];
                     }
-                    const unsigned long long m = __ballot(ok);
+                    // valid (optional, per ORIGINAL index): search a subset of the data points on the grid of all of them
+                    const bool keep = ok && d2 <= reach2 && (!valid || valid[id]);
+                    const unsigned long long m = __ballot(keep);
                     const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-                    if (ok && pos < MH_KNN_CAP) {
+                    if (keep && pos < MH_KNN_CAP) {
                         s_d[pos] = d2;
                         s_i[pos] = id;
                     }
@@ -68,8 +93,6 @@ __global__ __launch_bounds__(128) void mh_knn_kernel(MhGrid g, const float *__re
                 }
             }
         if (cnt > MH_KNN_CAP) overflow = true;
-        const bool whole_grid = (cx - ring <= 0) && (cy - ring <= 0) && (cz - ring <= 0) && (cx + ring >= g.dx - 1) &&
-                                (cy + ring >= g.dy - 1) && (cz + ring >= g.dz - 1);
         if (overflow) {
             st = 2;
             break;
@@ -103,24 +126,69 @@ __global__ __launch_bounds__(128) void mh_knn_kernel(MhGrid g, const float *__re
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
+        // every kept candidate is within reach, so with k of them (or the whole grid) the answer is final
         const int kk = min(k, cnt);
-        const double reach = (double)ring * (double)g.h;
-        if (whole_grid || (cnt >= k && s_d[k - 1] <= reach * reach)) {
-            for (int j = lane; j < k; j += MH_WAVE) out_idx[(size_t)qi * k + j] = (j < kk) ? s_i[j] : -1;
-            st = 0;
-            break;
-        }
+        for (int j = lane; j < k; j += MH_WAVE) out_idx[(size_t)qi * k + j] = (j < kk) ? s_i[j] : -1;
+        st = 0;
+        break;
     }
     if (lane == 0) status[qi] = st;
 }
 
 extern "C" int mh_launch_knn(float ox, float oy, float oz, float h, int dx, int dy, int dz, const float *pts,
-                             const int32_t *order, const int32_t *cell_start, const float *queries, int Q, int k,
-                             int32_t *out_idx, int32_t *status, hipStream_t st) {
+                             const int32_t *order, const int32_t *cell_start, const void *queries, int q64, int Q,
+                             int k, int ring0, const int32_t *qperm, const uint8_t *valid, int32_t *out_idx,
+                             int32_t *status, hipStream_t st) {
     if (k < 1 || k > MH_KNN_CAP) return -1;
     MhGrid g{ox, oy, oz, h, dx, dy, dz};
     const size_t lds = 2 * (size_t)MH_KNN_CAP * (sizeof(double) + sizeof(int));
-    hipLaunchKernelGGL(mh_knn_kernel, dim3((Q + 1) / 2), dim3(128), lds, st, g, pts, order, cell_start, queries, Q, k,
-                       out_idx, status);
+    hipLaunchKernelGGL(mh_knn_kernel, dim3((Q + 1) / 2), dim3(128), lds, st, g, pts, order, cell_start, queries, q64, Q,
+                       k, ring0, qperm, valid, out_idx, status);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Distance to the nearest of M reference points, exhaustive, in float64: the `scalp_tree.query(points, k=1)` of
+// PMVO.filter_head_points (PMVO.py:100-101; scipy's KDTree works in float64 and returns sqrt of the summed squares).
+// One lane per query point, the reference points staged through LDS in tiles; d2 = (dx*dx + dy*dy) + dz*dz, the
+// minimum of the squares, then one IEEE sqrt.  (A few thousand scalp vertices: 10^8..10^9 fp64 operations per call.)
+// ---------------------------------------------------------------------------------------------------------------
+#define MH_ND_TILE 1024
+__global__ __launch_bounds__(256) void mh_nearest_dist_kernel(const float *__restrict__ pts, int N,
+                                                              const double *__restrict__ ref, int M,
+                                                              double *__restrict__ out, double max_dist,
+                                                              double z_limit, uint8_t *__restrict__ mask) {
+    __shared__ double s_r[MH_ND_TILE * 3];
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    double px = 0.0, py = 0.0, pz = 0.0;
+    if (n < N) {
+        px = (double)pts[3 * n];
+        py = (double)pts[3 * n + 1];
+        pz = (double)pts[3 * n + 2];
+    }
+    double best = __builtin_inf();
+    for (int m0 = 0; m0 < M; m0 += MH_ND_TILE) {
+        const int nm = min(MH_ND_TILE, M - m0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nm * 3; i += 256) s_r[i] = ref[(size_t)m0 * 3 + i];
+        __syncthreads();
+        for (int j = 0; j < nm; ++j) {
+            const double dx = s_r[3 * j] - px, dy = s_r[3 * j + 1] - py, dz = s_r[3 * j + 2] - pz;
+            const double d2 = (dx * dx + dy * dy) + dz * dz;
+            best = d2 < best ? d2 : best;
+        }
+    }
+    if (n < N) {
+        const double d = __builtin_sqrt(best);
+        if (out) out[n] = d;
+        // filter_head_points' use of it (PMVO.py:102-106): nearer than max_dist AND below z_limit, both in float64
+        if (mask) mask[n] = (d < max_dist && pz < z_limit) ? 1 : 0;
+    }
+}
+
+extern "C" int mh_launch_nearest_dist(const float *pts, int N, const double *ref, int M, double *out, double max_dist,
+                                      double z_limit, uint8_t *mask, hipStream_t st) {
+    hipLaunchKernelGGL(mh_nearest_dist_kernel, dim3((N + 255) / 256), dim3(256), 0, st, pts, N, ref, M, out, max_dist,
+                       z_limit, mask);
     return (int)hipGetLastError();
 }

@@ -458,14 +458,31 @@ class PMVO:
         loss, _ = self.prj_loss_of(points, ori)
         return torch.where(filter_index, torch.full_like(loss, -1.0), loss)
 
-    def head_top_mask(self, points_numpy):
-        """The host half of filter_head_points (PMVO.py:98-107): within 4 cm of the scalp and more than 1 cm below
-        its top (scipy KDTree in float64, as the reference).  Depends on the points only."""
+    def head_top_mask_device(self, points_dev):
+        """The scalp half of filter_head_points (PMVO.py:98-107) for float32 points on the device: within 4 cm of the
+        scalp and more than 1 cm below its top -> uint8 (0/1) tensor on the device.  The reference asks a scipy KDTree for the
+        nearest scalp vertex (float64); here the distance to the nearest vertex is found exhaustively on the GPU in
+        float64 (mh_nearest_distance: the same sum of squares and one sqrt), so the 4 cm decision is scipy's."""
         if self.scalp_tree is None:
             raise _lib.MhError("filter_head_points needs set_head(bust_tree, scalp_tree, scalp_max)")
-        pts = np.asarray(points_numpy, dtype=np.float32)
-        nei_scalp_dist, _ = self.scalp_tree.query(pts, k=1, workers=-1)
-        return np.logical_and(nei_scalp_dist < 0.04, pts[:, 2] < self.scalp_max[2] - 0.01)
+        if getattr(self, "_scalp_dev", None) is None or self._scalp_dev[0] is not self.scalp_tree:
+            ref = np.ascontiguousarray(np.asarray(self.scalp_tree.data, dtype=np.float64).reshape(-1, 3))
+            self._scalp_dev = (self.scalp_tree, torch.from_numpy(ref).to(self.device))
+        ref = self._scalp_dev[1]
+        pts = points_dev if (points_dev.dtype == torch.float32 and points_dev.is_contiguous()) else \
+            points_dev.to(self.device).type(torch.float).contiguous()
+        N = pts.shape[0]
+        mask = torch.empty((N,), dtype=torch.uint8, device=self.device)
+        # (the height test in float64, as numpy evaluates `float32 array < float64 scalar` where the goldens were made)
+        _lib.check(self._L.mh_nearest_distance(self._ctx, _lib.ptr(pts), N, _lib.ptr(ref), ref.shape[0], None, 0.04,
+                                               float(self.scalp_max[2] - 0.01), _lib.ptr(mask), _lib.stream_ptr()),
+                   "mh_nearest_distance")
+        return mask
+
+    def head_top_mask(self, points_numpy):
+        """numpy in / numpy out form of head_top_mask_device (float32 points, as the reference passes them)."""
+        pts = np.ascontiguousarray(np.asarray(points_numpy, dtype=np.float32).reshape(-1, 3))
+        return self.head_top_mask_device(torch.from_numpy(pts).to(self.device)).cpu().numpy().astype(bool)
 
     def replace_dissimilar(self, center, ori, threshold=0.95):
         """ori[n] <- center[n] where |cos(center, ori)| < threshold, in place on the device (PMVO.py:631-636)."""
@@ -500,8 +517,8 @@ class PMVO:
         head_top_mask of the same points (bool tensor on the device)."""
         pts, (_, _, _, head) = self._votes(points, (False, False, False, True), visible_threshold)
         if head_top is None:
-            head_top = torch.from_numpy(self.head_top_mask(pts.cpu().numpy())).to(self.device)
-        return torch.logical_and(head, ~head_top)
+            head_top = self.head_top_mask_device(pts)
+        return torch.logical_and(head, ~head_top.bool())
 
 
 # =====================================================================================================
@@ -577,15 +594,19 @@ def optimize(points, pmvo, args):
     return select_points, select_ori, min_loss, high_conf_index
 
 
-def _knn(data_points, query_points, k, device, mode="device", int32=False):
+def _knn(data_points, query_points, k, device, mode="device", int32=False, self_query=False, keep_grid=None):
     """The `KDTree(data).query(queries, k)` of refine (PMVO.py:605,612,660,671) -> index [Q,k] int64 tensor on `device`.
     mode "device": exact grid k-NN kernel (csrc/knn.hip, scipy's result and order); "host": scipy on all cores.
-    scipy returns index n for missing neighbours when k > n (the reference would raise on ori[index]); k is clamped."""
+    scipy returns index n for missing neighbours when k > n (the reference would raise on ori[index]); k is clamped.
+    keep_grid: a list that receives the GridKNN object (device mode), so that a later query of a subset can reuse it."""
     k = min(k, data_points.shape[0])
     if mode == "device":
         from .pmvo_utils import GridKNN
 
-        return GridKNN(data_points, k_hint=k, device=device).query(query_points, k, int32=int32)
+        g = GridKNN(data_points, k_hint=k, device=device)
+        if keep_grid is not None:
+            keep_grid.append(g)
+        return g.query(query_points, k, int32=int32, self_query=self_query)
     from scipy.spatial import KDTree
 
     _, index = KDTree(data=data_points).query(query_points, k, workers=-1)
@@ -609,24 +630,20 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     voxel_size = U.VOXEL_SIZE if voxel_size is None else voxel_size
     grid_resolution = U.GRID_RESOLUTION if grid_resolution is None else np.asarray(grid_resolution).astype(np.int32)
     is_root = mdist.rank() == 0
+    grid_all = []          # the spatial index of ALL points (device k-NN), reused for the shell query below
     if not genrate_ori_only:
         print("filter nosiy points...")
         # Neighbour indices and the head-top mask depend on the points only: ONE host query for all chunks (all
         # cores), then the sequentially dependent smoothing loop (chunk k+1 reads the orientations chunk k wrote,
         # PMVO.py:614,640) runs entirely on the device, stream-ordered, without a host round trip per chunk.
         n_all = points.shape[0]
-        # the scalp query of filter_head_points is a host KDTree query (float64 scipy, kept for exactness): it runs
-        # on a worker thread while the GPU builds the grid and answers the neighbour queries
-        from concurrent.futures import ThreadPoolExecutor
-
-        with ThreadPoolExecutor(1) as pool:
-            head_job = pool.submit(pmvo.head_top_mask, points)
-            with stage("refine: knn (surface)", device):
-                index_all = _knn(points, points, 100, device, getattr(args, "knn", "device"), int32=True).contiguous()
-            with stage("refine: head-top mask", device):
-                head_top_all = torch.from_numpy(head_job.result().astype(np.uint8)).to(device)
+        with stage("refine: knn (surface)", device):
+            index_all = _knn(points, points, 100, device, getattr(args, "knn", "device"), int32=True,
+                             self_query=True, keep_grid=grid_all).contiguous()
         T_loop = stage("refine: smoothing loop", device).__enter__()
-        pts_dev = torch.from_numpy(points).to(device).type(torch.float).contiguous()
+        pts_dev = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(device)
+        with stage("refine: head-top mask", device):      # scalp half of filter_head_points, once for all chunks
+            head_top_all = pmvo.head_top_mask_device(pts_dev)
         ori_dev = torch.from_numpy(ori).to(device).type(torch.float).contiguous()
         loss_dev = torch.from_numpy(loss).to(device).type(torch.float).contiguous()
         sub_num = 5000
@@ -679,15 +696,21 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     select_filter_unvisible_points = np.zeros((0, 3), np.float32)
     if len(select_points) and len(filter_unvisible_points):
         fu = np.ascontiguousarray(filter_unvisible_points)
-        from concurrent.futures import ThreadPoolExecutor
-
-        with ThreadPoolExecutor(1) as pool:
-            head_job = pool.submit(pmvo.head_top_mask, fu.astype(np.float32))
-            with stage("refine: knn (shell)", device):
-                index_all = _knn(select_points, fu, 100, device, getattr(args, "knn", "device"), int32=True).contiguous()
-            head_top = head_job.result()
-        fu_dev = torch.from_numpy(fu).type(torch.float).to(device).contiguous()
-        sel_ori_dev = torch.from_numpy(select_ori).to(device).type(torch.float).contiguous()
+        with stage("refine: knn (shell)", device):
+            if grid_all and grid_all[0].M == len(points):
+                # KDTree(select_points).query(fu) on the grid that already exists for all points: the points kept by
+                # the loss threshold are flagged valid, the indices come back in terms of `points` (order-preserving
+                # compaction: same (distance, index) order), so the medoid reads the full orientation array
+                valid = np.zeros(len(points), np.uint8)
+                valid[index] = 1
+                index_all = grid_all[0].query(fu, 100, int32=True, valid=valid).contiguous()
+                ori_rows = ori
+            else:
+                index_all = _knn(select_points, fu, 100, device, getattr(args, "knn", "device"),
+                                 int32=True).contiguous()
+                ori_rows = select_ori
+        fu_dev = torch.from_numpy(fu.astype(np.float32)).to(device).contiguous()
+        sel_ori_dev = torch.from_numpy(np.ascontiguousarray(ori_rows, dtype=np.float32)).to(device)
         F, K = index_all.shape
         center = torch.empty((F, 3), dtype=torch.float32, device=device)
         head = torch.empty((F,), dtype=torch.uint8, device=device)
@@ -698,6 +721,7 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         _lib.check(pmvo._L.mh_filter_points(pmvo._ctx, _lib.ptr(fu_dev), F, pmvo.patch_size,
                                             float(pmvo.conf_threshold), float(args.PMVO.visible_threshold), None, None,
                                             None, _lib.ptr(head), _lib.stream_ptr()), "mh_filter_points")
+        head_top = pmvo.head_top_mask_device(fu_dev).cpu().numpy().astype(bool)
         keep = ~np.logical_and(head.cpu().numpy().astype(bool), ~head_top)     # not filter_head_points
         filter_unvisible_ori = center.cpu().numpy()[keep]
         select_filter_unvisible_points = fu_dev.cpu().numpy()[keep]

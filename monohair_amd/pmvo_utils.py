@@ -288,7 +288,9 @@ class GridKNN:
         dim = min(3.0, max(1.0, math.log(max(c2 / c1, 1.01), 2)))
         ball = {1: 2.0, 2: math.pi, 3: 4.18879}[int(round(dim))]
         rk = h0 * (max(k_hint, 1) / (c1 * ball)) ** (1.0 / dim)
-        self.h = max(rk / 1.5, ext / 480.0)
+        # cells a little larger than the radius of the k-ball: the 27 cells around a query hold every point within one
+        # cell size of it, so the first ring answers almost every query and only the points within that reach get sorted
+        self.h = max(rk * 1.2, ext / 480.0)
         self.last_retries = 0
 
     def _geometry(self, h):
@@ -320,7 +322,7 @@ class GridKNN:
             self._grids[h] = (grid, dims, pts, order, start)
         return self._grids[h]
 
-    def _run(self, h, q, k):
+    def _run(self, h, q, k, perm=None, valid=None):
         import ctypes
 
         grid, dims, pts, order, start = self._grid(h)
@@ -330,38 +332,57 @@ class GridKNN:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().mh_knn_grid(_ctx_for(self.device), grid.ctypes.data_as(ctypes.c_void_p),
                                               dims.ctypes.data_as(ctypes.c_void_p), _lib.ptr(pts), _lib.ptr(order),
-                                              _lib.ptr(start), _lib.ptr(q), Q, k, _lib.ptr(out), _lib.ptr(status),
-                                              _lib.stream_ptr()), "mh_knn_grid")
+                                              _lib.ptr(start), _lib.ptr(q), 1 if q.dtype == torch.float64 else 0, Q, k,
+                                              1, _lib.ptr(perm), _lib.ptr(valid), _lib.ptr(out), _lib.ptr(status),
+                                              _lib.stream_ptr()),
+                       "mh_knn_grid")
         return out, status
 
-    def query(self, queries, k, int32=False):
+    def query(self, queries, k, int32=False, self_query=False, valid=None):
         """-> index [Q,k] device tensor, int64 (or int32 as the kernel writes it); k clamped to the number of points,
-        like the drivers do."""
+        like the drivers do.  Queries keep their precision: float64 arrays (the shell points of refine, PMVO.py:671) are
+        searched with their exact coordinates, as scipy does.  self_query=True (queries are the data points, in the same
+        order): the waves take the queries in cell order, so neighbouring waves read the same cells.
+        valid (bool [M]): only these data points count as neighbours -- the answer equals
+        KDTree(points[valid]).query(...) with the indices mapped back to `points` (order-preserving, so the
+        (distance, index) order is the same); k is clamped to the number of valid points."""
+        if valid is not None:
+            vh = np.ascontiguousarray(valid, dtype=np.uint8)
+            k = min(int(k), int(vh.sum()))
+            valid = torch.from_numpy(vh).to(self.device)
         k = min(int(k), self.M)
-        q = torch.from_numpy(np.ascontiguousarray(queries).astype(np.float32)).to(self.device).contiguous()
-        out, status = self._run(self.h, q, k)
+        qn = np.ascontiguousarray(queries)
+        if qn.dtype != np.float64:
+            qn = qn.astype(np.float32, copy=False)
+        q = torch.from_numpy(qn.reshape(-1, 3)).to(self.device).contiguous()
+        perm = self._grid(self.h)[3] if (self_query and q.shape[0] == self.M) else None
+        out, status = self._run(self.h, q, k, perm, valid)
         self.last_retries = 0
+        st = status.cpu().numpy()                        # (host side: no torch kernels on this path)
         for code, factor in ((2, 0.5), (1, 2.0)):        # overflow -> finer cells, ring limit -> coarser cells
             h = self.h
             for _ in range(6):
-                bad = torch.nonzero(status == code).flatten()
-                if not bad.numel():
+                bad = np.flatnonzero(st == code)
+                if not bad.size:
                     break
                 h *= factor
-                o2, s2 = self._run(h, q[bad].contiguous(), k)
-                out[bad] = o2
-                status[bad] = s2
+                bad_d = torch.from_numpy(bad).to(self.device)
+                o2, s2 = self._run(h, q[bad_d].contiguous(), k, None, valid)
+                out[bad_d] = o2
+                st[bad] = s2.cpu().numpy()
                 self.last_retries += 1
         # extreme density contrast (a sparse query whose k-ball swallows a dense cluster) defeats every cell size:
         # those few queries are answered by exhaustive search, also on the GPU (same fp64 distances, stable sort =
         # ties by index)
-        left = torch.nonzero(status != 0).flatten()
-        self.last_exhaustive = int(left.numel())
-        if left.numel():
+        left = np.flatnonzero(st != 0)
+        self.last_exhaustive = int(left.size)
+        if left.size:
             p64 = self._raw.to(torch.float64)
             for i in left.tolist():
                 d = p64 - q[i].to(torch.float64)
                 d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+                if valid is not None:
+                    d2 = torch.where(valid.bool(), d2, torch.full_like(d2, float("inf")))
                 out[i] = torch.sort(d2, stable=True).indices[:k].to(torch.int32)
         return out if int32 else out.long()
 
@@ -464,30 +485,35 @@ def _mat5_prefix(name, dims):
     return head + struct.pack("<II", 14, len(body) + ndata + (-ndata % 8)) + body, ndata
 
 
-def save_ori_occ_mat_sparse(path, grid_resolution, voxels, ori):
+def save_ori_occ_mat_sparse(path, grid_resolution, voxels, ori, threads=1):
     """Same two files as save_ori_occ_mat (PMVO.py:753-764) written from the occupied voxels only: `voxels` [G,3]
     (x,y,z) and `ori` [G,3]; later rows win on duplicates, as the reference's fancy assignments do (:746-747).
     The float64 payload (Ori [Y,X,3Z] with last index c*Z+z, Occ [Y,X,Z], column-major as MAT v5 stores it) is
-    created as a zero-filled file and only the pages holding occupied voxels are written."""
+    created as a zero-filled sparse file and only the occupied elements are stored (mh_mat_write_sparse: a shared
+    mapping; the two files are written concurrently, one thread each -- measured on the GPU box, more threads per file
+    only contend for the page cache: 19 ms with one, 34 ms with sixteen, tools/bench_mat.py)."""
+    import ctypes
+    from concurrent.futures import ThreadPoolExecutor
+
     X, Y, Z = (int(v) for v in grid_resolution)
     v = np.asarray(voxels, dtype=np.int64).reshape(-1, 3)
-    o = np.asarray(ori, dtype=np.float64).reshape(-1, 3)
+    o = np.ascontiguousarray(np.asarray(ori, dtype=np.float64).reshape(-1, 3))
     lin = v[:, 1] + Y * (v[:, 0] + X * v[:, 2])                                # Occ[y,x,z], y fastest
-    for fname, name, dims, idx, val in (
-            ("Occ3D.mat", "Occ", (Y, X, Z), lin, np.ones(len(v))),
-            ("Ori3D.mat", "Ori", (Y, X, 3 * Z),
-             (lin[:, None] + (Y * X * Z) * np.arange(3)[None, :]).reshape(-1), o.reshape(-1))):
+    L = _lib.lib()
+
+    def write(fname, name, dims, idx, val):
         prefix, ndata = _mat5_prefix(name, dims)
-        full = os.path.join(path, fname)
-        with open(full, "wb") as f:
-            f.write(prefix)
-            f.truncate(len(prefix) + ndata)
-        if len(idx):
-            mm = np.memmap(full, dtype="<f8", mode="r+", offset=len(prefix), shape=(ndata // 8,))
-            order = np.argsort(idx, kind="stable")           # page order; duplicates keep their order -> last wins
-            mm[idx[order]] = val[order]
-            mm.flush()
-            del mm
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        _lib.check(L.mh_mat_write_sparse(os.path.join(path, fname).encode(), prefix, len(prefix), ndata,
+                                         idx.ctypes.data_as(ctypes.c_void_p), val.ctypes.data_as(ctypes.c_void_p),
+                                         len(idx), threads), "mh_mat_write_sparse")
+
+    jobs = (("Occ3D.mat", "Occ", (Y, X, Z), lin, np.ones(len(v))),
+            ("Ori3D.mat", "Ori", (Y, X, 3 * Z), (lin[:, None] + (Y * X * Z) * np.arange(3)[None, :]).reshape(-1),
+             o.reshape(-1)))
+    with ThreadPoolExecutor(2) as pool:           # ctypes releases the GIL during the call
+        list(pool.map(lambda j: write(*j), jobs))
 
 
 def merge_inner_points(voxels, ori, coarse_data, unvisible_index, voxel_min=VOXEL_MIN, voxel_size=VOXEL_SIZE,

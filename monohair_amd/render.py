@@ -1,4 +1,7 @@
-"""Depth-map producer on the GPU: the host mirror of the reference's
+"""Renderers either side of the PMVO path, on the GPU (no OpenGL context): the depth-map producer (SURVEY.md §8f
+rank 2) and the strand-segment renderer of infer_inner (rank 4, `render_data` at the end of this file).
+
+Depth-map producer: the host mirror of the reference's
 `Utils/Render_utils.py::render_bust_hair_depth` (:310-347) on top of `mh_render_depth` (csrc/raster.hip).
 
 The reference draws the COLMAP hair mesh and the bust mesh with moderngl/EGL and the BustObj shader (:146-188) and
@@ -95,3 +98,96 @@ def render_bust_hair_depth(colmap_points_path, camera_path, save_root, image_siz
         else:
             os.makedirs(os.path.join(save_root, view), exist_ok=True)
             Image.fromarray(u8).save(os.path.join(save_root, view, "bust_hair_depth.png"))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Strand-segment renderer: Utils/Render_utils.py:269-307 (render_data) -- the images infer_inner.py:60-73 renders from
+# the segments traced on the exterior volume and hands to DeepMVSHair.
+# ------------------------------------------------------------------------------------------------------------------
+def strand_line_buffers(strands):
+    """The two vertex buffers of the reference's StrandsObj (Render_utils.py:9-29): for every strand of n points the
+    n-1 segments as consecutive vertex pairs (0,1),(1,2),... and, per vertex, the tangent strand[i+1]-strand[i] (the
+    last point repeats the last difference) -> (Lines [2*S,3], tangent [2*S,3]) float32."""
+    lines, tans = [], []
+    for strand in strands:
+        strand = np.asarray(strand, dtype=np.float64).reshape(-1, 3)
+        n = strand.shape[0]
+        if n < 2:
+            continue
+        tangent = np.concatenate([strand[1:] - strand[:-1], strand[-1:] - strand[-2:-1]], 0)
+        index = np.stack([np.arange(0, n - 1), np.arange(1, n)], 1).reshape(-1)
+        lines.append(strand[index])
+        tans.append(tangent[index])
+    if not lines:
+        return np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32)
+    return np.concatenate(lines).astype(np.float32), np.concatenate(tans).astype(np.float32)
+
+
+class StrandRenderer:
+    """Bust mesh + strand segments resident on the device; render(view, ...) = one draw + read-back of the reference's
+    Renderer (Render_utils.py:206-266) with its clear colour and the two shader options."""
+
+    LINE_WIDTH = 3          # StrandsObj.__init__: ctx.line_width = 3.0 (Render_utils.py:30)
+
+    def __init__(self, strands, vertices, faces, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise _lib.MhError("monohair_amd.render needs a ROCm GPU: there is no CPU fallback")
+        self.device = torch.device(device)
+        lp, lt = strand_line_buffers(strands)
+        self.nseg = len(lp) // 2
+        self.line_pts = torch.from_numpy(lp).to(self.device)
+        self.line_tan = torch.from_numpy(lt).to(self.device)
+        self.verts = torch.from_numpy(np.asarray(vertices, dtype=np.float64).reshape(-1, 3).astype(np.float32)).to(self.device)
+        self.faces = torch.from_numpy(np.asarray(faces, dtype=np.int64).reshape(-1, 3).astype(np.int32)).to(self.device)
+        self._L = _lib.lib()
+        self._ctx = _ctx_for(self.device)
+        self._scratch = None
+
+    def render(self, cam_record, H, W, color_option, depth_option, clear, draw_strands=True, pixel_center=0.5, out=None):
+        """-> float32 [H,W,3] device tensor in the shader's range (0..1)."""
+        H, W = int(H), int(W)
+        Nv, Nf = self.verts.shape[0], self.faces.shape[0]
+        need = int(self._L.mh_render_strands_scratch_bytes(Nv, Nf, self.nseg, H, W))
+        if self._scratch is None or self._scratch.numel() < need:
+            self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if out is None:
+            out = torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
+        rec = np.ascontiguousarray(cam_record, dtype=np.float32)
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.mh_render_strands(
+                self._ctx, rec.ctypes.data_as(ctypes.c_void_p), _lib.ptr(self.verts), Nv, _lib.ptr(self.faces), Nf,
+                _lib.ptr(self.line_pts), _lib.ptr(self.line_tan), self.nseg, H, W, float(pixel_center), self.LINE_WIDTH,
+                int(color_option) if draw_strands else -1, int(depth_option), float(clear), _lib.ptr(self._scratch), need,
+                _lib.ptr(out), _lib.stream_ptr()), "mh_render_strands")
+        return out
+
+
+def _save_png(path, rgb01, swap):
+    """cv2.imwrite(path, image * 255): float -> 8 bit with saturation and round-half-even; the reference passes the colour
+    images as color[..., [2,1,0]] because OpenCV stores BGR, so the FILE holds the shader's (r, g, b)."""
+    from PIL import Image
+
+    u8 = np.clip(np.rint(rgb01 * 255.0), 0, 255).astype(np.uint8)
+    del swap            # [2,1,0] followed by OpenCV's BGR->file order is the identity on the file's RGB
+    Image.fromarray(u8).save(path)
+
+
+def render_data(camera, strands, vertices, faces, image_size=[1280, 720], save_root=None, device="cuda:0",
+                pixel_center=0.5):
+    """Same arguments and files as Render_utils.py:269-307.  Per view, under <save_root>/<view>/:
+      bust_depth.png          bust only, depth/2 on white                                   (:275-279)
+      undirectional_map.png   strands coloured by their 2D direction (2 theta), bust black   (:283-289)
+      mask.png                strands white, bust black                                      (:293-298)
+      hair_depth.png          strands depth/2, bust white, on white                          (:300-306)
+    (The depth images are grey, so OpenCV's channel order does not matter for them.)"""
+    H, W = int(image_size[0]), int(image_size[1])
+    r = StrandRenderer(strands, vertices, faces, device)
+    recs = camera_records(camera)
+    os.makedirs(save_root, exist_ok=True)
+    passes = (("bust_depth.png", False, 0, 0, 1.0), ("undirectional_map.png", True, 2, 1, 0.0),
+              ("mask.png", True, 3, 1, 0.0), ("hair_depth.png", True, 0, 2, 1.0))
+    for i, view in enumerate(camera.keys()):
+        os.makedirs(os.path.join(save_root, view), exist_ok=True)     # (cv2.imwrite fails silently without it)
+        for name, strands_on, copt, dopt, clear in passes:
+            img = r.render(recs[i], H, W, copt, dopt, clear, draw_strands=strands_on, pixel_center=pixel_center)
+            _save_png(os.path.join(save_root, view, name), img.cpu().numpy(), swap=name in ("undirectional_map.png", "mask.png"))

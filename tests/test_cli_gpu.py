@@ -127,3 +127,52 @@ def test_u8_upload_and_maps_pack_equal_the_float_loaders(tmp_path):
               "refine/min_loss.npy"):
         for other in ("pack", "pack2"):
             assert np.array_equal(np.load(out / "tree" / f), np.load(out / other / f), equal_nan=True), (f, other)
+
+
+def test_infer_inner_cli_renders_the_segment_images(tmp_path):
+    """infer_inner.py (the reference's caller of the second pass, :30-90): exterior pass -> traced segments ->
+    imgs/<view>/{bust_depth,undirectional_map,mask,hair_depth}.png + refine/render_segments.hair; with ours/raw.npy present
+    the second PMVO pass runs and writes full/."""
+    from PIL import Image
+
+    from monohair_amd import synth
+    from monohair_amd.pmvo_utils import load_strand
+
+    data = tmp_path / "data"
+    base = synth.write_case(str(data), "synthetic_sphere", V=24, H=240, W=136, res=32)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    common = ["--yaml=configs/reconstruct/synthetic_sphere", "--data.root=%s" % data, "--data.image_size=[240,136]",
+              "--PMVO.patch_size=3", "--name=t1"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "PMVO.py")] + common, cwd=ROOT, env=env,
+                       stdin=subprocess.DEVNULL, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    cam = os.path.join(base, "ours", "cam_params.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "infer_inner.py")] + common +
+                       ["--camera_path=%s" % cam, "--infer_inner.run_mvs="], cwd=ROOT, env=env, stdin=subprocess.DEVNULL,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = data / "synthetic_sphere" / "output" / "t1"
+    segs, pts = load_strand(str(out / "refine" / "render_segments.hair"))
+    assert len(segs) >= 1 and pts.shape[0] == sum(segs)     # (the 32^3 test volume is sparse: few, short segments)
+    views = sorted(os.listdir(os.path.join(base, "imgs")))
+    assert len(views) == 24
+    frac = []
+    for v in views[:6]:
+        ims = {n: np.array(Image.open(os.path.join(base, "imgs", v, n + ".png"))) for n in
+               ("bust_depth", "undirectional_map", "mask", "hair_depth")}
+        assert all(im.shape == (1280, 720, 3) and im.dtype == np.uint8 for im in ims.values())
+        m = ims["mask"][..., 0] == 255
+        frac.append(m.sum())
+        assert set(np.unique(ims["mask"]).tolist()) <= {0, 255}
+        assert (ims["undirectional_map"][m][:, 2] == 0).all() and (ims["undirectional_map"][~m] == 0).all()
+        assert (ims["hair_depth"][m][:, 0] < 255).all()                   # depth/2 of a point ~0.7 m away
+    assert max(frac) > 0                                                  # some view sees the traced segments
+    # second pass through infer_inner.py once DeepMVSHair's output exists
+    p = np.load(out / "refine" / "select_p.npy")
+    o = np.load(out / "refine" / "select_o.npy")
+    np.save(os.path.join(base, "ours", "raw.npy"), np.concatenate([p[:50] * 0.5, o[:50], np.ones((50, 1))], 1).astype(np.float32))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "infer_inner.py")] + common +
+                       ["--camera_path=%s" % cam, "--infer_inner.render_data="], cwd=ROOT, env=env,
+                       stdin=subprocess.DEVNULL, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert (out / "full" / "Ori3D.mat").exists() and (out / "full" / "coarse.npy").exists()

@@ -29,8 +29,13 @@ def test_surface_points_like_refine():
     pts = synth.candidate_points(res=128, seed=0).astype(np.float32)          # ~116 k points on a sphere shell
     knn = check(pts, pts[::37], 100)
     assert knn.last_retries == 0
-    shell = (pts[::53] * 1.02).astype(np.float64)                              # queries that are not data points
-    check(pts, shell, 100)
+    shell = (pts[::53].astype(np.float64) * 1.02 + 1e-9)                       # float64 queries that are not data points
+    assert not np.array_equal(shell, shell.astype(np.float32).astype(np.float64))
+    check(pts, shell, 100)                                                     # searched with their exact coordinates
+    # the self-query of refine: every data point, taken in cell order by the waves, answers in the caller's order
+    got = knn.query(pts, 100, self_query=True).cpu().numpy()
+    _, ref = KDTree(data=pts).query(pts, 100, workers=-1)
+    assert np.array_equal(got, ref)
 
 
 def test_volume_clusters_and_small_sets():
@@ -77,3 +82,32 @@ def test_refine_driver_uses_it_and_matches_host_kdtree(tmp_path):
         outs.append((occ, ori, np.load(d / "refine" / "select_o.npy"), np.load(d / "refine" / "min_loss.npy")))
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_scalp_distance_and_head_top_mask_equal_scipy():
+    """mh_nearest_distance (float64, exhaustive) == scipy.spatial.KDTree(scalp).query(points, k=1) bit for bit, and the
+    fused mask == the reference's head_top_index expression (PMVO.py:100-106)."""
+    import ctypes
+
+    import torch
+
+    from monohair_amd import _lib
+    from monohair_amd.pmvo_utils import _ctx_for
+
+    rng = np.random.default_rng(4)
+    scalp = rng.normal(size=(3001, 3))
+    scalp = scalp / np.linalg.norm(scalp, axis=1, keepdims=True) * 0.1
+    scalp = scalp[scalp[:, 1] > 0.02]
+    pts = (rng.normal(size=(20000, 3)) * 0.08).astype(np.float32)
+    pts[:500] = (scalp[:500] * (1 + rng.normal(0, 0.3, (500, 1)))).astype(np.float32)      # many near the 4 cm boundary
+    want_d, _ = KDTree(data=scalp).query(pts, k=1)
+    smax = scalp.max(0)
+    want_m = np.logical_and(want_d < 0.04, pts[:, 2] < smax[2] - 0.01)
+    ref = torch.from_numpy(np.ascontiguousarray(scalp)).to(DEV)
+    p = torch.from_numpy(pts).to(DEV)
+    d = torch.empty((len(pts),), dtype=torch.float64, device=DEV)
+    m = torch.empty((len(pts),), dtype=torch.uint8, device=DEV)
+    _lib.check(_lib.lib().mh_nearest_distance(_ctx_for(DEV), _lib.ptr(p), len(pts), _lib.ptr(ref), len(scalp), _lib.ptr(d),
+                                              0.04, float(smax[2] - 0.01), _lib.ptr(m), _lib.stream_ptr()))
+    assert np.array_equal(d.cpu().numpy(), want_d)
+    assert np.array_equal(m.cpu().numpy().astype(bool), want_m) and 0 < want_m.sum() < len(pts)

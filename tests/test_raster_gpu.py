@@ -113,3 +113,47 @@ def test_device_resident_hand_off_gabor_raster_pmvo():
     for name in ("visible", "Ori", "Conf", "mask", "Ori_patch", "Conf_patch"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     assert (a.visible > -1).any() and float(a.Conf.max()) > 0.5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# strand-segment renderer (mh_render_strands) == its C statement, bit for bit
+# ---------------------------------------------------------------------------------------------------------------------
+def _random_strands(rng, n, radius=0.125):
+    out = []
+    for _ in range(n):
+        d = rng.normal(size=3)
+        p = d / np.linalg.norm(d) * radius * rng.uniform(0.9, 1.15)
+        steps = rng.normal(0, 0.0025, size=(int(rng.integers(2, 60)), 3)) + rng.normal(0, 0.002, size=(1, 3))
+        out.append(p + np.cumsum(steps, 0))
+    return out
+
+
+@pytest.mark.parametrize("seed,H,W,pc", [(0, 160, 120, 0.5), (1, 333, 200, 0.0), (2, 1280, 720, 0.5)])
+def test_strand_renderer_bit_exact_vs_spec(seed, H, W, pc):
+    from monohair_amd.render import StrandRenderer, strand_line_buffers
+
+    rng = np.random.default_rng(seed)
+    cams = synth.make_cameras(12, H, W, scale=float(rng.uniform(0.8, 1.6)), rings=2)
+    rec = camera_records(cameras_from_list(cams))
+    bv, bf = uv_sphere(0.11, 48, 96)
+    strands = _random_strands(rng, 1500)
+    strands.append(np.zeros((1, 3)))                               # a one-point strand has no segment
+    strands.append(np.array([[0.2, 0, 0], [0.2, 0, 0]]))           # a zero-length segment (zero tangent)
+    strands.append(np.array([[0, 0, 5.0], [0.01, 0, 5.0]]))        # behind some cameras
+    lp, lt = strand_line_buffers(strands)
+    r = StrandRenderer(strands, bv, bf, DEV)
+    assert r.nseg == len(lp) // 2
+    for v in (0, 5, 9):
+        for copt, dopt, clear, on in ((2, 1, 0.0, True), (3, 1, 0.0, True), (0, 2, 1.0, True), (1, 0, 0.5, True),
+                                      (0, 0, 1.0, False)):
+            want, prim, owned = oracle.render_strands(rec[v], bv, bf, lp, lt, H, W, pc, 3, copt if on else -1, dopt, clear)
+            got = r.render(rec[v], H, W, copt, dopt, clear, draw_strands=on, pixel_center=pc).cpu().numpy()
+            assert np.array_equal(got, want), (v, copt, dopt)
+            if on:
+                assert owned > 0.01 * H * W and (prim >= 0).sum() > owned
+    # strands only (no mesh) and nothing at all
+    r2 = StrandRenderer(strands, np.zeros((0, 3)), np.zeros((0, 3), int), DEV)
+    want, prim, _ = oracle.render_strands(rec[1], np.zeros((0, 3)), np.zeros((0, 3), np.int32), lp, lt, H, W, pc, 3, 2, 1, 0.0)
+    assert np.array_equal(r2.render(rec[1], H, W, 2, 1, 0.0, pixel_center=pc).cpu().numpy(), want) and (prim >= 0).any()
+    r3 = StrandRenderer([], np.zeros((0, 3)), np.zeros((0, 3), int), DEV)
+    assert (r3.render(rec[1], 40, 30, 2, 1, 0.25).cpu().numpy() == 0.25).all()

@@ -5,6 +5,7 @@ synthetic scene, shared edges must be drawn exactly once, and depth ties go to t
 import math
 
 import numpy as np
+import pytest
 
 import oracle
 from monohair_amd import synth
@@ -79,3 +80,81 @@ def test_watertight_and_tie_rules():
     assert cov == 0 and (e == 255).all()
     e, cov = oracle.render_depth(rec, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32), H, W, channels=3)
     assert e.shape == (H, W, 3) and (e == 255).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# strand-segment renderer: the written specification on known answers + the reference's buffers
+# ---------------------------------------------------------------------------------------------------------------------
+def _front_camera(H, W):
+    from monohair_amd import synth
+    from monohair_amd.camera import camera_records, cameras_from_list
+
+    return camera_records(cameras_from_list(synth.make_cameras(4, H, W, scale=0.7, rings=1)))[0]
+
+
+QUAD = np.array([[-0.1, -0.1, 0], [0.1, -0.1, 0], [0.1, 0.1, 0], [-0.1, 0.1, 0]], np.float32)
+QUAD_F = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+
+
+def test_strand_vertex_buffers_equal_the_reference():
+    """strand_line_buffers == the `Lines` / `tangent` buffers the reference's StrandsObj builds (Render_utils.py:9-29;
+    tests/golden/strand_buffers.npz, tools/gen_golden_r2.py strands)."""
+    import os
+
+    from conftest import GOLDEN
+    from monohair_amd.render import strand_line_buffers
+
+    z = np.load(os.path.join(GOLDEN, "strand_buffers.npz"))
+    strands = [z["strand_%02d" % i] for i in range(int(z["n_strands"]))]
+    lines, tans = strand_line_buffers(strands)
+    assert np.array_equal(lines, z["Lines"].astype(np.float32))        # the reference uploads them as 'f4' (:33-34)
+    assert np.array_equal(tans, z["tangent"].astype(np.float32))
+
+
+def _expected_2theta(direction):
+    """colour option 2 of a world direction (dx, dy, 0) seen by the front camera: Tangent_2d lives in NDC, where the
+    camera's fx, fy scale the two axes (Render_utils.py:62-66), and NDC y points up while world y does too"""
+    from monohair_amd import synth
+
+    fx, fy = synth.make_cameras(4, 160, 120, scale=0.7, rings=1)[0]["ndc_prj"][:2]
+    tx, ty = fx * direction[0], fy * direction[1]
+    s2 = tx * tx + ty * ty
+    return ((tx * tx - ty * ty) / s2 + 1) / 2, (2 * tx * ty / s2 + 1) / 2
+
+
+@pytest.mark.parametrize("direction", [(1, 0, 0), (0, 1, 0), (1, 1, 0), (1, -1, 0)])
+def test_strand_colours_widths_and_depth_test(direction):
+    expect = _expected_2theta(direction)
+    """A straight strand in front of a quad: width-3 band in the minor direction, colour option 2 = ((cos 2th, sin 2th, 0)
+    + (1,1,0))/2 of its image direction (the same for both senses), option 3 white, option 0 depth/2; behind the quad it
+    is hidden; bust options 0/1/2 = depth/2, black, white; background = clear colour."""
+    from monohair_amd.render import strand_line_buffers
+
+    H, W = 160, 120
+    rec = _front_camera(H, W)
+    d = np.array(direction, np.float64) / np.linalg.norm(direction)
+    strand = np.linspace(-0.06, 0.06, 25)[:, None] * d[None] + np.array([0, 0, 0.03])
+    for pts in (strand, strand[::-1]):
+        lp, lt = strand_line_buffers([pts])
+        rgb, prim, owned = oracle.render_strands(rec, QUAD, QUAD_F, lp, lt, H, W, 0.5, 3, 2, 1, 0.0)
+        on = prim >= len(QUAD_F)
+        assert owned == on.sum() and owned >= 24
+        # image x runs with world x, image rows run against world y in this camera; 2*theta colouring is sense-free
+        assert np.allclose(rgb[on][:, 0], expect[0], atol=0.02) and np.allclose(rgb[on][:, 2], 0.0)
+        assert np.allclose(rgb[on][:, 1], expect[1], atol=0.02), (rgb[on][:, 1].min(), rgb[on][:, 1].max())
+        assert np.all(rgb[(prim >= 0) & ~on] == 0.0) and np.all(rgb[prim < 0] == 0.0)
+    # width: every fragment column of an axis-aligned strand carries exactly 3 pixels
+    if direction in ((1, 0, 0), (0, 1, 0)):
+        cols = on.sum(0 if direction[0] else 1)
+        assert set(cols[cols > 0].tolist()) == {3}
+    white, _, _ = oracle.render_strands(rec, QUAD, QUAD_F, lp, lt, H, W, 0.5, 3, 3, 1, 0.0)
+    assert np.all(white[on] == 1.0)
+    depth, _, _ = oracle.render_strands(rec, QUAD, QUAD_F, lp, lt, H, W, 0.5, 3, 0, 2, 1.0)
+    assert np.allclose(depth[on][:, 0], (0.8 - 0.03) / 2.0, atol=2e-3)      # camera ring radius 0.8 m, strand 3 cm nearer
+    assert np.all(depth[(prim >= 0) & ~on] == 1.0) and np.all(depth[prim < 0] == 1.0)
+    bust, pb, _ = oracle.render_strands(rec, QUAD, QUAD_F, lp, lt, H, W, 0.5, 3, -1, 0, 1.0)     # strands not drawn
+    assert (pb >= len(QUAD_F)).sum() == 0 and np.allclose(bust[pb >= 0][:, 0], 0.8 / 2.0, atol=2e-3)
+    # behind the quad: hidden by the depth test
+    lp2, lt2 = strand_line_buffers([strand - np.array([0, 0, 0.06])])
+    _, p2, owned2 = oracle.render_strands(rec, QUAD, QUAD_F, lp2, lt2, H, W, 0.5, 3, 3, 1, 0.0)
+    assert owned2 == 0 and (p2 >= 0).sum() == (prim >= 0).sum() - 0 * owned

@@ -11,6 +11,7 @@
         of the DeepMVSHair points (PMVO.py:733-751), coarse.npy / coarse_ori.npy and full/Ori3D.mat / Occ3D.mat.
 
     python tools/gen_golden_r2.py consensus   -> tests/golden/consensus_more.npz  (medoid on many group sizes)
+    python tools/gen_golden_r2.py strands     -> tests/golden/strand_buffers.npz  (StrandsObj vertex buffers)
 
 The fixtures hold data only (inputs + the reference's outputs).
 """
@@ -193,6 +194,26 @@ def gen_consensus_more(R):
     print("consensus_more written")
 
 
+def gen_strand_buffers(R):
+    """The vertex buffers of the reference's StrandsObj (Utils/Render_utils.py:9-29; its __init__ only needs an object
+    to hang `line_width` on, no GL context) for random strands of 2..40 points."""
+    import types as _t
+
+    _stub = _t.ModuleType("moderngl")
+    sys.modules.setdefault("moderngl", _stub)
+    import Utils.Render_utils as RU
+
+    rng = np.random.default_rng(77)
+    strands = [np.cumsum(rng.normal(0, 0.003, size=(int(n), 3)), 0) + rng.normal(0, 0.05, size=(1, 3))
+               for n in rng.integers(2, 41, size=30)]
+    obj = RU.StrandsObj([s.copy() for s in strands], _t.SimpleNamespace())
+    out = {"n_strands": np.array(len(strands)), "Lines": np.asarray(obj.Lines), "tangent": np.asarray(obj.tangent)}
+    for i, s in enumerate(strands):
+        out["strand_%02d" % i] = s
+    np.savez_compressed(os.path.join(OUT, "strand_buffers.npz"), **out)
+    print("strand buffers written:", out["Lines"].shape, out["Lines"].dtype)
+
+
 def main(which):
     cwd = os.getcwd()
     os.chdir("/tmp")
@@ -203,6 +224,8 @@ def main(which):
         gen_inner(R)
     if which in ("consensus", "all"):
         gen_consensus_more(R)
+    if which in ("strands", "all"):
+        gen_strand_buffers(R)
     os.chdir(cwd)
 
 
