@@ -322,14 +322,14 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P):
     ranks = list(pm.RANKS)
 
     def prepare(p):
-        _lib.check(L.mh_forward_prepare(ctx, _lib.ptr(p), N, pm.patch_size, float(pm.conf_threshold), _lib.ptr(vis),
+        _lib.check(L.mh_forward_prepare(ctx, _lib.ptr(p), N, pm._side, float(pm.conf_threshold), _lib.ptr(vis),
                                         _lib.ptr(ori), _lib.ptr(conf), _lib.ptr(mask), _lib.ptr(scratch), need, st))
 
     def topk():
         _lib.check(L.mh_topk_views(ctx, _lib.ptr(vis), _lib.ptr(conf), N, _lib.ptr(bidx), _lib.ptr(bval), st))
 
     def search(p):
-        _lib.check(L.mh_search_prepared(ctx, _lib.ptr(p), N, pm.patch_size, float(pm.conf_threshold), len(ranks),
+        _lib.check(L.mh_search_prepared(ctx, _lib.ptr(p), N, pm._side, float(pm.conf_threshold), len(ranks),
                                         ranks[1] - ranks[0], _lib.ptr(ori), _lib.ptr(bidx), _lib.ptr(bval),
                                         _lib.ptr(scratch), _lib.ptr(lo), _lib.ptr(ml), _lib.ptr(hc), None, None, None,
                                         st))

@@ -132,6 +132,9 @@ class PMVO:
         torch.cuda.set_device(self.device)
         self.image_size = [int(image_size[0]), int(image_size[1])]
         self.patch_size = int(patch_size)
+        # taps run over range(-(size//2), size//2+1) in both directions (PMVO.py:494-495): an even size s gives the same
+        # (s+1) x (s+1) window as s+1; the kernels are instantiated for the odd side
+        self._side = 2 * (self.patch_size // 2) + 1
         self.visible_threshold = visible_threshold
         self.conf_threshold = conf_threshold
         self._L = _lib.lib()
@@ -172,15 +175,18 @@ class PMVO:
         self.bust_tree, self.scalp_tree, self.scalp_max = bust_tree, scalp_tree, scalp_max
 
     def _dev_points(self, points):
+        """[N,3] points -> float32 on the device.  numpy input is cast on the host first, as the reference does
+        (`torch.from_numpy(points).type(torch.float).to(device)`, PMVO.py:40): same rounding, half the H2D bytes and no
+        cast kernel on the stream."""
         if isinstance(points, np.ndarray):
-            points = torch.from_numpy(points)
+            points = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32))
         return points.to(self.device).type(torch.float).contiguous()
 
     # ------------------------------------------------------------------ reference methods
     def Compute_Visible_and_Ori(self, points):
         """PMVO.py:346-376 -> one mh_project_gather launch."""
         points = self._dev_points(points)
-        V, N, P = self.num_view, points.shape[0], self.patch_size ** 2
+        V, N, P = self.num_view, points.shape[0], self._side ** 2
         f = dict(dtype=torch.float32, device=self.device)
         self.visible = torch.empty((V, N), **f)
         self.Ori = torch.empty((V, N, 2), **f)
@@ -190,7 +196,7 @@ class PMVO:
         self._Conf_patch = torch.empty((V, N, P), **f)
         self._pixf = torch.empty((V, N, 2), **f)
         self._points = points
-        _lib.check(self._L.mh_project_gather(self._ctx, _lib.ptr(points), N, self.patch_size, _lib.ptr(self.visible),
+        _lib.check(self._L.mh_project_gather(self._ctx, _lib.ptr(points), N, self._side, _lib.ptr(self.visible),
                                              _lib.ptr(self.Ori), _lib.ptr(self.Conf), _lib.ptr(self.mask),
                                              _lib.ptr(self._Ori_patch), _lib.ptr(self._Conf_patch),
                                              _lib.ptr(self._pixf), _lib.stream_ptr()), "mh_project_gather")
@@ -336,7 +342,7 @@ class PMVO:
         Compute_Visible_and_Ori (the reference ignores its `Ori` and `weight` arguments too)."""
         D = torch.as_tensor(Prj_Ori_2D).to(self.device).float().contiguous()
         V, N, S, _ = D.shape
-        P = self.patch_size ** 2
+        P = self._side ** 2
         loss = torch.empty((N,), dtype=torch.float32, device=self.device)
         idx = torch.empty((N,), dtype=torch.int64, device=self.device)
         hc = torch.empty((N,), dtype=torch.bool, device=self.device)
@@ -354,7 +360,7 @@ class PMVO:
     def _get_scratch(self, N):
         """Tap-list scratch of the search, one buffer per launch stream (chunks of `optimize` are independent and
         may be in flight on different streams)."""
-        need = int(self._L.mh_search_scratch_bytes(self._ctx, N, self.patch_size))
+        need = int(self._L.mh_search_scratch_bytes(self._ctx, N, self._side))
         key = torch.cuda.current_stream().cuda_stream
         if self._scratch is None:
             self._scratch = {}
@@ -370,7 +376,7 @@ class PMVO:
         the point); with base_val [20,N] the number of base-view ranks the search evaluated per point (rank 0 always,
         later ranks up to the last one with base_view_conf > 0, PMVO.py:64)."""
         buf, _ = self._get_scratch(N)
-        off = int(self._L.mh_search_counts_offset(self._ctx, N, self.patch_size))
+        off = int(self._L.mh_search_counts_offset(self._ctx, N, self._side))
         cnt = buf[off:off + self.num_view * N].view(self.num_view, N).to(torch.int64)
         nvalid = None
         if base_val is not None:
@@ -396,7 +402,7 @@ class PMVO:
             self._Ori_patch = self._Conf_patch = self._pixf = None
             self._points = points
             scratch, need = self._get_scratch(N)
-            _lib.check(self._L.mh_forward_prepare(self._ctx, _lib.ptr(points), N, self.patch_size,
+            _lib.check(self._L.mh_forward_prepare(self._ctx, _lib.ptr(points), N, self._side,
                                                   float(self.conf_threshold), _lib.ptr(self.visible),
                                                   _lib.ptr(self.Ori), _lib.ptr(self.Conf), _lib.ptr(self.mask),
                                                   _lib.ptr(scratch), need, _lib.stream_ptr()), "mh_forward_prepare")
@@ -418,13 +424,13 @@ class PMVO:
         bi = torch.empty((N,), dtype=torch.int32, device=self.device) if extras else None
         if fused:
             _lib.check(self._L.mh_search_prepared(
-                self._ctx, _lib.ptr(points), N, self.patch_size, float(self.conf_threshold), len(ranks),
+                self._ctx, _lib.ptr(points), N, self._side, float(self.conf_threshold), len(ranks),
                 ranks[1] - ranks[0], _lib.ptr(self.Ori), _lib.ptr(bidx32), _lib.ptr(bval), _lib.ptr(scratch),
                 _lib.ptr(line_ori), _lib.ptr(min_loss), _lib.ptr(hc), _lib.ptr(bs), _lib.ptr(br), _lib.ptr(bi),
                 _lib.stream_ptr()), "mh_search_prepared")
         else:
             _lib.check(self._L.mh_search_forward(
-                self._ctx, _lib.ptr(points), N, self.patch_size, float(self.conf_threshold), len(ranks),
+                self._ctx, _lib.ptr(points), N, self._side, float(self.conf_threshold), len(ranks),
                 ranks[1] - ranks[0], _lib.ptr(self.visible), _lib.ptr(self.Ori), _lib.ptr(self._pixf),
                 _lib.ptr(self._Ori_patch), _lib.ptr(self._Conf_patch), _lib.ptr(bidx32), _lib.ptr(bval),
                 _lib.ptr(scratch), need, _lib.ptr(line_ori), _lib.ptr(min_loss), _lib.ptr(hc), _lib.ptr(bs),
@@ -444,7 +450,7 @@ class PMVO:
         loss = torch.empty((N,), dtype=torch.float32, device=self.device)
         hc = torch.empty((N,), dtype=torch.uint8, device=self.device)
         _lib.check(self._L.mh_refine_loss(self._ctx, _lib.ptr(points), _lib.ptr(ori), 0.005, 4.0, N,
-                                          self.patch_size, float(self.conf_threshold), _lib.ptr(self.visible),
+                                          self._side, float(self.conf_threshold), _lib.ptr(self.visible),
                                           _lib.ptr(self.Ori_patch), _lib.ptr(self.Conf_patch), _lib.ptr(loss),
                                           _lib.ptr(hc), _lib.stream_ptr()), "mh_refine_loss")
         return loss, hc.bool()
@@ -495,7 +501,7 @@ class PMVO:
         N = points.shape[0]
         bufs = [torch.empty((N,), dtype=torch.uint8, device=self.device) if w else None for w in want]
         vt = self.visible_threshold if visible_threshold is None else visible_threshold
-        _lib.check(self._L.mh_filter_points(self._ctx, _lib.ptr(points), N, self.patch_size,
+        _lib.check(self._L.mh_filter_points(self._ctx, _lib.ptr(points), N, self._side,
                                             float(self.conf_threshold), float(vt), _lib.ptr(bufs[0]),
                                             _lib.ptr(bufs[1]), _lib.ptr(bufs[2]), _lib.ptr(bufs[3]),
                                             _lib.stream_ptr()), "mh_filter_points")
@@ -664,9 +670,9 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
             _lib.check(L.mh_medoid_indexed(ctx, _lib.ptr(ori_dev), off(index_all, lo, K), n, K, _lib.ptr(center), None,
                                            st), "mh_medoid_indexed")
             _lib.check(L.mh_refine_loss_maps(ctx, off(pts_dev, lo, 3), _lib.ptr(center), 0.005, 4.0, n,
-                                             pmvo.patch_size, float(pmvo.conf_threshold), _lib.ptr(loss_u), None, st),
+                                             pmvo._side, float(pmvo.conf_threshold), _lib.ptr(loss_u), None, st),
                        "mh_refine_loss_maps")
-            _lib.check(L.mh_filter_points(ctx, off(pts_dev, lo, 3), n, pmvo.patch_size, float(pmvo.conf_threshold),
+            _lib.check(L.mh_filter_points(ctx, off(pts_dev, lo, 3), n, pmvo._side, float(pmvo.conf_threshold),
                                           float(pmvo.visible_threshold), None, None, None, _lib.ptr(head), st),
                        "mh_filter_points")
             _lib.check(L.mh_refine_combine(ctx, _lib.ptr(center), _lib.ptr(loss_u), _lib.ptr(head),
@@ -718,7 +724,7 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         # 5000-point chunks only bound its memory)
         _lib.check(pmvo._L.mh_medoid_indexed(pmvo._ctx, _lib.ptr(sel_ori_dev), _lib.ptr(index_all), F, K,
                                              _lib.ptr(center), None, _lib.stream_ptr()), "mh_medoid_indexed")
-        _lib.check(pmvo._L.mh_filter_points(pmvo._ctx, _lib.ptr(fu_dev), F, pmvo.patch_size,
+        _lib.check(pmvo._L.mh_filter_points(pmvo._ctx, _lib.ptr(fu_dev), F, pmvo._side,
                                             float(pmvo.conf_threshold), float(args.PMVO.visible_threshold), None, None,
                                             None, _lib.ptr(head), _lib.stream_ptr()), "mh_filter_points")
         head_top = pmvo.head_top_mask_device(fu_dev).cpu().numpy().astype(bool)

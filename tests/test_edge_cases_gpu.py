@@ -111,9 +111,9 @@ def test_bad_arguments_are_reported_not_crashed():
 
     scene, pm, views = build(24, 64, 48, 3)
     with pytest.raises(_lib.MhError):
-        pm.patch_size = 4                                 # even patch sizes do not exist
-        pm.forward(synth.candidate_points(res=32, seed=6, limit=10))
-    pm.patch_size = 13                                    # larger than the instantiated kernels
+        pm._side = 4                                      # the C ABI takes odd window sides only (the class maps even
+        pm.forward(synth.candidate_points(res=32, seed=6, limit=10))    # patch sizes to the reference's odd window)
+    pm._side = 13                                         # larger than the instantiated kernels (documented limit: 11)
     with pytest.raises(_lib.MhError):
         pm.Compute_Visible_and_Ori(synth.candidate_points(res=32, seed=6, limit=10))
 
@@ -135,3 +135,26 @@ def test_medoid_groups_larger_than_lds():
     occ, ori_d = oracle.voxel_fit(p.copy(), o.copy(), [-0.32, -0.32, -0.24], 0.005 / 2, [256, 256, 192])
     assert np.array_equal(res["occ"], occ)
     assert np.array_equal(res["ori_dense"].astype(np.float32), ori_d.astype(np.float32))
+
+
+def test_even_patch_size_uses_the_reference_tap_window():
+    """range(-(size//2), size//2+1) (PMVO.py:494-495): patch_size 4 samples the same 5 x 5 taps as patch_size 5"""
+    from monohair_amd import synth
+    from monohair_amd.camera import camera_records, cameras_from_list
+    from monohair_amd.pmvo import PMVO
+
+    V, H, W = 24, 120, 90
+    scene = synth.make_scene(V, H, W, seed=2)
+    recs = camera_records(cameras_from_list(scene["cams"]))
+    pts = synth.candidate_points(res=32, seed=1)[:400]
+    out = []
+    for ps in (4, 5):
+        pm = PMVO.from_planes(recs, scene["depth"].to(DEV), scene["ori"].to(DEV), scene["conf"].to(DEV),
+                              scene["mask"].to(DEV), device=DEV, patch_size=ps, conf_threshold=0.15)
+        assert pm.patch_size == ps
+        pm.Compute_Visible_and_Ori(pts)
+        out.append((pm.Ori_patch.clone(), pm.Conf_patch.clone(), [t.clone() for t in pm.forward(pts)[1:]],
+                    [t.clone() for t in pm.filter_points(pts)]))
+    assert out[0][0].shape[2] == 25 and torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    for a, b in zip(out[0][2] + out[0][3], out[1][2] + out[1][3]):
+        assert torch.equal(torch.nan_to_num(a.float(), nan=-7.0), torch.nan_to_num(b.float(), nan=-7.0))

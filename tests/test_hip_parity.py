@@ -13,7 +13,7 @@ from conftest import golden_records, golden_scene, load_golden, scene_views
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["pmvo_small", "pmvo_mid", "pmvo_quant", "pmvo_views300"]
+CASES = ["pmvo_small", "pmvo_mid", "pmvo_quant", "pmvo_views300", "pmvo_views300c"]
 
 
 def eq_nan(a, b):
@@ -117,7 +117,9 @@ def test_forward_vs_reference_golden(case, depth_offsets):
     match = (loss == z["fwd_loss"]) | (np.isnan(loss) & np.isnan(z["fwd_loss"]))
     match &= np.all((ori == z["fwd_ori"]) | (np.isnan(ori) & np.isnan(z["fwd_ori"])), axis=1)
     match &= hc == z["fwd_hc"]
-    many = z["visible"].shape[0] >= 256       # 300 views x 48 points: most base views own ONE point (MKL's gemv path)
+    # 300 views x 48 scattered points: most base views own ONE point (MKL's gemv path); pmvo_views300c has the same views
+    # with the points in clusters of four, every base view owns >= 2 points there and the usual bar applies
+    many = z["visible"].shape[0] >= 256 and not meta.get("cluster")
     assert match[:-1].mean() >= (0.7 if many else 0.98)
     assert np.allclose(loss, z["fwd_loss"], rtol=0, atol=1e-3 if many else 1e-6, equal_nan=True)
     # the stated fp32 tolerance of the north star: 1e-4 L-inf on the orientation of matching choices

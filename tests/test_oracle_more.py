@@ -9,7 +9,7 @@ from scipy.spatial import KDTree
 import oracle
 from conftest import golden_records, golden_scene, load_golden, scene_views
 
-CASES = ["pmvo_small", "pmvo_mid", "pmvo_quant", "pmvo_views300"]
+CASES = ["pmvo_small", "pmvo_mid", "pmvo_quant", "pmvo_views300", "pmvo_views300c"]
 
 
 @pytest.fixture(scope="module", params=CASES)
@@ -48,7 +48,7 @@ def test_refine_method_loss(case):
     tail = len(pts) - (len(pts) % 64)
     assert np.array_equal(loss[:tail], ref[:tail], equal_nan=True)
     assert np.allclose(loss, ref, rtol=0, atol=2e-7, equal_nan=True)
-    assert (ref == -1).sum() > 0
+    assert (ref == -1).sum() > 0 or meta.get("cluster")      # (12 clustered points: the head filter may hit none)
 
 
 def test_consensus_medoid():

@@ -39,6 +39,11 @@ PMVO_CASES = {
     # values, and the GPU tests run on another CPU than the one the goldens come from)
     "pmvo_views300": dict(V=300, H=40, W=32, seed=2, scale=1.7, rings=3, quantize=False, res=32, N=48, patch=3,
                           thr=0.15, vis_thr=1.0, pt_seed=13, n_d=8, store_scene=True),
+    # the same 300 views with the points in tight clusters of four: every base view then owns >= 2 points at every rank,
+    # so the reference's 3x3 product in Camera.reprojection takes MKL's gemm kernel (the one the oracle restates) instead
+    # of the gemv path a single-point view lands in -- this case can be held to the thresholds of the small ones
+    "pmvo_views300c": dict(V=300, H=40, W=32, seed=2, scale=1.7, rings=3, quantize=False, res=32, N=48, patch=3,
+                           thr=0.15, vis_thr=1.0, pt_seed=14, n_d=8, store_scene=True, cluster=4),
 }
 
 
@@ -56,8 +61,12 @@ def ref_cameras(R, scene):
 def pick_points(case):
     pts = synth.candidate_points(res=case["res"], seed=case["pt_seed"])
     rng = np.random.default_rng(case["pt_seed"])
-    sel = np.sort(rng.choice(len(pts), case["N"], replace=False))
-    return pts[sel]
+    c = case.get("cluster", 1)
+    sel = np.sort(rng.choice(len(pts), case["N"] // c, replace=False))
+    out = pts[sel]
+    if c > 1:       # c copies of every seed point, a few float32 ulps apart: same view ranking, different arithmetic
+        out = np.repeat(out, c, axis=0) + rng.normal(0, 5e-8, size=(len(out) * c, 3))
+    return out
 
 
 def gen_pmvo(R, name, case):
