@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--taps-tile", type=int, default=0, help="points per workgroup of the tap-preparation kernel (A/B)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the independent iterations alternate on (as monohair_amd.pmvo.optimize does)")
     return ap.parse_args()
@@ -143,6 +144,8 @@ def main():
                           patch_size=a.patch, visible_threshold=1, conf_threshold=a.conf_threshold, camera=cams)
     if a.variant:
         pm.set_option("search_variant", a.variant)
+    if a.taps_tile:
+        pm.set_option("taps_tile", a.taps_tile)
 
     # candidate points of the 256^3 volume; keep the ones the reference would send to optimize()
     # (filter_negative_points, PMVO.py:535-557), then chunk by 5000 and deal the chunks to the ranks

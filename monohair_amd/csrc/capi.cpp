@@ -28,6 +28,7 @@ struct mh_ctx {
     float4 *lut = nullptr;    // [256] pixel-code table of the 8-bit map files
     int S = 0;
     int search_variant = 0;
+    int taps_tile = 64;       // points per workgroup of mh_project_taps_kernel (64 / 32 / 16)
     int gabor_variant = 1;    // 0: v_pk_fma, one pixel/lane; 1: FP32-MFMA im2col (default); 2: v_pk_fma, split bank
     MhViews views() const { return MhViews{V, H, W, rec, mask, cams}; }
 };
@@ -64,7 +65,7 @@ int mh_launch_topk(const float *, const float *, int, int, int32_t *, float *, h
 int mh_launch_prep_taps(const float *, const float *, const float *, const float *, int, int, float, float4 *,
                         uint8_t *, hipStream_t);
 int mh_launch_project_taps(MhViews, const float *, int, int, float, float *, float *, float *, float *, float4 *,
-                           uint8_t *, hipStream_t);
+                           uint8_t *, int, hipStream_t);
 int mh_launch_search(MhViews, const float *, int, int, int, const float *, int, int, float, const float *,
                      const int32_t *, const float *, const float4 *, int32_t *, const uint8_t *, float *, float *,
                      uint8_t *, float *, int32_t *, int32_t *, int, hipStream_t);
@@ -289,6 +290,10 @@ extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
         ctx->search_variant = value;
         return MH_OK;
     }
+    if (!strcmp(key, "taps_tile")) {
+        ctx->taps_tile = value;
+        return MH_OK;
+    }
     if (!strcmp(key, "gabor_variant")) {
         ctx->gabor_variant = value;
         return MH_OK;
@@ -384,7 +389,7 @@ extern "C" int mh_forward_prepare(mh_ctx *ctx, const float *points, int N, int p
         return fail(MH_ERR_ARG, "mh_forward_prepare: scratch too small");
     return launched(mh_launch_project_taps(ctx->views(), points, N, patch, conf_threshold, vis, ori, conf, mask,
                                            (float4 *)scratch,
-                                           (uint8_t *)scratch + search_count_offset(ctx, N, patch),
+                                           (uint8_t *)scratch + search_count_offset(ctx, N, patch), ctx->taps_tile,
                                            (hipStream_t)stream),
                     "mh_forward_prepare");
 }

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void mh_prep_taps_kernel(const float *__restri
 // patch is not even gathered.  Same arithmetic, same eligibility / duplicate rules and same record layout as
 // mh_project_gather_kernel + mh_prep_taps_kernel.
 // ---------------------------------------------------------------------------------------------
-template <int PATCH>
+template <int PATCH, int TILE>
 __global__ __launch_bounds__(256) void mh_project_taps_kernel(MhViews vw, const float *__restrict__ pts, int N,
                                                               int tiles, float thr, float *__restrict__ vis,
                                                               float *__restrict__ ori, float *__restrict__ conf,
@@ -284,8 +284,8 @@ __global__ __launch_bounds__(256) void mh_project_taps_kernel(MhViews vw, const 
     //            eligibility, duplicate removal (hash table in LDS), order-preserving compaction, list + header.
     //            The gather of the wave's next point is issued before the current one is processed.
     constexpr int P = PATCH * PATCH, HP = PATCH / 2;
-    __shared__ int s_r[MH_PG_TILE], s_cc[MH_PG_TILE];
-    __shared__ float s_vis[MH_PG_TILE], s_rowf[MH_PG_TILE], s_colf[MH_PG_TILE];
+    __shared__ int s_r[TILE], s_cc[TILE];
+    __shared__ float s_vis[TILE], s_rowf[TILE], s_colf[TILE];
     __shared__ float2 s_o[4][MH_PREP_PMAX];
     __shared__ float s_c[4][MH_PREP_PMAX];
     __shared__ unsigned char s_el[4][MH_PREP_PMAX];
@@ -295,11 +295,11 @@ __global__ __launch_bounds__(256) void mh_project_taps_kernel(MhViews vw, const 
     const int V = vw.V, H = vw.H, W = vw.W;
     if (bid >= V * tiles) return;
     const int v = bid / tiles, tile = bid - v * tiles;
-    const int n0 = tile * MH_PG_TILE;
-    const int npts = min(MH_PG_TILE, N - n0);
+    const int n0 = tile * TILE;
+    const int npts = min(TILE, N - n0);
     const float4 *__restrict__ rec = vw.rec + (size_t)v * H * W;
 
-    if (tid < MH_PG_TILE) {
+    if (tid < TILE) {
         float visv = -1.0f;
         if (tid < npts) {
             const int n = n0 + tid;
@@ -474,15 +474,23 @@ extern "C" int mh_launch_prep_taps(const float *ori_patch, const float *conf_pat
 }
 
 extern "C" int mh_launch_project_taps(MhViews vw, const float *pts, int N, int patch, float thr, float *vis,
-                                      float *ori, float *conf, float *mask, float4 *taps, uint8_t *cnt,
+                                      float *ori, float *conf, float *mask, float4 *taps, uint8_t *cnt, int tile,
                                       hipStream_t st) {
     if (patch * patch > MH_PREP_PMAX) return -1;
-    const int tiles = (N + MH_PG_TILE - 1) / MH_PG_TILE;
+    if (tile != 16 && tile != 32) tile = 64;
+    const int tiles = (N + tile - 1) / tile;
     const dim3 grid((vw.V * tiles + 7) & ~7), block(256);
-#define MH_PT_CASE(PS)                                                                                           \
-    case PS:                                                                                                     \
-        hipLaunchKernelGGL(mh_project_taps_kernel<PS>, grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, conf, \
-                           mask, taps, cnt);                                                                     \
+#define MH_PT_CASE(PS)                                                                                             \
+    case PS:                                                                                                       \
+        if (tile == 64)                                                                                            \
+            hipLaunchKernelGGL((mh_project_taps_kernel<PS, 64>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori,  \
+                               conf, mask, taps, cnt);                                                             \
+        else if (tile == 32)                                                                                       \
+            hipLaunchKernelGGL((mh_project_taps_kernel<PS, 32>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori,  \
+                               conf, mask, taps, cnt);                                                             \
+        else                                                                                                       \
+            hipLaunchKernelGGL((mh_project_taps_kernel<PS, 16>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori,  \
+                               conf, mask, taps, cnt);                                                             \
         break;
     switch (patch) {
         MH_PT_CASE(1)
