@@ -259,6 +259,11 @@ int mh_trace_scalp(mh_ctx *ctx, const void *vox, int W, int H, int Z, const floa
                    float thr_dot, float *out, int32_t *len, void *stream);
 int mh_strands_accept(int W, int H, int Z, float *flag, const float *pts, const int32_t *first, const int32_t *len,
                       int stride, const float *seeds, int n, int mode, uint8_t *accepted);
+/* Packs the fixed-stride rows of mh_trace_seeds / mh_trace_scalp (device) into one point list, strand after strand:
+ * packed[offsets[i] .. offsets[i]+len[i]) = rows[i][first[i] .. ) (first may be NULL = 0); offsets = exclusive prefix sum
+ * of len (device, int64).  mh_strands_accept reads the packed list with stride 0 and first = offsets. */
+int mh_strands_compact(mh_ctx *ctx, const float *rows, const int32_t *first, const int32_t *len, const long long *offsets,
+                       int n, int stride, float *packed, void *stream);
 
 /* ---- the one exchange of the data path, RCCL over xGMI.  The reference has no multi-GPU path
  * (options.py:112 asserts a single GPU); the voxel fit of refine (PMVO.py:695-726) is sharded here by x-slabs of

@@ -49,6 +49,7 @@ _SIGS = {
     "mh_trace_seeds": (ci, [vp, vp, ci, ci, ci, vp, ci, cf, vp, vp, vp, vp]),
     "mh_trace_scalp": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, cf, vp, vp, vp]),
     "mh_strands_accept": (ci, [ci, ci, ci, vp, vp, vp, vp, ci, vp, ci, ci, vp]),
+    "mh_strands_compact": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp]),
     "mh_knn_grid": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]),
     "mh_nearest_distance": (ci, [vp, vp, ci, vp, ci, vp, ctypes.c_double, ctypes.c_double, vp, vp]),
     "mh_grid_scratch_bytes": (csz, [ci]),

@@ -89,6 +89,8 @@ int mh_launch_nearest_dist(const float *, int, const double *, int, double *, do
 int mh_launch_pack_volume(const float *, const float *, size_t, float4 *, hipStream_t);
 int mh_launch_trace_seeds(const float4 *, int, int, int, const float *, int, float, float *, int32_t *, int32_t *,
                           hipStream_t);
+int mh_launch_strands_compact(const float *, const int32_t *, const int32_t *, const int64_t *, int, int, float *,
+                              hipStream_t);
 int mh_launch_trace_scalp(const float4 *, int, int, int, const float *, const float *, int, float, float *, int32_t *,
                           hipStream_t);
 }
@@ -633,13 +635,23 @@ extern "C" int mh_trace_scalp(mh_ctx *ctx, const void *vox, int W, int H, int Z,
                     "mh_trace_scalp");
 }
 
+extern "C" int mh_strands_compact(mh_ctx *ctx, const float *rows, const int32_t *first, const int32_t *len,
+                                  const long long *offsets, int n, int stride, float *packed, void *stream) {
+    if (n == 0) return MH_OK;
+    if (!ctx || !rows || !len || !offsets || !packed || n < 0 || stride < 1)
+        return fail(MH_ERR_ARG, "mh_strands_compact: bad arguments");
+    return launched(mh_launch_strands_compact(rows, first, len, (const int64_t *)offsets, n, stride, packed,
+                                              (hipStream_t)stream),
+                    "mh_strands_compact");
+}
+
 // The sequential `flag` gate (HairGrow.py:72,144,247,260,292), replayed on the HOST over finished traces: all
 // pointers are host pointers.  mode 0: voxel seeds (skip if flag[seed voxel] >= 3 or fewer than 5 points; an accepted
 // strand adds 1 to every distinct voxel it touches); mode 1: scalp roots (kept when len > 0; their voxels are set to 1).
 extern "C" int mh_strands_accept(int W, int H, int Z, float *flag, const float *pts, const int32_t *first,
                                  const int32_t *len, int stride, const float *seeds, int n, int mode,
                                  uint8_t *accepted) {
-    if (!flag || !pts || !first || !len || !seeds || !accepted || n < 0 || stride < 1)
+    if (!flag || !pts || !first || !len || !seeds || !accepted || n < 0 || stride < 0)
         return fail(MH_ERR_ARG, "mh_strands_accept: bad arguments");
     const size_t nvox = (size_t)W * H * Z;
     int32_t *stamp = new (std::nothrow) int32_t[nvox];

@@ -173,3 +173,26 @@ extern "C" int mh_launch_trace_scalp(const float4 *vox, int W, int H, int Z, con
                        len);
     return (int)hipGetLastError();
 }
+
+// The traces come back in fixed-stride rows (513 / 257 points per seed, mostly empty): pack the points that exist
+// one strand after the other before they cross PCIe.  One wave per strand; offs[i] = exclusive prefix sum of len.
+__global__ __launch_bounds__(256) void mh_strands_compact_kernel(const float *__restrict__ rows,
+                                                                 const int32_t *__restrict__ first,
+                                                                 const int32_t *__restrict__ len,
+                                                                 const int64_t *__restrict__ offs, int n, int stride,
+                                                                 float *__restrict__ packed) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const int l = len[i];
+    if (l <= 0) return;
+    const float *__restrict__ src = rows + ((size_t)i * stride + (first ? first[i] : 0)) * 3;
+    float *__restrict__ dst = packed + (size_t)offs[i] * 3;
+    for (int k = lane; k < 3 * l; k += MH_WAVE) dst[k] = src[k];
+}
+
+extern "C" int mh_launch_strands_compact(const float *rows, const int32_t *first, const int32_t *len, const int64_t *offs,
+                                         int n, int stride, float *packed, hipStream_t st) {
+    hipLaunchKernelGGL(mh_strands_compact_kernel, dim3((n + 3) / 4), dim3(256), 0, st, rows, first, len, offs, n, stride,
+                       packed);
+    return (int)hipGetLastError();
+}
