@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs")
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--taps-tile", type=int, default=0, help="points per workgroup of the tap-preparation kernel (A/B)")
+    ap.add_argument("--topk-order", type=int, default=-1, help="0 torch.topk's tie order (default), 1 index order (A/B)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the independent iterations alternate on (as monohair_amd.pmvo.optimize does)")
     return ap.parse_args()
@@ -146,6 +147,8 @@ def main():
         pm.set_option("search_variant", a.variant)
     if a.taps_tile:
         pm.set_option("taps_tile", a.taps_tile)
+    if a.topk_order >= 0:
+        pm.set_option("topk_order", a.topk_order)
 
     # candidate points of the 256^3 volume; keep the ones the reference would send to optimize()
     # (filter_negative_points, PMVO.py:535-557), then chunk by 5000 and deal the chunks to the ranks

@@ -73,7 +73,12 @@ int mh_project_gather(mh_ctx *ctx, const float *points /*[N,3]*/, int N, int pat
                       float *conf, float *mask, float *ori_patch, float *conf_patch, float *pixf, void *stream);
 
 /* ---- K6: PMVO.Find_max_conf_from_visible_view (PMVO.py:339-343).  out_idx/out_val are [MH_TOPK,N].
- * Tie order (unspecified in torch.topk): value descending, then view index ascending. */
+ * Equal values come back in the order torch.topk gives them on the CPU (std::nth_element + std::sort of libstdc++ on
+ * (value, view) pairs, restated step for step for one wave per point in csrc/mh_topk_wave.h) -- confidences from 8-bit
+ * maps saturate, ties are the rule, and the base views decide which candidates are tried.
+ * mh_ctx_set_option("topk_order", 1) selects the simpler rule of round 1 instead (value descending, then view index
+ * ascending), 2 the literal one-lane-per-point form (csrc/mh_topk_order.h; slow, cross-check).  Needs V >= MH_TOPK
+ * (the reference raises below 20 views). */
 int mh_topk_views(mh_ctx *ctx, const float *vis, const float *conf, int N, int32_t *out_idx, float *out_val,
                   void *stream);
 

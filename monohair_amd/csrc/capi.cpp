@@ -28,6 +28,7 @@ struct mh_ctx {
     float4 *lut = nullptr;    // [256] pixel-code table of the 8-bit map files
     int S = 0;
     int search_variant = 0;
+    int topk_order = 0;       // 0: torch.topk's CPU tie order (mh_topk_wave.h); 1: value desc, view asc; 2: mh_topk_order.h
     int taps_tile = 64;       // points per workgroup of mh_project_taps_kernel (64 / 32 / 16)
     int gabor_variant = 1;    // 0: v_pk_fma, one pixel/lane; 1: FP32-MFMA im2col (default); 2: v_pk_fma, split bank
     MhViews views() const { return MhViews{V, H, W, rec, mask, cams}; }
@@ -61,7 +62,7 @@ int mh_launch_prj_loss(const float *, const float *, const float *, const float 
                        long long *, uint8_t *, float *, hipStream_t);
 int mh_launch_project_gather(MhViews, const float *, int, int, float *, float *, float *, float *, float *, float *,
                              float *, hipStream_t);
-int mh_launch_topk(const float *, const float *, int, int, int32_t *, float *, hipStream_t);
+int mh_launch_topk(const float *, const float *, int, int, int32_t *, float *, int, hipStream_t);
 int mh_launch_prep_taps(const float *, const float *, const float *, const float *, int, int, float, float4 *,
                         uint8_t *, hipStream_t);
 int mh_launch_project_taps(MhViews, const float *, int, int, float, float *, float *, float *, float *, float4 *,
@@ -292,6 +293,10 @@ extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
         ctx->search_variant = value;
         return MH_OK;
     }
+    if (!strcmp(key, "topk_order")) {
+        ctx->topk_order = value;
+        return MH_OK;
+    }
     if (!strcmp(key, "taps_tile")) {
         ctx->taps_tile = value;
         return MH_OK;
@@ -323,7 +328,8 @@ extern "C" int mh_topk_views(mh_ctx *ctx, const float *vis, const float *conf, i
         return fail(MH_ERR_ARG, "mh_topk_views: %d views < %d (the reference's torch.topk raises too, PMVO.py:341)",
                     ctx->V, MH_TOPK);
     if (N == 0) return MH_OK;
-    return launched(mh_launch_topk(vis, conf, ctx->V, N, out_idx, out_val, (hipStream_t)stream), "mh_topk_views");
+    return launched(mh_launch_topk(vis, conf, ctx->V, N, out_idx, out_val, ctx->topk_order, (hipStream_t)stream),
+                    "mh_topk_views");
 }
 
 static size_t search_order_offset(const mh_ctx *ctx, int N, int patch) {

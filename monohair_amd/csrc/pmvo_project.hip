@@ -173,6 +173,64 @@ __global__ __launch_bounds__(256) void mh_topk_kernel(const float *__restrict__ 
     }
 }
 
+// The same ranking in torch.topk's CPU tie order, literal form (mh_topk_order.h): one lane per point runs the library's
+// selection and sort on its own V (value, view) pairs in LDS.  Sequential and divergent (~130 us for 5000 x 60); kept as
+// the cross-check of the wave form below (order = 2).
+#include "mh_topk_wave.h"
+__global__ __launch_bounds__(64) void mh_topk_torch_kernel(const float *__restrict__ vis, const float *__restrict__ conf,
+                                                           int V, int N, int T, int32_t *__restrict__ out_idx,
+                                                           float *__restrict__ out_val) {
+    extern __shared__ __attribute__((aligned(8))) unsigned char s_raw[];
+    const int t = threadIdx.x;
+    const int n = blockIdx.x * T + t;
+    if (t >= T || n >= N) return;
+    MhTkE *a = reinterpret_cast<MhTkE *>(s_raw) + (size_t)t * V;
+    for (int v = 0; v < V; ++v) {
+        const float vb = vis[(size_t)v * N + n], c = conf[(size_t)v * N + n];
+        a[v].v = (vb < 1.0f) ? c * fmaxf(vb, 0.0f) : c;
+        a[v].i = v;
+    }
+    mh_tk_topk(a, V, MH_TOPK);
+    for (int r = 0; r < MH_TOPK; ++r) {
+        out_idx[(size_t)r * N + n] = a[r].i;
+        out_val[(size_t)r * N + n] = a[r].v;
+    }
+}
+
+// torch.topk's CPU order, one WAVE per point (mh_topk_wave.h): the same steps, each scan / shift of the library one wave
+// operation.  The W waves of a workgroup take W consecutive points (their strided column reads share 64-byte sectors);
+// small workgroups spread the 5000 waves evenly over the SIMDs, which matters more: 33 us at W = 4, 41 us at W = 16
+// (rank-by-counting: 11 us; the literal form: 130 us).
+template <int R, int W>
+__global__ __launch_bounds__(64 * W) void mh_topk_wave_kernel(const float *__restrict__ vis, const float *__restrict__ conf,
+                                                            int V, int N, int32_t *__restrict__ out_idx,
+                                                            float *__restrict__ out_val) {
+    __shared__ int s_stack[W][72];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = blockIdx.x * W + wave;
+    if (n >= N) return;   // whole wave leaves together; no block-wide barrier below
+    MhTkWave<R> a;
+    a.lane = lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int v = r * 64 + lane;
+        int key = (int)0x80000000;    // below every value: padding lanes are never selected
+        if (v < V) {
+            const float vb = vis[(size_t)v * N + n], c = conf[(size_t)v * N + n];
+            key = mh_tk_key((vb < 1.0f) ? c * fmaxf(vb, 0.0f) : c);
+        }
+        a.k[r] = key;
+        a.i[r] = v;
+    }
+    a.topk(V, MH_TOPK, s_stack[wave]);
+    if (lane < MH_TOPK) {   // MH_TOPK <= 64: the result sits in register 0; the value is read again (keys fold NaN payloads)
+        const int v = a.i[0];
+        const float vb = vis[(size_t)v * N + n], c = conf[(size_t)v * N + n];
+        out_idx[(size_t)lane * N + n] = v;
+        out_val[(size_t)lane * N + n] = (vb < 1.0f) ? c * fmaxf(vb, 0.0f) : c;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Tap lists for the search kernel.  For every (view, point) the per-tap work that does not depend on
 // the candidate sample is done ONCE here instead of 900 times in the search:
@@ -458,9 +516,33 @@ extern "C" int mh_launch_project_gather(MhViews vw, const float *pts, int N, int
 }
 
 extern "C" int mh_launch_topk(const float *vis, const float *conf, int V, int N, int32_t *out_idx, float *out_val,
-                              hipStream_t st) {
-    if (V > MH_TOPK_VMAX) return -1;
-    hipLaunchKernelGGL(mh_topk_kernel, dim3((N + 3) / 4), dim3(256), 0, st, vis, conf, V, N, out_idx, out_val);
+                              int order, hipStream_t st) {
+    if (V > MH_TOPK_VMAX || V < MH_TOPK) return -1;
+    if ((order & 255) == 1) {   // value descending, view index ascending among equal values (round 1's rule; A/B)
+        hipLaunchKernelGGL(mh_topk_kernel, dim3((N + 3) / 4), dim3(256), 0, st, vis, conf, V, N, out_idx, out_val);
+    } else if ((order & 255) == 2) {   // torch.topk's CPU order, literal per-lane form (cross-check of the wave form)
+        int T = (order >> 8) > 0 ? (order >> 8) : 64;
+        const int cap = 65536 / (8 * V);
+        T = T > 64 ? 64 : T;
+        T = T > cap ? (cap < 1 ? 1 : cap) : T;
+        hipLaunchKernelGGL(mh_topk_torch_kernel, dim3((N + T - 1) / T), dim3(64), (size_t)T * V * 8, st, vis, conf, V, N,
+                           T, out_idx, out_val);
+    } else {            // torch.topk's CPU order, one wave per point
+        const int W = (order >> 8) == 16 ? 16 : ((order >> 8) == 8 ? 8 : 4);   // waves (= points) per workgroup; 4 measured best
+        const dim3 grid((N + W - 1) / W), block(64 * W);
+#define MH_TKW(RR)                                                                                                    \
+    do {                                                                                                              \
+        if (W == 4) hipLaunchKernelGGL((mh_topk_wave_kernel<RR, 4>), grid, block, 0, st, vis, conf, V, N, out_idx, out_val); \
+        else if (W == 8) hipLaunchKernelGGL((mh_topk_wave_kernel<RR, 8>), grid, block, 0, st, vis, conf, V, N, out_idx, out_val); \
+        else hipLaunchKernelGGL((mh_topk_wave_kernel<RR, 16>), grid, block, 0, st, vis, conf, V, N, out_idx, out_val); \
+    } while (0)
+        if (V <= 64) MH_TKW(1);
+        else if (V <= 128) MH_TKW(2);
+        else if (V <= 256) MH_TKW(4);
+        else if (V <= 512) MH_TKW(8);
+        else MH_TKW(16);
+#undef MH_TKW
+    }
     return (int)hipGetLastError();
 }
 

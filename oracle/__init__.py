@@ -128,13 +128,25 @@ def visible_and_ori(views, pts, patch):
     return out
 
 
-def topk_views(vis, conf, k=20):
+def topk_views(vis, conf, k=20, order="torch"):
+    """Find_max_conf_from_visible_view.  order "torch": equal values in torch.topk's CPU order (std::nth_element +
+    std::sort, topk_oracle.cpp); "index": value descending, view index ascending (the library's topk_order = 1)."""
     vis = np.ascontiguousarray(vis, np.float32)
     conf = np.ascontiguousarray(conf, np.float32)
     V, N = vis.shape
     idx = np.empty((k, N), np.int32)
     val = np.empty((k, N), np.float32)
-    lib().orc_topk_views(_p(vis), _p(conf), V, N, k, _p(idx, c_i), _p(val))
+    fn = lib().orc_topk_views if order == "torch" else lib().orc_topk_views_by_index
+    fn(_p(vis), _p(conf), V, N, k, _p(idx, c_i), _p(val))
+    return idx, val
+
+
+def topk_column(values, k):
+    """torch.topk(values, k) of one float32 vector -> (indices, values) in the CPU kernel's order"""
+    v = np.ascontiguousarray(values, np.float32)
+    idx = np.empty(k, np.int32)
+    val = np.empty(k, np.float32)
+    lib().orc_topk_column(_p(v), len(v), k, _p(idx, c_i), _p(val))
     return idx, val
 
 

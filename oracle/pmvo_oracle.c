@@ -188,10 +188,13 @@ void orc_visible_and_ori(const orc_views *vw, const float *pts, int N, int patch
 
 /*
  * PMVO.Find_max_conf_from_visible_view (PMVO.py:339-343): C' = vis<1 ? conf*max(vis,0) : conf; top-k over views.
- * torch.topk's order among equal values is unspecified; this restatement (and the HIP kernel) use
- * (value descending, view index ascending).  out_idx/out_val are [k,N].
+ * This is the SIMPLE rule (value descending, view index ascending among equal values) that round 1 shipped and that the
+ * HIP library still offers as topk_order = 1; the reference's own order among equal values -- torch.topk's, i.e.
+ * libstdc++'s nth_element + sort -- is orc_topk_views in topk_oracle.cpp, which forward() below uses.
+ * out_idx/out_val are [k,N].
  */
-void orc_topk_views(const float *vis, const float *conf, int V, int N, int k, int32_t *out_idx, float *out_val) {
+void orc_topk_views(const float *vis, const float *conf, int V, int N, int k, int32_t *out_idx, float *out_val);
+void orc_topk_views_by_index(const float *vis, const float *conf, int V, int N, int k, int32_t *out_idx, float *out_val) {
 #pragma omp parallel for schedule(static)
     for (int n = 0; n < N; ++n) {
         float cv[1024];

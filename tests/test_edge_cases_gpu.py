@@ -158,3 +158,66 @@ def test_even_patch_size_uses_the_reference_tap_window():
     assert out[0][0].shape[2] == 25 and torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     for a, b in zip(out[0][2] + out[0][3], out[1][2] + out[1][3]):
         assert torch.equal(torch.nan_to_num(a.float(), nan=-7.0), torch.nan_to_num(b.float(), nan=-7.0))
+
+
+def test_topk_tie_order_is_torchs_on_adversarial_columns():
+    """mh_topk_views (default order) == torch.topk on the CPU, index for index: heavy ties, NaNs, sorted / organ-pipe /
+    median-of-three-killer columns that push the library's selection into its heap fall-back, 20..1024 views."""
+    import ctypes
+
+    from monohair_amd import _lib
+    from monohair_amd.pmvo import PMVO
+
+    rng = np.random.default_rng(8)
+
+    def killer(n):
+        v, k = np.zeros(n, np.float32), n // 2
+        for i in range(1, k + 1):
+            if i % 2 == 1:
+                v[i - 1], v[i] = i, k + i
+            v[k + i - 1] = 2 * i
+        return v
+
+    for V in (20, 21, 37, 60, 63, 64, 65, 127, 128, 129, 300, 512, 1000, 1024):
+        N = 96
+        cols = []
+        for n in range(N):
+            m = n % 6
+            if m == 0:
+                c = rng.choice(np.round(rng.random(int(rng.integers(1, 6))), 2), size=V)
+            elif m == 1:
+                c = np.arange(V) / V
+            elif m == 2:
+                c = np.arange(V)[::-1] / V
+            elif m == 3:
+                c = killer(V) / (2 * V)
+            elif m == 4:
+                c = np.where(np.arange(V) % 2, np.arange(V), V - np.arange(V)) / V
+            else:
+                c = np.where(rng.random(V) < 0.5, 1.0, rng.random(V))
+            c = np.clip(np.asarray(c, np.float32), 0.0, 1.0)
+            if n % 17 == 0:
+                c[rng.integers(0, V, 2)] = np.nan
+            cols.append(c)
+        conf = np.stack(cols, 1).astype(np.float32)                     # [V,N]
+        vis = np.ones((V, N), np.float32)
+        vis[rng.random((V, N)) < 0.2] = -1.0                             # invisible views: value 0 (more ties)
+        want_i, want_v = oracle.topk_views(vis, conf, 20)
+        t = torch.where(torch.from_numpy(vis) < 1, torch.from_numpy(conf) * torch.clamp(torch.from_numpy(vis), min=0),
+                        torch.from_numpy(conf))
+        assert np.array_equal(torch.topk(t, 20, dim=0).indices.numpy(), want_i)       # the oracle really is torch's order
+        ctx = ctypes.c_void_p()
+        L = _lib.lib()
+        _lib.check(L.mh_ctx_create(0, ctypes.byref(ctx)))
+        _lib.check(L.mh_ctx_alloc_views(ctx, V, 4, 4))
+        vd, cd = torch.from_numpy(vis).to(DEV), torch.from_numpy(conf).to(DEV)
+        oi = torch.empty((20, N), dtype=torch.int32, device=DEV)
+        ov = torch.empty((20, N), dtype=torch.float32, device=DEV)
+        for order in (0, 2):       # the wave form (default) and the literal per-lane form
+            _lib.check(L.mh_ctx_set_option(ctx, b"topk_order", order))
+            oi.fill_(-1)
+            _lib.check(L.mh_topk_views(ctx, _lib.ptr(vd), _lib.ptr(cd), N, _lib.ptr(oi), _lib.ptr(ov), _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            assert np.array_equal(oi.cpu().numpy(), want_i), (V, order)
+            assert np.array_equal(ov.cpu().numpy(), want_v, equal_nan=True), (V, order)
+        L.mh_ctx_destroy(ctx)

@@ -86,7 +86,13 @@ def test_topk_vs_oracle(case):
     assert idx.dtype == torch.int64
     assert np.array_equal(idx.cpu().numpy(), oi)
     assert np.array_equal(val.cpu().numpy(), ov)
-    assert np.array_equal(val.cpu().numpy(), z["base_val"])
+    # ... which is the reference's own torch.topk output, equal values included (csrc/mh_topk_order.h)
+    assert np.array_equal(val.cpu().numpy(), z["base_val"]) and np.array_equal(idx.cpu().numpy(), z["base_idx"])
+    pm.set_option("topk_order", 1)                      # round 1's rule: value descending, view index ascending
+    idx1, val1 = pm.Find_max_conf_from_visible_view()
+    pm.set_option("topk_order", 0)
+    o1, v1 = oracle.topk_views(z["visible"], z["Conf"], 20, order="index")
+    assert np.array_equal(idx1.cpu().numpy(), o1) and np.array_equal(val1.cpu().numpy(), v1)
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 64, 128, 192, 256, 320, 1128, 1256])
