@@ -570,12 +570,33 @@ def secondary_full_pass(dev, pm, cand, dist):
         T[name] = round(dt, 3)
         return r
 
-    with contextlib.redirect_stdout(io.StringIO()):                   # the drivers print progress like the reference
-        s_idx, s_pts, f_idx = timed("filter_s", lambda: filter_negative_points(cand, pm, args))
-        sp, so, ml, _ = timed("optimize_s", lambda: optimize(s_pts, pm, args))
-        timed("refine_and_volume_s", lambda: refine(sp, so, ml, pm, cand[:len(f_idx)][f_idx].astype(np.float32), args,
-                                                   infer_inner=False, threshold=0.025, return_dense=False))
-    T["total_s"] = round(sum(T.values()), 3)
+    def one_pass(k):
+        T.clear()
+        # a fresh output directory per pass (overwriting the previous pass's 400 MB of .mat files would be timed too)
+        args.output_path = tmp + "/pass%d" % k
+        args.save_root, args.save_path = args.output_path + "/optimize", args.output_path + "/refine"
+        args.data.root = args.output_path
+        if dist is None or dist.get_rank() == 0:
+            os.makedirs(args.save_path, exist_ok=True)
+        with contextlib.redirect_stdout(io.StringIO()):               # the drivers print progress like the reference
+            s_idx, s_pts, f_idx = timed("filter_s", lambda: filter_negative_points(cand, pm, args))
+            sp, so, ml, _ = timed("optimize_s", lambda: optimize(s_pts, pm, args))
+            timed("refine_and_volume_s", lambda: refine(sp, so, ml, pm, cand[:len(f_idx)][f_idx].astype(np.float32), args,
+                                                       infer_inner=False, threshold=0.025, return_dense=False))
+        T["total_s"] = round(sum(T.values()), 3)
+        if dist is None or dist.get_rank() == 0:
+            shutil.rmtree(args.output_path, ignore_errors=True)
+        return dict(T), s_idx, s_pts, f_idx
+
+    # The first pass also pays for this process's first allocations of the pass's buffers (what a one-shot `python PMVO.py`
+    # run sees, next to its seconds of start-up and map loading); three more give the steady state.  The host side of
+    # refine (numpy, file writes) shares the box with other jobs: the median pass is reported, all totals are listed.
+    first = one_pass(0)[0]
+    runs = [one_pass(k) for k in (1, 2, 3)]
+    runs.sort(key=lambda r: r[0]["total_s"])
+    T, s_idx, s_pts, f_idx = runs[1]
+    T["passes_total_s"] = [first["total_s"]] + [r[0]["total_s"] for r in runs]
+    T["first_pass"] = first
     T.update(candidates=int(len(cand)), surface_points=int(s_idx.sum()), shell_points=int(f_idx.sum()),
              iterations=int(len(s_pts) // CHUNK + 1), unit="s", ranks=1 if dist is None else dist.get_world_size())
     if dist is None or dist.get_rank() == 0:

@@ -213,6 +213,17 @@ size_t mh_sort_scratch_bytes(int n);
 int mh_sort_keys(mh_ctx *ctx, const unsigned long long *keys, int n, int end_bit, void *scratch, size_t scratch_bytes,
                  unsigned long long *keys_out, int32_t *order, void *stream);
 
+/* The grouping step of the volume fit in one call (PMVO.py:697-715 + Utils/PMVO_utils.py:386-404 p2v): voxel keys
+ * (x*gy + y)*gz + z of the points evaluated in float64 exactly as numpy does (y, z negated, (p - min) / size, round half
+ * to even, x86 int32 cast, clip), stable sort -> keys_sorted[n], order[n]; ori_sorted[n,3] (optional, with ori) = the
+ * orientation rows in that order with the sign canonicalisation of :697-698 applied (y > 0 -> negated).  points are
+ * float32 or float64 (points_f64); voxel_min (3 doubles) and dims (3 int32) are host arrays.  Nothing is modified in
+ * place (the reference's p2v flips its input array). */
+size_t mh_voxel_group_scratch_bytes(int n);
+int mh_voxel_group(mh_ctx *ctx, const void *points, int points_f64, const float *ori, int n, const double *voxel_min,
+                   double voxel_size, const int32_t *dims, void *scratch, size_t scratch_bytes,
+                   unsigned long long *keys_sorted, int32_t *order, float *ori_sorted, void *stream);
+
 /* ---- depth-map producer (the step before the path): Utils/Render_utils.py:310-347 render_bust_hair_depth with
  * the BustObj shader (:146-188) and Renderer.draw/ReadBuffer (:239-262) -- triangles drawn with a LESS depth test,
  * value (-z_camera / 2) * 255, background 255, top-left image origin.  verts[Nv,3] (world, bust offset applied),

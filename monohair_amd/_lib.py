@@ -56,6 +56,8 @@ _SIGS = {
     "mh_grid_build": (ci, [vp, vp, vp, vp, ci, vp, csz, vp, vp, vp, vp, vp]),
     "mh_sort_scratch_bytes": (csz, [ci]),
     "mh_sort_keys": (ci, [vp, vp, ci, ci, vp, csz, vp, vp, vp]),
+    "mh_voxel_group_scratch_bytes": (csz, [ci]),
+    "mh_voxel_group": (ci, [vp, vp, ci, vp, ci, vp, ctypes.c_double, vp, vp, csz, vp, vp, vp, vp]),
     "mh_render_scratch_bytes": (csz, [ci, ci, ci, ci]),
     "mh_render_depth": (ci, [vp, vp, vp, ci, vp, ci, ci, ci, cf, vp, csz, vp, ci, vp]),
     "mh_comm_unique_id": (ci, [vp]),

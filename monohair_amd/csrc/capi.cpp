@@ -48,6 +48,9 @@ int mh_launch_grid_build(const float *, int, float, float, float, float, int, in
                          int32_t *, int32_t *, int32_t *, hipStream_t);
 int mh_launch_sort_keys(const unsigned long long *, int, int, void *, size_t, unsigned long long *, int32_t *,
                         hipStream_t);
+size_t mh_voxel_group_scratch_bytes_impl(int);
+int mh_launch_voxel_group(const void *, int, const float *, int, const double *, double, const int32_t *, void *, size_t,
+                          unsigned long long *, int32_t *, float *, hipStream_t);
 int mh_launch_render_strands(const float *, const float *, int, const int32_t *, int, const float *, const float *, int,
                              int, int, int, int, int, int, float, void *, void *, unsigned long long *, int32_t *,
                              unsigned int *, float *, hipStream_t);
@@ -555,6 +558,23 @@ extern "C" int mh_sort_keys(mh_ctx *ctx, const unsigned long long *keys, int n, 
     MH_HIP(hipSetDevice(ctx->device));
     return launched(mh_launch_sort_keys(keys, n, end_bit, scratch, scratch_bytes, keys_out, order, (hipStream_t)stream),
                     "mh_sort_keys");
+}
+
+extern "C" size_t mh_voxel_group_scratch_bytes(int n) { return n < 0 ? 0 : mh_voxel_group_scratch_bytes_impl(n); }
+
+extern "C" int mh_voxel_group(mh_ctx *ctx, const void *points, int points_f64, const float *ori, int n,
+                              const double *voxel_min, double voxel_size, const int32_t *dims, void *scratch,
+                              size_t scratch_bytes, unsigned long long *keys_sorted, int32_t *order, float *ori_sorted,
+                              void *stream) {
+    if (n == 0) return MH_OK;
+    if (!ctx || !points || !voxel_min || !dims || !scratch || !keys_sorted || !order || n < 0 || !(voxel_size > 0.0) ||
+        dims[0] < 1 || dims[1] < 1 || dims[2] < 1 || (ori == nullptr) != (ori_sorted == nullptr))
+        return fail(MH_ERR_ARG, "mh_voxel_group: bad arguments");
+    if (scratch_bytes < mh_voxel_group_scratch_bytes_impl(n)) return fail(MH_ERR_ARG, "mh_voxel_group: scratch too small");
+    MH_HIP(hipSetDevice(ctx->device));
+    return launched(mh_launch_voxel_group(points, points_f64, ori, n, voxel_min, voxel_size, dims, scratch, scratch_bytes,
+                                          keys_sorted, order, ori_sorted, (hipStream_t)stream),
+                    "mh_voxel_group");
 }
 
 // ---- the intermediate methods of the reference's class, as stand-alone calls (csrc/pmvo_pieces.hip) ---------------

@@ -61,6 +61,39 @@ __global__ __launch_bounds__(256) void mh_iota_kernel(int32_t *__restrict__ v, i
     if (i < n) v[i] = i;
 }
 
+// p2v of the volume fit (PMVO_utils.py:386-404) in float64, as numpy evaluates it: y and z negated, (p - min) / size,
+// round half to even, the int32 cast of x86 (NaN and out-of-range -> INT_MIN), clip to the grid -> key (x*gy + y)*gz + z
+template <typename T>
+__global__ __launch_bounds__(256) void mh_voxel_key_kernel(const T *__restrict__ pts, int n, double mx, double my,
+                                                           double mz, double vs, int gx, int gy, int gz,
+                                                           unsigned long long *__restrict__ keys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto q = [vs](double p, double m, int g) {
+        const double v = rint((p - m) / vs);
+        const int k = (v >= -2147483648.0 && v < 2147483648.0) ? (int)v : (int)0x80000000;
+        return min(max(k, 0), g - 1);
+    };
+    const long long x = q((double)pts[3 * i], mx, gx);
+    const long long y = q((double)(-pts[3 * i + 1]), my, gy);
+    const long long z = q((double)(-pts[3 * i + 2]), mz, gz);
+    keys[i] = (unsigned long long)((x * gy + y) * gz + z);
+}
+
+// rows of `ori` in sorted order, sign canonicalised as PMVO.py:697-698 does before the fit (y > 0 -> negated)
+__global__ __launch_bounds__(256) void mh_gather3_canon_kernel(const float *__restrict__ ori,
+                                                               const int32_t *__restrict__ order, int n,
+                                                               float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int s = order[i];
+    const float a = ori[3 * s], b = ori[3 * s + 1], c = ori[3 * s + 2];
+    const bool up = b > 0.0f;
+    out[3 * i] = up ? a * -1.0f : a;
+    out[3 * i + 1] = up ? b * -1.0f : b;
+    out[3 * i + 2] = up ? c * -1.0f : c;
+}
+
 static size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 static size_t radix_temp_u32(unsigned n) {
@@ -127,5 +160,34 @@ extern "C" int mh_launch_sort_keys(const unsigned long long *keys, int n, int en
     hipLaunchKernelGGL(mh_iota_kernel, dim3((n + 255) / 256), dim3(256), 0, st, vin, n);
     hipError_t e = rocprim::radix_sort_pairs(tmp, tb, keys, keys_out, vin, order, (unsigned)n, 0, end_bit, st);
     if (e != hipSuccess) return (int)e;
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t mh_voxel_group_scratch_bytes_impl(int n) {
+    const size_t m = (size_t)(n > 0 ? n : 1);
+    return align256(m * 8) + mh_sort_scratch_bytes_impl(n);
+}
+
+// voxel keys of the points (float64 p2v), stable sort, orientation rows gathered in that order (canonicalised)
+extern "C" int mh_launch_voxel_group(const void *pts, int pts_f64, const float *ori, int n, const double *vmin, double vs,
+                                     const int32_t *dims, void *scratch, size_t scratch_bytes,
+                                     unsigned long long *keys_out, int32_t *order, float *ori_sorted, hipStream_t st) {
+    char *base = (char *)scratch;
+    const size_t a = align256((size_t)n * 8);
+    unsigned long long *kin = (unsigned long long *)base;
+    const int nb = (n + 255) / 256;
+    if (pts_f64)
+        hipLaunchKernelGGL(mh_voxel_key_kernel<double>, dim3(nb), dim3(256), 0, st, (const double *)pts, n, vmin[0],
+                           vmin[1], vmin[2], vs, dims[0], dims[1], dims[2], kin);
+    else
+        hipLaunchKernelGGL(mh_voxel_key_kernel<float>, dim3(nb), dim3(256), 0, st, (const float *)pts, n, vmin[0], vmin[1],
+                           vmin[2], vs, dims[0], dims[1], dims[2], kin);
+    const long long ncell = (long long)dims[0] * dims[1] * dims[2];
+    int bits = 1;
+    while (bits < 63 && (1ll << bits) < ncell) ++bits;
+    const int rc = mh_launch_sort_keys(kin, n, bits, base + a, scratch_bytes - a, keys_out, order, st);
+    if (rc) return rc;
+    if (ori && ori_sorted)
+        hipLaunchKernelGGL(mh_gather3_canon_kernel, dim3(nb), dim3(256), 0, st, ori, order, n, ori_sorted);
     return (int)hipGetLastError();
 }

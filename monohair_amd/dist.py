@@ -177,9 +177,9 @@ def voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size, 
     g = np.asarray(grid_resolution).astype(np.int64)
     d = _dist()
     w, r = world(), rank()
-    # sign canonicalisation and p2v mutate their inputs in the reference; do it once, here, on copies
-    pts = np.array(select_points, copy=True)
-    ori = np.array(select_ori, copy=True)
+    pts, ori = select_points, select_ori          # (the fit does not modify its inputs)
+    if fit is not U.voxel_fit:                    # a caller-supplied fit may, like the reference's in-place flips
+        pts, ori = np.array(select_points, copy=True), np.array(select_ori, copy=True)
     if not d:
         res = fit(pts, ori, device, voxel_min, voxel_size, g, dense=not sparse)
         if sparse:

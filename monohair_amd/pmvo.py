@@ -681,16 +681,27 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         ori[:] = ori_dev.cpu().numpy()
         loss[:] = loss_dev.cpu().numpy()
         T_loop.__exit__()
+        saver = None
         if is_root:
-            os.makedirs(args.output_path + "/refine", exist_ok=True)
-            np.save(args.output_path + "/refine/select_p.npy", points)
-            np.save(args.output_path + "/refine/select_o.npy", ori)
-            np.save(args.output_path + "/refine/min_loss.npy", loss)
-        mdist.barrier()
+            # the three files of PMVO.py:645-648 are written by a worker thread while the shell stage runs; the reference
+            # reads them back right away (:650-652) -- the arrays in memory are what np.load would return
+            import threading
 
-    points = np.load(args.output_path + "/refine/select_p.npy")
-    ori = np.load(args.output_path + "/refine/select_o.npy")
-    min_loss = np.load(args.output_path + "/refine/min_loss.npy")
+            os.makedirs(args.output_path + "/refine", exist_ok=True)
+            held = (points, ori, loss)          # not written again before the join below
+
+            def _save():
+                for name, arr in zip(("select_p", "select_o", "min_loss"), held):
+                    np.save(args.output_path + "/refine/%s.npy" % name, arr)
+
+            saver = threading.Thread(target=_save)
+            saver.start()
+        min_loss = loss
+    else:
+        saver = None
+        points = np.load(args.output_path + "/refine/select_p.npy")
+        ori = np.load(args.output_path + "/refine/select_o.npy")
+        min_loss = np.load(args.output_path + "/refine/min_loss.npy")
     index = np.where(min_loss < threshold)[0]
     select_ori = ori[index]
     select_points = points[index]
@@ -732,6 +743,8 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         filter_unvisible_ori = center.cpu().numpy()[keep]
         select_filter_unvisible_points = fu_dev.cpu().numpy()[keep]
     T_shell.__exit__()
+    if saver is not None:
+        saver.join()
     if is_root:
         np.save(args.output_path + "/refine/filter_unvisible.npy", select_filter_unvisible_points)
         np.save(args.output_path + "/refine/filter_unvisible_ori.npy", filter_unvisible_ori)

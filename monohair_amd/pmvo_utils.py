@@ -268,7 +268,10 @@ class GridKNN:
         pts_np = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
         self._raw = torch.from_numpy(pts_np).to(self.device)
         self.M = pts_np.shape[0]
-        self._lo, self._hi = pts_np.min(0), pts_np.max(0)            # host: the points come from the host anyway
+        # bounding box: numpy's axis-0 reduction of an [M,3] array costs 2-5 ms per call at 3e5 points (inner loop of 3),
+        # the device needs two tiny launches
+        lo, hi = torch.aminmax(self._raw, dim=0) if self.M else (torch.zeros(3), torch.zeros(3))
+        self._lo, self._hi = lo.cpu().numpy(), hi.cpu().numpy()
         ext = float((self._hi - self._lo).max()) + 1e-6
         self._ext = ext
         self._grids = {}
@@ -401,40 +404,47 @@ def p2v(points, voxel_min, voxel_size, grid_resolution):
 
 def voxel_fit(select_points, select_ori, device, voxel_min=VOXEL_MIN, voxel_size=VOXEL_SIZE,
               grid_resolution=GRID_RESOLUTION, dense=True):
-    """The volume fit of refine (PMVO.py:695-726) on the GPU: sign canonicalisation (ori.y > 0 -> negate),
-    p2v in float64, stable sort by voxel key (point order inside a voxel is preserved, which is what the
-    reference's dict of lists does), one segmented-medoid launch for all voxels.
+    """The volume fit of refine (PMVO.py:695-726) on the GPU: one call (mh_voxel_group) evaluates p2v in float64, sorts the
+    voxel keys stably (point order inside a voxel is preserved, which is what the reference's dict of lists does) and
+    gathers the sign-canonicalised orientations (ori.y > 0 -> negated) in that order; one segmented-medoid launch for all
+    voxels.  Only the run boundaries of the sorted keys are found on the host.
 
     Returns dict(voxels [G,3] int64 (x,y,z), ori [G,3] f32) and, with dense=True, occ [X,Y,Z] / ori [X,Y,Z,3]
-    float64 numpy arrays as the reference builds them.  Mutates select_points / select_ori like the reference."""
+    float64 numpy arrays as the reference builds them.  The inputs are NOT modified (the reference flips them in place,
+    PMVO.py:697-698 and p2v; nothing reads them afterwards)."""
+    import ctypes
+
     g = np.asarray(grid_resolution).astype(np.int64)
-    up = select_ori[:, 1] > 0
-    select_ori[up] *= -1
-    x, y, z = p2v(select_points, np.asarray(voxel_min), voxel_size, g)
     dev = torch.device(device)
-    key = (x.astype(np.int64) * int(g[1]) + y.astype(np.int64)) * int(g[2]) + z.astype(np.int64)
-    n = int(key.shape[0])
+    pts = np.ascontiguousarray(select_points).reshape(-1, 3)
+    if pts.dtype != np.float64:
+        pts = pts.astype(np.float32, copy=False)
+    n = int(pts.shape[0])
     L = _lib.lib()
     if n:
-        # stable sort of the voxel keys on the device (csrc/sortgroup.hip); the run boundaries are found on the host
-        kd = torch.from_numpy(np.ascontiguousarray(key)).to(dev)          # non-negative int64 == the same u64 bits
-        ks_d = torch.empty_like(kd)
+        pd = torch.from_numpy(pts).to(dev)
+        od = torch.from_numpy(np.ascontiguousarray(select_ori, dtype=np.float32).reshape(-1, 3)).to(dev)
+        ks_d = torch.empty(n, dtype=torch.int64, device=dev)      # non-negative: the same bits as the u64 keys
         order_d = torch.empty(n, dtype=torch.int32, device=dev)
-        scratch = torch.empty(int(L.mh_sort_scratch_bytes(n)), dtype=torch.uint8, device=dev)
-        end_bit = max(1, int(int(g[0]) * int(g[1]) * int(g[2]) - 1).bit_length())
+        o = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        scratch = torch.empty(int(L.mh_voxel_group_scratch_bytes(n)), dtype=torch.uint8, device=dev)
+        vmin = np.ascontiguousarray(voxel_min, dtype=np.float64)
+        dims = np.ascontiguousarray(g, dtype=np.int32)
         with torch.cuda.device(dev):
-            _lib.check(L.mh_sort_keys(_ctx_for(dev), _lib.ptr(kd), n, end_bit, _lib.ptr(scratch), scratch.numel(),
-                                      _lib.ptr(ks_d), _lib.ptr(order_d), _lib.stream_ptr()), "mh_sort_keys")
+            _lib.check(L.mh_voxel_group(_ctx_for(dev), _lib.ptr(pd), 1 if pts.dtype == np.float64 else 0, _lib.ptr(od), n,
+                                        vmin.ctypes.data_as(ctypes.c_void_p), float(voxel_size),
+                                        dims.ctypes.data_as(ctypes.c_void_p), _lib.ptr(scratch), scratch.numel(),
+                                        _lib.ptr(ks_d), _lib.ptr(order_d), _lib.ptr(o), _lib.stream_ptr()),
+                       "mh_voxel_group")
         ks = ks_d.cpu().numpy()
-        order = order_d.cpu().numpy()
     else:
-        ks, order = key, np.zeros(0, np.int32)
+        ks = np.zeros(0, np.int64)
+        o = torch.empty((0, 3), dtype=torch.float32, device=dev)
     starts = np.flatnonzero(np.concatenate([[True], ks[1:] != ks[:-1]])) if n else np.zeros(0, np.int64)
     G = int(starts.size)
     seg_h = np.concatenate([starts, [n]]).astype(np.int32)
     max_group = int(np.diff(seg_h).max()) if G else 0
     seg = torch.from_numpy(seg_h).to(dev)
-    o = torch.from_numpy(np.ascontiguousarray(np.asarray(select_ori, dtype=np.float32)[order])).to(dev)
     med = torch.empty((G, 3), dtype=torch.float32, device=dev)
     if G:
         with torch.cuda.device(dev):
