@@ -423,8 +423,8 @@ template <int KA, int T, int LD>
 __device__ __forceinline__ void mh_search_slices(const MhViews &vw, const float *__restrict__ offs, int S, int rank_step,
                                                  float P0, float P1x, float P2, int n, int N, int P1, float thr,
                                                  const float *__restrict__ ori_c, const int32_t *__restrict__ base_idx,
-                                                 const float4 *__restrict__ taps, int nact, int tid, float *s_loss,
-                                                 uint8_t *s_pos) {
+                                                 const float4 *__restrict__ taps, const uint8_t *__restrict__ vcnt,
+                                                 int nact, int tid, float *s_loss, uint8_t *s_pos) {
     const int V = vw.V;
     const float Hf = (float)vw.H, Wf = (float)vw.W;
     float X0[KA], X1[KA], X2[KA];
@@ -441,17 +441,25 @@ __device__ __forceinline__ void mh_search_slices(const MhViews &vw, const float 
         num[j] = den[j] = MhCascV{0.0f, 0.0f, 0.0f};
         cnt[j] = 0;
     }
-    for (int v = 0; v < V; ++v) {
-        if (v > 0 && (v & 15) == 0) {
+    // The views that see the point, as a wave-uniform bit mask (64 views at a time) from the compact [V,N] array of tap-list
+    // lengths the preparation kernel leaves (0 = not visible): the loop visits only those -- no dependent header load and
+    // branch for the ~64 % of the views that do not see the point -- and the header of the NEXT visible view is requested
+    // before the current view is worked on.  The cascade of the weighted sums is flushed at the same view indices as
+    // before (every multiple of 16 below V, visible or not).
+    int nf = 16;
+    auto flush_upto = [&](int v) {
+        while (nf <= v) {
 #pragma unroll
             for (int j = 0; j < KA; ++j) {
-                mh_cascv_flush(num[j], v);
-                mh_cascv_flush(den[j], v);
+                mh_cascv_flush(num[j], nf);
+                mh_cascv_flush(den[j], nf);
             }
+            nf += 16;
         }
+    };
+    auto one_view = [&](int v, const float4 hdr) {
         const float4 *__restrict__ rec0 = taps + ((size_t)v * N + n) * P1;
-        const float4 hdr = rec0[0];
-        if (hdr.y == -1.0f) continue;   // uniform: point not visible in this view, weight 0
+        if (hdr.y == -1.0f) return;   // uniform: point not visible in this view, weight 0
         const int ntap = __float_as_int(hdr.x);
         const float *__restrict__ cam = vw.cams + v * MH_CAM_STRIDE;
         // LD == 0: the tap records travel as wave-uniform VECTOR loads (every lane gets a copy; the address is made
@@ -528,7 +536,36 @@ __device__ __forceinline__ void mh_search_slices(const MhViews &vw, const float 
             den[j].a0 = den[j].a0 + w;
             cnt[j] += (w > 0.0f) ? 1 : 0;
         }
+    };
+    const int lane = tid & 63;
+    for (int vb = 0; vb < V; vb += 64) {
+        unsigned long long vm;
+        if (vcnt) {
+            const int vv = vb + lane;
+            vm = __ballot(vv < V && vcnt[(size_t)vv * N + n] != 0);
+        } else {
+            vm = (V - vb >= 64) ? ~0ull : ((1ull << (V - vb)) - 1ull);
+        }
+        if (!vm) continue;
+        int v = vb + (int)__builtin_ctzll(vm);
+        vm &= vm - 1;
+        float4 hdr = taps[((size_t)v * N + n) * P1];
+        for (;;) {
+            int vnext = -1;
+            float4 hdr_n = hdr;
+            if (vm) {
+                vnext = vb + (int)__builtin_ctzll(vm);
+                vm &= vm - 1;
+                hdr_n = taps[((size_t)vnext * N + n) * P1];
+            }
+            flush_upto(v);
+            one_view(v, hdr);
+            if (vnext < 0) break;
+            v = vnext;
+            hdr = hdr_n;
+        }
     }
+    flush_upto(V - 1);
 #pragma unroll
     for (int j = 0; j < KA; ++j) {
         const int it = j * T + tid;
@@ -549,6 +586,7 @@ __global__ __launch_bounds__(T) void mh_search2_kernel(MhViews vw, const float *
                                                        const int32_t *__restrict__ base_idx,
                                                        const float *__restrict__ base_val,
                                                        const float4 *__restrict__ taps,
+                                                       const uint8_t *__restrict__ vcnt,
                                                        const int32_t *__restrict__ order, float *__restrict__ line_ori,
                                                        float *__restrict__ min_loss, uint8_t *__restrict__ high_conf,
                                                        float *__restrict__ best_sample, int32_t *__restrict__ best_rank,
@@ -571,12 +609,310 @@ __global__ __launch_bounds__(T) void mh_search2_kernel(MhViews vw, const float *
     const int wave0 = tid & ~63;   // first item of this wave in slice 0
     int ka = 0;
     for (int j = 0; j < 4; ++j) ka += (j * T + wave0 < nact) ? 1 : 0;
-#define MH_S2_ARGS vw, offs, S, rank_step, P0, P1x, P2, n, N, P1, thr, ori_c, base_idx, taps, nact, tid, s_loss, s_pos
+#define MH_S2_ARGS vw, offs, S, rank_step, P0, P1x, P2, n, N, P1, thr, ori_c, base_idx, taps, vcnt, nact, tid, s_loss, s_pos
     if (ka == 4) mh_search_slices<4, T, LD>(MH_S2_ARGS);
     else if (ka == 3) mh_search_slices<3, T, LD>(MH_S2_ARGS);
     else if (ka == 2) mh_search_slices<2, T, LD>(MH_S2_ARGS);
     else if (ka == 1) mh_search_slices<1, T, LD>(MH_S2_ARGS);
 #undef MH_S2_ARGS
+    __syncthreads();
+
+    // ---- per rank: low-confidence escape hatch, min / argmin over the S samples (PMVO.py:199-206)
+    const int wave = tid >> 6, lane = tid & 63, nwaves = T >> 6;
+    for (int r = wave; r < nvalid; r += nwaves) {
+        int npos = 0;
+        for (int s0 = 0; s0 < S; s0 += MH_WAVE) {
+            const int s = s0 + lane;
+            npos += __popcll(__ballot(s < S && s_pos[r * S + s]));
+        }
+        const bool low = npos < 5;
+        float bl = 0.0f;
+        int bi = 0x7fffffff;
+        for (int s = lane; s < S; s += MH_WAVE) {
+            float l = s_loss[r * S + s];
+            if (!low && !s_pos[r * S + s]) l = 1.0f;
+            if (bi == 0x7fffffff || mh_min_better(l, s, bl, bi)) {
+                bl = l;
+                bi = s;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ol = __shfl_xor(bl, o);
+            const int oi = __shfl_xor(bi, o);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || mh_min_better(ol, oi, bl, bi))) {
+                bl = ol;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            s_rl[r] = bl;
+            s_ri[r] = bi;
+            s_rh[r] = s_pos[r * S + bi];
+        }
+    }
+    __syncthreads();
+
+    // ---- best candidate across base-view ranks (PMVO.py:57-70) and the 3D direction (:73-74)
+    if (tid == 0) {
+        const float Hf = (float)vw.H, Wf = (float)vw.W;
+        float ml = s_rl[0];
+        int br = 0, bs = s_ri[0], hc = s_rh[0];
+        for (int r = 1; r < nvalid; ++r) {
+            const float l = s_rl[r];
+            if ((l < ml) && (base_val[(size_t)(r * rank_step) * N + n] > 0.0f)) {
+                ml = l;
+                br = r;
+                bs = s_ri[r];
+                hc = s_rh[r];
+            }
+        }
+        const int b = base_idx[(size_t)(br * rank_step) * N + n];
+        const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
+        float B0, B1, B2;
+        mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[bs], B0, B1, B2);
+        const float d0 = B0 - P0, d1 = B1 - P1x, d2 = B2 - P2;
+        float s2 = d0 * d0;
+        s2 = mh_fma(d1, d1, s2);
+        s2 = mh_fma(d2, d2, s2);
+        const float nrm = __builtin_sqrtf(s2);
+        line_ori[3 * n] = d0 / nrm;
+        line_ori[3 * n + 1] = d1 / nrm;
+        line_ori[3 * n + 2] = d2 / nrm;
+        min_loss[n] = ml;
+        high_conf[n] = (uint8_t)hc;
+        if (best_sample) {
+            best_sample[3 * n] = B0;
+            best_sample[3 * n + 1] = B1;
+            best_sample[3 * n + 2] = B2;
+        }
+        if (best_rank) best_rank[n] = br;
+        if (best_s) best_s[n] = bs;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// mh_search3_kernel -- mh_search2_kernel with the tap lists of the point STAGED IN LDS.  Same arithmetic in the same order;
+// what changes is where the wave-uniform tap records come from:
+//   * mh_search2 reads them with broadcast vector loads: every one of the 4 waves of the workgroup loads every tap record
+//     of every visible view (20.9 M wave-level loads per launch, 768 B of register return each through the CU's one
+//     vector-memory path), and the first two loads of a view (first tap, first group) are waited for at full L2 latency;
+//   * here the 256 threads copy the lists of the visible views into LDS once (coalesced 16-B loads, one copy per
+//     workgroup instead of four), one barrier, and the tap loop reads them back with same-address ds_read (broadcast, no
+//     bank conflict, ~100 cycles of latency that the ping-pong groups cover).  Lists that do not fit (MH_S3_CAP records)
+//     go in several batches; the typical point (22 visible views x 46 taps) needs one.
+//   * the visible views, their list lengths and LDS offsets come from the compact [V,N] byte array of list lengths: one
+//     lane per view, a wave prefix sum, v_readlane -- no per-view header load, no branch on it.
+// ---------------------------------------------------------------------------------------------
+#define MH_S3_GRP 4      // tap records per ping-pong group
+#define MH_S3_CAP 1280   // float4 records per workgroup (20 KB; 6 workgroups of 25 KB per CU)
+
+template <int KA, int T>
+__device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const float *__restrict__ offs, int S,
+                                                     int rank_step, float P0, float P1x, float P2, int n, int N, int P1,
+                                                     float thr, const float *__restrict__ ori_c,
+                                                     const int32_t *__restrict__ base_idx,
+                                                     const float4 *__restrict__ taps, const uint8_t *__restrict__ vcnt,
+                                                     int nact, int tid, float *s_loss, uint8_t *s_pos, float4 *s_taps) {
+    constexpr int KN = KA > 0 ? KA : 1;   // a wave without items (KA == 0) only helps to stage the lists
+    const int V = vw.V;
+    const float Hf = (float)vw.H, Wf = (float)vw.W;
+    float X0[KN], X1[KN], X2[KN];
+    MhCascV num[KN], den[KN];
+    int cnt[KN];
+    if constexpr (KA > 0) {
+#pragma unroll
+        for (int j = 0; j < KA; ++j) {
+            int it = j * T + tid;
+            it = it < nact ? it : 0;
+            const int r = it / S, s = it - r * S;
+            const int b = base_idx[(size_t)(r * rank_step) * N + n];
+            const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
+            mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[s], X0[j], X1[j], X2[j]);
+            num[j] = den[j] = MhCascV{0.0f, 0.0f, 0.0f};
+            cnt[j] = 0;
+        }
+    }
+    int nf = 16;   // next view index at which the cascade of the weighted sums is flushed (every multiple of 16 below V)
+    auto flush_upto = [&](int v) {
+        while (nf <= v) {
+#pragma unroll
+            for (int j = 0; j < KN; ++j) {
+                mh_cascv_flush(num[j], nf);
+                mh_cascv_flush(den[j], nf);
+            }
+            nf += 16;
+        }
+    };
+    // one visible view: rec = its list in LDS (header, then ntap taps)
+    auto one_view = [&](int v, const float4 *rec, int ntap) {
+        const float *__restrict__ cam = vw.cams + v * MH_CAM_STRIDE;
+        const float4 hdr = rec[0];
+        const float4 t0 = rec[1];
+        float DX[KN], DY[KN], ML[KN], BC[KN];
+#pragma unroll
+        for (int jp = 0; jp < KA / 2; ++jp) {
+            mh_v2f row, col, dx, dy;
+            mh_pixel_of_fast2(cam, mh_v2f{X0[2 * jp], X0[2 * jp + 1]}, mh_v2f{X1[2 * jp], X1[2 * jp + 1]},
+                              mh_v2f{X2[2 * jp], X2[2 * jp + 1]}, Hf, Wf, row, col);
+            mh_unit2_fast2(row - mh_splat(hdr.z), col - mh_splat(hdr.w), dx, dy);
+            DX[2 * jp] = dx.x;
+            DX[2 * jp + 1] = dx.y;
+            DY[2 * jp] = dy.x;
+            DY[2 * jp + 1] = dy.y;
+        }
+        if constexpr (KA & 1) {
+            mh_v2f row, col, dx, dy;
+            mh_pixel_of_fast2(cam, mh_splat(X0[KA - 1]), mh_splat(X1[KA - 1]), mh_splat(X2[KA - 1]), Hf, Wf, row, col);
+            mh_unit2_fast2(row - mh_splat(hdr.z), col - mh_splat(hdr.w), dx, dy);
+            DX[KA - 1] = dx.x;
+            DY[KA - 1] = dy.x;
+        }
+#pragma unroll
+        for (int j = 0; j < KA; ++j) {
+            ML[j] = mh_one_minus_abs(mh_vadd(mh_vmul(t0.x, DX[j]), mh_vmul(t0.y, DY[j])));
+            BC[j] = t0.z;
+        }
+        constexpr int GRP = MH_S3_GRP;
+        auto process = [&](const float4 (&g)[GRP], int t) {
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+                if (t + u < ntap) {   // uniform
+                    const float4 tp = g[u];
+                    float l[KN];
+#pragma unroll
+                    for (int j = 0; j < KA; ++j)
+                        l[j] = mh_one_minus_abs(mh_vadd(mh_vmul(tp.x, DX[j]), mh_vmul(tp.y, DY[j])));
+                    mh_tap_update<KN>(ML, BC, l, tp.z);
+                }
+            }
+        };
+        float4 ga[GRP], gb[GRP];
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) ga[u] = rec[2 + u];
+        for (int t = 1; t < ntap;) {
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) gb[u] = rec[1 + t + GRP + u];
+            process(ga, t);
+            t += GRP;
+            if (t >= ntap) break;
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) ga[u] = rec[1 + t + GRP + u];
+            process(gb, t);
+            t += GRP;
+        }
+#pragma unroll
+        for (int j = 0; j < KA; ++j) {
+            const float w = BC[j];   // (vis != -1) * best_conf
+            num[j].a0 = num[j].a0 + ML[j] * w;
+            den[j].a0 = den[j].a0 + w;
+            cnt[j] += (w > 0.0f) ? 1 : 0;
+        }
+    };
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int vb = 0; vb < V; vb += 64) {
+        const int vv = vb + lane;
+        const int c = (vv < V) ? (int)vcnt[(size_t)vv * N + n] : 0;   // list length of view vv (0: the view does not see the point)
+        const int len = c ? c + 1 : 0;                               // records: header + taps
+        int pre = len;                                               // inclusive prefix sum over the lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(pre, o);
+            pre += (lane >= o) ? y : 0;
+        }
+        unsigned long long todo = __ballot(c != 0);
+        int base = 0;
+        while (todo) {
+            // the next lists that fit together (pre is monotone: a prefix of the views left; one list always fits)
+            const unsigned long long take = todo & __ballot(pre - base <= MH_S3_CAP);
+            {
+                unsigned long long m = take;
+                int k = 0;
+                while (m) {
+                    const int b = (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    if ((k & (T / 64 - 1)) == wave) {
+                        const int L = __builtin_amdgcn_readlane(len, b);
+                        const int off = __builtin_amdgcn_readlane(pre, b) - L - base;
+                        const float4 *__restrict__ src = taps + ((size_t)(vb + b) * N + n) * P1;
+                        for (int i = lane; i < L; i += 64) s_taps[off + i] = src[i];
+                    }
+                    ++k;
+                }
+            }
+            __syncthreads();
+            if constexpr (KA > 0) {
+                unsigned long long m = take;
+                while (m) {
+                    const int b = (int)__builtin_ctzll(m);
+                    m &= m - 1;
+                    flush_upto(vb + b);
+                    const int L = __builtin_amdgcn_readlane(len, b);
+                    const int off = __builtin_amdgcn_readlane(pre, b) - L - base;
+                    one_view(vb + b, s_taps + off, L - 1);
+                }
+            }
+            __syncthreads();
+            base = __builtin_amdgcn_readlane(pre, 63 - (int)__builtin_clzll(take));
+            todo &= ~take;
+        }
+    }
+    if constexpr (KA > 0) {
+        flush_upto(V - 1);
+#pragma unroll
+        for (int j = 0; j < KA; ++j) {
+            const int it = j * T + tid;
+            if (it < nact) {
+                const float dn = mh_cascv_done(den[j]);
+                const float nm = mh_cascv_done(num[j]);
+                const float ratio = dn / (float)cnt[j];
+                s_pos[it] = (ratio > thr) ? 1 : 0;
+                s_loss[it] = nm / dn;
+            }
+        }
+    }
+}
+
+template <int T>
+// amdgpu_waves_per_eu(5): the register allocator stops at 96 VGPRs (it takes 109 unconstrained = 4 waves per SIMD); the
+// few values it spills are reloaded once per view.  Measured: 4 waves 1305 it/s, 5 waves 1345, 6 waves (80 VGPRs) 1328.
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5))) void mh_search3_kernel(MhViews vw, const float *__restrict__ offs, int S, int nrank,
+                                                       int rank_step, const float *__restrict__ pts, int N, int P1,
+                                                       float thr, const float *__restrict__ ori_c,
+                                                       const int32_t *__restrict__ base_idx,
+                                                       const float *__restrict__ base_val,
+                                                       const float4 *__restrict__ taps,
+                                                       const uint8_t *__restrict__ vcnt,
+                                                       const int32_t *__restrict__ order, float *__restrict__ line_ori,
+                                                       float *__restrict__ min_loss, uint8_t *__restrict__ high_conf,
+                                                       float *__restrict__ best_sample, int32_t *__restrict__ best_rank,
+                                                       int32_t *__restrict__ best_s) {
+    __shared__ float4 s_taps[MH_S3_CAP + 8];   // (+8: the last prefetch group of a list reads past its end)
+    __shared__ float s_loss[MH_MAX_ITEMS];
+    __shared__ uint8_t s_pos[MH_MAX_ITEMS];
+    __shared__ float s_rl[MH_MAX_RANKS];
+    __shared__ int s_ri[MH_MAX_RANKS];
+    __shared__ int s_rh[MH_MAX_RANKS];
+
+    const int tid = threadIdx.x;
+    const int n = order ? order[blockIdx.x] : (int)blockIdx.x;
+    const float P0 = pts[3 * n], P1x = pts[3 * n + 1], P2 = pts[3 * n + 2];
+    // usable base-view ranks: rank 0 always, rank r > 0 only if base_view_conf[r] > 0 (PMVO.py:57-64); keep every rank up
+    // to the last usable one
+    int nvalid = 1;
+    for (int r = 1; r < nrank; ++r)
+        if (base_val[(size_t)(r * rank_step) * N + n] > 0.0f) nvalid = r + 1;
+    const int nact = nvalid * S;
+    const int wave0 = tid & ~63;   // first item of this wave in slice 0
+    int ka = 0;
+    for (int j = 0; j < 4; ++j) ka += (j * T + wave0 < nact) ? 1 : 0;
+#define MH_S3_ARGS vw, offs, S, rank_step, P0, P1x, P2, n, N, P1, thr, ori_c, base_idx, taps, vcnt, nact, tid, s_loss, s_pos, s_taps
+    if (ka == 4) mh_search_slices_lds<4, T>(MH_S3_ARGS);
+    else if (ka == 3) mh_search_slices_lds<3, T>(MH_S3_ARGS);
+    else if (ka == 2) mh_search_slices_lds<2, T>(MH_S3_ARGS);
+    else if (ka == 1) mh_search_slices_lds<1, T>(MH_S3_ARGS);
+    else mh_search_slices_lds<0, T>(MH_S3_ARGS);
+#undef MH_S3_ARGS
     __syncthreads();
 
     // ---- per rank: low-confidence escape hatch, min / argmin over the S samples (PMVO.py:199-206)
@@ -921,23 +1257,32 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
 #define MH_SEARCH_LAUNCH(KK, TT) MH_SEARCH_LAUNCH_F(KK, TT, 0)
     // variant 0: mh_search2_kernel (256 threads, up to 4 item slices) when the items fit, ordered by work;
     // 2: the same without the work order (A/B); the others: earlier forms kept for A/B and cross-checks
-    if (variant == 0) variant = (nitems <= 64) ? 64 : (nitems <= 1024 ? 1 : 256);
-    if (variant >= 1 && variant <= 4) {   // 1: vector tap loads, ordered; 2: same, natural order; 3/4: scalar tap loads
+    if (variant == 0) variant = (nitems <= 64) ? 64 : (nitems <= 1024 ? (cnt ? 6 : 1) : 256);
+    if (variant >= 1 && variant <= 7) {
+        // 6: mh_search3_kernel (tap lists staged in LDS), ordered by work -- the shipped form; 7: the same in natural order;
+        // 1: mh_search2_kernel (broadcast vector tap loads), ordered; 2: natural order; 3/4: scalar tap loads; 5: variant 1
+        // with the loop over ALL views instead of the visible-view mask (A/B)
         if (nitems > 1024) return -1;
+        if ((variant == 6 || variant == 7) && !cnt) return -1;
         const int32_t *ord = nullptr;
-        if ((variant & 1) && order && cnt && N > 1) {
+        if ((variant == 1 || variant == 3 || variant == 5 || variant == 6) && order && cnt && N > 1) {
             hipLaunchKernelGGL(mh_search_work_kernel, dim3((N + 3) / 4), dim3(256), 0, st, cnt, vw.V, N, P1, base_val,
                                nrank, rank_step, S, 256, order);
             hipLaunchKernelGGL(mh_search_order_kernel, dim3(1), dim3(1024), 0, st, N, order);
             ord = order + N;
         }
-        if (variant <= 2)
+        const uint8_t *vc = (variant == 5) ? nullptr : cnt;
+        if (variant >= 6)
+            hipLaunchKernelGGL((mh_search3_kernel<256>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts, N,
+                               P1, thr, ori_c, base_idx, base_val, taps, cnt, ord, line_ori, min_loss, high_conf,
+                               best_sample, best_rank, best_s);
+        else if (variant <= 2 || variant == 5)
             hipLaunchKernelGGL((mh_search2_kernel<256, 0>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts,
-                               N, P1, thr, ori_c, base_idx, base_val, taps, ord, line_ori, min_loss, high_conf,
+                               N, P1, thr, ori_c, base_idx, base_val, taps, vc, ord, line_ori, min_loss, high_conf,
                                best_sample, best_rank, best_s);
         else
             hipLaunchKernelGGL((mh_search2_kernel<256, 1>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts,
-                               N, P1, thr, ori_c, base_idx, base_val, taps, ord, line_ori, min_loss, high_conf,
+                               N, P1, thr, ori_c, base_idx, base_val, taps, vc, ord, line_ori, min_loss, high_conf,
                                best_sample, best_rank, best_s);
     } else if (variant == 64) {
         if (nitems <= 64) MH_SEARCH_LAUNCH(1, 64);
