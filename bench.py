@@ -4,7 +4,7 @@
 One step = one PMVO iteration = one `PMVO.forward()` over a chunk of 5000 candidate points against all
 V views (one step of the trange at /root/reference/PMVO.py:572-574): the H2D upload of the chunk, project /
 visibility / tap lists (mh_project_taps_kernel), base-view ranking (mh_topk_kernel) and the fused loss search
-(mh_search2_kernel), maps resident in HBM, no file IO.
+(mh_search3_kernel), maps resident in HBM, no file IO.
 
     python bench.py [--gpus N --steps K --warmup W]
 
@@ -303,7 +303,7 @@ def main():
 def kernel_rooflines(a, pm, my, dev, V, H, W, P):
     """Per-kernel durations of one iteration with HIP events on the launch stream, each launch on a different chunk,
     and the roofline of each kernel from what it actually executed.
-      mh_search2_kernel  (dominant, fp32 VALU bound): executed (candidate, view, tap) evaluations x 8 FLOP
+      mh_search3_kernel  (dominant, fp32 VALU bound): executed (candidate, view, tap) evaluations x 8 FLOP
       mh_project_taps_kernel (HBM): bytes it has to move for what it produces
       mh_project_gather_kernel (HBM; the API form of Compute_Visible_and_Ori): SURVEY §8d's 2*V*N*(12P+20)+12N"""
     import torch
@@ -356,7 +356,7 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P):
         e[0].record(); topk(); e[1].record()            # noqa: E702
         torch.cuda.synchronize()
         t_topk += e[0].elapsed_time(e[1])
-        e[0].record(); search(p); e[1].record()         # noqa: E702  (order kernels + mh_search2_kernel)
+        e[0].record(); search(p); e[1].record()         # noqa: E702  (order kernels + mh_search3_kernel)
         torch.cuda.synchronize()
         t_search += e[0].elapsed_time(e[1])
         cnt, nvalid = pm.search_work(N, bval)
@@ -385,7 +385,7 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P):
     prof = load_profile_facts(V, H, W)
     return {
         "roofline": {
-            "kernel": "mh_search2_kernel<256,0>", "bound": "valu",
+            "kernel": "mh_search3_kernel<256>", "bound": "valu",
             "achieved": round(tf, 2), "peak": VALU_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TF, 4),
             "traffic": None,
             "launch_ms": round(t_search, 4),

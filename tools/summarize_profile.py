@@ -78,7 +78,7 @@ for k in ("mh_project_gather_kernel<7>", "mh_project_taps_kernel<7>"):
     if k.startswith("mh_project_gather") and k in dur:
         lines.append("#   algorithmic bytes (SURVEY.md §8d) = %.2f MB per launch -> %.2f TB/s algorithmic = %.1f %% of 8 TB/s"
                      % (ALGO_PG / 1e6, ALGO_PG / dur[k] / 1e6, ALGO_PG / dur[k] / 1e6 / 8 * 100))
-sk = next((k for k, c in pmc if k.startswith("mh_search2_kernel") and c == "SQ_INSTS_VALU"), None)
+sk = next((k for k, c in pmc if k.startswith(("mh_search3_kernel", "mh_search2_kernel")) and c == "SQ_INSTS_VALU"), None)
 if sk:
     insts, waves, wcyc = avg(sk, "SQ_INSTS_VALU"), avg(sk, "SQ_WAVES"), avg(sk, "SQ_WAVE_CYCLES")
     t_us = dur.get(sk)
