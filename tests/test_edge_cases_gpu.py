@@ -137,6 +137,53 @@ def test_medoid_groups_larger_than_lds():
     assert np.array_equal(res["ori_dense"].astype(np.float32), ori_d.astype(np.float32))
 
 
+def test_voxel_group_is_numpys_p2v_on_awkward_points():
+    """mh_voxel_group == the reference's grouping (p2v in float64 + dict of lists in point order, PMVO_utils.py:386-404,
+    PMVO.py:697-715) on points exactly between voxels (round half to even), outside the grid, non-finite, float64 input."""
+    import ctypes
+
+    from monohair_amd import _lib
+    from monohair_amd.pmvo_utils import GRID_RESOLUTION, VOXEL_MIN, VOXEL_SIZE, _ctx_for, p2v
+
+    rng = np.random.default_rng(5)
+    g = np.asarray(GRID_RESOLUTION).astype(np.int64)
+    vmin = np.asarray(VOXEL_MIN, np.float64)
+    for dtype in (np.float32, np.float64):
+        n = 20000
+        pts = rng.uniform(-0.4, 0.4, (n, 3))
+        k = rng.integers(0, 255, (4000, 3))
+        half = (vmin + (k + 0.5) * VOXEL_SIZE) * np.array([1.0, -1.0, -1.0])       # ties of the rounding (before the y,z flip)
+        pts[:4000] = half
+        pts[4000:4010] = [[np.nan, 0, 0], [0, np.inf, 0], [0, 0, -np.inf], [1e30, 0, 0], [-1e30, 0, 0], [0, 3e9, 0],
+                          [0, -3e9, 0], [0, 0, 5.0], [0, 0, -5.0], [np.nan, np.nan, np.nan]]
+        pts = pts.astype(dtype)
+        ori = rng.normal(size=(n, 3)).astype(np.float32)
+        ori[::7, 1] = 0.0
+        ori[3::11, 1] = -0.0
+        with np.errstate(all="ignore"):
+            x, y, z = p2v(pts.copy(), vmin, VOXEL_SIZE, g)
+        key = (x.astype(np.int64) * int(g[1]) + y.astype(np.int64)) * int(g[2]) + z.astype(np.int64)
+        want_order = np.argsort(key, kind="stable")
+        want_ori = ori.copy()
+        want_ori[want_ori[:, 1] > 0] *= -1
+        L = _lib.lib()
+        pd = torch.from_numpy(pts).to(DEV)
+        od = torch.from_numpy(ori).to(DEV)
+        ks = torch.empty(n, dtype=torch.int64, device=DEV)
+        order = torch.empty(n, dtype=torch.int32, device=DEV)
+        osort = torch.empty((n, 3), dtype=torch.float32, device=DEV)
+        scratch = torch.empty(int(L.mh_voxel_group_scratch_bytes(n)), dtype=torch.uint8, device=DEV)
+        dims = np.ascontiguousarray(g, dtype=np.int32)
+        _lib.check(L.mh_voxel_group(_ctx_for(DEV), _lib.ptr(pd), 1 if dtype == np.float64 else 0, _lib.ptr(od), n,
+                                    vmin.ctypes.data_as(ctypes.c_void_p), float(VOXEL_SIZE),
+                                    dims.ctypes.data_as(ctypes.c_void_p), _lib.ptr(scratch), scratch.numel(), _lib.ptr(ks),
+                                    _lib.ptr(order), _lib.ptr(osort), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert np.array_equal(ks.cpu().numpy(), key[want_order]), dtype
+        assert np.array_equal(order.cpu().numpy(), want_order), dtype
+        assert np.array_equal(osort.cpu().numpy(), want_ori[want_order]), dtype
+
+
 def test_even_patch_size_uses_the_reference_tap_window():
     """range(-(size//2), size//2+1) (PMVO.py:494-495): patch_size 4 samples the same 5 x 5 taps as patch_size 5"""
     from monohair_amd import synth
