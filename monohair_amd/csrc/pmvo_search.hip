@@ -707,7 +707,24 @@ __global__ __launch_bounds__(T) void mh_search2_kernel(MhViews vw, const float *
 #define MH_S3_GRP 4      // tap records per ping-pong group
 #define MH_S3_CAP 1280   // float4 records per workgroup (20 KB; 6 workgroups of 25 KB per CU)
 
-template <int KA, int T>
+// the cascade of mh_device.h (MhCascV) with the third level only where it can be reached
+template <bool BIG>
+struct MhCascS {
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+    __device__ __forceinline__ void flush(int v) {   // v > 0, v % 16 == 0, before adding row v
+        a1 = a1 + a0;
+        a0 = 0.0f;
+        if constexpr (BIG) {
+            if ((v & 0xF0) == 0) {
+                a2 = a2 + a1;
+                a1 = 0.0f;
+            }
+        }
+    }
+    __device__ __forceinline__ float done() const { return BIG ? (a0 + a1) + a2 : (a0 + a1); }
+};
+
+template <int KA, int T, bool BIGV>
 __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const float *__restrict__ offs, int S,
                                                      int rank_step, float P0, float P1x, float P2, int n, int N, int P1,
                                                      float thr, const float *__restrict__ ori_c,
@@ -718,7 +735,9 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
     const int V = vw.V;
     const float Hf = (float)vw.H, Wf = (float)vw.W;
     float X0[KN], X1[KN], X2[KN];
-    MhCascV num[KN], den[KN];
+    // BIGV = more than 256 views: only then does the cascade of the weighted sums reach its third level (the level stays
+    // +0 otherwise and x + (+0) = x for the non-negative sums: 8 registers less)
+    MhCascS<BIGV> num[KN], den[KN];
     int cnt[KN];
     if constexpr (KA > 0) {
 #pragma unroll
@@ -729,7 +748,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
             const int b = base_idx[(size_t)(r * rank_step) * N + n];
             const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
             mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[s], X0[j], X1[j], X2[j]);
-            num[j] = den[j] = MhCascV{0.0f, 0.0f, 0.0f};
+            num[j] = den[j] = MhCascS<BIGV>{};
             cnt[j] = 0;
         }
     }
@@ -738,8 +757,8 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
         while (nf <= v) {
 #pragma unroll
             for (int j = 0; j < KN; ++j) {
-                mh_cascv_flush(num[j], nf);
-                mh_cascv_flush(den[j], nf);
+                num[j].flush(nf);
+                den[j].flush(nf);
             }
             nf += 16;
         }
@@ -863,8 +882,8 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
         for (int j = 0; j < KA; ++j) {
             const int it = j * T + tid;
             if (it < nact) {
-                const float dn = mh_cascv_done(den[j]);
-                const float nm = mh_cascv_done(num[j]);
+                const float dn = den[j].done();
+                const float nm = num[j].done();
                 const float ratio = dn / (float)cnt[j];
                 s_pos[it] = (ratio > thr) ? 1 : 0;
                 s_loss[it] = nm / dn;
@@ -873,7 +892,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
     }
 }
 
-template <int T>
+template <int T, bool BIGV>
 // amdgpu_waves_per_eu(5): the register allocator stops at 96 VGPRs (it takes 109 unconstrained = 4 waves per SIMD); the
 // few values it spills are reloaded once per view.  Measured: 4 waves 1305 it/s, 5 waves 1345, 6 waves (80 VGPRs) 1328.
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5))) void mh_search3_kernel(MhViews vw, const float *__restrict__ offs, int S, int nrank,
@@ -907,11 +926,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5))) void mh_
     int ka = 0;
     for (int j = 0; j < 4; ++j) ka += (j * T + wave0 < nact) ? 1 : 0;
 #define MH_S3_ARGS vw, offs, S, rank_step, P0, P1x, P2, n, N, P1, thr, ori_c, base_idx, taps, vcnt, nact, tid, s_loss, s_pos, s_taps
-    if (ka == 4) mh_search_slices_lds<4, T>(MH_S3_ARGS);
-    else if (ka == 3) mh_search_slices_lds<3, T>(MH_S3_ARGS);
-    else if (ka == 2) mh_search_slices_lds<2, T>(MH_S3_ARGS);
-    else if (ka == 1) mh_search_slices_lds<1, T>(MH_S3_ARGS);
-    else mh_search_slices_lds<0, T>(MH_S3_ARGS);
+    if (ka == 4) mh_search_slices_lds<4, T, BIGV>(MH_S3_ARGS);
+    else if (ka == 3) mh_search_slices_lds<3, T, BIGV>(MH_S3_ARGS);
+    else if (ka == 2) mh_search_slices_lds<2, T, BIGV>(MH_S3_ARGS);
+    else if (ka == 1) mh_search_slices_lds<1, T, BIGV>(MH_S3_ARGS);
+    else mh_search_slices_lds<0, T, BIGV>(MH_S3_ARGS);
 #undef MH_S3_ARGS
     __syncthreads();
 
@@ -1272,9 +1291,13 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
             ord = order + N;
         }
         const uint8_t *vc = (variant == 5) ? nullptr : cnt;
-        if (variant >= 6)
-            hipLaunchKernelGGL((mh_search3_kernel<256>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts, N,
-                               P1, thr, ori_c, base_idx, base_val, taps, cnt, ord, line_ori, min_loss, high_conf,
+        if (variant >= 6 && vw.V > 256)
+            hipLaunchKernelGGL((mh_search3_kernel<256, true>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts,
+                               N, P1, thr, ori_c, base_idx, base_val, taps, cnt, ord, line_ori, min_loss, high_conf,
+                               best_sample, best_rank, best_s);
+        else if (variant >= 6)
+            hipLaunchKernelGGL((mh_search3_kernel<256, false>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step,
+                               pts, N, P1, thr, ori_c, base_idx, base_val, taps, cnt, ord, line_ori, min_loss, high_conf,
                                best_sample, best_rank, best_s);
         else if (variant <= 2 || variant == 5)
             hipLaunchKernelGGL((mh_search2_kernel<256, 0>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts,
