@@ -387,7 +387,7 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P):
         "roofline": {
             "kernel": "mh_search3_kernel<256>", "bound": "valu",
             "achieved": round(tf, 2), "peak": VALU_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TF, 4),
-            "traffic": None,
+            "traffic": prof.get("traffic", {}).get("mh_search3_kernel<256>"),
             "launch_ms": round(t_search, 4),
             "pair_evals_executed": int(pairs), "flop_per_pair_eval": FLOP_PER_PAIR,
             "gpair_per_s_executed": round(pairs / (t_search * 1e-3) / 1e9, 1),

@@ -67,12 +67,18 @@ facts = {"_comment": "facts from rocprofv3 passes of `python bench.py` (tools/pr
                      "profiles/%s_summary.txt); FETCH_SIZE doubled per MI355X_MICROARCH.md (16-B/lane reads), KiB*1024" % tag,
          "round": 2, "tag": tag, "workload": "60 views @ 1920x1080, 5000 points, patch 7"}
 lines += ["", "# Derived (MI355X_MICROARCH.md: FETCH_SIZE/WRITE_SIZE in KiB; FETCH_SIZE doubled for 16-B/lane reads):"]
-for k in ("mh_project_gather_kernel<7>", "mh_project_taps_kernel<7>"):
+names = sorted({k for k, c in pmc})
+for short, prefix in (("mh_project_gather_kernel<7>", "mh_project_gather_kernel<7"),
+                      ("mh_project_taps_kernel<7>", "mh_project_taps_kernel<7"),
+                      ("mh_search3_kernel<256>", "mh_search3_kernel<256")):
+    k = next((n for n in names if n.startswith(prefix)), None)
+    if k is None:
+        continue
     fs, ws = avg(k, "FETCH_SIZE"), avg(k, "WRITE_SIZE")
     if fs is None or ws is None:
         continue
     fetch, write = 2 * 1024 * fs, 1024 * ws
-    facts[k] = {"fetch_bytes": int(fetch), "write_bytes": int(write), "traffic_bytes": int(fetch + write)}
+    facts[short] = {"fetch_bytes": int(fetch), "write_bytes": int(write), "traffic_bytes": int(fetch + write)}
     lines.append("# %s: fetch = %.1f MB, write = %.1f MB, traffic = %.1f MB per launch; avg duration %.1f us"
                  % (k, fetch / 1e6, write / 1e6, (fetch + write) / 1e6, dur.get(k, float("nan"))))
     if k.startswith("mh_project_gather") and k in dur:
