@@ -167,12 +167,23 @@ def convert_numpy(tensor):
     return torch.squeeze(tensor, 0).permute(1, 2, 0).data.cpu().numpy()
 
 
+def _img_as_float(image):
+    """skimage.util.img_as_float for the inputs that occur here: uint8 -> float64 by a MULTIPLICATION with 1/255
+    (skimage/util/dtype.py `_convert`: np.multiply(image, 1. / imax_in, dtype=float64) -- not a division: the two differ
+    in the last bit for many codes); float32 / float64 arrays pass through with their precision."""
+    image = np.asarray(image)
+    if image.dtype == np.uint8:
+        return np.multiply(image, 1.0 / 255, dtype=np.float64)
+    return image if image.dtype in (np.float32, np.float64) else image.astype(np.float64)
+
+
 def difference_of_gaussians(image, low_sigma, high_sigma):
-    """skimage.filters.difference_of_gaussians (scikit-image 0.23, the reference's pin): float image,
-    gaussian(low) - gaussian(high), mode='nearest', truncate=4.0."""
+    """skimage.filters.difference_of_gaussians as the reference calls it (GaborFilter.py:192): img_as_float, two
+    scipy.ndimage.gaussian_filter passes (mode='nearest', truncate=4.0), their difference.  Pinned to the real
+    scikit-image by tests/golden/dog.npz (tools/gen_golden_dog.py)."""
     from scipy import ndimage as ndi
 
-    img = image.astype(np.float64) / 255.0 if image.dtype == np.uint8 else image.astype(np.float64)
+    img = _img_as_float(image)
     lo = ndi.gaussian_filter(img, low_sigma, mode="nearest", truncate=4.0)
     hi = ndi.gaussian_filter(img, high_sigma, mode="nearest", truncate=4.0)
     return lo - hi
@@ -201,12 +212,12 @@ def _correlate1d_nearest(x, w, radius, axis):
 
 def difference_of_gaussians_device(image, low_sigma, high_sigma, device):
     """difference_of_gaussians on the GPU in float64 with scipy's operation order (separable passes along axis 0
-    then 1); image: uint8 [H,W] (scaled by 1/255 like skimage's img_as_float) or float array."""
+    then 1); image: uint8 [H,W] (what the reference passes; scaled like skimage's img_as_float) or a float array, which is
+    filtered in float64 (scikit-image keeps a float32 image in float32 -- use difference_of_gaussians for that)."""
     img = np.asarray(image)
     x = torch.from_numpy(img).to(device)
-    # true IEEE division: torch's GPU kernels turn `tensor / python_scalar` into a multiplication by the reciprocal
-    x = x.to(torch.float64) / torch.tensor(255.0, dtype=torch.float64, device=device) if img.dtype == np.uint8 \
-        else x.to(torch.float64)
+    # img_as_float: uint8 codes are MULTIPLIED by the float64 constant 1/255 (see _img_as_float)
+    x = x.to(torch.float64) * (1.0 / 255) if img.dtype == np.uint8 else x.to(torch.float64)
     out = []
     for sigma in (low_sigma, high_sigma):
         w, r = _gaussian_kernel1d(sigma)

@@ -325,6 +325,13 @@ def test_gabor_to_pmvo_device_handoff_equals_file_roundtrip(tmp_path):
     a = difference_of_gaussians(imgs[0], 0.4, 10)
     b = difference_of_gaussians_device(imgs[0], 0.4, 10, DEV).cpu().numpy()
     assert np.array_equal(a, b)
+    # ... and both == the real scikit-image (tests/golden/dog.npz; 1e-15: numpy's exp in the Gaussian weights differs in the
+    # last bit between numpy versions)
+    zd = np.load(os.path.join(GOLDEN, "dog.npz"))
+    for k in ("stripes", "noise", "ramp", "small", "codes"):
+        d = difference_of_gaussians_device(zd["in_" + k], 0.4, 10, DEV).cpu().numpy()
+        assert np.array_equal(d, difference_of_gaussians(zd["in_" + k], 0.4, 10))
+        assert np.abs(d - zd["dog_" + k]).max() <= 1e-15
     ori, conf = orientation_maps_device(imgs, device=DEV)
     batch_generate(str(tmp_path), "capture_images")
     cam = {"v%d" % v: None for v in range(V)}
