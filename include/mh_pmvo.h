@@ -306,7 +306,14 @@ int mh_volume_reduce(mh_ctx *ctx, void *comm, int rank, int nranks, int root, fl
 int mh_mat_write_sparse(const char *path, const void *prefix, size_t prefix_bytes, size_t payload_bytes,
                         const long long *elem_index, const double *values, size_t n, int threads);
 
-/* Tuning knobs (e.g. "search_variant": threads per point in the search kernel; 0 = default). */
+/* Tuning knobs for A/B runs and cross-checks; every setting computes the same results (except "topk_order" 1, which
+ * returns tied confidences in view order).
+ *   "search_variant": 0 = default (6 when the list-length array of mh_forward_prepare is available);
+ *       6 / 7 mh_search3_kernel (tap lists staged in LDS) in work order / natural order; 1 / 2 mh_search2_kernel (broadcast
+ *       vector tap loads) in work order / natural order; 3 / 4 the same with scalar tap loads; 5 = 1 with the loop over all
+ *       views; 64, 128, 192, 256, 320, 1128, 1256, 2256: round 1's kernel with that many threads per point.
+ *   "topk_order": see mh_topk_views.   "taps_tile": points per workgroup of the tap preparation (64 / 32 / 16).
+ *   "gabor_variant": 0 v_pk_fma, 1 FP32-MFMA im2col (default), 2 v_pk_fma with a split bank. */
 int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus
