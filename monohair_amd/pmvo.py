@@ -690,9 +690,14 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
             os.makedirs(args.output_path + "/refine", exist_ok=True)
             held = (points, ori, loss)          # not written again before the join below
 
+            save_error = []
+
             def _save():
-                for name, arr in zip(("select_p", "select_o", "min_loss"), held):
-                    np.save(args.output_path + "/refine/%s.npy" % name, arr)
+                try:
+                    for name, arr in zip(("select_p", "select_o", "min_loss"), held):
+                        np.save(args.output_path + "/refine/%s.npy" % name, arr)
+                except BaseException as e:      # re-raised on the calling thread after the join
+                    save_error.append(e)
 
             saver = threading.Thread(target=_save)
             saver.start()
@@ -745,6 +750,8 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     T_shell.__exit__()
     if saver is not None:
         saver.join()
+        if save_error:
+            raise save_error[0]
     if is_root:
         np.save(args.output_path + "/refine/filter_unvisible.npy", select_filter_unvisible_points)
         np.save(args.output_path + "/refine/filter_unvisible_ori.npy", filter_unvisible_ori)
