@@ -241,8 +241,9 @@ int mh_render_depth(mh_ctx *ctx, const float *cam_host, const float *verts, int 
  * (infer_inner.py:60-73).  line_pts / line_tan [2*Nseg,3]: the reference's `Lines` / `tangent` vertex buffers (two
  * vertices per segment).  color_option 0 depth/2, 1 direction, 2 undirected direction (2 theta), 3 white, < 0: strands
  * not drawn; depth_option (mesh fragments) 0 depth/2, 1 black, 2 white; clear: background value of all three channels.
- * out [H,W,3] float32 in the shader's range, top-left origin.  A specified rasteriser (header of csrc/raster.hip);
- * parity with an OpenGL driver is unpinned. */
+ * out [H,W,3] float32 in the shader's range, top-left origin.  A specified rasteriser (header of csrc/raster.hip) that
+ * follows the GL specification's rules; pinned against a real OpenGL implementation (Google SwiftShader,
+ * tests/golden/gl_raster.npz) up to what GL leaves to the implementation (sub-pixel snapping, interpolation rounding). */
 size_t mh_render_strands_scratch_bytes(int Nv, int Nf, int Nseg, int H, int W);
 int mh_render_strands(mh_ctx *ctx, const float *cam_host, const float *verts, int Nv, const int32_t *faces, int Nf,
                       const float *line_pts, const float *line_tan, int Nseg, int H, int W, float pixel_center,
@@ -313,7 +314,9 @@ int mh_mat_write_sparse(const char *path, const void *prefix, size_t prefix_byte
  *       vector tap loads) in work order / natural order; 3 / 4 the same with scalar tap loads; 5 = 1 with the loop over all
  *       views; 64, 128, 192, 256, 320, 1128, 1256, 2256: round 1's kernel with that many threads per point.
  *   "topk_order": see mh_topk_views.   "taps_tile": points per workgroup of the tap preparation (64 / 32 / 16).
- *   "gabor_variant": 0 v_pk_fma, 1 FP32-MFMA im2col (default), 2 v_pk_fma with a split bank. */
+ *   "gabor_variant": 0 v_pk_fma, 1 FP32-MFMA im2col (default), 2 v_pk_fma with a split bank.
+ *   "line_rule" (mh_render_strands): 0 = OpenGL's diamond-exit rule (default), 1 = the pixel that holds a segment's end
+ *       point is drawn too (what Google SwiftShader does; changes the image: used to compare with that GL). */
 int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value);
 
 #ifdef __cplusplus

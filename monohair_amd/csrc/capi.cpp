@@ -30,6 +30,7 @@ struct mh_ctx {
     int search_variant = 0;
     int topk_order = 0;       // 0: torch.topk's CPU tie order (mh_topk_wave.h); 1: value desc, view asc; 2: mh_topk_order.h
     int taps_tile = 64;       // points per workgroup of mh_project_taps_kernel (64 / 32 / 16)
+    int line_rule = 0;        // strand renderer: 0 GL's diamond-exit, 1 every touched diamond (SwiftShader)
     int gabor_variant = 1;    // 0: v_pk_fma, one pixel/lane; 1: FP32-MFMA im2col (default); 2: v_pk_fma, split bank
     MhViews views() const { return MhViews{V, H, W, rec, mask, cams}; }
 };
@@ -52,7 +53,7 @@ size_t mh_voxel_group_scratch_bytes_impl(int);
 int mh_launch_voxel_group(const void *, int, const float *, int, const double *, double, const int32_t *, void *, size_t,
                           unsigned long long *, int32_t *, float *, hipStream_t);
 int mh_launch_render_strands(const float *, const float *, int, const int32_t *, int, const float *, const float *, int,
-                             int, int, int, int, int, int, float, void *, void *, unsigned long long *, int32_t *,
+                             int, int, int, int, int, int, int, float, void *, void *, unsigned long long *, int32_t *,
                              unsigned int *, float *, hipStream_t);
 int mh_launch_project_points(const float *, const float *, int, int, int, int32_t *, float *, uint8_t *, float *,
                              hipStream_t);
@@ -275,7 +276,8 @@ extern "C" int mh_render_strands(mh_ctx *ctx, const float *cam_host, const float
     char *lv = base + ((mh_render_scratch_bytes(Nv, Nf, H, W) + 63) / 64) * 64;
     const int off = (int)(pixel_center * 256.0f + 0.5f);
     return launched(mh_launch_render_strands(cam, verts, Nv, faces, Nf, line_pts, line_tan, Nseg, H, W, off, line_width,
-                                             color_option, depth_option, clear, vt, lv, zbuf, queue, qcount, out, st),
+                                             ctx->line_rule, color_option, depth_option, clear, vt, lv, zbuf, queue, qcount,
+                                             out, st),
                     "mh_render_strands");
 }
 
@@ -306,6 +308,10 @@ extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
     }
     if (!strcmp(key, "gabor_variant")) {
         ctx->gabor_variant = value;
+        return MH_OK;
+    }
+    if (!strcmp(key, "line_rule")) {
+        ctx->line_rule = value ? 1 : 0;
         return MH_OK;
     }
     return fail(MH_ERR_ARG, "mh_ctx_set_option: unknown key %s", key);

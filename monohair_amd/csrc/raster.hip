@@ -4,8 +4,9 @@
 // shader (:146-188): triangles of the hair + bust meshes are drawn with a depth test, the colour written is
 // depth/2 with depth = -z_camera, the clear colour is 1.0, the image is flipped to a top-left origin and saved
 // times 255.  OpenGL leaves sub-pixel snapping and attribute interpolation precision to the implementation, so
-// this is a specified rasteriser of its own (oracle/raster_oracle.c restates it; parity with a GL driver is
-// unpinned):
+// this is a specified rasteriser of its own (oracle/raster_oracle.c restates it).  It is pinned against a real OpenGL
+// implementation -- Google SwiftShader, tests/golden/gl_raster.npz, tools/gen_golden_gl.py -- up to those
+// implementation-defined parts:
 //   * vertex: (u, v, z) = Camera.projection (mh_cam_project), pixel = PMVO's own ndc->pixel map, so a depth
 //     map is sampled exactly where PMVO.project_points will look it up; snapped to 1/256 pixel;
 //   * coverage: exact int64 edge functions at the pixel centre (+centre offset), top-left fill rule -> every
@@ -199,15 +200,17 @@ extern "C" int mh_launch_render_depth(const float *cam, const float *verts, int 
 // Strand-segment renderer: the moderngl pass of Utils/Render_utils.py:269-307 (render_data) with
 // the StrandsObj line shader (:8-127) drawn over the BustObj mesh (:130-203) -- what infer_inner.py:60-73 feeds to
 // DeepMVSHair.  As for the depth maps, OpenGL leaves line rasterisation details to the driver, so this is a
-// SPECIFIED rasteriser (oracle/raster_oracle.c restates it in C; parity with a GL driver is unpinned):
+// SPECIFIED rasteriser (oracle/raster_oracle.c restates it in C; pinned against SwiftShader like the depth maps):
 //   * line vertices: window position / window z / 1/w exactly as the mesh vertices above; per vertex the shader's
 //     `Tangent_2d` = ndc(p + normalize(T) * 0.01) - ndc(p) in GL's clip convention (ndc_gl = -(u, v) of
 //     Camera.projection) and `depth` = -z_camera (:57-68);
-//   * a segment is x-major if |dx| >= |dy| (1/256 pixel units), else y-major; it produces one fragment column per
-//     sample position m = i*256 + off of the major axis inside the half-open interval [min, max) of its end points
-//     (the interval form of GL's diamond-exit rule); t = (m - A) / (B - A); the minor coordinate is interpolated
-//     linearly, the centre fragment is the pixel whose sample is nearest, and `width` fragments (ctx.line_width = 3,
-//     :30) are stacked around it in the minor direction (GL's wide-line rule);
+//   * a segment is x-major if |dx| >= |dy| (1/256 pixel units), else y-major; its fragments follow OpenGL's
+//     diamond-exit rule (GL 4.6 14.5.1, mh_seg_fragment below): one fragment in every column whose sample line the
+//     segment crosses (the pixel whose sample is nearest), one in the column of an end point that lies inside its pixel's
+//     diamond, none for the pixel whose diamond holds the END point; t = (m - A) / (B - A) clamped to the segment;
+//     `width` fragments (ctx.line_width = 3, :30) are stacked around it in the minor direction (GL's wide-line rule).
+//     Option "line_rule" 1 keeps the end pixel (every diamond touched): what Google SwiftShader draws -- with it this
+//     rasteriser reproduces a real GL's line coverage (tests/golden/gl_raster.npz, tools/gen_golden_gl.py);
 //   * window z linear in t, depth test LESS against the mesh and the other segments (same 64-bit key buffer; ties to
 //     the earlier primitive: mesh before strands, segments in buffer order);
 //   * attributes perspective-correct in t: a = ((1-t) a0/w0 + t a1/w1) / ((1-t)/w0 + t/w1);
@@ -257,9 +260,9 @@ __global__ __launch_bounds__(256) void mh_raster_linevert_kernel(const float *__
 }
 
 struct MhRSeg {
-    int A, B, ma, mb;   // major / minor coordinates of the two ends (1/256 pixel)
+    int A, B, ma, mb;   // major / minor coordinates of the two ends (1/256 pixel): a = start (p_a), b = end (p_b)
     int xmaj;
-    int i0, i1;         // fragment columns along the major axis
+    int i0, i1;         // pixel columns along the major axis that can hold a fragment
 };
 
 __device__ __forceinline__ bool mh_setup_seg(const MhRLVert &a, const MhRLVert &b, int H, int W, int off, MhRSeg &g) {
@@ -272,23 +275,50 @@ __device__ __forceinline__ bool mh_setup_seg(const MhRLVert &a, const MhRLVert &
     g.mb = g.xmaj ? b.y : b.x;
     if (g.A == g.B) return false;
     const int lo = min(g.A, g.B), hi = max(g.A, g.B);
-    g.i0 = max(-mh_floor_div(-(lo - off), MH_R_SUB), 0);                       // first sample >= lo
-    g.i1 = min(-mh_floor_div(-(hi - off), MH_R_SUB) - 1, (g.xmaj ? W : H) - 1);   // last sample < hi
+    g.i0 = max(mh_floor_div(lo - off + MH_R_SUB / 2, MH_R_SUB), 0);                        // the column that holds the lower end
+    g.i1 = min(mh_floor_div(hi - off + MH_R_SUB / 2, MH_R_SUB), (g.xmaj ? W : H) - 1);     // ... the upper end
     return g.i0 <= g.i1;
 }
+// parameter of the fragment of major index i: where the segment crosses the column's sample line, or the end point
+// itself for a column whose sample line the segment does not reach
 __device__ __forceinline__ float mh_seg_t(const MhRSeg &g, int i, int off) {
-    return (float)(i * MH_R_SUB + off - g.A) / (float)(g.B - g.A);
+    const float t = (float)(i * MH_R_SUB + off - g.A) / (float)(g.B - g.A);
+    return t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
 }
-// first of the `width` stacked fragments in the minor direction for major index i
-__device__ __forceinline__ int mh_seg_minor0(const MhRSeg &g, float t, int off, int width) {
+// nearest pixel in the minor direction at parameter t
+__device__ __forceinline__ int mh_seg_minor(const MhRSeg &g, float t, int off) {
     const float minor = (float)g.ma + t * (float)(g.mb - g.ma);
     const float jf = (minor - (float)off) / (float)MH_R_SUB;
-    const int jc = (int)__builtin_floorf(jf + 0.5f);
-    return jc - (width - 1) / 2;
+    return (int)__builtin_floorf(jf + 0.5f);
+}
+// Does column i of the segment produce a fragment (at minor pixel jc)?  OpenGL's diamond-exit rule (GL 4.6 14.5.1) for a
+// segment that is no steeper than 45 degrees in (major, minor): along such a segment |dM| + |dm| to a pixel centre is
+// smallest where the segment crosses the column's sample line, or at the end point if it does not reach that line, so
+//   * a column whose sample line is crossed has exactly one pixel whose diamond |dM| + |dm| < 1/2 is entered: the nearest;
+//   * the column of an end point that stops short of (or starts beyond) the sample line yields a fragment iff that end
+//     point lies inside the pixel's diamond;
+//   * rule 0 (GL): the pixel whose diamond contains the END point p_b produces no fragment ("exit");
+//     rule 1: it does -- every diamond the closed segment touches (what Google SwiftShader draws; used to pin this
+//     rasteriser to a real GL, tests/golden/gl_raster.npz).
+__device__ __forceinline__ bool mh_seg_fragment(const MhRSeg &g, int i, int off, int rule, int &jc) {
+    const int m = i * MH_R_SUB + off;
+    const int lo = min(g.A, g.B), hi = max(g.A, g.B);
+    jc = mh_seg_minor(g, mh_seg_t(g, i, off), off);
+    const int half = MH_R_SUB / 2;
+    if (m < lo || m > hi) {
+        const bool at_a = (m < lo) == (g.A < g.B);          // which end point this column belongs to
+        const int eM = at_a ? g.A : g.B, em = at_a ? g.ma : g.mb;
+        if (!(abs(eM - m) + abs(em - (jc * MH_R_SUB + off)) < half)) return false;
+    }
+    if (rule == 0) {
+        const int ib = mh_floor_div(g.B - off + half, MH_R_SUB), jb = mh_floor_div(g.mb - off + half, MH_R_SUB);
+        if (i == ib && jc == jb && abs(g.B - (ib * MH_R_SUB + off)) + abs(g.mb - (jb * MH_R_SUB + off)) < half) return false;
+    }
+    return true;
 }
 
 __global__ __launch_bounds__(256) void mh_raster_lines_kernel(const MhRLVert *__restrict__ lv, int Ns, int H, int W,
-                                                              int off, int width, unsigned prim_base,
+                                                              int off, int width, int rule, unsigned prim_base,
                                                               unsigned long long *__restrict__ zbuf) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= Ns) return;
@@ -297,11 +327,13 @@ __global__ __launch_bounds__(256) void mh_raster_lines_kernel(const MhRLVert *__
     if (!mh_setup_seg(a, b, H, W, off, g)) return;
     const int nminor = g.xmaj ? H : W;
     for (int i = g.i0; i <= g.i1; ++i) {
+        int jc;
+        if (!mh_seg_fragment(g, i, off, rule, jc)) continue;
         const float t = mh_seg_t(g, i, off);
         const float zw = a.zw + t * (b.zw - a.zw);
         if (!(zw >= 0.0f && zw <= 1.0f)) continue;
         const unsigned long long key = ((unsigned long long)__float_as_uint(zw) << 32) | (prim_base + (unsigned)s);
-        const int j0 = mh_seg_minor0(g, t, off, width);
+        const int j0 = jc - (width - 1) / 2;     // `width` fragments stacked in the minor direction (GL's wide lines)
         for (int k = 0; k < width; ++k) {
             const int j = j0 + k;
             if (j < 0 || j >= nminor) continue;
@@ -372,7 +404,8 @@ __global__ __launch_bounds__(256) void mh_raster_resolve_color_kernel(
 
 extern "C" int mh_launch_render_strands(const float *cam, const float *verts, int Nv, const int32_t *faces, int Nf,
                                         const float *lpts, const float *ltan, int Ns, int H, int W, int off, int width,
-                                        int color_option, int depth_option, float clear, MhRVert *vt, MhRLVert *lv,
+                                        int rule, int color_option, int depth_option, float clear, MhRVert *vt,
+                                        MhRLVert *lv,
                                         unsigned long long *zbuf, int32_t *queue, unsigned int *qcount, float *out,
                                         hipStream_t st) {
     hipError_t e = hipMemsetAsync(zbuf, 0xff, (size_t)H * W * sizeof(unsigned long long), st);
@@ -392,7 +425,7 @@ extern "C" int mh_launch_render_strands(const float *cam, const float *verts, in
         hipLaunchKernelGGL(mh_raster_linevert_kernel, dim3((2 * Ns + 255) / 256), dim3(256), 0, st, cam, lpts, ltan,
                            2 * Ns, (float)H, (float)W, lv);
         hipLaunchKernelGGL(mh_raster_lines_kernel, dim3((Ns + 255) / 256), dim3(256), 0, st, lv, Ns, H, W, off, width,
-                           (unsigned)(Nf > 0 && Nv > 0 ? Nf : 0), zbuf);
+                           rule, (unsigned)(Nf > 0 && Nv > 0 ? Nf : 0), zbuf);
     }
     hipLaunchKernelGGL(mh_raster_resolve_color_kernel, dim3((unsigned)(((size_t)H * W + 255) / 256)), dim3(256), 0, st,
                        vt, faces, Nv, (Nf > 0 && Nv > 0) ? Nf : 0, lv, H, W, off, color_option, depth_option, clear, zbuf,

@@ -7,8 +7,9 @@ Depth-map producer: the host mirror of the reference's
 The reference draws the COLMAP hair mesh and the bust mesh with moderngl/EGL and the BustObj shader (:146-188) and
 writes `render_depth/<view>.npy` = float32 [H,W,3], value (-z_cam / 2) * 255, background 255.  Here the same maps
 come from a specified HIP rasteriser (no OpenGL context needed) and can stay on the device: `render_depth_planes`
-returns a [V,H,W] tensor that `PMVO.from_planes` / `PMVO.from_u8` take as is.  Parity with an OpenGL driver is
-unpinned: sub-pixel snapping and fill-rule ties are implementation-defined in GL.
+returns a [V,H,W] tensor that `PMVO.from_planes` / `PMVO.from_u8` take as is.  The rasterisers follow the GL
+specification and are pinned against a real OpenGL implementation (SwiftShader) up to what GL leaves to the driver
+(sub-pixel snapping, interpolation rounding).
 """
 import ctypes
 import os
@@ -143,8 +144,10 @@ class StrandRenderer:
         self._ctx = _ctx_for(self.device)
         self._scratch = None
 
-    def render(self, cam_record, H, W, color_option, depth_option, clear, draw_strands=True, pixel_center=0.5, out=None):
-        """-> float32 [H,W,3] device tensor in the shader's range (0..1)."""
+    def render(self, cam_record, H, W, color_option, depth_option, clear, draw_strands=True, pixel_center=0.5, out=None,
+               line_width=None, line_rule=0):
+        """-> float32 [H,W,3] device tensor in the shader's range (0..1).  line_width defaults to the reference's 3;
+        line_rule 0 = OpenGL's diamond-exit rule, 1 = the end pixel of every segment too (the comparison with SwiftShader)."""
         H, W = int(H), int(W)
         Nv, Nf = self.verts.shape[0], self.faces.shape[0]
         need = int(self._L.mh_render_strands_scratch_bytes(Nv, Nf, self.nseg, H, W))
@@ -153,12 +156,17 @@ class StrandRenderer:
         if out is None:
             out = torch.empty((H, W, 3), dtype=torch.float32, device=self.device)
         rec = np.ascontiguousarray(cam_record, dtype=np.float32)
+        width = self.LINE_WIDTH if line_width is None else int(line_width)
         with torch.cuda.device(self.device):
-            _lib.check(self._L.mh_render_strands(
-                self._ctx, rec.ctypes.data_as(ctypes.c_void_p), _lib.ptr(self.verts), Nv, _lib.ptr(self.faces), Nf,
-                _lib.ptr(self.line_pts), _lib.ptr(self.line_tan), self.nseg, H, W, float(pixel_center), self.LINE_WIDTH,
-                int(color_option) if draw_strands else -1, int(depth_option), float(clear), _lib.ptr(self._scratch), need,
-                _lib.ptr(out), _lib.stream_ptr()), "mh_render_strands")
+            _lib.check(self._L.mh_ctx_set_option(self._ctx, b"line_rule", int(line_rule)), "line_rule")
+            try:
+                _lib.check(self._L.mh_render_strands(
+                    self._ctx, rec.ctypes.data_as(ctypes.c_void_p), _lib.ptr(self.verts), Nv, _lib.ptr(self.faces), Nf,
+                    _lib.ptr(self.line_pts), _lib.ptr(self.line_tan), self.nseg, H, W, float(pixel_center), width,
+                    int(color_option) if draw_strands else -1, int(depth_option), float(clear), _lib.ptr(self._scratch),
+                    need, _lib.ptr(out), _lib.stream_ptr()), "mh_render_strands")
+            finally:
+                self._L.mh_ctx_set_option(self._ctx, b"line_rule", 0)
         return out
 
 

@@ -403,9 +403,10 @@ def render_depth(cam_rec, verts, faces, H, W, pixel_center=0.5, channels=1):
 
 
 def render_strands(cam_rec, verts, faces, line_pts, line_tan, H, W, pixel_center=0.5, width=3, color_option=2,
-                   depth_option=1, clear=0.0):
+                   depth_option=1, clear=0.0, line_rule=0):
     """CPU statement of mh_render_strands (oracle/raster_oracle.c: ora_render_strands) -> (rgb [H,W,3] float32,
-    prim [H,W] int32 (-1 background, < len(faces) mesh, else len(faces)+segment), pixels owned by strands)."""
+    prim [H,W] int32 (-1 background, < len(faces) mesh, else len(faces)+segment), pixels owned by strands).
+    line_rule 0: GL's diamond-exit rule; 1: the end pixel of a segment is drawn too (the ctx option "line_rule")."""
     verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
     faces = np.ascontiguousarray(faces, dtype=np.int32).reshape(-1, 3)
     lp = np.ascontiguousarray(line_pts, dtype=np.float32).reshape(-1, 3)
@@ -417,10 +418,11 @@ def render_strands(cam_rec, verts, faces, line_pts, line_tan, H, W, pixel_center
     L = lib()
     L.ora_render_strands.restype = ctypes.c_long
     L.ora_render_strands.argtypes = [c_f, c_f, ctypes.c_int, c_i, ctypes.c_int, c_f, c_f, ctypes.c_int, ctypes.c_int,
-                                     ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_float, c_f, c_i]
     n = L.ora_render_strands(_p(rec), _p(verts), len(verts), _p(faces, c_i), len(faces), _p(lp), _p(lt), len(lp) // 2, H,
-                             W, pixel_center, width, color_option, depth_option, clear, _p(out), _p(prim, c_i))
+                             W, pixel_center, width, int(line_rule), color_option, depth_option, clear, _p(out),
+                             _p(prim, c_i))
     if n < 0:
         raise MemoryError("ora_render_strands")
     return out, prim, int(n)

@@ -4,10 +4,11 @@
  * What it stands in for: Utils/Render_utils.py:310-347 (render_bust_hair_depth) = moderngl draw of the hair and
  * bust meshes with the BustObj shader (:146-188: gl_Position = projection * transform * v, colour = -z_cam / 2),
  * DEPTH_TEST (:221), clear colour 1.0 (:239-240), vertical flip on read-back (:255-258), saved times 255 (:338).
- * PARITY UNPINNED against the reference here: the reference rasterises with an OpenGL driver (moderngl / EGL are
- * not installed; GL leaves sub-pixel snapping, fill-rule ties and interpolation precision to the implementation),
- * so this file pins the HIP kernel to a written specification and the tests pin the specification to the analytic
- * depth of a sphere.
+ * The reference rasterises with an OpenGL driver; GL leaves sub-pixel snapping, fill-rule ties and interpolation
+ * precision to the implementation, so this file pins the HIP kernel to a written specification, and the tests pin the
+ * specification (a) to the analytic depth of a sphere and (b) to images drawn by a real OpenGL implementation (Google
+ * SwiftShader: tests/golden/gl_raster.npz, tools/gen_golden_gl.py, tests/gl_checks.py) up to those parts.  Parity
+ * with the reference's own driver remains unpinned.
  *
  * Specification: vertices through Camera.projection (Utils/Camera_utils.py:38-58) and PMVO's ndc->pixel map
  * (PMVO.py:380-382), snapped to 1/256 pixel; coverage by exact integer edge functions at the pixel centre with a
@@ -133,9 +134,11 @@ long ora_render_depth(const float *cam, const float *verts, int Nv, const int32_
 /* ---------------------------------------------------------------------------------------------------------------
  * Strand-segment renderer: CPU statement of the second half of monohair_amd/csrc/raster.hip (mh_render_strands).
  * Stands in for Utils/Render_utils.py:269-307 (render_data) = StrandsObj (:8-127, GL_LINES of width 3, colour options
- * 0..3) drawn over BustObj (:130-203, depth options 0..2) with DEPTH_TEST.  PARITY UNPINNED against the reference
- * (no OpenGL here); the specification is in the header of that section of raster.hip:
- * half-open major-axis sample interval, `width` fragments stacked in the minor direction around the nearest pixel,
+ * 0..3) drawn over BustObj (:130-203, depth options 0..2) with DEPTH_TEST.  Pinned against a real OpenGL
+ * implementation (Google SwiftShader: tests/golden/gl_raster.npz, tools/gen_golden_gl.py) up to what GL leaves to the
+ * implementation; the specification is in the header of that section of raster.hip:
+ * GL's diamond-exit rule for the fragments of a segment (line_rule 1: the end pixel too, as SwiftShader draws), `width`
+ * fragments stacked in the minor direction around the nearest pixel,
  * window z linear in t (LESS, ties to the earlier primitive: mesh, then segments in order), perspective-correct
  * attributes, colours evaluated algebraically.  Every float operation below is written in the kernel's order. */
 typedef struct {
@@ -190,8 +193,8 @@ static int floor_div_i(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) 
 /* out[H,W,3]; prim[H,W] (may be NULL) receives the winning primitive per pixel (-1 background, < Nf mesh triangle,
  * else Nf + segment).  Returns the number of pixels owned by strand fragments, -1 on allocation failure. */
 long ora_render_strands(const float *cam, const float *verts, int Nv, const int32_t *faces, int Nf, const float *lpts,
-                        const float *ltan, int Ns, int H, int W, float pixel_center, int width, int color_option,
-                        int depth_option, float clear, float *out, int32_t *prim_out) {
+                        const float *ltan, int Ns, int H, int W, float pixel_center, int width, int line_rule,
+                        int color_option, int depth_option, float clear, float *out, int32_t *prim_out) {
     const int off = (int)(pixel_center * 256.0f + 0.5f);
     const int mesh = (Nv > 0 && Nf > 0);
     const int nf = mesh ? Nf : 0;
@@ -273,12 +276,29 @@ long ora_render_strands(const float *cam, const float *verts, int Nv, const int3
             const int ma = xmaj ? a->y : a->x, mb = xmaj ? b->y : b->x;
             if (A == B) continue;
             const int lo = A < B ? A : B, hi = A < B ? B : A;
-            int i0 = -floor_div_i(-(lo - off), 256), i1 = -floor_div_i(-(hi - off), 256) - 1;
+            /* OpenGL's diamond-exit rule (GL 4.6 14.5.1), see mh_seg_fragment in raster.hip: columns from the one holding
+             * the lower end point to the one holding the upper end point */
+            int i0 = floor_div_i(lo - off + 128, 256), i1 = floor_div_i(hi - off + 128, 256);
             const int nmaj = xmaj ? W : H, nmin = xmaj ? H : W;
             if (i0 < 0) i0 = 0;
             if (i1 > nmaj - 1) i1 = nmaj - 1;
             for (int i = i0; i <= i1; ++i) {
-                const float t = (float)(i * 256 + off - A) / (float)(B - A);
+                const int m = i * 256 + off;
+                float t = (float)(m - A) / (float)(B - A);
+                t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);     /* a column the segment does not reach: the end point */
+                {
+                    const float minor_ = (float)ma + t * (float)(mb - ma);
+                    const int jc_ = (int)floorf((minor_ - (float)off) / 256.0f + 0.5f);
+                    if (m < lo || m > hi) {                      /* fragment only if that end point is inside the diamond */
+                        const int at_a = (m < lo) == (A < B);
+                        const int eM = at_a ? A : B, em = at_a ? ma : mb;
+                        if (!(abs(eM - m) + abs(em - (jc_ * 256 + off)) < 128)) continue;
+                    }
+                    if (line_rule == 0) {                        /* no fragment for the pixel whose diamond holds p_b */
+                        const int ib = floor_div_i(B - off + 128, 256), jb = floor_div_i(mb - off + 128, 256);
+                        if (i == ib && jc_ == jb && abs(B - (ib * 256 + off)) + abs(mb - (jb * 256 + off)) < 128) continue;
+                    }
+                }
                 const float zw = a->zw + t * (b->zw - a->zw);
                 if (!(zw >= 0.0f && zw <= 1.0f)) continue;
                 const float minor = (float)ma + t * (float)(mb - ma);

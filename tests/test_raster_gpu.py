@@ -151,9 +151,50 @@ def test_strand_renderer_bit_exact_vs_spec(seed, H, W, pc):
             assert np.array_equal(got, want), (v, copt, dopt)
             if on:
                 assert owned > 0.01 * H * W and (prim >= 0).sum() > owned
+        # 1-pixel lines, and the end-pixel-included rule used for the comparison with SwiftShader
+        for width, rule in ((1, 0), (1, 1), (3, 1)):
+            want, _, _ = oracle.render_strands(rec[v], bv, bf, lp, lt, H, W, pc, width, 2, 1, 0.0, line_rule=rule)
+            got = r.render(rec[v], H, W, 2, 1, 0.0, pixel_center=pc, line_width=width, line_rule=rule).cpu().numpy()
+            assert np.array_equal(got, want), (v, width, rule)
     # strands only (no mesh) and nothing at all
     r2 = StrandRenderer(strands, np.zeros((0, 3)), np.zeros((0, 3), int), DEV)
     want, prim, _ = oracle.render_strands(rec[1], np.zeros((0, 3)), np.zeros((0, 3), np.int32), lp, lt, H, W, pc, 3, 2, 1, 0.0)
     assert np.array_equal(r2.render(rec[1], H, W, 2, 1, 0.0, pixel_center=pc).cpu().numpy(), want) and (prim >= 0).any()
     r3 = StrandRenderer([], np.zeros((0, 3)), np.zeros((0, 3), int), DEV)
     assert (r3.render(rec[1], 40, 30, 2, 1, 0.25).cpu().numpy() == 0.25).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# both rasterisers against a REAL OpenGL implementation (Google SwiftShader, tests/golden/gl_raster.npz written by
+# tools/gen_golden_gl.py in the build container): same thresholds as the oracle's CPU test (tests/test_raster_host.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_hip_rasterisers_against_real_opengl():
+    import os
+
+    from conftest import GOLDEN
+    from gl_checks import check_depth_against_gl, check_strands_against_gl
+    from monohair_amd.render import DepthRenderer, StrandRenderer
+
+    z = np.load(os.path.join(GOLDEN, "gl_raster.npz"))
+    H, W = int(z["H"]), int(z["W"])
+    cams = [dict(file="v%d" % i, pose=z["cam_pose"][i].tolist(), ndc_prj=z["cam_ndc"][i].tolist())
+            for i in range(len(z["cam_pose"]))]
+    rec = camera_records(cameras_from_list(cams))
+    two = DepthRenderer([(z["v1"], z["f1"]), (z["v2"], z["f2"])], DEV)
+    soup = DepthRenderer([(z["soup_v"], z["soup_f"])], DEV)
+    strands = StrandRenderer([], z["v1"], z["f1"], DEV)
+    strands.line_pts = torch.from_numpy(z["line_pts"]).to(DEV)
+    strands.line_tan = torch.from_numpy(z["line_tan"]).to(DEV)
+    strands.nseg = len(z["line_pts"]) // 2
+    for vi in z["views"]:
+        vi = int(vi)
+        check_depth_against_gl(two.render(rec[vi], H, W, pixel_center=0.5).cpu().numpy().reshape(H, W),
+                               z["depth_two_meshes_%d" % vi] * 255, smooth=True)
+        check_depth_against_gl(soup.render(rec[vi], H, W, pixel_center=0.5).cpu().numpy().reshape(H, W),
+                               z["depth_soup_%d" % vi] * 255, smooth=False)
+
+        def draw(copt, dopt, clear, rule):
+            return strands.render(rec[vi], H, W, copt, dopt, clear, pixel_center=0.5, line_width=1,
+                                  line_rule=rule).cpu().numpy()
+
+        check_strands_against_gl(draw, z, vi)

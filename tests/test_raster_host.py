@@ -1,5 +1,5 @@
-"""CPU: the depth-rasteriser specification (oracle/raster_oracle.c) against analytic answers.  The reference renders
-depth with an OpenGL driver (Utils/Render_utils.py:310-347), which cannot run here -> parity with it is unpinned; these
+"""CPU: the depth-rasteriser specification (oracle/raster_oracle.c) against analytic answers and against a real OpenGL
+implementation (last test).  The reference renders depth with an OpenGL driver (Utils/Render_utils.py:310-347); these
 tests pin the written specification: a finely tessellated sphere must reproduce the analytic ray-sphere depth of the
 synthetic scene, shared edges must be drawn exactly once, and depth ties go to the earlier primitive."""
 import math
@@ -158,3 +158,36 @@ def test_strand_colours_widths_and_depth_test(direction):
     lp2, lt2 = strand_line_buffers([strand - np.array([0, 0, 0.06])])
     _, p2, owned2 = oracle.render_strands(rec, QUAD, QUAD_F, lp2, lt2, H, W, 0.5, 3, 3, 1, 0.0)
     assert owned2 == 0 and (p2 >= 0).sum() == (prim >= 0).sum() - 0 * owned
+
+
+def test_oracle_rasterisers_against_real_opengl():
+    """The C statements of both rasterisers against images drawn by a real OpenGL implementation (Google SwiftShader,
+    tests/golden/gl_raster.npz, tools/gen_golden_gl.py): the reference's triangle pass with two intersecting meshes and
+    a random triangle soup, and its line pass over the bust in the three colourings (see tests/gl_checks.py for what is
+    compared and why the comparison has tolerances).  pixel_center 0.5 is GL's sample position: 0.0 does not fit."""
+    import os
+
+    from conftest import GOLDEN
+    from gl_checks import check_depth_against_gl, check_strands_against_gl
+
+    z = np.load(os.path.join(GOLDEN, "gl_raster.npz"))
+    H, W = int(z["H"]), int(z["W"])
+    cams = [dict(file="v%d" % i, pose=z["cam_pose"][i].tolist(), ndc_prj=z["cam_ndc"][i].tolist())
+            for i in range(len(z["cam_pose"]))]
+    rec = camera_records(cameras_from_list(cams))
+    v = np.concatenate([z["v1"], z["v2"]])
+    f = np.concatenate([z["f1"], z["f2"] + len(z["v1"])])
+    for vi in z["views"]:
+        vi = int(vi)
+        got, _ = oracle.render_depth(rec[vi], v, f, H, W, pixel_center=0.5)
+        check_depth_against_gl(got.reshape(H, W), z["depth_two_meshes_%d" % vi] * 255, smooth=True)
+        shifted, _ = oracle.render_depth(rec[vi], v, f, H, W, pixel_center=0.0)
+        assert ((shifted.reshape(H, W) < 255) != (z["depth_two_meshes_%d" % vi] < 1.0)).sum() > 100
+        got, _ = oracle.render_depth(rec[vi], z["soup_v"], z["soup_f"], H, W, pixel_center=0.5)
+        check_depth_against_gl(got.reshape(H, W), z["depth_soup_%d" % vi] * 255, smooth=False)
+
+        def draw(copt, dopt, clear, rule):
+            return oracle.render_strands(rec[vi], z["v1"], z["f1"], z["line_pts"], z["line_tan"], H, W, 0.5, 1, copt,
+                                         dopt, clear, line_rule=rule)[0]
+
+        check_strands_against_gl(draw, z, vi)
