@@ -126,7 +126,7 @@ def main():
             img, _ = run(exe, ss, tmp, W, H, (1, 1, 1), [tri(soup_v, soup_f)])
             out["depth_soup_%d" % vi] = img[..., 0]
             # render_data: strands over the bust; undirectional map (option 2 / bust black), mask (3), hair depth (0 / bust white)
-            for width in (1.0, 3.0):
+            for width in (1.0,):        # this GL's line width range is [1, 1]: a request for 3 (the reference's) is clamped
                 tag = "w%d_%d" % (int(width), vi)
                 img, _ = run(exe, ss, tmp, W, H, (0, 0, 0), [tri(v1, f1, 1), lines(2, width)])
                 out["strand_color_" + tag] = img
