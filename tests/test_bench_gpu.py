@@ -30,7 +30,7 @@ def test_single_gpu_line_and_rooflines_of_the_timed_kernels():
     d = run_bench(SMALL)
     assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["steps"] == 3 and d["unit"] == "iterations/s"
     rf = d["roofline"]
-    assert rf["kernel"].startswith("mh_search2_kernel") and rf["bound"] == "valu" and rf["peak"] == 157.3
+    assert rf["kernel"].startswith("mh_search3_kernel") and rf["bound"] == "valu" and rf["peak"] == 157.3
     assert 0 < rf["pair_evals_executed"] <= rf["pair_evals_nominal"]
     # frac must be recomputable from the line itself
     assert abs(rf["pair_evals_executed"] * rf["flop_per_pair_eval"] / (rf["launch_ms"] * 1e-3) / 1e12 - rf["achieved"]) < 0.05
