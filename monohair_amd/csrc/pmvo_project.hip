@@ -399,13 +399,20 @@ __global__ __launch_bounds__(256) void mh_project_taps_kernel(MhViews vw, const 
         while (nl < npts && s_vis[nl] == -1.0f) nl += 4;
         return nl;
     };
+    // The kernel is bound by memory-level parallelism (8192 resident waves x one 784-byte patch gather in flight each at
+    // ~3 us of loaded HBM latency = the 2.3 TB/s it reached with a one-point look-ahead): the gathers of the wave's next
+    // THREE visible points are in flight while the current one is processed.
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     int cur = next_visible(wave);
-    float4 qcur = make_float4(0.f, 0.f, 0.f, 0.f);
+    int n1 = next_visible(cur + 4), n2 = next_visible(n1 + 4);
+    float4 qcur = zero4, q1 = zero4, q2 = zero4;
     if (cur < npts && lane < P) qcur = gather(cur, lane);
+    if (n1 < npts && lane < P) q1 = gather(n1, lane);
+    if (n2 < npts && lane < P) q2 = gather(n2, lane);
     while (cur < npts) {
-        const int nxt = next_visible(cur + 4);
-        float4 qnxt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (nxt < npts && lane < P) qnxt = gather(nxt, lane);
+        const int n3 = next_visible(n2 + 4);
+        float4 q3 = zero4;
+        if (n3 < npts && lane < P) q3 = gather(n3, lane);
         const size_t vn = (size_t)v * N + n0 + cur;
         float4 *__restrict__ out = taps + vn * (P + 1);
         for (int b = lane; b < 256; b += MH_WAVE) s_first[wave][b] = 0xffffffffu;
@@ -465,8 +472,8 @@ __global__ __launch_bounds__(256) void mh_project_taps_kernel(MhViews vw, const 
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        cur = nxt;
-        qcur = qnxt;
+        cur = n1, n1 = n2, n2 = n3;
+        qcur = q1, q1 = q2, q2 = q3;
     }
 }
 
