@@ -191,3 +191,47 @@ def test_oracle_rasterisers_against_real_opengl():
                                          dopt, clear, line_rule=rule)[0]
 
         check_strands_against_gl(draw, z, vi)
+
+
+def test_line_rule_known_answers():
+    """The fragments of single horizontal segments, start x0 = 5 + f0, end x1 = 12 + f1 (GL window coordinates, pixel
+    centres at +0.5).  line_rule 1 = every diamond |dx| + |dy| < 1/2 the closed segment touches -- the columns below are
+    what Google SwiftShader drew for these segments (probed with tools/gl_ref; exact diamond-boundary cases left out);
+    line_rule 0 = OpenGL 4.6 14.5.1: the same minus the pixel whose diamond contains the END point."""
+    H = W = 32
+    cam = synth.make_cameras(20, H, W, scale=1.0)[0]
+    rec = camera_records(cameras_from_list([cam]))[0]
+    c2w = np.array(cam["pose"], np.float64)
+    fx, fy, cx, cy = cam["ndc_prj"]
+
+    def world(col, row, depth=1.0):          # the 3D point that projects to pixel coordinates (col, row)
+        z = -depth
+        u, v = 1.0 - 2.0 * col / W, 2.0 * row / H - 1.0
+        x, y = (u - cx) * z / fx, (v - cy) * z / fy
+        return (c2w @ np.array([x, y, z, 1.0]))[:3]
+
+    def columns(x0, x1, y_gl, rule):
+        row = H - y_gl                        # image rows run downwards, GL's y upwards
+        p = np.stack([world(x0, row), world(x1, row)]).astype(np.float32)
+        t = np.stack([p[1] - p[0]] * 2).astype(np.float32)
+        img, prim, _ = oracle.render_strands(rec, np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32), p, t, H, W,
+                                             0.5, 1, 3, 1, 0.0, line_rule=rule)
+        rows, cols = np.nonzero(prim >= 0)
+        assert len(set(rows.tolist())) <= 1 and (not len(rows) or rows[0] == int(np.floor(row)))
+        return (int(cols.min()), int(cols.max())) if len(cols) else None
+
+    # through the pixel centres (y = 10.5): the diamonds reach the pixel borders on this line
+    for f0, first in ((0.1, 5), (0.25, 5), (0.45, 5), (0.55, 5), (0.7, 5), (0.9, 5)):
+        for f1, last_touch, last_exit in ((0.1, 12, 11), (0.25, 12, 11), (0.45, 12, 11), (0.55, 12, 11), (0.9, 12, 11)):
+            assert columns(5 + f0, 12 + f1, 10.5, 1) == (first, last_touch), (f0, f1)
+            assert columns(5 + f0, 12 + f1, 10.5, 0) == (first, last_exit), (f0, f1)
+    # 0.2 below the centres (y = 10.3): the diamond of pixel i is cut at i + 0.2 .. i + 0.8
+    for f0, first in ((0.1, 5), (0.25, 5), (0.45, 5), (0.55, 5), (0.7, 5), (0.9, 6)):
+        for f1, last_touch, last_exit in ((0.1, 11, 11), (0.25, 12, 11), (0.45, 12, 11), (0.55, 12, 11), (0.7, 12, 11),
+                                          (0.9, 12, 12)):
+            assert columns(5 + f0, 12 + f1, 10.3, 1) == (first, last_touch), (f0, f1)
+            assert columns(5 + f0, 12 + f1, 10.3, 0) == (first, last_exit), (f0, f1)
+    # drawn backwards, the roles of the ends swap: the start pixel stays, the end pixel (now on the left) goes
+    assert columns(12.45, 5.45, 10.5, 1) == (5, 12) and columns(12.45, 5.45, 10.5, 0) == (6, 12)
+    # a segment inside one diamond: touched, but not left
+    assert columns(8.4, 8.6, 10.5, 1) == (8, 8) and columns(8.4, 8.6, 10.5, 0) is None
