@@ -31,6 +31,7 @@ struct mh_ctx {
     int topk_order = 0;       // 0: torch.topk's CPU tie order (mh_topk_wave.h); 1: value desc, view asc; 2: mh_topk_order.h
     int taps_tile = 64;       // points per workgroup of mh_project_taps_kernel (64 / 32 / 16)
     int line_rule = 0;        // strand renderer: 0 GL's diamond-exit, 1 every touched diamond (SwiftShader)
+    int raster_subpixel_bits = 8;   // both rasterisers: window positions snapped to 2^-bits pixel (SwiftShader: 4)
     int gabor_variant = 1;    // 0: v_pk_fma, one pixel/lane; 1: FP32-MFMA im2col (default); 2: v_pk_fma, split bank
     MhViews views() const { return MhViews{V, H, W, rec, mask, cams}; }
 };
@@ -41,7 +42,7 @@ int mh_launch_pack_view(float4 *, float *, const float *, int, const float *, co
                         size_t, hipStream_t);
 int mh_launch_pack_view_u8(float4 *, float *, const float *, int, const uint8_t *, const uint8_t *, const uint8_t *,
                            const float4 *, size_t, hipStream_t);
-int mh_launch_render_depth(const float *, const float *, int, const int32_t *, int, int, int, int, void *,
+int mh_launch_render_depth(const float *, const float *, int, const int32_t *, int, int, int, int, int, void *,
                            unsigned long long *, int32_t *, unsigned int *, float *, int, hipStream_t);
 size_t mh_grid_scratch_bytes_impl(int);
 size_t mh_sort_scratch_bytes_impl(int);
@@ -53,7 +54,7 @@ size_t mh_voxel_group_scratch_bytes_impl(int);
 int mh_launch_voxel_group(const void *, int, const float *, int, const double *, double, const int32_t *, void *, size_t,
                           unsigned long long *, int32_t *, float *, hipStream_t);
 int mh_launch_render_strands(const float *, const float *, int, const int32_t *, int, const float *, const float *, int,
-                             int, int, int, int, int, int, int, float, void *, void *, unsigned long long *, int32_t *,
+                             int, int, int, int, int, int, int, int, float, void *, void *, unsigned long long *, int32_t *,
                              unsigned int *, float *, hipStream_t);
 int mh_launch_project_points(const float *, const float *, int, int, int, int32_t *, float *, uint8_t *, float *,
                              hipStream_t);
@@ -241,8 +242,8 @@ extern "C" int mh_render_depth(mh_ctx *ctx, const float *cam_host, const float *
     unsigned long long *zbuf = (unsigned long long *)(base + 512 + render_vt_bytes(Nv));
     int32_t *queue = (int32_t *)((char *)zbuf + (size_t)H * W * sizeof(unsigned long long));
     const int off = (int)(pixel_center * 256.0f + 0.5f);
-    return launched(mh_launch_render_depth(cam, verts, Nv, faces, Nf, H, W, off, vt, zbuf, queue, qcount, out,
-                                           channels, st),
+    return launched(mh_launch_render_depth(cam, verts, Nv, faces, Nf, H, W, off, 1 << ctx->raster_subpixel_bits, vt, zbuf,
+                                           queue, qcount, out, channels, st),
                     "mh_render_depth");
 }
 
@@ -275,8 +276,8 @@ extern "C" int mh_render_strands(mh_ctx *ctx, const float *cam_host, const float
     int32_t *queue = (int32_t *)((char *)zbuf + (size_t)H * W * sizeof(unsigned long long));
     char *lv = base + ((mh_render_scratch_bytes(Nv, Nf, H, W) + 63) / 64) * 64;
     const int off = (int)(pixel_center * 256.0f + 0.5f);
-    return launched(mh_launch_render_strands(cam, verts, Nv, faces, Nf, line_pts, line_tan, Nseg, H, W, off, line_width,
-                                             ctx->line_rule, color_option, depth_option, clear, vt, lv, zbuf, queue, qcount,
+    return launched(mh_launch_render_strands(cam, verts, Nv, faces, Nf, line_pts, line_tan, Nseg, H, W, off,
+                                             1 << ctx->raster_subpixel_bits, line_width, ctx->line_rule, color_option, depth_option, clear, vt, lv, zbuf, queue, qcount,
                                              out, st),
                     "mh_render_strands");
 }
@@ -312,6 +313,11 @@ extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
     }
     if (!strcmp(key, "line_rule")) {
         ctx->line_rule = value ? 1 : 0;
+        return MH_OK;
+    }
+    if (!strcmp(key, "raster_subpixel_bits")) {
+        if (value < 4 || value > 8) return fail(MH_ERR_ARG, "mh_ctx_set_option: raster_subpixel_bits must be 4..8");
+        ctx->raster_subpixel_bits = value;
         return MH_OK;
     }
     return fail(MH_ERR_ARG, "mh_ctx_set_option: unknown key %s", key);

@@ -5,8 +5,8 @@
 // depth/2 with depth = -z_camera, the clear colour is 1.0, the image is flipped to a top-left origin and saved
 // times 255.  OpenGL leaves sub-pixel snapping and attribute interpolation precision to the implementation, so
 // this is a specified rasteriser of its own (oracle/raster_oracle.c restates it).  It is pinned against a real OpenGL
-// implementation -- Google SwiftShader, tests/golden/gl_raster.npz, tools/gen_golden_gl.py -- up to those
-// implementation-defined parts:
+// implementation -- Google SwiftShader, tests/golden/gl_raster.npz, tools/gen_golden_gl.py: on SwiftShader's sub-pixel
+// grid (option "raster_subpixel_bits" 4) the images have identical coverage and depth within 2e-3 of 255:
 //   * vertex: (u, v, z) = Camera.projection (mh_cam_project), pixel = PMVO's own ndc->pixel map, so a depth
 //     map is sampled exactly where PMVO.project_points will look it up; snapped to 1/256 pixel;
 //   * coverage: exact int64 edge functions at the pixel centre (+centre offset), top-left fill rule -> every
@@ -26,7 +26,7 @@ struct MhRVert {
 
 __global__ __launch_bounds__(256) void mh_raster_vertex_kernel(const float *__restrict__ cam,
                                                                const float *__restrict__ verts, int Nv, float Hf,
-                                                               float Wf, MhRVert *__restrict__ out) {
+                                                               float Wf, int snap, MhRVert *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Nv) return;
     float u, v, z, rowf, colf;
@@ -38,8 +38,9 @@ __global__ __launch_bounds__(256) void mh_raster_vertex_kernel(const float *__re
     r.zw = (zc / w) * 0.5f + 0.5f;
     r.iw = 1.0f / w;
     const bool ok = (w > 0.0f) && (__builtin_fabsf(colf) < 1.0e5f) && (__builtin_fabsf(rowf) < 1.0e5f);
-    r.x = ok ? (int)__builtin_rintf(colf * (float)MH_R_SUB) : MH_R_BAD;
-    r.y = ok ? (int)__builtin_rintf(rowf * (float)MH_R_SUB) : MH_R_BAD;
+    // 1/256 pixel units on a grid of 1/snap pixel (snap = 256 shipped; 16 = the 4 sub-pixel bits of SwiftShader)
+    r.x = ok ? (int)__builtin_rintf(colf * (float)snap) * (MH_R_SUB / snap) : MH_R_BAD;
+    r.y = ok ? (int)__builtin_rintf(rowf * (float)snap) * (MH_R_SUB / snap) : MH_R_BAD;
     out[i] = r;
 }
 
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void mh_raster_resolve_kernel(const MhRVert *_
 }
 
 extern "C" int mh_launch_render_depth(const float *cam, const float *verts, int Nv, const int32_t *faces, int Nf,
-                                      int H, int W, int off, MhRVert *vt, unsigned long long *zbuf, int32_t *queue,
+                                      int H, int W, int off, int snap, MhRVert *vt, unsigned long long *zbuf, int32_t *queue,
                                       unsigned int *qcount, float *out, int channels, hipStream_t st) {
     hipError_t e = hipMemsetAsync(zbuf, 0xff, (size_t)H * W * sizeof(unsigned long long), st);
     if (e != hipSuccess) return (int)e;
@@ -184,7 +185,7 @@ extern "C" int mh_launch_render_depth(const float *cam, const float *verts, int 
         e = hipMemsetAsync(qcount, 0, sizeof(unsigned int), st);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(mh_raster_vertex_kernel, dim3((Nv + 255) / 256), dim3(256), 0, st, cam, verts, Nv, (float)H,
-                           (float)W, vt);
+                           (float)W, snap, vt);
         hipLaunchKernelGGL(mh_raster_small_kernel, dim3((Nf + 255) / 256), dim3(256), 0, st, vt, faces, Nf, Nv, H, W,
                            off, zbuf, queue, qcount);
         const int blocks = (Nf + 3) / 4 < 4096 ? (Nf + 3) / 4 : 4096;
@@ -209,8 +210,9 @@ extern "C" int mh_launch_render_depth(const float *cam, const float *verts, int 
 //     segment crosses (the pixel whose sample is nearest), one in the column of an end point that lies inside its pixel's
 //     diamond, none for the pixel whose diamond holds the END point; t = (m - A) / (B - A) clamped to the segment;
 //     `width` fragments (ctx.line_width = 3, :30) are stacked around it in the minor direction (GL's wide-line rule).
-//     Option "line_rule" 1 keeps the end pixel (every diamond touched): what Google SwiftShader draws -- with it this
-//     rasteriser reproduces a real GL's line coverage (tests/golden/gl_raster.npz, tools/gen_golden_gl.py);
+//     Option "line_rule" 1 keeps the end pixel (every diamond touched): what Google SwiftShader draws -- with it and
+//     "raster_subpixel_bits" 4 this rasteriser draws exactly SwiftShader's line pixels (tests/golden/gl_raster.npz,
+//     tools/gen_golden_gl.py);
 //   * window z linear in t, depth test LESS against the mesh and the other segments (same 64-bit key buffer; ties to
 //     the earlier primitive: mesh before strands, segments in buffer order);
 //   * attributes perspective-correct in t: a = ((1-t) a0/w0 + t a1/w1) / ((1-t)/w0 + t/w1);
@@ -229,7 +231,7 @@ struct MhRLVert {
 __global__ __launch_bounds__(256) void mh_raster_linevert_kernel(const float *__restrict__ cam,
                                                                  const float *__restrict__ pts,
                                                                  const float *__restrict__ tans, int Nlv, float Hf,
-                                                                 float Wf, MhRLVert *__restrict__ out) {
+                                                                 float Wf, int snap, MhRLVert *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Nlv) return;
     const float p0 = pts[3 * i], p1 = pts[3 * i + 1], p2 = pts[3 * i + 2];
@@ -243,8 +245,9 @@ __global__ __launch_bounds__(256) void mh_raster_linevert_kernel(const float *__
     r.zw = (zc / w) * 0.5f + 0.5f;
     r.iw = 1.0f / w;
     const bool ok = (w > 0.0f) && (__builtin_fabsf(colf) < 1.0e5f) && (__builtin_fabsf(rowf) < 1.0e5f);
-    r.x = ok ? (int)__builtin_rintf(colf * (float)MH_R_SUB) : MH_R_BAD;
-    r.y = ok ? (int)__builtin_rintf(rowf * (float)MH_R_SUB) : MH_R_BAD;
+    // 1/256 pixel units on a grid of 1/snap pixel (snap = 256 shipped; 16 = the 4 sub-pixel bits of SwiftShader)
+    r.x = ok ? (int)__builtin_rintf(colf * (float)snap) * (MH_R_SUB / snap) : MH_R_BAD;
+    r.y = ok ? (int)__builtin_rintf(rowf * (float)snap) * (MH_R_SUB / snap) : MH_R_BAD;
     float s = t0 * t0;
     s = mh_fma(t1, t1, s);
     s = mh_fma(t2, t2, s);
@@ -275,7 +278,7 @@ __device__ __forceinline__ bool mh_setup_seg(const MhRLVert &a, const MhRLVert &
     g.mb = g.xmaj ? b.y : b.x;
     if (g.A == g.B) return false;
     const int lo = min(g.A, g.B), hi = max(g.A, g.B);
-    g.i0 = max(mh_floor_div(lo - off + MH_R_SUB / 2, MH_R_SUB), 0);                        // the column that holds the lower end
+    g.i0 = max(-mh_floor_div(MH_R_SUB / 2 - (lo - off), MH_R_SUB), 0);                     // the column that holds the lower end
     g.i1 = min(mh_floor_div(hi - off + MH_R_SUB / 2, MH_R_SUB), (g.xmaj ? W : H) - 1);     // ... the upper end
     return g.i0 <= g.i1;
 }
@@ -285,34 +288,56 @@ __device__ __forceinline__ float mh_seg_t(const MhRSeg &g, int i, int off) {
     const float t = (float)(i * MH_R_SUB + off - g.A) / (float)(g.B - g.A);
     return t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
 }
-// nearest pixel in the minor direction at parameter t
-__device__ __forceinline__ int mh_seg_minor(const MhRSeg &g, float t, int off) {
-    const float minor = (float)g.ma + t * (float)(g.mb - g.ma);
-    const float jf = (minor - (float)off) / (float)MH_R_SUB;
-    return (int)__builtin_floorf(jf + 0.5f);
+// index of the sample nearest to v (1/256 units, samples at i*256): exact halves to the lower / the upper index
+__device__ __forceinline__ int mh_half_down(int v) { return -mh_floor_div(MH_R_SUB / 2 - v, MH_R_SUB); }
+__device__ __forceinline__ int mh_half_up(int v) { return mh_floor_div(v + MH_R_SUB / 2, MH_R_SUB); }
+__device__ __forceinline__ long long mh_floor_div_ll(long long a, long long b) {   // b > 0
+    return (a >= 0) ? a / b : -((-a + b - 1) / b);
 }
-// Does column i of the segment produce a fragment (at minor pixel jc)?  OpenGL's diamond-exit rule (GL 4.6 14.5.1) for a
-// segment that is no steeper than 45 degrees in (major, minor): along such a segment |dM| + |dm| to a pixel centre is
-// smallest where the segment crosses the column's sample line, or at the end point if it does not reach that line, so
-//   * a column whose sample line is crossed has exactly one pixel whose diamond |dM| + |dm| < 1/2 is entered: the nearest;
-//   * the column of an end point that stops short of (or starts beyond) the sample line yields a fragment iff that end
-//     point lies inside the pixel's diamond;
-//   * rule 0 (GL): the pixel whose diamond contains the END point p_b produces no fragment ("exit");
-//     rule 1: it does -- every diamond the closed segment touches (what Google SwiftShader draws; used to pin this
-//     rasteriser to a real GL, tests/golden/gl_raster.npz).
+__device__ __forceinline__ bool mh_in_diamond(int dcol, int drow) {
+    const int s = abs(dcol) + abs(drow);
+    return s < MH_R_SUB / 2 || (s == MH_R_SUB / 2 && dcol > 0);
+}
+// Does major index i of the segment produce a fragment, and at which minor pixel (jc)?  OpenGL 4.6 14.5.1, literally: a
+// fragment for every pixel whose diamond |dx| + |dy| < 1/2 the segment intersects, except the one whose diamond contains
+// the END point p_b (rule 0), with the specification's tie-break -- "shift" the segment by (-e, -e^2) in window
+// coordinates, which in this image's coordinates (column right, row DOWN) is (-e in column, +e^2 in row):
+//   * a sample line is crossed on [lo, hi) of the columns, on (lo, hi] of the rows;
+//   * a coordinate exactly between two pixels belongs to the left column, to the lower row (larger index); where the
+//     segment crosses a COLUMN's sample line exactly between two rows, the row it is heading to decides (the column
+//     shift dominates), a horizontal segment goes to the lower row;
+//   * a point exactly on a diamond's boundary is inside iff it is on the right half (dx > 0).
+// For a segment no steeper than 45 degrees in (major, minor), |dM| + |dm| to a pixel centre is smallest where the segment
+// crosses the column's sample line or, if it does not reach it, at the end point: a crossed column has exactly one
+// fragment (the nearest pixel) and the column of an end point that stops short has one iff the end point is inside the
+// diamond.  Exact integer arithmetic.  rule 1: the pixel that holds p_b is kept -- what Google SwiftShader draws; with it
+// and 4 sub-pixel bits this rasteriser reproduces SwiftShader's lines pixel for pixel (tests/golden/gl_raster.npz).
 __device__ __forceinline__ bool mh_seg_fragment(const MhRSeg &g, int i, int off, int rule, int &jc) {
     const int m = i * MH_R_SUB + off;
-    const int lo = min(g.A, g.B), hi = max(g.A, g.B);
-    jc = mh_seg_minor(g, mh_seg_t(g, i, off), off);
-    const int half = MH_R_SUB / 2;
-    if (m < lo || m > hi) {
-        const bool at_a = (m < lo) == (g.A < g.B);          // which end point this column belongs to
-        const int eM = at_a ? g.A : g.B, em = at_a ? g.ma : g.mb;
-        if (!(abs(eM - m) + abs(em - (jc * MH_R_SUB + off)) < half)) return false;
+    const int A = g.A, B = g.B, ma = g.ma, mb = g.mb;
+    const int lo = min(A, B), hi = max(A, B);
+    const bool xmaj = g.xmaj != 0;
+    const bool crossed = xmaj ? (m >= lo && m < hi) : (m > lo && m <= hi);
+    if (crossed) {
+        // minor coordinate on the sample line, exactly: ma + (mb - ma) (m - A) / (B - A); nearest pixel
+        long long N = (long long)(ma - off) * (B - A) + (long long)(mb - ma) * (m - A), D = (long long)MH_R_SUB * (B - A);
+        if (D < 0) N = -N, D = -D;
+        const bool up = xmaj && ((long long)(mb - ma) * (B - A) >= 0);
+        jc = up ? (int)mh_floor_div_ll(2 * N + D, 2 * D) : (int)-mh_floor_div_ll(D - 2 * N, 2 * D);
+    } else {
+        const bool at_a = (m <= lo) == (A < B);   // the end point on this side of the sample line
+        const int eM = at_a ? A : B, em = at_a ? ma : mb;
+        const int ie = xmaj ? mh_half_down(eM - off) : mh_half_up(eM - off);
+        if (i != ie) return false;
+        jc = xmaj ? mh_half_up(em - off) : mh_half_down(em - off);
+        const int dM = eM - m, dm = em - (jc * MH_R_SUB + off);
+        if (!mh_in_diamond(xmaj ? dM : dm, xmaj ? dm : dM)) return false;
     }
     if (rule == 0) {
-        const int ib = mh_floor_div(g.B - off + half, MH_R_SUB), jb = mh_floor_div(g.mb - off + half, MH_R_SUB);
-        if (i == ib && jc == jb && abs(g.B - (ib * MH_R_SUB + off)) + abs(g.mb - (jb * MH_R_SUB + off)) < half) return false;
+        const int ib = xmaj ? mh_half_down(B - off) : mh_half_up(B - off);
+        const int jb = xmaj ? mh_half_up(mb - off) : mh_half_down(mb - off);
+        const int dM = B - (ib * MH_R_SUB + off), dm = mb - (jb * MH_R_SUB + off);
+        if (i == ib && jc == jb && mh_in_diamond(xmaj ? dM : dm, xmaj ? dm : dM)) return false;
     }
     return true;
 }
@@ -403,8 +428,8 @@ __global__ __launch_bounds__(256) void mh_raster_resolve_color_kernel(
 }
 
 extern "C" int mh_launch_render_strands(const float *cam, const float *verts, int Nv, const int32_t *faces, int Nf,
-                                        const float *lpts, const float *ltan, int Ns, int H, int W, int off, int width,
-                                        int rule, int color_option, int depth_option, float clear, MhRVert *vt,
+                                        const float *lpts, const float *ltan, int Ns, int H, int W, int off, int snap,
+                                        int width, int rule, int color_option, int depth_option, float clear, MhRVert *vt,
                                         MhRLVert *lv,
                                         unsigned long long *zbuf, int32_t *queue, unsigned int *qcount, float *out,
                                         hipStream_t st) {
@@ -414,7 +439,7 @@ extern "C" int mh_launch_render_strands(const float *cam, const float *verts, in
         e = hipMemsetAsync(qcount, 0, sizeof(unsigned int), st);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(mh_raster_vertex_kernel, dim3((Nv + 255) / 256), dim3(256), 0, st, cam, verts, Nv, (float)H,
-                           (float)W, vt);
+                           (float)W, snap, vt);
         hipLaunchKernelGGL(mh_raster_small_kernel, dim3((Nf + 255) / 256), dim3(256), 0, st, vt, faces, Nf, Nv, H, W,
                            off, zbuf, queue, qcount);
         const int blocks = (Nf + 3) / 4 < 4096 ? (Nf + 3) / 4 : 4096;
@@ -423,7 +448,7 @@ extern "C" int mh_launch_render_strands(const float *cam, const float *verts, in
     }
     if (Ns > 0 && color_option >= 0) {
         hipLaunchKernelGGL(mh_raster_linevert_kernel, dim3((2 * Ns + 255) / 256), dim3(256), 0, st, cam, lpts, ltan,
-                           2 * Ns, (float)H, (float)W, lv);
+                           2 * Ns, (float)H, (float)W, snap, lv);
         hipLaunchKernelGGL(mh_raster_lines_kernel, dim3((Ns + 255) / 256), dim3(256), 0, st, lv, Ns, H, W, off, width,
                            rule, (unsigned)(Nf > 0 && Nv > 0 ? Nf : 0), zbuf);
     }

@@ -385,6 +385,12 @@ def randomly_generate_segments(vol, thr, jitter):
     return voxel_seed_rounds(vol, flag, thr, jitter, 3), flag
 
 
+def set_subpixel_bits(bits):
+    """Sub-pixel grid of the two rasteriser statements: window positions are snapped to 2^-bits pixel (8 = shipped, 4 =
+    what Google SwiftShader uses; the ctx option "raster_subpixel_bits" of the HIP library).  Stays set until changed."""
+    lib().ora_set_subpixel_bits(int(bits))
+
+
 def render_depth(cam_rec, verts, faces, H, W, pixel_center=0.5, channels=1):
     """CPU statement of monohair_amd/csrc/raster.hip (oracle/raster_oracle.c) -> (depth [H,W(,channels)], covered)."""
     verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)

@@ -24,6 +24,17 @@ typedef struct {
     float zw, iw;
 } rvert;
 
+/* sub-pixel grid the window positions are snapped to: 2^-bits pixel, 4 <= bits <= 8 (8 = the shipped 1/256; OpenGL asks
+ * for at least 4, which is what Google SwiftShader uses -- the comparison with it, tests/gl_checks.py) */
+static float g_snap = 256.0f;
+static int g_snap_mul = 1;
+void ora_set_subpixel_bits(int bits) {
+    if (bits < 4) bits = 4;
+    if (bits > 8) bits = 8;
+    g_snap = (float)(1 << bits);
+    g_snap_mul = 256 >> bits;
+}
+
 static void project_vertex(const float *cam, const float *X, int H, int W, rvert *o) {
     const float *P = cam, *Q = cam + 16;
     float c[4], q[4];
@@ -48,8 +59,8 @@ static void project_vertex(const float *cam, const float *X, int H, int W, rvert
     o->zw = (q[2] / w) * 0.5f + 0.5f;
     o->iw = 1.0f / w;
     o->ok = (w > 0.0f) && (fabsf(col) < 1.0e5f) && (fabsf(row) < 1.0e5f);
-    o->x = o->ok ? (int)rintf(col * 256.0f) : INT_MIN;
-    o->y = o->ok ? (int)rintf(row * 256.0f) : INT_MIN;
+    o->x = o->ok ? (int)rintf(col * g_snap) * g_snap_mul : INT_MIN;     /* 1/256 pixel units, on a grid of 2^-bits pixel */
+    o->y = o->ok ? (int)rintf(row * g_snap) * g_snap_mul : INT_MIN;
 }
 
 static int64_t edge_fn(const rvert *s, const rvert *t, int px, int py) {
@@ -173,8 +184,8 @@ static void project_line_vertex(const float *cam, const float *X, const float *T
     o->zw = (zc / w) * 0.5f + 0.5f;
     o->iw = 1.0f / w;
     o->ok = (w > 0.0f) && (fabsf(col) < 1.0e5f) && (fabsf(row) < 1.0e5f);
-    o->x = o->ok ? (int)rintf(col * 256.0f) : INT_MIN;
-    o->y = o->ok ? (int)rintf(row * 256.0f) : INT_MIN;
+    o->x = o->ok ? (int)rintf(col * g_snap) * g_snap_mul : INT_MIN;     /* 1/256 pixel units, on a grid of 2^-bits pixel */
+    o->y = o->ok ? (int)rintf(row * g_snap) * g_snap_mul : INT_MIN;
     float s = T[0] * T[0];
     s = fmaf(T[1], T[1], s);
     s = fmaf(T[2], T[2], s);
@@ -189,6 +200,56 @@ static void project_line_vertex(const float *cam, const float *X, const float *T
 }
 
 static int floor_div_i(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+/* index of the sample nearest to v (1/256 units, samples at i*256): exact halves to the lower / the upper index */
+static int half_down_i(int v) { return -floor_div_i(128 - v, 256); }
+static int half_up_i(int v) { return floor_div_i(v + 128, 256); }
+static long long floor_div_ll(long long a, long long b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }   /* b > 0 */
+
+/* Does major index i of a segment produce a fragment, and at which minor pixel (*jc)?  (A, ma) = p_a, (B, mb) = p_b in
+ * (major, minor) coordinates, 1/256 pixel; xmaj: major = column.  OpenGL 4.6 14.5.1, literally: a fragment for every
+ * pixel whose diamond |dx| + |dy| < 1/2 the segment intersects, except the one whose diamond contains p_b (rule 0), with
+ * the specification's tie-break -- "shift" the segment by (-e, -e^2) in window coordinates, which in this image's
+ * coordinates (column right, row DOWN) is (-e in column, +e^2 in row):
+ *   - a sample line is crossed on [lo, hi) of the columns, on (lo, hi] of the rows;
+ *   - a coordinate exactly between two pixels belongs to the left column, to the lower row (larger index); where the
+ *     segment crosses a COLUMN's sample line exactly between two rows, the row it is heading to decides (the column shift
+ *     dominates), a horizontal segment goes to the lower row;
+ *   - a point exactly on a diamond's boundary is inside iff it is on the right half (dx > 0).
+ * For a segment no steeper than 45 degrees in (major, minor), |dM| + |dm| to a pixel centre is smallest where the segment
+ * crosses the column's sample line or, if it does not reach it, at the end point: so a crossed column has exactly one
+ * fragment (the nearest pixel) and the column of an end point that stops short has one iff the end point is inside the
+ * diamond.  Exact integer arithmetic.  rule 1: the pixel that holds p_b is kept (what Google SwiftShader draws). */
+static int in_diamond(int dcol, int drow) {
+    const int s = abs(dcol) + abs(drow);
+    return s < 128 || (s == 128 && dcol > 0);
+}
+static int seg_fragment(int xmaj, int A, int B, int ma, int mb, int i, int off, int rule, int *jc) {
+    const int m = i * 256 + off;
+    const int lo = A < B ? A : B, hi = A < B ? B : A;
+    const int crossed = xmaj ? (m >= lo && m < hi) : (m > lo && m <= hi);
+    if (crossed) {
+        /* minor coordinate on the sample line, exactly: ma + (mb - ma) (m - A) / (B - A); nearest pixel */
+        long long N = (long long)(ma - off) * (B - A) + (long long)(mb - ma) * (m - A), D = (long long)256 * (B - A);
+        if (D < 0) N = -N, D = -D;
+        const int up = xmaj ? ((long long)(mb - ma) * (B - A) >= 0) : 0;     /* tie: see above */
+        *jc = up ? (int)floor_div_ll(2 * N + D, 2 * D) : (int)-floor_div_ll(D - 2 * N, 2 * D);
+    } else {
+        const int at_a = (m < lo || (m == lo)) == (A < B);   /* the end point on this side of the sample line */
+        const int eM = at_a ? A : B, em = at_a ? ma : mb;
+        const int ie = xmaj ? half_down_i(eM - off) : half_up_i(eM - off);
+        if (i != ie) return 0;
+        *jc = xmaj ? half_up_i(em - off) : half_down_i(em - off);
+        const int dM = eM - m, dm = em - (*jc * 256 + off);
+        if (!in_diamond(xmaj ? dM : dm, xmaj ? dm : dM)) return 0;
+    }
+    if (rule == 0) {
+        const int ib = xmaj ? half_down_i(B - off) : half_up_i(B - off);
+        const int jb = xmaj ? half_up_i(mb - off) : half_down_i(mb - off);
+        const int dM = B - (ib * 256 + off), dm = mb - (jb * 256 + off);
+        if (i == ib && *jc == jb && in_diamond(xmaj ? dM : dm, xmaj ? dm : dM)) return 0;
+    }
+    return 1;
+}
 
 /* out[H,W,3]; prim[H,W] (may be NULL) receives the winning primitive per pixel (-1 background, < Nf mesh triangle,
  * else Nf + segment).  Returns the number of pixels owned by strand fragments, -1 on allocation failure. */
@@ -276,34 +337,19 @@ long ora_render_strands(const float *cam, const float *verts, int Nv, const int3
             const int ma = xmaj ? a->y : a->x, mb = xmaj ? b->y : b->x;
             if (A == B) continue;
             const int lo = A < B ? A : B, hi = A < B ? B : A;
-            /* OpenGL's diamond-exit rule (GL 4.6 14.5.1), see mh_seg_fragment in raster.hip: columns from the one holding
-             * the lower end point to the one holding the upper end point */
-            int i0 = floor_div_i(lo - off + 128, 256), i1 = floor_div_i(hi - off + 128, 256);
+            /* OpenGL's diamond-exit rule (GL 4.6 14.5.1) with the specification's tie-breaking shift: see seg_fragment */
+            int i0 = half_down_i(lo - off), i1 = floor_div_i(hi - off + 128, 256);
             const int nmaj = xmaj ? W : H, nmin = xmaj ? H : W;
             if (i0 < 0) i0 = 0;
             if (i1 > nmaj - 1) i1 = nmaj - 1;
             for (int i = i0; i <= i1; ++i) {
+                int jc;
+                if (!seg_fragment(xmaj, A, B, ma, mb, i, off, line_rule, &jc)) continue;
                 const int m = i * 256 + off;
                 float t = (float)(m - A) / (float)(B - A);
                 t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);     /* a column the segment does not reach: the end point */
-                {
-                    const float minor_ = (float)ma + t * (float)(mb - ma);
-                    const int jc_ = (int)floorf((minor_ - (float)off) / 256.0f + 0.5f);
-                    if (m < lo || m > hi) {                      /* fragment only if that end point is inside the diamond */
-                        const int at_a = (m < lo) == (A < B);
-                        const int eM = at_a ? A : B, em = at_a ? ma : mb;
-                        if (!(abs(eM - m) + abs(em - (jc_ * 256 + off)) < 128)) continue;
-                    }
-                    if (line_rule == 0) {                        /* no fragment for the pixel whose diamond holds p_b */
-                        const int ib = floor_div_i(B - off + 128, 256), jb = floor_div_i(mb - off + 128, 256);
-                        if (i == ib && jc_ == jb && abs(B - (ib * 256 + off)) + abs(mb - (jb * 256 + off)) < 128) continue;
-                    }
-                }
                 const float zw = a->zw + t * (b->zw - a->zw);
                 if (!(zw >= 0.0f && zw <= 1.0f)) continue;
-                const float minor = (float)ma + t * (float)(mb - ma);
-                const float jf = (minor - (float)off) / 256.0f;
-                const int jc = (int)floorf(jf + 0.5f);
                 const int j0 = jc - (width - 1) / 2;
                 const float wa = (1.0f - t) * a->iw, wb = t * b->iw;
                 const float den = wa + wb;

@@ -7,8 +7,17 @@ a few silhouette / line-edge pixels, values by the attribute gradient times a fr
 import numpy as np
 
 
+def check_depth_same_grid(mine, gl):
+    """With window positions snapped to SwiftShader's own sub-pixel grid (1/16 pixel) the triangle pass is the same image:
+    identical coverage -- silhouettes, shared edges, intersection lines of the depth test -- and values to 4e-3 of 255
+    (the rounding of two different interpolation formulas)."""
+    assert np.array_equal(mine < 255, gl < 255)
+    assert np.abs(mine - gl).max() < 4e-3
+
+
 def check_depth_against_gl(mine, gl, smooth):
-    """mine / gl: [H,W] depth images in the reference's units (value = -z_camera / 2 * 255, background 255)."""
+    """The shipped 1/256-pixel grid.  mine / gl: [H,W] depth images in the reference's units (value = -z_camera / 2 * 255,
+    background 255)."""
     hm, hg = mine < 255, gl < 255
     n = int(hg.sum())
     assert n > 5000
@@ -23,24 +32,26 @@ def check_depth_against_gl(mine, gl, smooth):
 
 
 def check_strands_against_gl(draw, z, vi):
-    """draw(color_option, depth_option, clear, line_rule) -> [H,W,3] image of 1-pixel lines over the bust;
+    """draw(color_option, depth_option, clear, line_rule, subpixel_bits) -> [H,W,3] image of 1-pixel lines over the bust;
     z: the fixture; vi: view index."""
     gm = z["strand_mask_w1_%d" % vi] > 0.5
     n = int(gm.sum())
     assert n > 500
-    touch = draw(3, 1, 0.0, 1)[..., 0] > 0.5                            # every touched diamond: SwiftShader's rule
-    exitr = draw(3, 1, 0.0, 0)[..., 0] > 0.5                            # OpenGL's diamond-exit rule (shipped)
-    assert int((touch != gm).sum()) <= 0.04 * n                         # measured 2.5-3.5 %: sub-pixel snapping
-    assert abs(int(touch.sum()) - n) <= 0.01 * n                        # no systematic surplus or deficit
-    # the specified rule draws a subset: it only drops pixels that hold the end point of a segment
-    assert not (exitr & ~touch).any() and 0 < int((touch & ~exitr).sum()) <= 0.04 * n
-    both = touch & gm
-    col = draw(2, 1, 0.0, 1)
-    d = np.abs(col[both] - z["strand_color_w1_%d" % vi][both]).max(1)
-    assert np.median(d) < 3e-3 and np.mean(d > 0.02) < 0.06             # undirected-orientation colours (measured 1e-3 / 0.04)
-    dep = draw(0, 2, 1.0, 1)[..., 0]
-    dd = np.abs(dep[both] - z["strand_depth_w1_%d" % vi][both])
-    assert np.median(dd) < 1e-3 and np.mean(dd > 0.01) < 0.05           # depth / 2 along the strands
-    # pixels of the bust that no strand covers are black / white exactly as in GL
-    bust_gl = (z["strand_depth_w1_%d" % vi] == 1.0) & ~gm
-    assert np.mean(dep[bust_gl & ~touch] == 1.0) > 0.999
+    # SwiftShader's grid (4 sub-pixel bits) and its end-pixel rule: the same line pixels, all of them
+    same = draw(3, 1, 0.0, 1, 4)[..., 0] > 0.5
+    assert np.array_equal(same, gm)
+    col = draw(2, 1, 0.0, 1, 4)
+    d = np.abs(col[gm] - z["strand_color_w1_%d" % vi][gm]).max(1)
+    # colours: where several sub-pixel segments of a strand (or two strands) share a pixel at almost the same depth, GL's
+    # 24-bit depth buffer and this rasteriser's float z may let different ones win: 2-4 % of the line pixels
+    assert np.median(d) < 2e-3 and np.mean(d > 0.02) < 0.05
+    dep = draw(0, 2, 1.0, 1, 4)[..., 0]
+    dd = np.abs(dep[gm] - z["strand_depth_w1_%d" % vi][gm])
+    assert np.median(dd) < 1e-4 and dd.max() < 0.02                    # depth / 2 along the strands
+    assert np.array_equal(dep == 1.0, z["strand_depth_w1_%d" % vi] == 1.0)     # background and white bust pixels
+    # OpenGL's own rule (line_rule 0) draws a subset: it only drops pixels that hold the end point of a segment
+    exit4 = draw(3, 1, 0.0, 0, 4)[..., 0] > 0.5
+    assert not (exit4 & ~same).any() and 0 < int((same & ~exit4).sum()) <= 0.04 * n
+    # the shipped grid (8 bits): the same picture up to the snapping
+    touch = draw(3, 1, 0.0, 1, 8)[..., 0] > 0.5
+    assert int((touch != gm).sum()) <= 0.04 * n and abs(int(touch.sum()) - n) <= 0.01 * n

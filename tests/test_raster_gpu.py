@@ -172,7 +172,9 @@ def test_hip_rasterisers_against_real_opengl():
     import os
 
     from conftest import GOLDEN
-    from gl_checks import check_depth_against_gl, check_strands_against_gl
+    from gl_checks import check_depth_against_gl, check_depth_same_grid, check_strands_against_gl
+    from monohair_amd import _lib
+    from monohair_amd.pmvo_utils import _ctx_for
     from monohair_amd.render import DepthRenderer, StrandRenderer
 
     z = np.load(os.path.join(GOLDEN, "gl_raster.npz"))
@@ -186,15 +188,30 @@ def test_hip_rasterisers_against_real_opengl():
     strands.line_pts = torch.from_numpy(z["line_pts"]).to(DEV)
     strands.line_tan = torch.from_numpy(z["line_tan"]).to(DEV)
     strands.nseg = len(z["line_pts"]) // 2
-    for vi in z["views"]:
-        vi = int(vi)
-        check_depth_against_gl(two.render(rec[vi], H, W, pixel_center=0.5).cpu().numpy().reshape(H, W),
-                               z["depth_two_meshes_%d" % vi] * 255, smooth=True)
-        check_depth_against_gl(soup.render(rec[vi], H, W, pixel_center=0.5).cpu().numpy().reshape(H, W),
-                               z["depth_soup_%d" % vi] * 255, smooth=False)
+    L, ctx = _lib.lib(), _ctx_for(torch.device(DEV))
 
-        def draw(copt, dopt, clear, rule):
-            return strands.render(rec[vi], H, W, copt, dopt, clear, pixel_center=0.5, line_width=1,
-                                  line_rule=rule).cpu().numpy()
+    def bits(b):
+        _lib.check(L.mh_ctx_set_option(ctx, b"raster_subpixel_bits", b))
 
-        check_strands_against_gl(draw, z, vi)
+    try:
+        for vi in z["views"]:
+            vi = int(vi)
+            bits(8)
+            check_depth_against_gl(two.render(rec[vi], H, W, pixel_center=0.5).cpu().numpy().reshape(H, W),
+                                   z["depth_two_meshes_%d" % vi] * 255, smooth=True)
+            check_depth_against_gl(soup.render(rec[vi], H, W, pixel_center=0.5).cpu().numpy().reshape(H, W),
+                                   z["depth_soup_%d" % vi] * 255, smooth=False)
+            bits(4)
+            check_depth_same_grid(two.render(rec[vi], H, W, pixel_center=0.5).cpu().numpy().reshape(H, W),
+                                  z["depth_two_meshes_%d" % vi] * 255)
+            check_depth_same_grid(soup.render(rec[vi], H, W, pixel_center=0.5).cpu().numpy().reshape(H, W),
+                                  z["depth_soup_%d" % vi] * 255)
+
+            def draw(copt, dopt, clear, rule, b):
+                bits(b)
+                return strands.render(rec[vi], H, W, copt, dopt, clear, pixel_center=0.5, line_width=1,
+                                      line_rule=rule).cpu().numpy()
+
+            check_strands_against_gl(draw, z, vi)
+    finally:
+        bits(8)

@@ -168,7 +168,7 @@ def test_oracle_rasterisers_against_real_opengl():
     import os
 
     from conftest import GOLDEN
-    from gl_checks import check_depth_against_gl, check_strands_against_gl
+    from gl_checks import check_depth_against_gl, check_depth_same_grid, check_strands_against_gl
 
     z = np.load(os.path.join(GOLDEN, "gl_raster.npz"))
     H, W = int(z["H"]), int(z["W"])
@@ -177,20 +177,30 @@ def test_oracle_rasterisers_against_real_opengl():
     rec = camera_records(cameras_from_list(cams))
     v = np.concatenate([z["v1"], z["v2"]])
     f = np.concatenate([z["f1"], z["f2"] + len(z["v1"])])
-    for vi in z["views"]:
-        vi = int(vi)
-        got, _ = oracle.render_depth(rec[vi], v, f, H, W, pixel_center=0.5)
-        check_depth_against_gl(got.reshape(H, W), z["depth_two_meshes_%d" % vi] * 255, smooth=True)
-        shifted, _ = oracle.render_depth(rec[vi], v, f, H, W, pixel_center=0.0)
-        assert ((shifted.reshape(H, W) < 255) != (z["depth_two_meshes_%d" % vi] < 1.0)).sum() > 100
-        got, _ = oracle.render_depth(rec[vi], z["soup_v"], z["soup_f"], H, W, pixel_center=0.5)
-        check_depth_against_gl(got.reshape(H, W), z["depth_soup_%d" % vi] * 255, smooth=False)
+    try:
+        for vi in z["views"]:
+            vi = int(vi)
+            oracle.set_subpixel_bits(8)
+            got, _ = oracle.render_depth(rec[vi], v, f, H, W, pixel_center=0.5)
+            check_depth_against_gl(got.reshape(H, W), z["depth_two_meshes_%d" % vi] * 255, smooth=True)
+            shifted, _ = oracle.render_depth(rec[vi], v, f, H, W, pixel_center=0.0)
+            assert ((shifted.reshape(H, W) < 255) != (z["depth_two_meshes_%d" % vi] < 1.0)).sum() > 100
+            got, _ = oracle.render_depth(rec[vi], z["soup_v"], z["soup_f"], H, W, pixel_center=0.5)
+            check_depth_against_gl(got.reshape(H, W), z["depth_soup_%d" % vi] * 255, smooth=False)
+            oracle.set_subpixel_bits(4)
+            got, _ = oracle.render_depth(rec[vi], v, f, H, W, pixel_center=0.5)
+            check_depth_same_grid(got.reshape(H, W), z["depth_two_meshes_%d" % vi] * 255)
+            got, _ = oracle.render_depth(rec[vi], z["soup_v"], z["soup_f"], H, W, pixel_center=0.5)
+            check_depth_same_grid(got.reshape(H, W), z["depth_soup_%d" % vi] * 255)
 
-        def draw(copt, dopt, clear, rule):
-            return oracle.render_strands(rec[vi], z["v1"], z["f1"], z["line_pts"], z["line_tan"], H, W, 0.5, 1, copt,
-                                         dopt, clear, line_rule=rule)[0]
+            def draw(copt, dopt, clear, rule, bits):
+                oracle.set_subpixel_bits(bits)
+                return oracle.render_strands(rec[vi], z["v1"], z["f1"], z["line_pts"], z["line_tan"], H, W, 0.5, 1, copt,
+                                             dopt, clear, line_rule=rule)[0]
 
-        check_strands_against_gl(draw, z, vi)
+            check_strands_against_gl(draw, z, vi)
+    finally:
+        oracle.set_subpixel_bits(8)
 
 
 def test_line_rule_known_answers():
