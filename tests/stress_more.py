@@ -20,7 +20,8 @@ from monohair_amd import synth  # noqa: E402
 from monohair_amd.camera import camera_records, cameras_from_list  # noqa: E402
 from monohair_amd.gabor import calOrientationGabor, gabor_bank  # noqa: E402
 from monohair_amd.pmvo_utils import GridKNN, compute_points_similarity, voxel_fit  # noqa: E402
-from monohair_amd.render import DepthRenderer  # noqa: E402
+from monohair_amd import _lib  # noqa: E402
+from monohair_amd.render import DepthRenderer, StrandRenderer, strand_line_buffers  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--minutes", type=float, default=3.0)
@@ -29,7 +30,7 @@ a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 DEV = "cuda:0"
 t_end = time.time() + a.minutes * 60
-count = {"knn": 0, "raster": 0, "gabor": 0, "medoid": 0, "voxel_fit": 0, "trace": 0}
+count = {"knn": 0, "raster": 0, "strands": 0, "gabor": 0, "medoid": 0, "voxel_fit": 0, "trace": 0}
 bad = []
 gabs = {v: calOrientationGabor(device=DEV, variant=v) for v in ("valu", "mfma", "split")}
 bank = gabor_bank()
@@ -76,6 +77,29 @@ while time.time() < t_end:
     if not np.array_equal(got, want):
         bad.append(("raster", H, W, nv, len(faces), pc))
     count["raster"] += 1
+    # ---- strand-segment renderer: random polylines (many sub-pixel segments, coordinates on pixel borders after the
+    # coarse snapping), both line rules, 1..3 pixel wide, 4..8 sub-pixel bits
+    strands = []
+    for _ in range(int(rng.integers(1, 60))):
+        m = int(rng.integers(2, 40))
+        p0 = rng.normal(0, 0.08, 3)
+        strands.append((p0 + np.cumsum(rng.normal(0, rng.uniform(0.0005, 0.01), (m, 3)), 0)).astype(np.float32))
+    lp, lt = strand_line_buffers(strands)
+    sr = StrandRenderer(strands, verts, faces[: int(rng.integers(0, 200))], DEV)
+    rule, width, sbits = int(rng.integers(0, 2)), int(rng.integers(1, 4)), int(rng.integers(4, 9))
+    copt, dopt = int(rng.integers(0, 4)), int(rng.integers(0, 3))
+    oracle.set_subpixel_bits(sbits)
+    _lib.check(_lib.lib().mh_ctx_set_option(sr._ctx, b"raster_subpixel_bits", sbits))
+    try:
+        want, _, _ = oracle.render_strands(rec, sr.verts.cpu().numpy(), sr.faces.cpu().numpy(), lp, lt, H, W, pc, width, copt,
+                                           dopt, 0.25, line_rule=rule)
+        got = sr.render(rec, H, W, copt, dopt, 0.25, pixel_center=pc, line_width=width, line_rule=rule).cpu().numpy()
+    finally:
+        oracle.set_subpixel_bits(8)
+        _lib.lib().mh_ctx_set_option(sr._ctx, b"raster_subpixel_bits", 8)
+    if not np.array_equal(got, want):
+        bad.append(("strands", H, W, len(lp), rule, width, sbits, copt, dopt, pc))
+    count["strands"] += 1
     # ---- Gabor bank, three kernels
     H, W = int(rng.integers(5, 90)), int(rng.integers(5, 120))
     img = (rng.normal(size=(H, W)) * rng.uniform(0.01, 3)).astype(np.float32)
