@@ -208,7 +208,8 @@ extern "C" int mh_launch_render_depth(const float *cam, const float *verts, int 
 //   * a segment is x-major if |dx| >= |dy| (1/256 pixel units), else y-major; its fragments follow OpenGL's
 //     diamond-exit rule (GL 4.6 14.5.1, mh_seg_fragment below): one fragment in every column whose sample line the
 //     segment crosses (the pixel whose sample is nearest), one in the column of an end point that lies inside its pixel's
-//     diamond, none for the pixel whose diamond holds the END point; t = (m - A) / (B - A) clamped to the segment;
+//     diamond, none for the pixel whose diamond holds the END point; the interpolation parameter of a fragment is GL's
+//     t = (p_r - p_a).(p_b - p_a) / |p_b - p_a|^2 with p_r the fragment's centre (mh_seg_t);
 //     `width` fragments (ctx.line_width = 3, :30) are stacked around it in the minor direction (GL's wide-line rule).
 //     Option "line_rule" 1 keeps the end pixel (every diamond touched): what Google SwiftShader draws -- with it and
 //     "raster_subpixel_bits" 4 this rasteriser draws exactly SwiftShader's line pixels (tests/golden/gl_raster.npz,
@@ -282,11 +283,13 @@ __device__ __forceinline__ bool mh_setup_seg(const MhRLVert &a, const MhRLVert &
     g.i1 = min(mh_floor_div(hi - off + MH_R_SUB / 2, MH_R_SUB), (g.xmaj ? W : H) - 1);     // ... the upper end
     return g.i0 <= g.i1;
 }
-// parameter of the fragment of major index i: where the segment crosses the column's sample line, or the end point
-// itself for a column whose sample line the segment does not reach
-__device__ __forceinline__ float mh_seg_t(const MhRSeg &g, int i, int off) {
-    const float t = (float)(i * MH_R_SUB + off - g.A) / (float)(g.B - g.A);
-    return t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+// interpolation parameter of the fragment at (major index i, minor index jc): GL 4.6 14.5.1,
+// t = (p_r - p_a) . (p_b - p_a) / |p_b - p_a|^2 with p_r the CENTRE of the fragment -- the foot of the perpendicular from
+// the pixel centre, not clamped to the segment (window z and the perspective-correct attributes both use it)
+__device__ __forceinline__ float mh_seg_t(const MhRSeg &g, int i, int jc, int off) {
+    const int m = i * MH_R_SUB + off, mn = jc * MH_R_SUB + off;
+    return (float)((long long)(m - g.A) * (g.B - g.A) + (long long)(mn - g.ma) * (g.mb - g.ma)) /
+           (float)((long long)(g.B - g.A) * (g.B - g.A) + (long long)(g.mb - g.ma) * (g.mb - g.ma));
 }
 // index of the sample nearest to v (1/256 units, samples at i*256): exact halves to the lower / the upper index
 __device__ __forceinline__ int mh_half_down(int v) { return -mh_floor_div(MH_R_SUB / 2 - v, MH_R_SUB); }
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256) void mh_raster_lines_kernel(const MhRLVert *__
     for (int i = g.i0; i <= g.i1; ++i) {
         int jc;
         if (!mh_seg_fragment(g, i, off, rule, jc)) continue;
-        const float t = mh_seg_t(g, i, off);
+        const float t = mh_seg_t(g, i, jc, off);
         const float zw = a.zw + t * (b.zw - a.zw);
         if (!(zw >= 0.0f && zw <= 1.0f)) continue;
         const unsigned long long key = ((unsigned long long)__float_as_uint(zw) << 32) | (prim_base + (unsigned)s);
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(256) void mh_raster_lines_kernel(const MhRLVert *__
 
 __global__ __launch_bounds__(256) void mh_raster_resolve_color_kernel(
     const MhRVert *__restrict__ vt, const int32_t *__restrict__ faces, int Nv, int Nf, const MhRLVert *__restrict__ lv,
-    int H, int W, int off, int color_option, int depth_option, float clear,
+    int H, int W, int off, int rule, int color_option, int depth_option, float clear,
     const unsigned long long *__restrict__ zbuf, float *__restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)H * W) return;
@@ -397,7 +400,11 @@ __global__ __launch_bounds__(256) void mh_raster_resolve_color_kernel(
             const MhRLVert a = lv[2 * s], b = lv[2 * s + 1];
             MhRSeg g;
             mh_setup_seg(a, b, H, W, off, g);
-            const float t = mh_seg_t(g, g.xmaj ? c : r, off);
+            // the fragment of the 1-pixel line in this pixel's column (a wide line stacks `width` copies of it)
+            const int mi = g.xmaj ? c : r;
+            int jc = g.xmaj ? r : c;
+            mh_seg_fragment(g, mi, off, rule, jc);
+            const float t = mh_seg_t(g, mi, jc, off);
             const float wa = (1.0f - t) * a.iw, wb = t * b.iw;
             const float den = wa + wb;
             const float depth = (wa * a.depth + wb * b.depth) / den;
@@ -453,7 +460,7 @@ extern "C" int mh_launch_render_strands(const float *cam, const float *verts, in
                            rule, (unsigned)(Nf > 0 && Nv > 0 ? Nf : 0), zbuf);
     }
     hipLaunchKernelGGL(mh_raster_resolve_color_kernel, dim3((unsigned)(((size_t)H * W + 255) / 256)), dim3(256), 0, st,
-                       vt, faces, Nv, (Nf > 0 && Nv > 0) ? Nf : 0, lv, H, W, off, color_option, depth_option, clear, zbuf,
-                       out);
+                       vt, faces, Nv, (Nf > 0 && Nv > 0) ? Nf : 0, lv, H, W, off, rule, color_option, depth_option, clear,
+                       zbuf, out);
     return (int)hipGetLastError();
 }

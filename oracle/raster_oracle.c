@@ -345,9 +345,11 @@ long ora_render_strands(const float *cam, const float *verts, int Nv, const int3
             for (int i = i0; i <= i1; ++i) {
                 int jc;
                 if (!seg_fragment(xmaj, A, B, ma, mb, i, off, line_rule, &jc)) continue;
-                const int m = i * 256 + off;
-                float t = (float)(m - A) / (float)(B - A);
-                t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);     /* a column the segment does not reach: the end point */
+                /* GL 4.6 14.5.1: t = (p_r - p_a) . (p_b - p_a) / |p_b - p_a|^2 with p_r the centre of the fragment -- the
+                 * foot of the perpendicular from the pixel centre, not clamped to the segment */
+                const int m = i * 256 + off, mn = jc * 256 + off;
+                const float t = (float)((long long)(m - A) * (B - A) + (long long)(mn - ma) * (mb - ma)) /
+                                (float)((long long)(B - A) * (B - A) + (long long)(mb - ma) * (mb - ma));
                 const float zw = a->zw + t * (b->zw - a->zw);
                 if (!(zw >= 0.0f && zw <= 1.0f)) continue;
                 const int j0 = jc - (width - 1) / 2;
