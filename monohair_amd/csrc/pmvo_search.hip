@@ -806,6 +806,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
                 }
             }
         };
+        __builtin_amdgcn_s_setprio(0);   // the tap loop: see mh_search3_kernel
         float4 ga[GRP], gb[GRP];
 #pragma unroll
         for (int u = 0; u < GRP; ++u) ga[u] = rec[2 + u];
@@ -820,6 +821,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
             process(gb, t);
             t += GRP;
         }
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < KA; ++j) {
             const float w = BC[j];   // (vis != -1) * best_conf
@@ -913,6 +915,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5))) void mh_
     __shared__ int s_ri[MH_MAX_RANKS];
     __shared__ int s_rh[MH_MAX_RANKS];
 
+    // Wave priority: everything that is not the tap loop -- prologue, staging, the per-view projection, the epilogue -- runs
+    // at priority 1, the tap loop at 0.  The tap loops saturate the VALU whatever the arbiter picks; the other phases are
+    // chains of dependent long-latency operations (loads, LDS, rcp / sqrt) whose waves should get their instruction in as
+    // soon as it is ready, so that they are back in a tap loop sooner: +5 % (the other way round: -8 %).
+    __builtin_amdgcn_s_setprio(1);
     const int tid = threadIdx.x;
     const int n = order ? order[blockIdx.x] : (int)blockIdx.x;
     const float P0 = pts[3 * n], P1x = pts[3 * n + 1], P2 = pts[3 * n + 2];
