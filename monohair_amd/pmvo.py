@@ -496,7 +496,9 @@ class PMVO:
         _lib.check(self._L.mh_replace_dissimilar(self._ctx, _lib.ptr(center), _lib.ptr(ori), float(threshold), N,
                                                  _lib.stream_ptr()), "mh_replace_dissimilar")
 
-    def _votes(self, points, want, visible_threshold=None):
+    def _votes(self, points, want, visible_threshold=None, raw=False):
+        """mask / visibility votes of mh_filter_points for the requested outputs; raw=True returns the kernel's uint8 0/1
+        arrays instead of bool tensors."""
         points = self._dev_points(points)
         N = points.shape[0]
         bufs = [torch.empty((N,), dtype=torch.uint8, device=self.device) if w else None for w in want]
@@ -505,6 +507,8 @@ class PMVO:
                                             float(self.conf_threshold), float(vt), _lib.ptr(bufs[0]),
                                             _lib.ptr(bufs[1]), _lib.ptr(bufs[2]), _lib.ptr(bufs[3]),
                                             _lib.stream_ptr()), "mh_filter_points")
+        if raw:
+            return points, bufs
         return points, [None if b is None else b.bool() for b in bufs]
 
     def filter_points(self, points):
@@ -542,8 +546,10 @@ def filter_negative_points(points, pmvo, args, step=30):
     pieces = [points[i * num_sub_p:(i + 1) * num_sub_p] for i in range(step)]
 
     def work(sub):
-        s, _, f = pmvo.filter_points(torch.from_numpy(sub).to(pmvo.device).type(torch.float))
-        return torch.stack([s, f], 1).to(torch.uint8)
+        # the two vote arrays as the kernel writes them (uint8); the numpy piece is cast to float32 on the host like every
+        # other entry point (PMVO.py:40), the gathered surface points of filter_points are not needed here
+        _, (s, f, _, _) = pmvo._votes(sub, (True, True, False, False), raw=True)
+        return torch.stack([s, f], 1)
 
     flags = mdist.map_chunks(pieces, work, pmvo.device, empty=lambda: torch.empty((0, 2), dtype=torch.uint8,
                                                                                device=pmvo.device))
@@ -576,8 +582,9 @@ def optimize(points, pmvo, args):
         st = streams[counter[0] % 2]
         counter[0] += 1
         with torch.cuda.stream(st):
-            p, o, l, h = pmvo.forward(sub)
-            out = torch.cat([p, o, l[:, None], h[:, None].to(torch.float32)], 1)
+            _, o, l, h = pmvo.forward(sub)
+            # (the points forward() returns are the float32 copy of its input: they do not travel back)
+            out = torch.cat([o, l[:, None], h[:, None].to(torch.float32)], 1)
         out.record_stream(main)
         return out
 
@@ -586,10 +593,12 @@ def optimize(points, pmvo, args):
             main.wait_stream(st)
 
     res = mdist.map_chunks(chunks, work, pmvo.device,
-                           empty=lambda: torch.empty((0, 8), dtype=torch.float32, device=pmvo.device), after=join)
+                           empty=lambda: torch.empty((0, 5), dtype=torch.float32, device=pmvo.device), after=join)
     res = torch.cat(res, 0).cpu().numpy()
-    select_points, select_ori, min_loss = res[:, 0:3], res[:, 3:6], res[:, 6]
-    high_conf_index = res[:, 7] > 0.5
+    pts_np = points if isinstance(points, np.ndarray) else torch.as_tensor(points).detach().cpu().numpy()
+    select_points = np.ascontiguousarray(pts_np[:res.shape[0]], dtype=np.float32)      # PMVO.py:40: .type(torch.float)
+    select_ori, min_loss = res[:, 0:3], res[:, 3]
+    high_conf_index = res[:, 4] > 0.5
     if mdist.rank() == 0:
         os.makedirs(args.save_root, exist_ok=True)
         np.save(args.save_root + "/select_p.npy", np.ascontiguousarray(select_points))
