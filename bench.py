@@ -191,6 +191,10 @@ def main():
     # pools are those of a running job whatever --warmup is (measured with --steps 20: --warmup 3 alone gives 1180-1220
     # it/s, --warmup 50 gives 1377; the first ~20 iterations after an idle period run 10-15 % slower).  Reported in
     # config.prewarm_steps.
+    import gc
+
+    gc.collect()
+    gc.freeze()          # no full collection of the set-up's objects (scene, chunks) in the middle of the timed region
     for i in range(PREWARM):
         step(i)
     for i in range(a.warmup):
@@ -606,6 +610,12 @@ def secondary_full_pass(dev, pm, cand, dist):
     # The first pass also pays for this process's first allocations of the pass's buffers (what a one-shot `python PMVO.py`
     # run sees, next to its seconds of start-up and map loading); three more give the steady state.  The host side of
     # refine (numpy, file writes) shares the box with other jobs: the median pass is reported, all totals are listed.
+    # everything this process has built so far (scenes, chunks, modules) goes to the collector's permanent generation: a
+    # full collection in the middle of a 10 ms stage is a 20-30 ms pause with that many live objects
+    import gc
+
+    gc.collect()
+    gc.freeze()
     first = one_pass(0)[0]
     runs = [one_pass(k) for k in (1, 2, 3)]
     runs.sort(key=lambda r: r[0]["total_s"])
