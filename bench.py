@@ -523,13 +523,13 @@ def secondary_quantized(a, dev, recs, cams, my):
     scene_q = synth.make_scene(a.views, a.height, a.width, device=dev, seed=0, quantize=True)
     pm = PMVO.from_planes(recs, scene_q["depth"], scene_q["ori"], scene_q["conf"], scene_q["mask"], device=dev,
                           patch_size=a.patch, visible_threshold=1, conf_threshold=a.conf_threshold, camera=cams)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, a.streams))]
+    streams = pm.side_streams(max(1, a.streams))
 
     def step(i):
         with torch.cuda.stream(streams[i % len(streams)]):
             return pm.forward(my[i % len(my)])
 
-    for i in range(a.warmup):
+    for i in range(PREWARM + a.warmup):     # same set-up iterations as the headline loop
         step(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
