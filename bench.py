@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--taps-tile", type=int, default=0, help="points per workgroup of the tap-preparation kernel (A/B)")
     ap.add_argument("--topk-order", type=int, default=-1, help="0 torch.topk's tie order (default), 1 index order (A/B)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the independent iterations alternate on (as monohair_amd.pmvo.optimize does)")
     return ap.parse_args()
 

@@ -351,7 +351,7 @@ class PMVO:
                                        _lib.ptr(idx), _lib.ptr(hc), None, _lib.stream_ptr()), "mh_prj_loss")
         return loss, idx, hc
 
-    def side_streams(self, n=2):
+    def side_streams(self, n=3):
         """n HIP streams owned by this object (created once; the per-stream search scratch is keyed by them)."""
         if len(getattr(self, "_side_streams", [])) < n:
             self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(n)]
@@ -570,16 +570,17 @@ def optimize(points, pmvo, args):
     step = points.shape[0] // num_sub_p + 1
     chunks = [points[i * num_sub_p:(i + 1) * num_sub_p] for i in range(step)]
 
-    # consecutive chunks are independent: alternate two HIP streams so that the tail of one chunk's search
-    # kernel (workgroups of points that see many views) overlaps the head of the next chunk
-    streams = pmvo.side_streams(2)     # kept on the object: their tap-list scratch (1.2 GB each) is reused
+    # consecutive chunks are independent: they rotate over three HIP streams so that the tail of one chunk's search
+    # kernel (workgroups of points that see many views) overlaps the front end and the head of the next chunks (two
+    # streams: -1 % on continuous maps, -5 % on 8-bit maps, where the front end is a third of an iteration)
+    streams = pmvo.side_streams(3)     # kept on the object: their tap-list scratch (1.2 GB each) is reused
     counter = [0]
     main = torch.cuda.current_stream()
     for st in streams:
         st.wait_stream(main)          # whatever produced the maps / points has finished
 
     def work(sub):
-        st = streams[counter[0] % 2]
+        st = streams[counter[0] % len(streams)]
         counter[0] += 1
         with torch.cuda.stream(st):
             _, o, l, h = pmvo.forward(sub)
