@@ -263,6 +263,7 @@ class PMVO:
 
     def _gather(self, uv, view, size=1, want_mask=False):
         uv = torch.as_tensor(uv).to(self.device).long().contiguous()
+        size = 2 * (int(size) // 2) + 1          # range(-(size // 2), size // 2 + 1): an even size is the next odd window
         N, P = uv.shape[0], size * size
         rec = torch.empty((N, P, 4), dtype=torch.float32, device=self.device)
         mask = torch.empty((N, P), dtype=torch.float32, device=self.device) if want_mask else None
@@ -287,11 +288,11 @@ class PMVO:
         return self._gather(uv, view, want_mask=True)[1][:, 0]
 
     def get_ori_patch(self, uv, view, size=1):
-        """PMVO.py:491-502 -> [N, size*size, 2]"""
+        """PMVO.py:491-502 -> [N, side*side, 2], side = 2 * (size // 2) + 1"""
         return self._gather(uv, view, size)[0][..., 0:2].contiguous()
 
     def get_c_patch(self, uv, view, size=1):
-        """PMVO.py:504-515 -> [N, size*size]"""
+        """PMVO.py:504-515 -> [N, side*side], side = 2 * (size // 2) + 1"""
         return self._gather(uv, view, size)[0][..., 2].contiguous()
 
     def compute_visible(self, depth, z):

@@ -110,7 +110,14 @@ def project_points(cam_rec, pts, H, W):
     return rc, zp, oob.astype(bool), pixf
 
 
+def _side(patch):
+    """the reference's tap window for a given patch_size: range(-(p // 2), p // 2 + 1) (PMVO.py:494-495), i.e. an even
+    size samples the next odd window"""
+    return 2 * (int(patch) // 2) + 1
+
+
 def visible_and_ori(views, pts, patch):
+    patch = _side(patch)
     pts = np.ascontiguousarray(pts, dtype=np.float32)
     N, V, P = pts.shape[0], views.V, patch * patch
     out = dict(
@@ -190,6 +197,7 @@ def prj_loss(D, ori_patch, conf_patch, vis, thr, want_all=False):
 
 def forward(views, pts, patch, thr, offsets, base_idx=None, base_val=None, nrank=10, rank_step=2, extra=False):
     """PMVO.forward (PMVO.py:39-78): returns (points, line_ori, min_loss, high_conf[, extras])."""
+    patch = _side(patch)
     pts = np.ascontiguousarray(pts, np.float32)
     offsets = np.ascontiguousarray(offsets, np.float32)
     N, S = pts.shape[0], offsets.shape[0]
@@ -212,6 +220,7 @@ def forward(views, pts, patch, thr, offsets, base_idx=None, base_val=None, nrank
 
 def refine_loss(views, pts, dirs, patch, thr, mul=0.005, div=4.0):
     """Loss of one given direction per point: the core of PMVO.refine (PMVO.py:86-90)."""
+    patch = _side(patch)
     pts = np.ascontiguousarray(pts, np.float32)
     dirs = np.ascontiguousarray(dirs, np.float32)
     N = pts.shape[0]
@@ -224,6 +233,7 @@ def refine_loss(views, pts, dirs, patch, thr, mul=0.005, div=4.0):
 
 def filter_votes(views, pts, patch, thr, vis_thr):
     """(surface_index, filter_index, unvisible_index, head_filter_votes) -- PMVO.py:402-480, :110-137."""
+    patch = _side(patch)
     pts = np.ascontiguousarray(pts, np.float32)
     N = pts.shape[0]
     outs = [np.empty(N, np.uint8) for _ in range(4)]

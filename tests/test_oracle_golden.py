@@ -6,7 +6,7 @@ import pytest
 import oracle
 from conftest import golden_records, golden_scene, load_golden, scene_views
 
-CASES = ["pmvo_small", "pmvo_mid", "pmvo_quant", "pmvo_views300", "pmvo_views300c"]
+CASES = ["pmvo_small", "pmvo_mid", "pmvo_quant", "pmvo_views300", "pmvo_views300c", "pmvo_patch9", "pmvo_patch4"]
 
 
 def eq_nan(a, b):

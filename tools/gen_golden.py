@@ -44,6 +44,12 @@ PMVO_CASES = {
     # of the gemv path a single-point view lands in -- this case can be held to the thresholds of the small ones
     "pmvo_views300c": dict(V=300, H=40, W=32, seed=2, scale=1.7, rings=3, quantize=False, res=32, N=48, patch=3,
                            thr=0.15, vis_thr=1.0, pt_seed=14, n_d=8, store_scene=True, cluster=4),
+    # the other patch sizes: 9 x 9 taps on 8-bit maps with the minimum number of views the reference accepts (20), and an
+    # EVEN patch size (range(-(4//2), 4//2+1) is the 5 x 5 window, PMVO.py:494-495) with another confidence threshold
+    "pmvo_patch9": dict(V=20, H=160, W=120, seed=5, scale=1.7, rings=1, quantize=True, res=48, N=96, patch=9,
+                        thr=0.2, vis_thr=1.0, pt_seed=21, n_d=6),
+    "pmvo_patch4": dict(V=22, H=128, W=96, seed=9, scale=1.7, rings=2, quantize=False, res=48, N=96, patch=4,
+                        thr=0.05, vis_thr=1.0, pt_seed=23, n_d=8),
 }
 
 
