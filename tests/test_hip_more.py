@@ -13,7 +13,7 @@ import oracle
 from conftest import GOLDEN, golden_records, golden_scene, load_golden, scene_views
 
 pytestmark = pytest.mark.gpu
-CASES = ["pmvo_small", "pmvo_mid", "pmvo_quant", "pmvo_views300", "pmvo_views300c"]
+CASES = ["pmvo_small", "pmvo_mid", "pmvo_quant", "pmvo_views300", "pmvo_views300c", "pmvo_patch9", "pmvo_patch4"]
 DEV = "cuda:0"
 
 

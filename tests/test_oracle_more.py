@@ -9,7 +9,7 @@ from scipy.spatial import KDTree
 import oracle
 from conftest import golden_records, golden_scene, load_golden, scene_views
 
-CASES = ["pmvo_small", "pmvo_mid", "pmvo_quant", "pmvo_views300", "pmvo_views300c"]
+CASES = ["pmvo_small", "pmvo_mid", "pmvo_quant", "pmvo_views300", "pmvo_views300c", "pmvo_patch9", "pmvo_patch4"]
 
 
 @pytest.fixture(scope="module", params=CASES)

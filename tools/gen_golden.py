@@ -47,9 +47,9 @@ PMVO_CASES = {
     # the other patch sizes: 9 x 9 taps on 8-bit maps with the minimum number of views the reference accepts (20), and an
     # EVEN patch size (range(-(4//2), 4//2+1) is the 5 x 5 window, PMVO.py:494-495) with another confidence threshold
     "pmvo_patch9": dict(V=20, H=160, W=120, seed=5, scale=1.7, rings=1, quantize=True, res=48, N=96, patch=9,
-                        thr=0.2, vis_thr=1.0, pt_seed=21, n_d=6),
+                        thr=0.2, vis_thr=2.0, pt_seed=21, n_d=6),
     "pmvo_patch4": dict(V=22, H=128, W=96, seed=9, scale=1.7, rings=2, quantize=False, res=48, N=96, patch=4,
-                        thr=0.05, vis_thr=1.0, pt_seed=23, n_d=8),
+                        thr=0.05, vis_thr=0.5, pt_seed=23, n_d=8),
 }
 
 
