@@ -315,3 +315,28 @@ def test_camera_tensor_utilities_match_the_oracle():
         camv = cam.reprojection(uv, z, to_world=False)
         assert camv.shape == (200, 4) and np.allclose(cam.camera2world(camv[:, :3]).numpy()[:, :3], pts, atol=1e-5)
     assert list(cams.values())[0].get_projection_matrix(2.0, 3.0, 0.1, -0.2).shape == (4, 4)
+
+
+def test_options_equal_the_reference_on_yaml_trees_and_command_lines(tmp_path):
+    """monohair_amd.options against the reference's own options.py (tests/golden/options.json, written by
+    tools/gen_golden_options.py from the imported reference): `_parent_` chains and lists of parents, nested overrides,
+    the --key=value / --flag / --flag! / --key= grammar with yaml-typed values, the seed -> run-name rule."""
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from monohair_amd import options
+
+    fx = json.load(open(os.path.join(GOLDEN, "options.json")))
+    for k, run in enumerate(fx["runs"]):
+        d = tmp_path / ("t%d" % k)
+        d.mkdir()
+        for fn, text in fx["trees"][run["tree"]].items():
+            (d / fn).write_text(text.replace("{DIR}", str(d)))
+        opt = options.set(options.parse_arguments(["--yaml=%s" % (d / "case")] + run["argv"]))
+        got = options.to_dict(opt)
+        want = dict(run["expect"])
+        for key in ("yaml", "device"):       # the path of this run; "cuda:<gpu>" where a GPU is visible
+            got.pop(key, None)
+            want.pop(key, None)
+        assert got == want, (run["tree"], run["argv"])
