@@ -340,3 +340,37 @@ def test_options_equal_the_reference_on_yaml_trees_and_command_lines(tmp_path):
             got.pop(key, None)
             want.pop(key, None)
         assert got == want, (run["tree"], run["argv"])
+
+
+def test_small_file_boundary_helpers_equal_the_reference(tmp_path):
+    """voxel <-> world, the .mat readers and the .hair reader / writers against the reference's own functions
+    (tests/golden/utils_small.npz, tools/gen_golden_utils.py): arrays and file bytes."""
+    import os
+
+    import scipy.io
+    import torch
+
+    from conftest import GOLDEN
+    from monohair_amd import pmvo_utils as U
+
+    z = np.load(os.path.join(GOLDEN, "utils_small.npz"))
+    assert np.array_equal(U.voxel_to_points(torch.from_numpy(z["vox_in"].copy())).numpy(), z["vox_to_points"])
+    assert np.array_equal(U.points_to_voxel(torch.from_numpy(z["pts_in"].copy())).numpy(), z["points_to_voxel"])
+    scipy.io.savemat(str(tmp_path / "Occ3D.mat"), {"Occ": z["mat_occ"]})
+    scipy.io.savemat(str(tmp_path / "Ori3D.mat"), {"Ori": z["mat_ori"]})
+    for flip in (0, 1):
+        occ = U.get_ground_truth_3D_occ(str(tmp_path / "Occ3D.mat"), flip=bool(flip))
+        ori = U.get_ground_truth_3D_ori(str(tmp_path / "Ori3D.mat"), flip=bool(flip))
+        assert occ.dtype == z["occ_flip%d" % flip].dtype and np.array_equal(occ, z["occ_flip%d" % flip])
+        assert ori.dtype == z["ori_flip%d" % flip].dtype and np.array_equal(ori, z["ori_flip%d" % flip])
+    strands = [z["strand%d" % k] for k in range(4)]
+    for t in (1, 0):
+        p = str(tmp_path / ("s%d.hair" % t))
+        U.save_hair_strands(p, [s.copy() for s in strands], z["bust_to_origin"], translate=bool(t))
+        assert np.array_equal(np.frombuffer(open(p, "rb").read(), np.uint8), z["hair_bytes_t%d" % t])
+        seg, pts = U.load_strand(p)
+        assert np.array_equal(np.array(seg), z["load_seg_t%d" % t])
+        assert pts.dtype == z["load_pts_t%d" % t].dtype and np.array_equal(pts, z["load_pts_t%d" % t])
+    p = str(tmp_path / "w.hair")
+    U.write_strand(np.concatenate(strands, 0), p, [len(s) for s in strands])
+    assert np.array_equal(np.frombuffer(open(p, "rb").read(), np.uint8), z["write_strand_bytes"])
