@@ -374,3 +374,36 @@ def test_small_file_boundary_helpers_equal_the_reference(tmp_path):
     p = str(tmp_path / "w.hair")
     U.write_strand(np.concatenate(strands, 0), p, [len(s) for s in strands])
     assert np.array_equal(np.frombuffer(open(p, "rb").read(), np.uint8), z["write_strand_bytes"])
+
+
+def test_camera_tensor_utilities_equal_the_reference():
+    """Camera.projection / uv2pixel / pixel2uv / reprojection / camera2world against the reference's own Camera class
+    (tests/golden/utils_small.npz).  Element-wise steps are bit-identical; the matrix products go through the host's
+    BLAS, whose last bit depends on the CPU the fixture was written on: 1e-6."""
+    import os
+
+    from conftest import GOLDEN
+    from monohair_amd.camera import cameras_from_list
+
+    z = np.load(os.path.join(GOLDEN, "utils_small.npz"))
+    H, W = 120, 90
+    cams = cameras_from_list([dict(file="v%d" % i, pose=z["cam_pose_c2w"][i].tolist(), ndc_prj=z["cam_ndc"][i].tolist())
+                              for i in range(len(z["cam_pose_c2w"]))])
+    P = torch.from_numpy(z["cam_points"])
+    for i in z["cam_views"]:
+        i = int(i)
+        cam = list(cams.values())[i]
+        uv, zz = cam.projection(P)
+        assert np.allclose(uv.numpy(), z["cam%d_uv" % i], rtol=0, atol=1e-6)
+        assert np.allclose(zz.numpy(), z["cam%d_z" % i], rtol=0, atol=1e-6)
+        ref_uv = torch.from_numpy(z["cam%d_uv" % i])
+        pix = cam.uv2pixel(ref_uv.clone(), [H, W], "cpu")
+        assert np.array_equal(pix.numpy(), z["cam%d_pix" % i])                     # element-wise: exact
+        back = cam.pixel2uv(torch.from_numpy(z["cam%d_pix" % i]).clone(), [H, W], "cpu")
+        assert np.array_equal(back.numpy(), z["cam%d_uvback" % i])
+        ref_z = torch.from_numpy(z["cam%d_z" % i])
+        assert np.allclose(cam.reprojection(ref_uv, ref_z, to_world=True).numpy(), z["cam%d_world" % i], rtol=0, atol=1e-6)
+        camv = cam.reprojection(ref_uv, ref_z, to_world=False)
+        assert np.allclose(camv.numpy(), z["cam%d_camv" % i], rtol=0, atol=1e-6)
+        c2w = cam.camera2world(torch.from_numpy(z["cam%d_camv" % i])[:, :3])
+        assert np.allclose(c2w.numpy(), z["cam%d_c2w" % i], rtol=0, atol=1e-6)

@@ -11,6 +11,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(1, ROOT)
 from ref_import import import_reference  # noqa: E402
 
 
@@ -49,6 +50,28 @@ def main():
         p = os.path.join(d, "w.hair")
         U.write_strand(np.concatenate(strands, 0), p, [len(s) for s in strands])
         out["write_strand_bytes"] = np.frombuffer(open(p, "rb").read(), np.uint8)
+    # Camera tensor utilities (Utils/Camera_utils.py:38-116) of three cameras of a synthetic rig
+    from monohair_amd import synth
+
+    H, W = 120, 90
+    cams = synth.make_cameras(24, H, W, scale=1.5, rings=2)
+    C = R["Camera_utils"]
+    P = rng.normal(0, 0.1, (64, 3)).astype(np.float32)
+    out["cam_points"] = P
+    out["cam_pose_c2w"] = np.stack([np.asarray(c["pose"], np.float64) for c in cams])
+    out["cam_ndc"] = np.stack([np.asarray(c["ndc_prj"], np.float64) for c in cams])
+    out["cam_views"] = np.array([0, 5, 17])
+    for i in (0, 5, 17):
+        cam = C.Camera(cams[i]["ndc_prj"], np.linalg.inv(np.array(cams[i]["pose"])), cams[i]["file"])
+        uv, zz = cam.projection(torch.from_numpy(P))
+        out["cam%d_uv" % i], out["cam%d_z" % i] = uv.numpy(), zz.numpy()
+        pix = cam.uv2pixel(uv.clone(), [H, W], "cpu")
+        out["cam%d_pix" % i] = pix.numpy()
+        out["cam%d_uvback" % i] = cam.pixel2uv(pix.clone(), [H, W], "cpu").numpy()
+        out["cam%d_world" % i] = cam.reprojection(uv, zz, to_world=True).numpy()
+        camv = cam.reprojection(uv, zz, to_world=False)
+        out["cam%d_camv" % i] = camv.numpy()
+        out["cam%d_c2w" % i] = cam.camera2world(camv[:, :3]).numpy()
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "utils_small.npz"), **out)
     print("written", len(out), "arrays")
 
