@@ -23,6 +23,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--minutes", type=float, default=3.0)
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--variant", type=int, default=0, help="search-kernel variant (0 = shipped default)")
+ap.add_argument("--max-views", type=int, default=70, help="scenes draw 20 .. max-views cameras (above 64: several view chunks\n"
+                "of the search, above 256: third level of the view cascade)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 DEV = "cuda:0"
@@ -37,9 +39,10 @@ def eq(x, y):
 
 
 while time.time() < t_end:
-    V = int(rng.integers(20, 70))
-    H = int(rng.integers(48, 400))
-    W = int(rng.integers(40, 300))
+    V = int(rng.integers(20, a.max_views))
+    big = V > 80                         # many views: small images keep a scene to seconds
+    H = int(rng.integers(48, 120 if big else 400))
+    W = int(rng.integers(40, 100 if big else 300))
     patch = int(rng.choice([1, 3, 5, 7, 9, 11]))
     thr = float(rng.choice([0.05, 0.1, 0.15, 0.3, 0.6]))
     quant = bool(rng.integers(0, 2))
