@@ -212,10 +212,15 @@ def main():
         step(a.warmup + i)
     barrier()
     dt = time.perf_counter() - t0
+    per_rank = [a.steps / dt]
     if dist is not None:
+        # (both ends of every rank's interval are barriers, so the per-rank figures differ only by how early a rank left
+        # the first and reached the last one; the headline uses the maximum, as the contract asks)
         t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        every = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        per_rank = [a.steps / float(x.item()) for x in every]
+        dt = max(float(x.item()) for x in every)
 
     ms = dt / a.steps * 1e3
     value = a.steps * world / dt
@@ -229,6 +234,7 @@ def main():
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": round(ms, 4),
+        "per_rank_iterations_per_s": [round(v, 2) for v in per_rank],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -453,9 +459,12 @@ def load_profile_facts(V, H, W):
 
 def secondary_volume_reduce(dev, backend):
     """The one exchange of the data path: the 256 x 256 x 192 x 4 fp32 orientation/occupancy volume of
-    the voxel fit, every rank owning an x-slab, assembled on rank 0 over xGMI.  Three forms, each timed with a barrier
-    on both sides, max over ranks: the shipped one (mh_volume_reduce mode 0: slab gather, direct to root), the dense
-    ncclReduce through the same C entry point (mode 1), and torch.distributed.reduce."""
+    the voxel fit, every rank owning an x-slab, assembled on rank 0 over xGMI.  Each form is timed with a barrier on both
+    sides, max over ranks, and checked on the root; the proven bindings run first, the hand-bound C-ABI ones last (the
+    caller's watchdog prints the line with what has been measured if one of them does not come back):
+      slab_gather_torch   peers hold their slab only, torch.distributed.batch_isend_irecv (the default of voxel_fit_reduced)
+      dense_reduce_torch  torch.distributed.reduce of a dense volume per rank
+      slab_gather_c_abi   mh_volume_gather (slab-sized peers)      dense_reduce_c_abi  mh_volume_reduce mode 1"""
     import torch
     import torch.distributed as dist
 
@@ -465,50 +474,73 @@ def secondary_volume_reduce(dev, backend):
     X, Y, Z, C = 256, 256, 192, 4
     nbytes = X * Y * Z * C * 4
     b = mdist.slab_bounds(X, w)
-    res = {"volume": [X, Y, Z, C], "bytes_dense": nbytes, "unit": "ms", "ranks": w}
-    if backend != "nccl":
-        res["note"] = "gloo test backend: RCCL legs skipped"
+    res = {"volume": [X, Y, Z, C], "bytes_dense": nbytes, "unit": "ms", "ranks": w,
+           "default_exchange": mdist.exchange_mode()}
+    fake = bool(os.environ.get("MH_RCCL_LIB"))
+    if backend != "nccl" and not fake:
+        res["note"] = "gloo test backend without MH_RCCL_LIB: RCCL legs skipped"
         return res
-    base = torch.zeros((X, Y, Z, C), device=dev)
-    base[b[r]:b[r + 1]] = float(r + 1)
+    cdev = dev if backend == "nccl" else "cpu"
+    lo, hi = int(b[r]), int(b[r + 1])
+    slab0 = torch.full((hi - lo, Y, Z, C), float(r + 1), device=dev)
 
-    def timed(fn, reps=5):
-        vol = base.clone()
-        fn(vol)                                     # warm (communicator set-up, first-use buffers)
-        torch.cuda.synchronize()
-        ts = []
-        for _ in range(reps):
-            vol.copy_(base)
+    def check(vol):
+        if r != 0:
+            return True
+        want = torch.cat([torch.full((int(b[k + 1] - b[k]),), float(k + 1)) for k in range(w)]).to(dev)
+        return bool(torch.equal(vol[:, 0, 0, 0], want) and torch.equal(vol[:, -1, -1, -1], want))
+
+    def timed(make, fn, reps=5):
+        ts, ok = [], True
+        for k in range(reps + 1):                   # the first round is the warm-up (communicator set-up, buffers)
+            slab, vol = make()
             dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            fn(vol)
+            fn(slab, vol)
             torch.cuda.synchronize()
-            t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            t = torch.tensor([time.perf_counter() - t0], device=cdev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            ts.append(float(t.item()))
-        ok = True
-        if r == 0:
-            want = torch.cat([torch.full((int(b[k + 1] - b[k]),), float(k + 1)) for k in range(w)]).to(dev)
-            ok = bool(torch.equal(vol[:, 0, 0, 0], want) and torch.equal(vol[:, -1, -1, -1], want))
+            if k:
+                ts.append(float(t.item()))
+            ok = ok and check(vol)
+            del slab, vol
         return min(ts) * 1e3, ok
 
+    def slabs():                                    # peers: their slab; root: the zero volume with its slab in place
+        if r != 0:
+            return slab0.clone(), None
+        vol = torch.zeros((X, Y, Z, C), device=dev)
+        vol[lo:hi] = slab0
+        return vol[lo:hi], vol
+
+    def dense():
+        vol = torch.zeros((X, Y, Z, C), device=dev)
+        vol[lo:hi] = slab0
+        return None, vol
+
     moved = nbytes * (w - 1) / w
-    for name, fn in (("slab_gather_c_abi", lambda v: mdist.volume_reduce(v, dev, mode=0)),
-                     ("dense_reduce_c_abi", lambda v: mdist.volume_reduce(v, dev, mode=1)),
-                     ("dense_reduce_torch", lambda v: dist.reduce(v, dst=0, op=dist.ReduceOp.SUM))):
+    legs = [("slab_gather_torch", slabs, lambda s_, v: mdist.slab_gather_torch(s_, v, (X, Y, Z, C), dev)),
+            ("dense_reduce_torch", dense, lambda s_, v: dist.reduce(v, dst=0, op=dist.ReduceOp.SUM)),
+            ("slab_gather_c_abi", slabs, lambda s_, v: mdist.volume_gather(s_, v, (X, Y, Z, C), dev)),
+            ("dense_reduce_c_abi", dense, lambda s_, v: mdist.volume_reduce(v, dev, mode=1))]
+    if backend != "nccl":                            # shared-GPU test hook: torch's dense reduce would need host staging
+        legs = [l for l in legs if l[0] != "dense_reduce_torch"]
+        res["note"] = "ranks share one GPU; RCCL entry points bound to MH_RCCL_LIB (test stand-in): times mean nothing"
+    for name, make, fn in legs:
         try:
-            ms, ok = timed(fn)
+            ms, ok = timed(make, fn, reps=1 if fake else 5)
             res[name + "_ms"] = round(ms, 3)
             res[name + "_correct"] = ok
         except Exception as e:
             res[name + "_error"] = repr(e)[:200]
-    if "slab_gather_c_abi_ms" in res:
-        res["slab_gather_GBps_into_root"] = round(moved / (res["slab_gather_c_abi_ms"] * 1e-3) / 1e9, 1)
-        res["xgmi_expectation"] = ("%d peers x %.0f GB/s links into the root: %.2f ms for %.0f MB"
-                                   % (w - 1, XGMI_LINK_GBS, moved / ((w - 1) * XGMI_LINK_GBS * 1e9) * 1e3, moved / 1e6))
-    if "dense_reduce_c_abi_ms" in res:
-        res["dense_reduce_GBps_volume"] = round(nbytes / (res["dense_reduce_c_abi_ms"] * 1e-3) / 1e9, 1)
+    for name in ("slab_gather_torch", "slab_gather_c_abi"):
+        if name + "_ms" in res:
+            res[name + "_GBps_into_root"] = round(moved / (res[name + "_ms"] * 1e-3) / 1e9, 1)
+    res["xgmi_expectation"] = ("%d peers x %.0f GB/s links into the root: %.2f ms for %.0f MB"
+                               % (w - 1, XGMI_LINK_GBS, moved / ((w - 1) * XGMI_LINK_GBS * 1e9) * 1e3, moved / 1e6))
+    if "dense_reduce_torch_ms" in res:
+        res["dense_reduce_GBps_volume"] = round(nbytes / (res["dense_reduce_torch_ms"] * 1e-3) / 1e9, 1)
     return res
 
 

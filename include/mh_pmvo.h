@@ -298,6 +298,15 @@ int mh_comm_init(mh_ctx *ctx, const void *id_host /*128 bytes*/, int nranks, int
 int mh_comm_destroy(void *comm);
 int mh_volume_reduce(mh_ctx *ctx, void *comm, int rank, int nranks, int root, float *volume /*[X,Y,Z,C] in place*/,
                      int X, int Y, int Z, int C, const int32_t *slab_host, int mode, void *stream);
+/* The slab gather with slab-sized buffers on the peers (what monohair_amd.dist.voxel_fit_reduced uses): `slab` is this
+ * rank's own x-slab [slab_host[rank+1]-slab_host[rank], Y, Z, C] (device, contiguous; may be NULL when the slab is empty),
+ * `volume` the dense [X,Y,Z,C] volume on the root only (NULL elsewhere).  The root's own slab is copied into place on the
+ * stream unless slab == volume + slab_host[root]*Y*Z*C.  Wire traffic = mode 0 above; a peer holds 1/nranks of the volume.
+ * The environment variable MH_RCCL_LIB=<path> binds another library for these entry points (e.g. tests/fake_rccl.cpp, a
+ * stand-in built against rccl.h that lets several ranks share one GPU: how the nranks > 1 branches are tested on a
+ * one-GPU box); an unloadable path is an error. */
+int mh_volume_gather(mh_ctx *ctx, void *comm, int rank, int nranks, int root, const float *slab, float *volume, int X,
+                     int Y, int Z, int C, const int32_t *slab_host, void *stream);
 
 /* ---- host-side IO of the volume files: scipy.io.savemat of PMVO.py:753-764 writes dense float64 arrays that are zero
  * except at the occupied voxels.  Creates `path` = prefix (the MAT-v5 header + array tags, built by the caller) + a

@@ -64,6 +64,7 @@ _SIGS = {
     "mh_comm_init": (ci, [vp, vp, ci, ci, ctypes.POINTER(vp)]),
     "mh_comm_destroy": (ci, [vp]),
     "mh_volume_reduce": (ci, [vp, vp, ci, ci, ci, vp, ci, ci, ci, ci, vp, ci, vp]),
+    "mh_volume_gather": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, ci, ci, ci, vp, vp]),
     "mh_render_strands_scratch_bytes": (csz, [ci, ci, ci, ci, ci]),
     "mh_render_strands": (ci, [vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, cf, ci, ci, ci, cf, vp, csz, vp, vp]),
     "mh_mat_write_sparse": (ci, [ctypes.c_char_p, vp, csz, csz, vp, vp, csz, ci]),

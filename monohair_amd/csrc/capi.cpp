@@ -791,10 +791,19 @@ const int MH_NCCL_FLOAT32 = 7, MH_NCCL_SUM = 0;   // rccl.h: ncclFloat32, ncclSu
 
 int rccl_load() {
     if (g_rccl.h) return MH_OK;
+    // MH_RCCL_LIB=<path>: bind this library instead (a site's own RCCL build; tests/fake_rccl.cpp -- a stand-in compiled
+    // against rccl.h that moves the data between processes sharing ONE GPU, so that the nranks > 1 branches below run on a
+    // one-GPU box).  It must be loadable: a wrong path is an error, never a silent fall-through to the system library.
+    const char *over = getenv("MH_RCCL_LIB");
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void *h = nullptr;
-    for (const char *n : names)
-        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (over && *over) {
+        h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+        if (!h) return fail(MH_ERR_STATE, "MH_RCCL_LIB=%s cannot be loaded: %s", over, dlerror());
+    } else {
+        for (const char *n : names)
+            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    }
     if (!h) return fail(MH_ERR_STATE, "librccl.so.1 not found: %s", dlerror());
     MhRccl r;
     r.h = h;
@@ -821,6 +830,35 @@ int rccl_load() {
         int e_ = (call);                                                                                \
         if (e_ != 0) return fail(MH_ERR_HIP, "%s: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(e_) : "?"); \
     } while (0)
+
+// The grouped point-to-point exchange both entry points below issue: every peer sends its slab to the root, the root
+// receives each one at its place in the dense volume.  The group is closed on every path (a failed call inside an open
+// group would otherwise leave the thread's group depth raised for every later call).
+static int slab_exchange(int rank, int nranks, int root, const float *own_slab, float *volume, size_t plane,
+                         const int32_t *slab_host, MhNcclComm comm, hipStream_t st) {
+    MH_NCCL(g_rccl.GroupStart());
+    int e = 0;
+    const char *what = "";
+    if (rank == root) {
+        for (int r = 0; r < nranks && e == 0; ++r) {
+            const size_t cnt = (size_t)(slab_host[r + 1] - slab_host[r]) * plane;
+            if (r == root || cnt == 0) continue;
+            e = g_rccl.Recv(volume + (size_t)slab_host[r] * plane, cnt, MH_NCCL_FLOAT32, r, comm, st);
+            what = "ncclRecv";
+        }
+    } else if (own_slab) {
+        const size_t cnt = (size_t)(slab_host[rank + 1] - slab_host[rank]) * plane;
+        e = g_rccl.Send(own_slab, cnt, MH_NCCL_FLOAT32, root, comm, st);
+        what = "ncclSend";
+    }
+    const int e2 = g_rccl.GroupEnd();
+    if (e == 0 && e2 != 0) {
+        e = e2;
+        what = "ncclGroupEnd";
+    }
+    if (e != 0) return fail(MH_ERR_HIP, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(e) : "?");
+    return MH_OK;
+}
 
 extern "C" int mh_comm_unique_id(void *id_out_host) {
     if (!id_out_host) return fail(MH_ERR_ARG, "mh_comm_unique_id: NULL");
@@ -867,19 +905,36 @@ extern "C" int mh_volume_reduce(mh_ctx *ctx, void *comm, int rank, int nranks, i
     // mode 0: slab ownership is disjoint, so nothing has to be added: every peer sends its own slab straight to the
     // root over its own xGMI link and the root receives it in place -- (nranks-1)/nranks of the volume in total, each
     // link carrying one slab
-    MH_NCCL(g_rccl.GroupStart());
+    const size_t own = (size_t)(slab_host[rank + 1] - slab_host[rank]) * plane;
+    return slab_exchange(rank, nranks, root, own ? volume + (size_t)slab_host[rank] * plane : nullptr, volume, plane,
+                         slab_host, (MhNcclComm)comm, st);
+}
+
+// mh_volume_gather: the slab gather with slab-sized buffers on the peers.  `slab` holds this rank's own x-slab
+// ([slab_host[rank+1]-slab_host[rank], Y, Z, C], contiguous); only the root has the dense volume.  The root's own slab is
+// copied into place on the stream unless it already lives there (slab == volume + offset).  Same wire traffic as mode 0
+// of mh_volume_reduce; a peer allocates 1/nranks of the volume instead of all of it (2.15 GB at 512^3).
+extern "C" int mh_volume_gather(mh_ctx *ctx, void *comm, int rank, int nranks, int root, const float *slab, float *volume,
+                                int X, int Y, int Z, int C, const int32_t *slab_host, void *stream) {
+    if (!ctx || !comm || !slab_host || nranks < 1 || rank < 0 || rank >= nranks || root < 0 || root >= nranks || X < 1 ||
+        Y < 1 || Z < 1 || C < 1)
+        return fail(MH_ERR_ARG, "mh_volume_gather: bad arguments");
+    if (slab_host[0] != 0 || slab_host[nranks] != X) return fail(MH_ERR_ARG, "mh_volume_gather: slabs must cover [0, X)");
+    for (int r = 0; r < nranks; ++r)
+        if (slab_host[r] > slab_host[r + 1]) return fail(MH_ERR_ARG, "mh_volume_gather: slabs must be ascending");
+    const size_t plane = (size_t)Y * Z * C;
+    const size_t mine = (size_t)(slab_host[rank + 1] - slab_host[rank]) * plane;
+    if (mine && !slab) return fail(MH_ERR_ARG, "mh_volume_gather: rank %d owns %zu floats but slab is NULL", rank, mine);
+    if (rank == root && !volume) return fail(MH_ERR_ARG, "mh_volume_gather: the root needs the dense volume");
+    if (int rc = rccl_load()) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    MH_HIP(hipSetDevice(ctx->device));
     if (rank == root) {
-        for (int r = 0; r < nranks; ++r) {
-            const size_t cnt = (size_t)(slab_host[r + 1] - slab_host[r]) * plane;
-            if (r == root || cnt == 0) continue;
-            MH_NCCL(g_rccl.Recv(volume + (size_t)slab_host[r] * plane, cnt, MH_NCCL_FLOAT32, r, (MhNcclComm)comm, st));
-        }
-    } else {
-        const size_t cnt = (size_t)(slab_host[rank + 1] - slab_host[rank]) * plane;
-        if (cnt) MH_NCCL(g_rccl.Send(volume + (size_t)slab_host[rank] * plane, cnt, MH_NCCL_FLOAT32, root, (MhNcclComm)comm, st));
+        float *dst = volume + (size_t)slab_host[root] * plane;
+        if (mine && dst != slab) MH_HIP(hipMemcpyAsync(dst, slab, mine * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
-    MH_NCCL(g_rccl.GroupEnd());
-    return MH_OK;
+    if (nranks == 1) return MH_OK;
+    return slab_exchange(rank, nranks, root, mine ? slab : nullptr, volume, plane, slab_host, (MhNcclComm)comm, st);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -5,11 +5,15 @@ The path shards by POINTS, not by views: a point's result needs every view but n
 holds all packed views (2.5 GB at 60 x 1080p, nothing against 288 GB), so an iteration has no collective at
 all and results are bit-identical to the single-GPU run.  Exactly two kinds of exchange exist:
   * map_chunks: independent chunks dealt round-robin, one all_gather of the per-chunk results at the end;
-  * voxel_fit_reduced: every rank fits a disjoint x-slab of voxels and writes them into a zero volume; ONE
-    exchange over xGMI assembles the shared 3D orientation/occupancy volume on rank 0: mh_volume_reduce (RCCL
-    through the C ABI) -- because ownership is disjoint, every peer sends its slab straight to the root
-    (ncclSend/ncclRecv), 1/N of the bytes of a dense reduce per link; the dense ncclReduce(sum) is kept as mode 1
-    (x + 0 is exact, so both give the single-GPU volume bit for bit).
+  * voxel_fit_reduced: every rank fits a disjoint x-slab of voxels into a zero SLAB-sized buffer; ONE exchange over
+    xGMI assembles the shared 3D orientation/occupancy volume on rank 0 (the only rank that holds it dense).  Because
+    ownership is disjoint, every peer sends its slab straight to the root (RCCL send/recv), 1/N of the bytes of a dense
+    reduce per link.  Which binding issues those sends is MH_VOLUME_EXCHANGE:
+      "torch" (default)  torch.distributed.batch_isend_irecv -- ncclSend/ncclRecv through torch's own RCCL binding;
+      "capi"             mh_volume_gather of the C ABI (librccl bound by hand in csrc/capi.cpp) -- opt-in until it has
+                         run across devices; tested with several ranks sharing one GPU through tests/fake_rccl.cpp;
+      "dense"            the dense ncclReduce(sum) of a full volume per rank (x + 0 is exact: the same volume).
+    All three give the single-GPU volume bit for bit.
 """
 import numpy as np
 import torch
@@ -102,12 +106,36 @@ def all_gather_views(local, n_views, shape, dtype, device):
 
 
 _COMMS = {}
+_CAPI_BROKEN = []          # non-empty once the hand-bound RCCL path failed to come up on some rank: stay on torch
+
+
+def exchange_mode():
+    """MH_VOLUME_EXCHANGE: torch (default) | capi | dense -- see the module docstring"""
+    import os
+
+    m = os.environ.get("MH_VOLUME_EXCHANGE", "torch").lower()
+    if m not in ("torch", "capi", "dense"):
+        raise ValueError("MH_VOLUME_EXCHANGE must be torch, capi or dense, not %r" % m)
+    return m
+
+
+def _destroy_comms():
+    """ncclCommDestroy for every communicator made here (registered with atexit by rccl_comm)"""
+    from . import _lib
+
+    while _COMMS:
+        _, (ctx, comm) = _COMMS.popitem()
+        try:
+            _lib.lib().mh_comm_destroy(comm)
+        except Exception:
+            pass
 
 
 def rccl_comm(device):
     """The ncclComm_t of this job created through the C ABI (mh_comm_init): rank 0 draws the 128-byte unique id
-    (mh_comm_unique_id), torch.distributed carries it to the other ranks, every rank joins.  Cached per device.
-    -> (ctx, comm) handles for mh_volume_reduce."""
+    (mh_comm_unique_id), torch.distributed carries it to the other ranks, every rank joins.  Cached per device and
+    destroyed at interpreter exit.  -> (ctx, comm) handles for mh_volume_reduce / mh_volume_gather."""
+    import atexit
     import ctypes
 
     from . import _lib
@@ -120,19 +148,54 @@ def rccl_comm(device):
         L = _lib.lib()
         ctx = _ctx_for(dev)
         raw = (ctypes.c_ubyte * 128)()
+        id_error = None
         if rank() == 0:
-            _lib.check(L.mh_comm_unique_id(ctypes.cast(raw, ctypes.c_void_p)), "mh_comm_unique_id")
+            try:
+                _lib.check(L.mh_comm_unique_id(ctypes.cast(raw, ctypes.c_void_p)), "mh_comm_unique_id")
+            except _lib.MhError as e:      # the peers are waiting in the broadcast below: tell them (an all-zero id)
+                id_error = e
+                raw = (ctypes.c_ubyte * 128)()
         if d and world() > 1:
             cdev = _comm_device(dev)
             t = torch.tensor(list(raw), dtype=torch.uint8, device=cdev)
             d.broadcast(t, src=0)
             raw = (ctypes.c_ubyte * 128)(*t.cpu().tolist())
+        if id_error is not None or not any(raw):
+            raise id_error or _lib.MhError("mh_comm_unique_id failed on rank 0")
         comm = ctypes.c_void_p()
         with torch.cuda.device(dev):
             _lib.check(L.mh_comm_init(ctx, ctypes.cast(raw, ctypes.c_void_p), world(), rank(), ctypes.byref(comm)),
                        "mh_comm_init")
+        if not _COMMS:
+            atexit.register(_destroy_comms)
         _COMMS[key] = (ctx, comm)
     return _COMMS[key]
+
+
+def capi_comm_or_none(device):
+    """rccl_comm, agreed on by ALL ranks: if the hand-bound communicator cannot be created on any rank (librccl missing,
+    a binding error), every rank learns it through one torch.distributed all_reduce and the caller stays on the torch
+    exchange -- a rank must never enter a collective its peers have given up on."""
+    import warnings
+
+    d = _dist()
+    if _CAPI_BROKEN:
+        return None
+    ok, err = 1, None
+    try:
+        handles = rccl_comm(device)
+    except Exception as e:          # MhError (library, symbol, ncclCommInitRank) -- reported below
+        ok, err, handles = 0, e, None
+    if d and world() > 1:
+        t = torch.tensor([ok], dtype=torch.int32, device=_comm_device(device))
+        d.all_reduce(t, op=d.ReduceOp.MIN)
+        ok = int(t.item())
+    if not ok:
+        _CAPI_BROKEN.append(repr(err) if err else "a peer rank failed")
+        warnings.warn("MH_VOLUME_EXCHANGE=capi: the C-ABI RCCL communicator did not come up (%s); using the "
+                      "torch.distributed exchange" % _CAPI_BROKEN[0])
+        return None
+    return handles
 
 
 def slab_bounds(grid_x, n_ranks):
@@ -159,6 +222,59 @@ def volume_reduce(vol, device, mode=0, root=0):
     return vol
 
 
+def volume_gather(slab, vol, grid, device, root=0, handles=None):
+    """mh_volume_gather: `slab` = this rank's own [b[r+1]-b[r], Y, Z, C] fp32 device tensor (on the root it may be the
+    view vol[b[r]:b[r+1]] itself: no copy), `vol` = the dense [X,Y,Z,C] tensor on the root, None elsewhere."""
+    import ctypes
+
+    from . import _lib
+
+    X, Y, Z, C = (int(v) for v in grid)
+    slabs = slab_bounds(X, world())
+    r = rank()
+    assert slab is None or (slab.is_cuda and slab.dtype == torch.float32 and slab.is_contiguous()
+                            and tuple(slab.shape) == (int(slabs[r + 1] - slabs[r]), Y, Z, C)), "slab shape"
+    assert (vol is not None) == (r == root), "the dense volume lives on the root only"
+    if vol is not None:
+        assert vol.is_cuda and vol.dtype == torch.float32 and vol.is_contiguous() and tuple(vol.shape) == (X, Y, Z, C)
+    ctx, comm = handles if handles is not None else rccl_comm(device)
+    with torch.cuda.device(torch.device(device)):
+        _lib.check(_lib.lib().mh_volume_gather(ctx, comm, r, world(), root, _lib.ptr(slab) if slab is not None and
+                                               slab.numel() else None, _lib.ptr(vol), X, Y, Z, C,
+                                               slabs.ctypes.data_as(ctypes.c_void_p), _lib.stream_ptr()),
+                   "mh_volume_gather")
+    return vol
+
+
+def slab_gather_torch(slab, vol, grid, device, root=0):
+    """The same exchange through torch.distributed's own binding: every peer isend's its slab, the root irecv's it in
+    place (batch_isend_irecv = one ncclGroupStart/End under the nccl backend).  Under gloo (CPU tests, ranks sharing a
+    GPU) the slabs are staged on the host."""
+    d = _dist()
+    w, r = world(), rank()
+    X = int(grid[0])
+    b = slab_bounds(X, w)
+    on_gpu = d.get_backend() == "nccl"
+    ops, staged = [], []
+    if r == root:
+        for k in range(w):
+            if k == root or b[k + 1] == b[k]:
+                continue
+            dst = vol[b[k]:b[k + 1]]
+            if not on_gpu:
+                dst = torch.empty(dst.shape, dtype=dst.dtype, device="cpu")
+                staged.append((k, dst))
+            ops.append(d.P2POp(d.irecv, dst, k))
+    elif slab is not None and slab.numel():
+        ops.append(d.P2POp(d.isend, slab if on_gpu else slab.cpu(), root))
+    if ops:
+        for req in d.batch_isend_irecv(ops):
+            req.wait()
+    for k, t in staged:
+        vol[b[k]:b[k + 1]] = t.to(vol.device)
+    return vol
+
+
 def voxel_owner_mask(x, n_ranks, r, grid_x):
     """Spatial partition of the volume into n_ranks slabs along x: rank r owns x in [r*G/n, (r+1)*G/n)."""
     lo = (grid_x * r) // n_ranks
@@ -168,7 +284,7 @@ def voxel_owner_mask(x, n_ranks, r, grid_x):
 
 def voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size, grid_resolution, fit=None,
                       sparse=False):
-    """Voxel fit with disjoint voxel ownership + the single reduce.  Returns dense (occ [X,Y,Z], ori [X,Y,Z,3])
+    """Voxel fit with disjoint voxel ownership + the single exchange.  Returns dense (occ [X,Y,Z], ori [X,Y,Z,3])
     float64 numpy arrays on rank 0 (zeros elsewhere); with sparse=True the occupied voxels instead:
     (voxels [G,3] int64 (x,y,z) in ascending voxel order, ori [G,3] float32), empty off rank 0."""
     from . import pmvo_utils as U
@@ -188,23 +304,40 @@ def voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size, 
     probe = pts.copy()
     x, _, _ = U.p2v(probe, np.asarray(voxel_min), voxel_size, g)
     own = voxel_owner_mask(x, w, r, int(g[0]))
-    vol = torch.zeros((int(g[0]), int(g[1]), int(g[2]), 4), dtype=torch.float32, device=device)
+    X, Y, Z = int(g[0]), int(g[1]), int(g[2])
+    b = slab_bounds(X, w)
+    lo, hi = int(b[r]), int(b[r + 1])
+    mode = exchange_mode()
+    handles = capi_comm_or_none(device) if (mode == "capi" and torch.device(device).type == "cuda") else None
+    if mode == "capi" and handles is None:
+        mode = "torch"
+    # peers hold their own slab only; the root holds the shared volume (the dense-reduce comparison mode needs it everywhere)
+    if r == 0 or mode == "dense":
+        vol = torch.zeros((X, Y, Z, 4), dtype=torch.float32, device=device)
+        slab = vol[lo:hi]
+    else:
+        vol = None
+        slab = torch.zeros((hi - lo, Y, Z, 4), dtype=torch.float32, device=device)
     if own.any():
         res = fit(pts[own], ori[own], device, voxel_min, voxel_size, g, dense=False)
         v = res["voxels"].to(device)
-        vol[v[:, 0], v[:, 1], v[:, 2], 0] = 1.0
-        vol[v[:, 0], v[:, 1], v[:, 2], 1:] = res["ori"].to(device)
-    # the one exchange of the data path: RCCL through the C ABI (slab gather over xGMI, direct to rank 0); under the
-    # gloo backend of the CPU / single-GPU multi-rank tests the same volume is summed by torch.distributed on the host
-    if d.get_backend() == "nccl":
-        volume_reduce(vol, device, mode=0, root=0)
+        slab[v[:, 0] - lo, v[:, 1], v[:, 2], 0] = 1.0
+        slab[v[:, 0] - lo, v[:, 1], v[:, 2], 1:] = res["ori"].to(device)
+    # the one exchange of the data path
+    if mode == "capi":
+        volume_gather(slab, vol, (X, Y, Z, 4), device, root=0, handles=handles)
+    elif mode == "dense":
+        if d.get_backend() == "nccl":
+            d.reduce(vol, dst=0, op=d.ReduceOp.SUM)
+        else:
+            host = vol.to("cpu")
+            d.reduce(host, dst=0, op=d.ReduceOp.SUM)
+            vol = host.to(device) if r == 0 else vol
     else:
-        vol = vol.to("cpu")
-        d.reduce(vol, dst=0, op=d.ReduceOp.SUM)
+        slab_gather_torch(slab, vol, (X, Y, Z, 4), device, root=0)
     if sparse:
         if r != 0:
             return np.zeros((0, 3), np.int64), np.zeros((0, 3), np.float32)
-        vol = vol.to(device)
         nz = torch.nonzero(vol[..., 0])                     # row-major order == ascending voxel key
         return nz.cpu().numpy(), vol[nz[:, 0], nz[:, 1], nz[:, 2], 1:].cpu().numpy()
     if r != 0:

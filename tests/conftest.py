@@ -16,6 +16,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def fake_rccl_lib():
+    """tests/lib/libfake_rccl.so, (re)built from tests/fake_rccl.cpp when missing or older than its source: the test-only
+    stand-in for the RCCL entry points (MH_RCCL_LIB) that lets several ranks share one GPU."""
+    import subprocess
+
+    src = os.path.join(ROOT, "tests", "fake_rccl.cpp")
+    out = os.path.join(ROOT, "tests", "lib", "libfake_rccl.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "-O2", src, "-o", out, "-lrt"])
+    return out
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     meta = ast.literal_eval(str(z["meta"]))

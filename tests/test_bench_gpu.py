@@ -45,6 +45,21 @@ def test_gpus_2_spawns_two_ranks_itself():
     d = run_bench(["--gpus", "2"] + SMALL, env={"MH_DIST_BACKEND": "gloo", "MH_DEVICE_OVERRIDE": "0"})
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo"
     assert d["secondary_full_pass"]["ranks"] == 2 and "total_s" in d["secondary_full_pass"]
+    assert len(d["per_rank_iterations_per_s"]) == 2 and min(d["per_rank_iterations_per_s"]) > 0
+
+
+def test_gpus_2_volume_exchange_legs_run_through_the_rccl_stand_in():
+    """the C-ABI exchange legs of `bench.py --gpus 2` (and the full pass with MH_VOLUME_EXCHANGE=capi) with two ranks on
+    the one GPU: the RCCL entry points are bound to tests/fake_rccl.cpp"""
+    from conftest import fake_rccl_lib
+
+    d = run_bench(["--gpus", "2"] + SMALL, env={"MH_DIST_BACKEND": "gloo", "MH_DEVICE_OVERRIDE": "0",
+                                                  "MH_RCCL_LIB": fake_rccl_lib(), "MH_VOLUME_EXCHANGE": "capi"})
+    v = d["secondary_volume_reduce"]
+    assert v["default_exchange"] == "capi"
+    for leg in ("slab_gather_torch", "slab_gather_c_abi", "dense_reduce_c_abi"):
+        assert v.get(leg + "_correct") is True, v
+    assert d["secondary_full_pass"]["ranks"] == 2 and "error" not in d["secondary_full_pass"]
 
 
 def test_gpus_more_than_present_is_refused():

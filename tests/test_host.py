@@ -183,9 +183,15 @@ if r == 0:
     from monohair_amd.pmvo_utils import dense_from_sparse
     occ2, vol2 = dense_from_sparse(g, vx, vo)
     assert np.array_equal(occ2, occ1) and np.array_equal(vol2.astype(np.float32), vol1.astype(np.float32)), "sparse"
-    print("DIST_OK", int(occ.sum()))
 else:
     assert len(vx) == 0
+# the dense-reduce comparison mode (a full volume on every rank, summed into rank 0) gives the same volume
+os.environ["MH_VOLUME_EXCHANGE"] = "dense"
+occ3, vol3 = mdist.voxel_fit_reduced(pts, ori, "cpu", [-0.32, -0.32, -0.24], 0.01, g, fit=fit)
+os.environ["MH_VOLUME_EXCHANGE"] = "torch"
+if r == 0:
+    assert np.array_equal(occ3, occ1) and np.array_equal(vol3.astype(np.float32), vol1.astype(np.float32)), "dense mode"
+    print("DIST_OK", int(occ.sum()))
 dist.barrier()
 dist.destroy_process_group()
 '''

@@ -1,7 +1,11 @@
-"""mh_volume_reduce (RCCL through the C ABI).  On a one-GPU box only the single-rank communicator can
-be exercised (RCCL refuses two ranks on one device): that covers the run-time binding of librccl, mh_comm_unique_id /
-mh_comm_init / mh_comm_destroy and both modes of the call.  With two or more GPUs the real exchange runs: two processes,
-one GPU each, slab gather and dense reduce against the volume a single process builds."""
+"""mh_volume_reduce / mh_volume_gather (RCCL through the C ABI).
+  * real librccl, one rank (RCCL refuses two ranks on one device): the run-time binding, mh_comm_unique_id / mh_comm_init /
+    mh_comm_destroy and every entry point with a single-rank communicator;
+  * tests/fake_rccl.cpp bound through MH_RCCL_LIB, 2 and 3 ranks SHARING the one GPU: the nranks > 1 branches -- grouped
+    send/recv, peer numbers, slab offsets and counts, uneven and empty slabs, a root other than 0 -- assembled volume
+    compared bit for bit; and monohair_amd.dist.voxel_fit_reduced with MH_VOLUME_EXCHANGE=capi against the single-process
+    fit.  The stand-in is compiled against <rccl/rccl.h>, so the hand-written prototypes in capi.cpp meet the real ABI;
+  * with two or more GPUs the real exchange runs as well (skips on a one-GPU box -- the only skip of the suite)."""
 import os
 import subprocess
 import sys
@@ -31,6 +35,119 @@ def test_single_rank_communicator_and_both_modes():
         assert torch.equal(vol, want), mode            # one rank owns everything: the volume is unchanged
 
 
+def test_single_rank_gather_with_slab_sized_buffer():
+    import torch
+
+    from monohair_amd import dist as mdist
+
+    dev = torch.device("cuda:0")
+    full = torch.rand((16, 12, 10, 4), generator=torch.Generator().manual_seed(1)).to(dev)
+    vol = torch.zeros_like(full)
+    mdist.volume_gather(full.clone(), vol, full.shape, dev)          # a separate slab buffer: copied into place
+    torch.cuda.synchronize()
+    assert torch.equal(vol, full)
+    vol2 = full.clone()
+    mdist.volume_gather(vol2[0:16], vol2, full.shape, dev)           # the slab IS the root's region: nothing to do
+    torch.cuda.synchronize()
+    assert torch.equal(vol2, full)
+
+
+FAKE_WORKER = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+sys.path.insert(0, os.path.join(%(root)r, "tests"))
+from monohair_amd import dist as mdist, _lib
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", 0)                      # every rank on the one GPU
+torch.cuda.set_device(dev)
+dist.init_process_group("gloo")
+assert os.environ["MH_RCCL_LIB"].endswith("libfake_rccl.so")
+import ctypes
+for X, Y, Z, C in ((64, 12, 10, 4), (7, 5, 3, 4), (2, 4, 4, 4), (33, 6, 5, 1)):      # uneven slabs; X < world: empty slabs
+    full = torch.rand((X, Y, Z, C), generator=torch.Generator().manual_seed(3 + X))
+    b = mdist.slab_bounds(X, world)
+    # dense in-place forms (mh_volume_reduce): mode 0 slab gather, mode 1 dense reduce
+    for mode in (0, 1):
+        vol = torch.zeros((X, Y, Z, C), device=dev)
+        vol[b[rank]:b[rank + 1]] = full[b[rank]:b[rank + 1]].to(dev)
+        mdist.volume_reduce(vol, dev, mode=mode)
+        torch.cuda.synchronize()
+        if rank == 0:
+            assert torch.equal(vol.cpu(), full), ("reduce", mode, X)
+        else:                                           # a peer's buffer is left alone outside... its own slab
+            assert torch.equal(vol[b[rank]:b[rank + 1]].cpu(), full[b[rank]:b[rank + 1]])
+    # slab-sized peers (mh_volume_gather), every rank as the root once
+    for root in range(world):
+        slab = full[b[rank]:b[rank + 1]].to(dev).contiguous()
+        vol = torch.full((X, Y, Z, C), -7.0, device=dev) if rank == root else None
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):                      # on a side stream: the call is ordered on the CURRENT stream
+            slab = slab * 1.0
+            mdist.volume_gather(slab, vol, (X, Y, Z, C), dev, root=root)
+        s.synchronize()
+        if rank == root:
+            assert torch.equal(vol.cpu(), full), ("gather", root, X)
+    dist.barrier()
+# a receive that does not match the peer's send is an ERROR here (real RCCL would hang): rank 1 lies about its slab
+if world == 2:
+    L = _lib.lib(); ctx, comm = mdist.rccl_comm(dev)
+    X, Y, Z, C = 8, 2, 2, 4
+    good = np.array([0, 4, 8], np.int32); bad = np.array([0, 5, 8], np.int32)
+    slabs = good if rank == 0 else bad
+    buf = torch.zeros((X, Y, Z, C), device=dev)
+    rc = L.mh_volume_reduce(ctx, comm, rank, world, 0, _lib.ptr(buf), X, Y, Z, C, slabs.ctypes.data_as(ctypes.c_void_p), 0,
+                            _lib.stream_ptr())
+    if rank == 0:
+        assert rc != 0 and b"invalid argument" in L.mh_last_error(), (rc, L.mh_last_error())
+    dist.barrier()
+# --- the caller: voxel_fit_reduced over the C-ABI exchange == the single-process fit, bit for bit
+from monohair_amd import pmvo_utils as U
+rng = np.random.default_rng(5)
+pts = rng.uniform(-0.1, 0.1, size=(6000, 3)); ori = rng.normal(size=(6000, 3)).astype(np.float32)
+g = [64, 64, 48]
+for mode in ("capi", "torch", "dense"):
+    os.environ["MH_VOLUME_EXCHANGE"] = mode
+    vx, vo = mdist.voxel_fit_reduced(pts, ori, dev, [-0.32, -0.32, -0.24], 0.01, g, sparse=True)
+    occ, vol = mdist.voxel_fit_reduced(pts, ori, dev, [-0.32, -0.32, -0.24], 0.01, g)
+    if rank == 0:
+        one = U.voxel_fit(pts, ori, dev, [-0.32, -0.32, -0.24], 0.01, np.asarray(g), dense=True)
+        assert np.array_equal(vx, one["voxels"].cpu().numpy()) and np.array_equal(vo, one["ori"].cpu().numpy()), mode
+        assert np.array_equal(occ, one["occ"]) and np.array_equal(vol, one["ori_dense"]), mode
+    else:
+        assert len(vx) == 0
+assert not mdist._CAPI_BROKEN
+dist.barrier()
+if rank == 0:
+    print("FAKE_RCCL_OK")
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_multi_rank_branches_on_one_gpu_through_the_rccl_stand_in(tmp_path, nranks):
+    from conftest import fake_rccl_lib
+
+    script = tmp_path / "w.py"
+    script.write_text(FAKE_WORKER % {"root": ROOT})
+    env = dict(os.environ, PYTHONPATH=ROOT, MH_RCCL_LIB=fake_rccl_lib(), MASTER_ADDR="127.0.0.1")
+    env.pop("MH_VOLUME_EXCHANGE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nranks,
+                        "--master-addr", "127.0.0.1", "--master-port", str(29741 + nranks), str(script)], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "FAKE_RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_unloadable_rccl_override_is_an_error_not_a_fall_through(tmp_path):
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import ctypes\nfrom monohair_amd import _lib\nL = _lib.lib()\n"
+            "raw = (ctypes.c_ubyte * 128)()\nrc = L.mh_comm_unique_id(ctypes.cast(raw, ctypes.c_void_p))\n"
+            "assert rc != 0 and b'MH_RCCL_LIB' in L.mh_last_error(), (rc, L.mh_last_error())\nprint('REFUSED')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MH_RCCL_LIB=str(tmp_path / "nope.so")),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "REFUSED" in r.stdout, r.stdout + r.stderr
+
+
 WORKER = r"""
 import os, sys
 import numpy as np, torch, torch.distributed as dist
@@ -50,6 +167,12 @@ for mode in (0, 1):
     torch.cuda.synchronize()
     if rank == 0:
         assert torch.equal(vol.cpu(), full), mode
+slab = full[b[rank]:b[rank + 1]].to(dev).contiguous()                # slab-sized peers
+vol = torch.zeros((X, Y, Z, C), device=dev) if rank == 0 else None
+mdist.volume_gather(slab, vol, (X, Y, Z, C), dev)
+torch.cuda.synchronize()
+if rank == 0:
+    assert torch.equal(vol.cpu(), full), "gather"
 dist.barrier()
 if rank == 0:
     print("VOLUME_REDUCE_OK")
