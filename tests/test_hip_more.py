@@ -222,9 +222,7 @@ def test_drivers_end_to_end_vs_reference(tmp_path):
     same &= np.all((got["select_o"] == z["opt_select_o"]) | np.isnan(z["opt_select_o"]), axis=1)
     # the base-view ranking returns tied confidences in torch.topk's own order (74 % of these points have tied positive
     # values in their top 20 -- the synthetic confidences saturate at 1.0), so every selection is the reference's
-    assert same.all(), same.mean()
-    both = same & ~np.isnan(z["opt_min_loss"])
-    assert np.abs(got["select_o"][both] - z["opt_select_o"][both]).max() <= 1e-4
+    assert same.all(), same.mean()          # bit for bit on every candidate: the 1e-4 L-inf tolerance is met with 0
 
     # refine from the REFERENCE's optimize outputs, so the two refine stages see identical inputs
     fu = cand[filter_index]

@@ -137,19 +137,15 @@ def _comparable(z, depth_offsets, views, pts):
     return ok
 
 
-def test_forward(case, depth_offsets):
+def test_forward(case, depth_offsets, request):
+    """oracle.forward == the reference's forward, stated without a masked tolerance: see conftest.check_forward_against_reference"""
+    from conftest import check_forward_against_reference
+
     meta, z, scene, views = case
     pts = z["points"]
     _, ori, loss, hc = oracle.forward(views, pts, meta["patch"], meta["thr"], depth_offsets,
                                       base_idx=z["base_idx"], base_val=z["base_val"])
-    body = _comparable(z, depth_offsets, views, pts)
-    match = (loss == z["fwd_loss"]) | (np.isnan(loss) & np.isnan(z["fwd_loss"]))
-    match &= np.all((ori == z["fwd_ori"]) | (np.isnan(ori) & np.isnan(z["fwd_ori"])), axis=1)
-    match &= hc == z["fwd_hc"]
-    # bit-exact on (nearly) every point; the exceptions are gemv-path points at ranks we did not store (with 300 views
-    # and 64 points nearly every base view owns a single point, so that fixture has more of them)
-    assert match[body].mean() >= (0.98 if z["visible"].shape[0] < 256 else 0.9)
-    assert np.allclose(loss, z["fwd_loss"], rtol=0, atol=1e-6, equal_nan=True)
+    check_forward_against_reference(request.node.callspec.params["case"], z, ori, loss, hc)
 
 
 def test_forward_own_topk(case, depth_offsets):
@@ -161,8 +157,10 @@ def test_forward_own_topk(case, depth_offsets):
     ev = np.arange(0, 20, 2)
     # a rank > 0 whose confidence is 0 can never win (PMVO.py:64), so its view index is irrelevant
     ok = (idx[ev] == z["base_idx"][ev]) | ((val[ev] == 0) & (ev[:, None] > 0))
-    same_rank = np.all(ok, axis=0) & _comparable(z, depth_offsets, views, pts)
-    assert same_rank.sum() >= 10
-    match = (loss == z["fwd_loss"]) | (np.isnan(loss) & np.isnan(z["fwd_loss"]))
-    assert match[same_rank].mean() >= (0.98 if z["visible"].shape[0] < 256 else 0.9)     # (see test_forward)
-    assert np.allclose(loss[same_rank], z["fwd_loss"][same_rank], rtol=0, atol=1e-6, equal_nan=True)
+    same_rank = np.all(ok, axis=0)
+    assert same_rank.all()            # torch.topk's order is reproduced, ties included: every usable rank is the reference's
+    # ... so the result is the one test_forward pins against the reference, bit for bit
+    _, ori2, loss2, hc2 = oracle.forward(views, pts, meta["patch"], meta["thr"], depth_offsets,
+                                         base_idx=z["base_idx"], base_val=z["base_val"])
+    assert np.array_equal(loss, loss2, equal_nan=True) and np.array_equal(ori, ori2, equal_nan=True)
+    assert np.array_equal(hc, hc2)
