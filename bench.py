@@ -306,6 +306,10 @@ def main():
             out["secondary_gabor_bank"] = secondary_gabor(a, dev)
         except Exception as e:
             out["secondary_gabor_bank"] = {"error": repr(e)[:200]}
+        try:
+            out["secondary_gabor_stage"] = secondary_gabor_stage(a, dev)
+        except Exception as e:
+            out["secondary_gabor_stage"] = {"error": repr(e)[:200]}
     # last: its 128 OpenMP workers keep spinning for a while after the parallel region and would slow the host side
     # of the secondary legs
     if not a.no_cpu and world == 1:      # the CPU leg runs on rank 0 at N=1 only
@@ -689,6 +693,55 @@ def secondary_gabor(a, dev):
             "image": [H, W], "kernel": "mh_gabor_mfma_kernel",
             "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
                          "frac": round(tf / 157.3, 4), "traffic": None}}
+
+
+def secondary_gabor_stage(a, dev):
+    """The Gabor STAGE per view, device to device: gray uint8 image resident in HBM -> DoG prefilter
+    (float64, mh_dog: 2 launches) -> 180-kernel bank (mh_gabor_mfma_kernel) -> confidence + the two 8-bit file codes the
+    reference hands to PMVO (mh_gabor_finish_kernel).  One call of mh_gabor_view per view; HIP events around 10 views, and
+    around the DoG alone."""
+    import numpy as np
+    import torch
+
+    from monohair_amd.gabor import calOrientationGabor, difference_of_gaussians_device
+
+    H, W = a.height, a.width
+    g = torch.Generator(device="cpu").manual_seed(0)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    img = (127 + 70 * torch.cos(2 * np.pi * (0.6 * xx + 0.8 * yy) / 4.0) + 6 * torch.randn((H, W), generator=g))
+    views = [(img.roll(7 * k, 1)).clamp(0, 255).to(torch.uint8).to(dev) for k in range(4)]
+    gab = calOrientationGabor(device=dev)
+    gab.view(views[0])
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    e[0].record()
+    for k in range(10):
+        out = gab.view(views[k % 4])
+    e[1].record()
+    torch.cuda.synchronize()
+    ms = e[0].elapsed_time(e[1]) / 10
+    difference_of_gaussians_device(views[0], 0.4, 10, dev, out32=True)
+    e[2].record()
+    for k in range(10):
+        difference_of_gaussians_device(views[k % 4], 0.4, 10, dev, out32=True)
+    e[3].record()
+    torch.cuda.synchronize()
+    dog_ms = e[2].elapsed_time(e[3]) / 10
+    tf = 2.0 * 180 * 289 * H * W / ms / 1e9
+    dog_bytes = H * W * (1 + 16 + 16 + 4)        # codes in, two float64 planes written and read back, float32 out
+    prof = {}
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("gabor_stage", {})
+    except Exception:
+        pass
+    return {"metric": "Gabor stage views/s (uint8 image -> DoG -> bank -> 8-bit codes)", "value": round(1e3 / ms, 1),
+            "unit": "views/s", "ms_per_view": round(ms, 3), "image": [H, W], "launches_per_view": 5,
+            "dog_ms": round(dog_ms, 4), "dog_fraction_of_stage": round(dog_ms / ms, 4),
+            "dog_GBps": round(dog_bytes / (dog_ms * 1e-3) / 1e9, 1), "dog_bytes_model": "H*W*(1 + 2*8 + 2*8 + 4)",
+            "codes_checksum": [int(out[3].sum().item()), int(out[4].sum().item())],
+            "roofline": {"kernel": "mh_gabor_mfma_kernel (whole stage timed)", "bound": "mfma", "achieved": round(tf, 1),
+                         "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+                         "traffic": prof.get("traffic_bytes"), "mfma_busy": prof.get("mfma_busy")}}
 
 
 def cpu_baseline(a, scene, recs, chunk, gpu_ms):

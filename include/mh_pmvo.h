@@ -260,6 +260,22 @@ int mh_gabor_bank(mh_ctx *ctx, const float *image, int H, int W, int32_t *orient
  * the bank the library builds on the device; lets the host reproduce the reference's CPU transcendental
  * functions bit for bit. */
 int mh_gabor_set_bank(mh_ctx *ctx, const float *bank_host);
+/* The difference-of-Gaussians prefilter of the stage (GaborFilter.py:190-192: skimage.filters.difference_of_gaussians(img,
+ * 0.4, 10) = img_as_float, two scipy.ndimage.gaussian_filter passes with mode='nearest', their difference) in float64 with
+ * scipy's operation order -- two launches.  image: uint8 [H,W] (in_kind 0; codes are multiplied by the double 1/255) or
+ * float64 [H,W] (in_kind 1), device.  w_lo / w_hi: HOST pointers to the symmetric halves w[0..r] (w[r] = centre) of the two
+ * normalised 1-D Gaussians as scipy builds them (radius = int(4 sigma + 0.5) <= 48).  scratch: mh_dog_scratch_bytes(H, W)
+ * device bytes.  out64 and/or out32 (device, [H,W]; either may be NULL): lo - hi and its float32 cast. */
+size_t mh_dog_scratch_bytes(int H, int W);
+int mh_dog(mh_ctx *ctx, const void *image, int in_kind, int H, int W, const double *w_lo, int r_lo, const double *w_hi,
+           int r_hi, void *scratch, double *out64, float *out32, void *stream);
+/* One view of the Gabor stage, device to device (calculate_orientation, GaborFilter.py:164-224, without the file IO):
+ * gray uint8 [H,W] -> DoG -> bank -> orient_index / conf / variance as mh_gabor_bank, plus (k8, c8 non-NULL) the two 8-bit
+ * codes the reference writes to best_ori/<view> and conf/<view> (orientation in degrees; floor(conf*255+0.5)) -- what the
+ * PMVO loaders read back (mh_ctx_set_view_u8).  conf may be NULL.  scratch: mh_gabor_view_scratch_bytes(H, W). */
+size_t mh_gabor_view_scratch_bytes(int H, int W);
+int mh_gabor_view(mh_ctx *ctx, const uint8_t *gray, int H, int W, const double *w_lo, int r_lo, const double *w_hi, int r_hi,
+                  void *scratch, int32_t *orient_index, float *conf, float *variance, uint8_t *k8, uint8_t *c8, void *stream);
 
 /* ---- strand tracing on the fitted volume (HairGrow.py).
  * mh_volume_pack: occ[Z,H,W] + ori[Z,H,W,3] (the .mat readers' layout, Utils/PMVO_utils.py:86-113) -> 16-byte voxels

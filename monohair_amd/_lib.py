@@ -70,6 +70,10 @@ _SIGS = {
     "mh_mat_write_sparse": (ci, [ctypes.c_char_p, vp, csz, csz, vp, vp, csz, ci]),
     "mh_gabor_bank": (ci, [vp, vp, ci, ci, vp, vp, vp, vp]),
     "mh_gabor_set_bank": (ci, [vp, vp]),
+    "mh_dog_scratch_bytes": (csz, [ci, ci]),
+    "mh_dog": (ci, [vp, vp, ci, ci, ci, vp, ci, vp, ci, vp, vp, vp, vp]),
+    "mh_gabor_view_scratch_bytes": (csz, [ci, ci]),
+    "mh_gabor_view": (ci, [vp, vp, ci, ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp]),
 }
 
 EXPORTS = sorted(_SIGS)

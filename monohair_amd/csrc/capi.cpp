@@ -16,6 +16,12 @@ struct MhViews {
     const float *cams;
 };
 
+#define MH_DG_MAXR 48
+struct MhDogWeightsHost {          // = MhDogWeights of csrc/dog.hip
+    double w[2][MH_DG_MAXR + 1];
+    int r[2];
+};
+
 struct mh_ctx {
     int device = 0;
     int V = 0, H = 0, W = 0;
@@ -25,6 +31,8 @@ struct mh_ctx {
     float *offs = nullptr;    // [S]
     float *gabor = nullptr;   // tap-major Gabor bank [289][192]
     unsigned int *gabor_max = nullptr;
+    void *dog_w = nullptr;    // device MhDogWeights of the difference-of-Gaussians prefilter (csrc/dog.hip)
+    MhDogWeightsHost *dog_w_host = nullptr;   // what dog_w holds
     float4 *lut = nullptr;    // [256] pixel-code table of the 8-bit map files
     int S = 0;
     int search_variant = 0;
@@ -86,7 +94,8 @@ int mh_launch_refine_combine(const float *, const float *, const uint8_t *, cons
                              int, hipStream_t);
 int mh_launch_medoid_segmented(const float *, const int32_t *, int, int, float *, int32_t *, hipStream_t);
 int mh_launch_gabor_bank(const float *, const float *, int, int, int32_t *, float *, float *, unsigned int *, int,
-                         hipStream_t);
+                         uint8_t *, uint8_t *, hipStream_t);
+int mh_launch_dog(const void *, int, int, int, const void *, double *, double *, float *, hipStream_t);
 int mh_launch_gabor_build(float *, hipStream_t);
 int mh_launch_replace_dissimilar(const float *, float *, float, int, hipStream_t);
 int mh_launch_knn(float, float, float, float, int, int, int, const float *, const int32_t *, const int32_t *,
@@ -155,6 +164,8 @@ extern "C" void mh_ctx_destroy(mh_ctx *ctx) {
     if (ctx->offs) (void)hipFree(ctx->offs);
     if (ctx->gabor) (void)hipFree(ctx->gabor);
     if (ctx->gabor_max) (void)hipFree(ctx->gabor_max);
+    if (ctx->dog_w) (void)hipFree(ctx->dog_w);
+    delete ctx->dog_w_host;
     if (ctx->lut) (void)hipFree(ctx->lut);
     delete ctx;
 }
@@ -757,8 +768,78 @@ extern "C" int mh_gabor_bank(mh_ctx *ctx, const float *image, int H, int W, int3
         if (rc) return rc;
     }
     return launched(mh_launch_gabor_bank(ctx->gabor, image, H, W, orient_index, conf, variance, ctx->gabor_max,
-                                         ctx->gabor_variant, st),
+                                         ctx->gabor_variant, nullptr, nullptr, st),
                     "mh_gabor_bank");
+}
+
+// The DoG weights (two symmetric halves, float64, computed by the caller the way scipy.ndimage does) live in a small device
+// struct; it is re-uploaded only when they change (in practice once: the reference always calls (0.4, 10)).
+static int dog_weights(mh_ctx *ctx, const double *w_lo, int r_lo, const double *w_hi, int r_hi, hipStream_t st) {
+    if (!w_lo || !w_hi || r_lo < 0 || r_hi < 0)
+        return fail(MH_ERR_ARG, "mh_dog: weights missing");
+    if (r_lo > MH_DG_MAXR || r_hi > MH_DG_MAXR)
+        return fail(MH_ERR_ARG, "mh_dog: kernel radius %d exceeds the built-in limit of %d (sigma <= %.1f at truncate 4); the "
+                                "reference uses sigma 0.4 and 10 (radius 2 and 40)", r_lo > r_hi ? r_lo : r_hi, MH_DG_MAXR,
+                    (MH_DG_MAXR + 0.49) / 4.0);
+    MhDogWeightsHost h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.w[0], w_lo, sizeof(double) * (r_lo + 1));
+    memcpy(h.w[1], w_hi, sizeof(double) * (r_hi + 1));
+    h.r[0] = r_lo;
+    h.r[1] = r_hi;
+    MH_HIP(hipSetDevice(ctx->device));
+    if (!ctx->dog_w) {
+        MH_HIP(hipMalloc(&ctx->dog_w, sizeof(MhDogWeightsHost)));
+        ctx->dog_w_host = new MhDogWeightsHost;
+        memset(ctx->dog_w_host, 0xff, sizeof(MhDogWeightsHost));
+    }
+    if (memcmp(ctx->dog_w_host, &h, sizeof h) != 0) {
+        // (other streams may still be reading the old weights: wait for the device before replacing them)
+        MH_HIP(hipDeviceSynchronize());
+        *ctx->dog_w_host = h;
+        MH_HIP(hipMemcpy(ctx->dog_w, ctx->dog_w_host, sizeof h, hipMemcpyHostToDevice));
+    }
+    (void)st;
+    return MH_OK;
+}
+
+extern "C" size_t mh_dog_scratch_bytes(int H, int W) { return (size_t)2 * H * W * sizeof(double); }
+
+extern "C" int mh_dog(mh_ctx *ctx, const void *image, int in_kind, int H, int W, const double *w_lo, int r_lo,
+                      const double *w_hi, int r_hi, void *scratch, double *out64, float *out32, void *stream) {
+    if (!ctx || !image || !scratch || (!out64 && !out32) || H < 1 || W < 1 || (in_kind != 0 && in_kind != 1))
+        return fail(MH_ERR_ARG, "mh_dog: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = dog_weights(ctx, w_lo, r_lo, w_hi, r_hi, st)) return rc;
+    return launched(mh_launch_dog(image, in_kind, H, W, ctx->dog_w, (double *)scratch, out64, out32, st), "mh_dog");
+}
+
+// One view of the Gabor stage, device to device: gray uint8 image -> DoG (float64, cast to float32) -> bank -> confidence
+// -> the two 8-bit file codes.  scratch: mh_gabor_view_scratch_bytes(H, W) = two float64 planes + the float32 DoG image +
+// the image-maximum slot (in the caller's scratch, so views on different streams do not share it).
+extern "C" size_t mh_gabor_view_scratch_bytes(int H, int W) { return (size_t)H * W * (16 + 4) + 256; }
+
+extern "C" int mh_gabor_view(mh_ctx *ctx, const uint8_t *gray, int H, int W, const double *w_lo, int r_lo, const double *w_hi,
+                             int r_hi, void *scratch, int32_t *orient_index, float *conf, float *variance, uint8_t *k8,
+                             uint8_t *c8, void *stream) {
+    if (!ctx || !gray || !scratch || !orient_index || !variance || H < 1 || W < 1)
+        return fail(MH_ERR_ARG, "mh_gabor_view: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = dog_weights(ctx, w_lo, r_lo, w_hi, r_hi, st)) return rc;
+    if (!ctx->gabor) {
+        int rc = gabor_alloc(ctx);
+        if (rc) return rc;
+        rc = launched(mh_launch_gabor_build(ctx->gabor, st), "mh_gabor_view(build)");
+        if (rc) return rc;
+    }
+    char *base = (char *)scratch;
+    double *planes = (double *)base;
+    float *dog32 = (float *)(base + (size_t)H * W * 16);
+    unsigned int *maxbits = (unsigned int *)(base + (size_t)H * W * 20);
+    if (int rc = launched(mh_launch_dog(gray, 0, H, W, ctx->dog_w, planes, nullptr, dog32, st), "mh_gabor_view(dog)")) return rc;
+    return launched(mh_launch_gabor_bank(ctx->gabor, dog32, H, W, orient_index, conf, variance, maxbits, ctx->gabor_variant,
+                                         k8, c8, st),
+                    "mh_gabor_view");
 }
 
 // ---------------------------------------------------------------------------------------------

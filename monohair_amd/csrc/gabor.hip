@@ -426,15 +426,26 @@ __global__ __launch_bounds__(256, 2) void mh_gabor_mfma_kernel(const float *__re
     if (lane == 0) atomicMax(maxbits, __float_as_uint(vmax));
 }
 
+// confidence = clamp((var / max_image(var)) / 0.2, 0, 1)  (GaborFilter.py:80-93).  Optionally also the two 8-bit FILE CODES
+// the reference hands to PMVO: best_ori/<view> = the orientation index in degrees (cv2.imwrite of
+// b*180/pi, GaborFilter.py:209) and conf/<view> = floor(conf*255 + 0.5) (torchvision.utils.save_image, :210) -- fp32 mul, add,
+// clamp, truncation, exactly the tensor ops (conf*255+0.5).clamp(0,255).to(uint8).
 __global__ __launch_bounds__(256) void mh_gabor_finish_kernel(const float *__restrict__ var,
                                                               const unsigned int *__restrict__ maxbits, size_t npix,
-                                                              float *__restrict__ conf) {
+                                                              float *__restrict__ conf, const int32_t *__restrict__ orient,
+                                                              uint8_t *__restrict__ k8, uint8_t *__restrict__ c8) {
     const float mx = __uint_as_float(*maxbits);
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;
     for (; i < npix; i += step) {
         const float v = var[i] / mx;
-        conf[i] = mh_clampf((v - 0.0f) / 0.2f, 0.0f, 1.0f);
+        const float c = mh_clampf((v - 0.0f) / 0.2f, 0.0f, 1.0f);
+        if (conf) conf[i] = c;
+        if (c8) c8[i] = (uint8_t)mh_clampf(c * 255.0f + 0.5f, 0.0f, 255.0f);     // (a NaN confidence -- an all-zero image -- stores 0)
+        if (k8) {
+            const int32_t k = orient[i];
+            k8[i] = (uint8_t)(k < 0 ? 0 : (k > 255 ? 255 : k));
+        }
     }
 }
 
@@ -445,7 +456,8 @@ extern "C" int mh_launch_gabor_build(float *bankT, hipStream_t st) {
 }
 
 extern "C" int mh_launch_gabor_bank(const float *bankT, const float *img, int H, int W, int32_t *orient, float *conf,
-                                    float *var, unsigned int *maxbits, int variant, hipStream_t st) {
+                                    float *var, unsigned int *maxbits, int variant, uint8_t *k8, uint8_t *c8,
+                                    hipStream_t st) {
     (void)hipMemsetAsync(maxbits, 0, sizeof(unsigned int), st);
     if (variant == 2) {
         const dim3 grid((W + MH_GB_TILE - 1) / MH_GB_TILE, (H + MH_GB_TILE - 1) / MH_GB_TILE);
@@ -459,6 +471,6 @@ extern "C" int mh_launch_gabor_bank(const float *bankT, const float *img, int H,
     }
     const size_t npix = (size_t)H * W;
     const int blocks = (int)((npix + 255) / 256 < 2048 ? (npix + 255) / 256 : 2048);
-    hipLaunchKernelGGL(mh_gabor_finish_kernel, dim3(blocks), dim3(256), 0, st, var, maxbits, npix, conf);
+    hipLaunchKernelGGL(mh_gabor_finish_kernel, dim3(blocks), dim3(256), 0, st, var, maxbits, npix, conf, orient, k8, c8);
     return (int)hipGetLastError();
 }

@@ -93,6 +93,33 @@ class calOrientationGabor:
                                                 _lib.ptr(var), _lib.stream_ptr()), "mh_gabor_bank")
         return idx, conf, var
 
+    def view(self, gray_u8, codes=True, low_sigma=0.4, high_sigma=10):
+        """One view of the stage, device to device (mh_gabor_view): gray uint8 [H,W] (numpy or device tensor) -> DoG ->
+        bank -> (orient index int32, conf fp32, variance fp32, best_ori code uint8, conf code uint8); the codes are what the
+        reference writes to best_ori/<view> and conf/<view> (None with codes=False).  Four launches, no tensor op."""
+        g = gray_u8 if torch.is_tensor(gray_u8) else torch.from_numpy(np.ascontiguousarray(gray_u8))
+        g = g.to(self.device).contiguous()
+        assert g.dtype == torch.uint8 and g.dim() == 2
+        self._install_bank(1.8, 2.4, 4.0)
+        H, W = g.shape
+        L = _lib.lib()
+        key = (H, W, torch.cuda.current_stream(self.device).cuda_stream)
+        if getattr(self, "_view_scratch_key", None) != key:          # one scratch per (size, stream), reused across views
+            self._view_scratch = torch.empty((L.mh_gabor_view_scratch_bytes(H, W),), dtype=torch.uint8, device=self.device)
+            self._view_scratch_key = key
+        idx = torch.empty((H, W), dtype=torch.int32, device=self.device)
+        conf = torch.empty((H, W), dtype=torch.float32, device=self.device)
+        var = torch.empty((H, W), dtype=torch.float32, device=self.device)
+        k8 = torch.empty((H, W), dtype=torch.uint8, device=self.device) if codes else None
+        c8 = torch.empty((H, W), dtype=torch.uint8, device=self.device) if codes else None
+        w0, r0, w1, r1 = _dog_weights(low_sigma, high_sigma)
+        with torch.cuda.device(self.device):
+            _lib.check(L.mh_gabor_view(self._ctx, _lib.ptr(g), H, W, w0.ctypes.data_as(ctypes.c_void_p), r0,
+                                       w1.ctypes.data_as(ctypes.c_void_p), r1, _lib.ptr(self._view_scratch), _lib.ptr(idx),
+                                       _lib.ptr(conf), _lib.ptr(var), _lib.ptr(k8), _lib.ptr(c8), _lib.stream_ptr()),
+                       "mh_gabor_view")
+        return idx, conf, var, k8, c8
+
     def gabor_fn(self, kernel_size, channel_in, channel_out, theta, sigma_x, sigma_y, Lambda, phase=0.):
         """GaborFilter.py:115-145 with the reference's signature -> [channel_out, channel_in, k, k] on the device"""
         th = torch.as_tensor(theta, dtype=torch.float32).reshape(-1).cpu()
@@ -210,10 +237,9 @@ def _correlate1d_nearest(x, w, radius, axis):
     return acc
 
 
-def difference_of_gaussians_device(image, low_sigma, high_sigma, device):
-    """difference_of_gaussians on the GPU in float64 with scipy's operation order (separable passes along axis 0
-    then 1); image: uint8 [H,W] (what the reference passes; scaled like skimage's img_as_float) or a float array, which is
-    filtered in float64 (scikit-image keeps a float32 image in float32 -- use difference_of_gaussians for that)."""
+def difference_of_gaussians_torch(image, low_sigma, high_sigma, device):
+    """The first device form (about 250 float64 tensor launches per image); kept as the cross-check of the HIP kernel
+    (tests assert array_equal)."""
     img = np.asarray(image)
     x = torch.from_numpy(img).to(device)
     # img_as_float: uint8 codes are MULTIPLIED by the float64 constant 1/255 (see _img_as_float)
@@ -224,6 +250,48 @@ def difference_of_gaussians_device(image, low_sigma, high_sigma, device):
         y = _correlate1d_nearest(x, w, r, 0)
         out.append(_correlate1d_nearest(y, w, r, 1))
     return out[0] - out[1]
+
+
+_DOG_W = {}
+
+
+def _dog_weights(low_sigma, high_sigma):
+    """the two symmetric half kernels (float64, w[r] = centre) as contiguous host arrays for mh_dog / mh_gabor_view"""
+    key = (float(low_sigma), float(high_sigma))
+    if key not in _DOG_W:
+        out = []
+        for sigma in key:
+            w, r = _gaussian_kernel1d(sigma)
+            out += [np.ascontiguousarray(w[:r + 1], dtype=np.float64), int(r)]
+        _DOG_W[key] = tuple(out)
+    return _DOG_W[key]
+
+
+def difference_of_gaussians_device(image, low_sigma, high_sigma, device, out32=False):
+    """difference_of_gaussians on the GPU in float64 with scipy's operation order (separable passes along axis 0 then 1):
+    mh_dog, two launches (csrc/dog.hip).  image: uint8 [H,W] (what the reference passes; scaled like skimage's
+    img_as_float) or a float array, which is filtered in float64 (scikit-image keeps a float32 image in float32 -- use
+    difference_of_gaussians for that); a numpy array or a device tensor.  Returns the float64 image, or with out32=True its
+    float32 cast (what the bank takes)."""
+    device = torch.device(device)
+    if torch.is_tensor(image):
+        x = image.to(device)
+    else:
+        x = torch.from_numpy(np.ascontiguousarray(image)).to(device)
+    if x.dtype != torch.uint8:
+        x = x.to(torch.float64)
+    x = x.contiguous()
+    H, W = x.shape
+    w0, r0, w1, r1 = _dog_weights(low_sigma, high_sigma)
+    L = _lib.lib()
+    scratch = torch.empty((L.mh_dog_scratch_bytes(H, W),), dtype=torch.uint8, device=device)
+    out = torch.empty((H, W), dtype=torch.float32 if out32 else torch.float64, device=device)
+    with torch.cuda.device(device):
+        _lib.check(L.mh_dog(_ctx_for(device), _lib.ptr(x), 0 if x.dtype == torch.uint8 else 1, H, W,
+                            w0.ctypes.data_as(ctypes.c_void_p), r0, w1.ctypes.data_as(ctypes.c_void_p), r1,
+                            _lib.ptr(scratch), None if out32 else _lib.ptr(out), _lib.ptr(out) if out32 else None,
+                            _lib.stream_ptr()), "mh_dog")
+    return out
 
 
 _FILE_LUT = None
@@ -272,9 +340,7 @@ def orientation_maps_device(images, device=None, gabor=None, return_codes=False)
     for i in range(V):
         if mdist.owner(i) != mdist.rank():
             continue
-        dog = difference_of_gaussians_device(images[i], 0.4, 10, device).to(torch.float32)
-        idx, conf, _ = gabor.filter_index(dog)
-        _, _, k8, c8 = pmvo_maps_from_gabor(idx, conf)
+        _, _, _, k8, c8 = gabor.view(images[i])
         local.append(torch.stack([k8, c8], 0))
     planes = mdist.all_gather_views(local, V, (2, H, W), torch.uint8, device)      # [V,2,H,W]
     if return_codes:
@@ -286,7 +352,7 @@ def orientation_maps_device(images, device=None, gabor=None, return_codes=False)
 def _orientation_arrays(image_u8, gabor, iter=1, threshold=0.0):
     """gray uint8 image -> (deg uint8 [H,W], conf uint8 [H,W], viz uint8 [H,W,3]) as calculate_orientation writes
     them; DoG and Gabor bank on the device (the device DoG reproduces scipy's float64 result bit for bit)."""
-    dog = difference_of_gaussians_device(image_u8, 0.4, 10, gabor.device).to(torch.float32)
+    dog = difference_of_gaussians_device(image_u8, 0.4, 10, gabor.device, out32=True)
     two, best, confidence = gabor(dog[None, None], None, iter, threshold=threshold)
     deg = torch.round(best[0, 0] / math.pi * 180).clamp(0, 255).to(torch.uint8).cpu().numpy()
     c8 = (confidence[0, 0] * 255 + 0.5).clamp(0, 255).to(torch.uint8).cpu().numpy()
