@@ -30,6 +30,7 @@ struct mh_ctx {
     float *cams = nullptr;    // [V][MH_CAM_STRIDE]
     float *offs = nullptr;    // [S]
     float *gabor = nullptr;   // tap-major Gabor bank [289][192]
+    float *gabor_q = nullptr; // the same coefficients in the operand order of mh_gabor_mfma2_kernel [145][64][8]
     unsigned int *gabor_max = nullptr;
     void *dog_w = nullptr;    // device MhDogWeights of the difference-of-Gaussians prefilter (csrc/dog.hip)
     MhDogWeightsHost *dog_w_host = nullptr;   // what dog_w holds
@@ -40,7 +41,8 @@ struct mh_ctx {
     int taps_tile = 64;       // points per workgroup of mh_project_taps_kernel (64 / 32 / 16)
     int line_rule = 0;        // strand renderer: 0 GL's diamond-exit, 1 every touched diamond (SwiftShader)
     int raster_subpixel_bits = 8;   // both rasterisers: window positions snapped to 2^-bits pixel (SwiftShader: 4)
-    int gabor_variant = 1;    // 0: v_pk_fma, one pixel/lane; 1: FP32-MFMA im2col (default); 2: v_pk_fma, split bank
+    int gabor_variant = 3;    // 0: v_pk_fma, one pixel/lane; 1: FP32-MFMA im2col, first form; 2: v_pk_fma, split bank;
+                              // 3: FP32-MFMA im2col with re-laid-out bank and immediate-offset LDS reads (default)
     MhViews views() const { return MhViews{V, H, W, rec, mask, cams}; }
 };
 
@@ -93,8 +95,11 @@ int mh_launch_refine_loss_maps(MhViews, const float *, const float *, float, flo
 int mh_launch_refine_combine(const float *, const float *, const uint8_t *, const uint8_t *, float, float *, float *,
                              int, hipStream_t);
 int mh_launch_medoid_segmented(const float *, const int32_t *, int, int, float *, int32_t *, hipStream_t);
-int mh_launch_gabor_bank(const float *, const float *, int, int, int32_t *, float *, float *, unsigned int *, int,
-                         uint8_t *, uint8_t *, hipStream_t);
+int mh_launch_gabor_bank(const float *, const float *, const float *, int, int, int32_t *, float *, float *, unsigned int *,
+                         int, uint8_t *, uint8_t *, hipStream_t);
+size_t mh_gabor_state_bytes();
+size_t mh_gabor_bankq_bytes();
+int mh_launch_gabor_relayout(const float *, float *, hipStream_t);
 int mh_launch_dog(const void *, int, int, int, const void *, double *, double *, float *, hipStream_t);
 int mh_launch_gabor_build(float *, hipStream_t);
 int mh_launch_replace_dissimilar(const float *, float *, float, int, hipStream_t);
@@ -164,6 +169,7 @@ extern "C" void mh_ctx_destroy(mh_ctx *ctx) {
     if (ctx->offs) (void)hipFree(ctx->offs);
     if (ctx->gabor) (void)hipFree(ctx->gabor);
     if (ctx->gabor_max) (void)hipFree(ctx->gabor_max);
+    if (ctx->gabor_q) (void)hipFree(ctx->gabor_q);
     if (ctx->dog_w) (void)hipFree(ctx->dog_w);
     delete ctx->dog_w_host;
     if (ctx->lut) (void)hipFree(ctx->lut);
@@ -737,7 +743,8 @@ static int gabor_alloc(mh_ctx *ctx) {
     if (ctx->gabor) return MH_OK;
     MH_HIP(hipSetDevice(ctx->device));
     MH_HIP(hipMalloc(&ctx->gabor, 290 * 192 * sizeof(float)));   // 289 taps + one zero pad tap (MFMA K = 290)
-    MH_HIP(hipMalloc(&ctx->gabor_max, sizeof(unsigned int)));
+    MH_HIP(hipMalloc(&ctx->gabor_max, mh_gabor_state_bytes()));
+    MH_HIP(hipMalloc(&ctx->gabor_q, mh_gabor_bankq_bytes()));
     return MH_OK;
 }
 
@@ -753,6 +760,9 @@ extern "C" int mh_gabor_set_bank(mh_ctx *ctx, const float *bank_host) {
     hipError_t e = hipMemcpy(ctx->gabor, tmp, 290 * 192 * sizeof(float), hipMemcpyHostToDevice);
     delete[] tmp;
     if (e != hipSuccess) return fail(MH_ERR_HIP, "mh_gabor_set_bank: %s", hipGetErrorString(e));
+    rc = launched(mh_launch_gabor_relayout(ctx->gabor, ctx->gabor_q, nullptr), "mh_gabor_set_bank(relayout)");
+    if (rc) return rc;
+    MH_HIP(hipStreamSynchronize(nullptr));      // (installation is rare; later launches may come on any stream)
     return MH_OK;
 }
 
@@ -766,8 +776,10 @@ extern "C" int mh_gabor_bank(mh_ctx *ctx, const float *image, int H, int W, int3
         if (rc) return rc;
         rc = launched(mh_launch_gabor_build(ctx->gabor, st), "mh_gabor_bank(build)");
         if (rc) return rc;
+        rc = launched(mh_launch_gabor_relayout(ctx->gabor, ctx->gabor_q, st), "mh_gabor_bank(relayout)");
+        if (rc) return rc;
     }
-    return launched(mh_launch_gabor_bank(ctx->gabor, image, H, W, orient_index, conf, variance, ctx->gabor_max,
+    return launched(mh_launch_gabor_bank(ctx->gabor, ctx->gabor_q, image, H, W, orient_index, conf, variance, ctx->gabor_max,
                                          ctx->gabor_variant, nullptr, nullptr, st),
                     "mh_gabor_bank");
 }
@@ -817,7 +829,7 @@ extern "C" int mh_dog(mh_ctx *ctx, const void *image, int in_kind, int H, int W,
 // One view of the Gabor stage, device to device: gray uint8 image -> DoG (float64, cast to float32) -> bank -> confidence
 // -> the two 8-bit file codes.  scratch: mh_gabor_view_scratch_bytes(H, W) = two float64 planes + the float32 DoG image +
 // the image-maximum slot (in the caller's scratch, so views on different streams do not share it).
-extern "C" size_t mh_gabor_view_scratch_bytes(int H, int W) { return (size_t)H * W * (16 + 4) + 256; }
+extern "C" size_t mh_gabor_view_scratch_bytes(int H, int W) { return (size_t)H * W * (16 + 4) + mh_gabor_state_bytes(); }
 
 extern "C" int mh_gabor_view(mh_ctx *ctx, const uint8_t *gray, int H, int W, const double *w_lo, int r_lo, const double *w_hi,
                              int r_hi, void *scratch, int32_t *orient_index, float *conf, float *variance, uint8_t *k8,
@@ -831,14 +843,16 @@ extern "C" int mh_gabor_view(mh_ctx *ctx, const uint8_t *gray, int H, int W, con
         if (rc) return rc;
         rc = launched(mh_launch_gabor_build(ctx->gabor, st), "mh_gabor_view(build)");
         if (rc) return rc;
+        rc = launched(mh_launch_gabor_relayout(ctx->gabor, ctx->gabor_q, st), "mh_gabor_view(relayout)");
+        if (rc) return rc;
     }
     char *base = (char *)scratch;
     double *planes = (double *)base;
     float *dog32 = (float *)(base + (size_t)H * W * 16);
     unsigned int *maxbits = (unsigned int *)(base + (size_t)H * W * 20);
     if (int rc = launched(mh_launch_dog(gray, 0, H, W, ctx->dog_w, planes, nullptr, dog32, st), "mh_gabor_view(dog)")) return rc;
-    return launched(mh_launch_gabor_bank(ctx->gabor, dog32, H, W, orient_index, conf, variance, maxbits, ctx->gabor_variant,
-                                         k8, c8, st),
+    return launched(mh_launch_gabor_bank(ctx->gabor, ctx->gabor_q, dog32, H, W, orient_index, conf, variance, maxbits,
+                                         ctx->gabor_variant, k8, c8, st),
                     "mh_gabor_view");
 }
 

@@ -367,6 +367,9 @@ __global__ __launch_bounds__(256, 2) void mh_gabor_mfma_kernel(const float *__re
     // 4*(lane>>5).  One N-tile (32 orientations x 2 x 32 pixels) at a time is transposed through LDS so that lane L
     // owns pixel L&31 of M-tile L>>5 and walks the orientations in index order: pass 1 first-maximum argmax, pass 2
     // the cascade-ordered variance -- the same operations in the same order as the VALU kernels.
+    // the epilogue is a chain of dependent LDS round trips and VALU: it gets issue priority over the co-resident wave,
+    // whose MFMAs keep the matrix pipe full whichever wave the arbiter picks
+    __builtin_amdgcn_s_setprio(1);
     float *__restrict__ st = stage[wave];
     const int mt = lane >> 5;
     const float PI_F = 3.14159265358979323846f;
@@ -390,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void mh_gabor_mfma_kernel(const float *__re
             __builtin_amdgcn_wave_barrier();
             const int kmax = (n == 5) ? MH_GB_NK - 160 : 32;
             if (pass == 0) {
+#pragma unroll
                 for (int kl = 0; kl < kmax; ++kl) {
                     const float r = st[(mt * 32 + kl) * MH_GM_RS + pix];
                     if ((n | kl) == 0) {
@@ -400,6 +404,7 @@ __global__ __launch_bounds__(256, 2) void mh_gabor_mfma_kernel(const float *__re
                     }
                 }
             } else {
+#pragma unroll
                 for (int kl = 0; kl < kmax; ++kl) {
                     if (kl == 16 || (kl == 0 && n > 0)) mh_casc_flush(sc);
                     const float t1 = bh - s_theta[n * 32 + kl];
@@ -412,6 +417,197 @@ __global__ __launch_bounds__(256, 2) void mh_gabor_mfma_kernel(const float *__re
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
+    }
+    const float var = __builtin_sqrtf(sc.a0 + sc.a1);
+    const int y = y0 + 2 * wave + mt, x = x0 + pix;
+    float vmax = 0.0f;
+    if (y < H && x < W) {
+        var_out[(size_t)y * W + x] = var;
+        orient[(size_t)y * W + x] = (var > 0.0f) ? b : 0;
+        vmax = var;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if (lane == 0) atomicMax(maxbits, __float_as_uint(vmax));
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// mh_gabor_mfma2_kernel (the default since round 3): the same contraction, same K order, same epilogue -- bit-identical
+// maps -- with the operand traffic of the main loop cut down.  Experiments on the first form (tools/ubench: loads removed
+// one kind at a time) showed the 12 MFMAs of a K-step waiting on its own operand plumbing: the six 4-byte bank loads cost
+// 7 %, the two LDS reads with their ~20 VALU of address arithmetic 5 %.  Here
+//   * the bank is re-laid out once per installation as bankQ[step][lane][8]: the six coefficients a lane needs for one K-step
+//     are 32 contiguous bytes -> two dwordx4 loads instead of six dword loads (coalesced 2 KB per wave);
+//   * the K loop runs in blocks of 17 steps (34 taps = two rows of the 17 x 17 window), fully unrolled, so that every LDS
+//     read is `base register + immediate`: lanes 32-63 (tap 2s+1) keep a second base for the one step per block whose
+//     odd tap wraps to the next window row.  No address arithmetic is left in the loop.
+// ---------------------------------------------------------------------------------------------
+#define MH_GM_NSTEP ((MH_GB_NT + 1) / 2)     // 145 K-steps; tap 289 is the zero row
+
+// bankT [290][192] -> bankQ [145][64][8]: lane (c = lane & 31, kk = lane >> 5) of step s holds bankT[2s+kk][n*32 + c], n = 0..5
+__global__ void mh_gabor_relayout_kernel(const float *__restrict__ bankT, float *__restrict__ bankQ) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int c = lane & 31, kk = lane >> 5;
+#pragma unroll
+    for (int n = 0; n < 8; ++n)
+        bankQ[((size_t)s * 64 + lane) * 8 + n] = n < 6 ? bankT[(size_t)(2 * s + kk) * MH_GB_KPAD + n * 32 + c] : 0.0f;
+}
+
+__host__ __device__ constexpr int mh_gm_off(int u) { return ((2 * u) / MH_GB_KS) * MH_GM_LDW + (2 * u) % MH_GB_KS; }
+__host__ __device__ constexpr bool mh_gm_wrap(int u) { return (2 * u) % MH_GB_KS == MH_GB_KS - 1; }
+
+// NU steps of one 17-step block.  lds_n / lds_w: LDS byte addresses of this lane for the block's first window row (normal
+// / wrapping step); bqs: the (wave-uniform) bankQ pointer at the block's first step, voff: this lane's byte offset in a
+// step's 2 KB; (a0, a1, b0, b1) hold the operands of the block's first step on entry and those of the next block's first
+// step on exit.
+// The operand requests of step u+1 are written as inline assembly in front of step u's 12 MFMAs and waited for BEHIND them
+// (`s_waitcnt` in a second asm that passes the registers through): left to the compiler, the bank loads were sunk to
+// just in front of their first use and every K-step began with an exposed L2 round trip (2.00 ms instead of 1.93).
+typedef float mh_f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NU, bool LAST>
+__device__ __forceinline__ void mh_gm_block(unsigned lds_n, unsigned lds_w, const float *__restrict__ bqs, unsigned voff,
+                                            float &a0, float &a1, mh_f32x4 &b0, mh_f32x4 &b1, mh_f32x16 (&acc)[2][6]) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        mh_f32x4 n0 = b0, n1 = b1;
+        float a0n = a0, a1n = a1;
+        constexpr bool dummy = false;
+        (void)dummy;
+        if (!(LAST && u == NU - 1)) {
+            const float *__restrict__ bsrc = bqs + (size_t)(u + 1) * 512;
+            const unsigned la = mh_gm_wrap(u + 1) ? lds_w : lds_n;
+            asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
+                         "global_load_dwordx4 %1, %4, %5 offset:16\n\t"
+                         "ds_read_b32 %2, %6 offset:%7\n\t"
+                         "ds_read_b32 %3, %6 offset:%8"
+                         : "=&v"(n0), "=&v"(n1), "=&v"(a0n), "=&v"(a1n)
+                         : "v"(voff), "s"(bsrc), "v"(la), "n"(mh_gm_off(u + 1) * 4), "n"((mh_gm_off(u + 1) + MH_GM_LDW) * 4)
+                         : "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0.x, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0.x, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0.y, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0.y, acc[1][1], 0, 0, 0);
+        acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0.z, acc[0][2], 0, 0, 0);
+        acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0.z, acc[1][2], 0, 0, 0);
+        acc[0][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0.w, acc[0][3], 0, 0, 0);
+        acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0.w, acc[1][3], 0, 0, 0);
+        acc[0][4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1.x, acc[0][4], 0, 0, 0);
+        acc[1][4] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.x, acc[1][4], 0, 0, 0);
+        acc[0][5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1.y, acc[0][5], 0, 0, 0);
+        acc[1][5] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1.y, acc[1][5], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(LAST && u == NU - 1))
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(n0), "+v"(n1), "+v"(a0n), "+v"(a1n)::"memory");
+        b0 = n0, b1 = n1, a0 = a0n, a1 = a1n;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void mh_gabor_mfma2_kernel(const float *__restrict__ bankQ,
+                                                                const float *__restrict__ img, int H, int W,
+                                                                int32_t *__restrict__ orient,
+                                                                float *__restrict__ var_out,
+                                                                unsigned int *__restrict__ maxbits) {
+    __shared__ float tile[MH_GM_LDH * MH_GM_LDW];              // [25][48]
+    __shared__ float stage[4][2 * 32 * MH_GM_RS];              // per wave: [M-tile][orientation of the N-tile][33]
+    __shared__ float s_theta[MH_GB_KPAD];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int y0 = blockIdx.y * MH_GM_ROWS, x0 = blockIdx.x * MH_GM_COLS;
+    for (int q = tid; q < MH_GM_LDH * MH_GM_LDW; q += 256) {
+        const int ly = q / MH_GM_LDW, lx = q - ly * MH_GM_LDW;
+        const int gy = y0 + ly - 8, gx = x0 + lx - 8;
+        tile[q] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : 0.0f;
+    }
+    if (tid < MH_GB_KPAD) s_theta[tid] = mh_theta((float)tid);
+    __syncthreads();
+
+    mh_f32x16 acc[2][6];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int n = 0; n < 6; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][n][r] = 0.0f;
+
+    const int pix = lane & 31, kk = lane >> 5;
+    // lane bases into the LDS tile for window row 0 of M-tile 0: tap 2s (+1 for the upper half of the wave); in the one
+    // step per block whose even tap sits in window column 16 the odd tap is column 0 of the next row: +(48 - 16) floats
+    const float *__restrict__ an = tile + (2 * wave) * MH_GM_LDW + pix + kk;
+    const float *__restrict__ aw = tile + (2 * wave) * MH_GM_LDW + pix + kk * (MH_GM_LDW - (MH_GB_KS - 1));
+    unsigned lds_n = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)an;
+    unsigned lds_w = (unsigned)(size_t)(__attribute__((address_space(3))) const float *)aw;
+    const unsigned voff = lane * 32;
+    const mh_f32x4 *__restrict__ bq0 = reinterpret_cast<const mh_f32x4 *>(bankQ) + lane * 2;
+    mh_f32x4 b0 = bq0[0], b1 = bq0[1];
+    float a0 = an[0], a1 = an[MH_GM_LDW];
+    // (the first operands are consumed here so that no compiler-tracked load is pending at the loop header: it would
+    // otherwise wait there between every block's first requests and its MFMAs)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(b0), "+v"(b1), "+v"(a0), "+v"(a1)::"memory");
+    const float *__restrict__ bqs = bankQ;
+    constexpr int NBLK = MH_GM_NSTEP / MH_GB_KS, NREM = MH_GM_NSTEP - NBLK * MH_GB_KS;    // 8 blocks of 17 steps + 9
+#pragma unroll 1
+    for (int q = 0; q < NBLK; ++q) {
+        mh_gm_block<MH_GB_KS, false>(lds_n, lds_w, bqs, voff, a0, a1, b0, b1, acc);
+        lds_n += 2 * MH_GM_LDW * 4;
+        lds_w += 2 * MH_GM_LDW * 4;
+        bqs += MH_GB_KS * 512;
+    }
+    mh_gm_block<NREM, true>(lds_n, lds_w, bqs, voff, a0, a1, b0, b1, acc);
+    // Epilogue.  C layout of the 32x32 MFMA: column (orientation) = lane & 31, row (pixel) = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Each N-tile (32 orientations x 2 x 32 pixels) is transposed ONCE through LDS so that lane L owns pixel L&31 of
+    // M-tile L>>5; the 32 transposed |responses| come back into registers (the tile's accumulators are dead by then), the
+    // first-maximum argmax runs on the fly, and when all six tiles are through the lane holds its pixel's 180 responses in
+    // registers: the cascade-ordered variance is straight-line code on them with theta_k as literals.  Same operations in
+    // the same order as the VALU kernels; half the LDS traffic and none of the per-value LDS reads of the first form (the
+    // epilogue's issue time adds to the kernel's: VALU / LDS instructions of one wave are not hidden behind the other
+    // wave's MFMAs on the same SIMD -- de-phasing the two workgroups of a CU, priorities and one workgroup per CU all
+    // measured the same 1.91 ms, and 1.58 ms with the epilogue removed).
+    float *__restrict__ st = stage[wave];
+    const int mt = lane >> 5;
+    const float PI_F = 3.14159265358979323846f;
+    float R[MH_GB_NK];
+    float M = 0.0f;
+    int b = 0;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+                st[(p * 32 + pix) * MH_GM_RS + row] = __builtin_fabsf(acc[p][n][r]);
+            }
+        // (16-byte stores of four consecutive rows with a 36-float row stride were measured slower: 1.94 vs 1.76 ms)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int km = (n == 5) ? MH_GB_NK - 160 : 32;
+#pragma unroll
+        for (int kl = 0; kl < km; ++kl) R[n * 32 + kl] = st[(mt * 32 + kl) * MH_GM_RS + pix];
+#pragma unroll
+        for (int kl = 0; kl < km; ++kl) {
+            const float r = R[n * 32 + kl];
+            if ((n | kl) == 0) {
+                M = r;
+            } else if (r > M) {
+                M = r;
+                b = n * 32 + kl;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const float bh = s_theta[b];
+    MhCasc sc = {0.f, 0.f};
+#pragma unroll
+    for (int k2 = 0; k2 < MH_GB_NK; ++k2) {
+        if (k2 > 0 && (k2 & 15) == 0) mh_casc_flush(sc);
+        const float t1 = bh - mh_theta((float)k2);
+        const float d = fminf(__builtin_fabsf(t1), fminf(__builtin_fabsf(t1 - PI_F), __builtin_fabsf(t1 + PI_F)));
+        const float rd = R[k2] - M;
+        sc.a0 = sc.a0 + (d * rd) * rd;
     }
     const float var = __builtin_sqrtf(sc.a0 + sc.a1);
     const int y = y0 + 2 * wave + mt, x = x0 + pix;
@@ -455,13 +651,27 @@ extern "C" int mh_launch_gabor_build(float *bankT, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
-extern "C" int mh_launch_gabor_bank(const float *bankT, const float *img, int H, int W, int32_t *orient, float *conf,
-                                    float *var, unsigned int *maxbits, int variant, uint8_t *k8, uint8_t *c8,
+// maxbits: the image maximum of the variance (one uint, zeroed per launch)
+extern "C" size_t mh_gabor_state_bytes() { return 64; }
+
+// bankQ: the re-laid-out copy for mh_gabor_mfma2_kernel, mh_gabor_bankq_bytes() bytes, made by mh_launch_gabor_relayout
+extern "C" size_t mh_gabor_bankq_bytes() { return (size_t)MH_GM_NSTEP * 64 * 8 * sizeof(float); }
+
+extern "C" int mh_launch_gabor_relayout(const float *bankT, float *bankQ, hipStream_t st) {
+    hipLaunchKernelGGL(mh_gabor_relayout_kernel, dim3(MH_GM_NSTEP), dim3(64), 0, st, bankT, bankQ);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mh_launch_gabor_bank(const float *bankT, const float *bankQ, const float *img, int H, int W, int32_t *orient,
+                                    float *conf, float *var, unsigned int *maxbits, int variant, uint8_t *k8, uint8_t *c8,
                                     hipStream_t st) {
     (void)hipMemsetAsync(maxbits, 0, sizeof(unsigned int), st);
     if (variant == 2) {
         const dim3 grid((W + MH_GB_TILE - 1) / MH_GB_TILE, (H + MH_GB_TILE - 1) / MH_GB_TILE);
         hipLaunchKernelGGL(mh_gabor_split_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);
+    } else if (variant == 3) {
+        const dim3 grid((W + MH_GM_COLS - 1) / MH_GM_COLS, (H + MH_GM_ROWS - 1) / MH_GM_ROWS);
+        hipLaunchKernelGGL(mh_gabor_mfma2_kernel, grid, dim3(256), 0, st, bankQ, img, H, W, orient, var, maxbits);
     } else if (variant == 1) {
         const dim3 grid((W + MH_GM_COLS - 1) / MH_GM_COLS, (H + MH_GM_ROWS - 1) / MH_GM_ROWS);
         hipLaunchKernelGGL(mh_gabor_mfma_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);

@@ -53,7 +53,7 @@ def orientation_table():
 
 
 class calOrientationGabor:
-    def __init__(self, channel_in=1, channel_out=1, stride=1, device=None, bank=None, variant="mfma"):
+    def __init__(self, channel_in=1, channel_out=1, stride=1, device=None, bank=None, variant="mfma2"):
         """bank: optional [180,17,17] kernels to install instead of gabor_bank() (torch's CPU sin/cos/exp differ
         in the last bit between host CPU types; tests pin the reference's own kernels this way)."""
         self.numKernels = NUM_KERNELS
@@ -73,9 +73,11 @@ class calOrientationGabor:
         self._cos = torch.cos(th).to(self.device)
 
     def set_variant(self, variant):
-        """'valu': direct form on v_pk_fma_f32; 'mfma': im2col contraction on v_mfma_f32_32x32x2_f32.  Same bits."""
+        """'valu' / 'split': direct forms on v_pk_fma_f32; 'mfma': im2col contraction on v_mfma_f32_32x32x2_f32, first form;
+        'mfma2' (default): the same with the bank in operand order and immediate-offset LDS reads.  Same bits."""
         self.variant = variant
-        _lib.check(_lib.lib().mh_ctx_set_option(self._ctx, b"gabor_variant", {"valu": 0, "mfma": 1, "split": 2}[variant]),
+        _lib.check(_lib.lib().mh_ctx_set_option(self._ctx, b"gabor_variant",
+                                                {"valu": 0, "mfma": 1, "split": 2, "mfma2": 3}[variant]),
                    "mh_ctx_set_option")
 
     def cuda(self):

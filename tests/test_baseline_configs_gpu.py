@@ -67,7 +67,7 @@ def test_gabor_4k_mfma_variant():
     yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
     img = (0.25 * torch.cos(2 * np.pi * (0.6 * xx + 0.8 * yy) / 4.0) + 0.02 * torch.randn((H, W), generator=g)).float()
     outs = {}
-    for variant in ("valu", "mfma", "split"):
+    for variant in ("valu", "mfma", "split", "mfma2"):
         gf = calOrientationGabor(device=DEV, variant=variant)
         idx, conf, var = gf.filter_index(img.to(DEV))
         outs[variant] = (idx.cpu().numpy(), conf.cpu().numpy(), var.cpu().numpy())

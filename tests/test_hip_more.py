@@ -167,7 +167,7 @@ def test_gabor_vs_oracle_and_golden():
     assert torch.equal(o1, b1) and torch.equal(c1, cf1) and float(v1.max()) == 1.0
 
 
-@pytest.mark.parametrize("variant", ["valu", "mfma", "split"])
+@pytest.mark.parametrize("variant", ["valu", "mfma", "split", "mfma2"])
 def test_gabor_odd_sizes_and_border(variant):
     """ragged sizes (not multiples of the pixel tiles) incl. an image smaller than the kernel; both kernel variants
     (direct v_pk_fma form and the FP32-MFMA im2col contraction) are bit-identical to the oracle"""

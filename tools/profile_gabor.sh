@@ -12,7 +12,7 @@ for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES"; do
   i=$((i+1))
   timeout 240 rocprofv3 --pmc $SET --kernel-include-regex "mh_gabor" --output-format csv -d $OUT/prof_gabor_$i -o pmc -- \
-      python $R/tools/bench_gabor.py --reps 2 --variant ${GABOR_VARIANT:-mfma} > $OUT/prof_gabor_$i.log 2>&1
+      python $R/tools/bench_gabor.py --reps 2 --variant ${GABOR_VARIANT:-mfma2} > $OUT/prof_gabor_$i.log 2>&1
   echo "set $i rc=$?"
 done
 python - <<PY
