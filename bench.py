@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--patch", type=int, default=7)          # big_wavy1.yaml:18
     ap.add_argument("--conf-threshold", type=float, default=0.15)
     ap.add_argument("--quantize", action="store_true", help="8-bit orientation/confidence maps (file hand-off)")
+    ap.add_argument("--codes", action="store_true",
+                    help="headline on maps uploaded as 8-bit file codes (PMVO.from_u8; the regime of real captures) -- for "
+                         "profiling that regime; the default run reports it as secondary_8bit_maps")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU baseline sample (0 = auto)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs")
@@ -139,11 +142,21 @@ def main():
     n_gpus = world
 
     V, H, W, P = a.views, a.height, a.width, a.patch * a.patch
-    scene = synth.make_scene(V, H, W, device=dev, seed=0, quantize=a.quantize)
-    cams = cameras_from_list(scene["cams"])
-    recs = camera_records(cams)
-    pm = PMVO.from_planes(recs, scene["depth"], scene["ori"], scene["conf"], scene["mask"], device=dev,
-                          patch_size=a.patch, visible_threshold=1, conf_threshold=a.conf_threshold, camera=cams)
+    if a.codes:
+        a.no_cpu = a.quantize = True      # (the CPU leg and the 8-bit secondary leg belong to the default run)
+        sc = synth.make_scene_codes(V, H, W, device=dev, seed=0)
+        cams = cameras_from_list(sc["cams"])
+        recs = camera_records(cams)
+        pm = PMVO.from_u8(cams, sc["depth"], sc["ori_u8"], sc["conf_u8"], sc["mask_u8"], device=dev, image_size=[H, W],
+                          patch_size=a.patch, visible_threshold=1, conf_threshold=a.conf_threshold)
+        scene = None
+        del sc
+    else:
+        scene = synth.make_scene(V, H, W, device=dev, seed=0, quantize=a.quantize)
+        cams = cameras_from_list(scene["cams"])
+        recs = camera_records(cams)
+        pm = PMVO.from_planes(recs, scene["depth"], scene["ori"], scene["conf"], scene["mask"], device=dev,
+                              patch_size=a.patch, visible_threshold=1, conf_threshold=a.conf_threshold, camera=cams)
     if a.variant:
         pm.set_option("search_variant", a.variant)
     if a.taps_tile:
@@ -252,7 +265,7 @@ def main():
             "parallelism": "points sharded over %d GPU(s) (one process each), views replicated; no collective inside "
                            "an iteration" % world,
             "devices": devices_seen,
-            "maps": "quantized-8bit" if a.quantize else "continuous",
+            "maps": "8-bit file codes (PMVO.from_u8)" if a.codes else ("quantized-8bit" if a.quantize else "continuous"),
             "streams": len(streams),
             "prewarm_steps": PREWARM,
             "step_input": "host numpy chunk [5000,3] float64, uploaded inside the step (PMVO.py:40); maps resident in HBM",
@@ -289,7 +302,7 @@ def main():
     # --- the kernels of the timed loop, one by one (rank 0, outside the timed region): HIP events on the launch
     # stream around launches that ROTATE over the chunks, so that no launch finds its read set in the Infinity Cache
     try:
-        out.update(kernel_rooflines(a, pm, my, dev, V, H, W, P))
+        out.update(kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=a.codes))
     except Exception as e:
         out["roofline"] = {"error": repr(e)[:300]}
     if not a.no_secondary and world == 1:
@@ -322,7 +335,7 @@ def main():
         dist.destroy_process_group()
 
 
-def kernel_rooflines(a, pm, my, dev, V, H, W, P):
+def kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=False):
     """Per-kernel durations of one iteration with HIP events on the launch stream, each launch on a different chunk,
     and the roofline of each kernel from what it actually executed.
       mh_search3_kernel  (dominant, fp32 VALU bound): executed (candidate, view, tap) evaluations x 8 FLOP
@@ -408,15 +421,16 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P):
     tf = pairs * FLOP_PER_PAIR / (t_search * 1e-3) / 1e12
     # bytes mh_project_taps_kernel has to move (per launch): points + centre record and mask sample of every (view, point)
     # + the patch of every visible pair in; vis/ori/conf/mask + one header per pair + the tap lists + list lengths out
-    taps_in = 12 * N + V * N * (16 + 4) + nvis * P * 16
+    taps_in = 12 * N + V * N * (16 + 4) + nvis * P * (2 if codes else 16)      # a tap is 2 B of codes or a 16-B record
     taps_out = V * N * (4 + 8 + 4 + 4) + V * N * 16 + taps_vis * 16 + V * N
     pg_bytes = 2 * V * N * (12 * P + 20) + 12 * N
     prof = load_profile_facts(V, H, W)
+    pre = "8bit:" if codes else ""          # profiles/traffic.json keeps the 8-bit regime's PMC figures under this prefix
     return {
         "roofline": {
             "kernel": "mh_search3_kernel<256>", "bound": "valu",
             "achieved": round(tf, 2), "peak": VALU_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TF, 4),
-            "traffic": prof.get("traffic", {}).get("mh_search3_kernel<256>"),
+            "traffic": prof.get("traffic", {}).get(pre + "mh_search3_kernel<256>"),
             "launch_ms": round(t_search, 4),
             "pair_evals_executed": int(pairs), "flop_per_pair_eval": FLOP_PER_PAIR,
             "gpair_per_s_executed": round(pairs / (t_search * 1e-3) / 1e9, 1),
@@ -425,21 +439,21 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P):
             "note": "executed = sum over points of (taps of the views that see the point) x (usable base-view ranks) x 90 "
                     "samples, read back from the launch's own work arrays; launch_ms includes the two small ordering "
                     "kernels in front of the search",
-            "valu_issue": prof.get("search_valu_issue"),
+            "valu_issue": prof.get("search_valu_issue") if not codes else None,
         },
         "roofline_kernels": [
             {"kernel": "mh_project_taps_kernel<%d>" % a.patch, "bound": "hbm", "launch_ms": round(t_taps, 4),
              "algorithmic_bytes_per_launch": int(taps_in + taps_out),
              "achieved": round((taps_in + taps_out) / (t_taps * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round((taps_in + taps_out) / (t_taps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-             "traffic": prof.get("traffic", {}).get("mh_project_taps_kernel<%d>" % a.patch),
-             "bytes_model": "in: 12N + V*N*20 + visible*P*16; out: V*N*20 + V*N*16 + taps*16 + V*N",
+             "traffic": prof.get("traffic", {}).get(pre + "mh_project_taps_kernel<%d>" % a.patch),
+             "bytes_model": "in: 12N + V*N*20 + visible*P*%d; out: V*N*20 + V*N*16 + taps*16 + V*N" % (2 if codes else 16),
              "visible_pairs": int(nvis), "taps_written": int(taps_vis)},
             {"kernel": "mh_project_gather_kernel<%d>" % a.patch, "bound": "hbm", "launch_ms": round(t_pg, 4),
              "algorithmic_bytes_per_launch": pg_bytes,
              "achieved": round(pg_bytes / (t_pg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(pg_bytes / (t_pg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-             "traffic": prof.get("traffic", {}).get("mh_project_gather_kernel<%d>" % a.patch),
+             "traffic": prof.get("traffic", {}).get(pre + "mh_project_gather_kernel<%d>" % a.patch),
              "note": "the API form of Compute_Visible_and_Ori (patch tensors materialised, SURVEY.md §8d byte count); "
                      "forward() uses mh_project_taps_kernel instead; launches rotate over %d chunks" % reps},
         ],
@@ -549,16 +563,28 @@ def secondary_volume_reduce(dev, backend):
 
 
 def secondary_quantized(a, dev, recs, cams, my):
-    """The same iteration on maps pushed through the reference's 8-bit file hand-off (integer degrees, conf/255 --
-    what a real capture delivers): duplicate tap orientations are dropped exactly."""
+    """The same iteration on maps that went through the reference's 8-bit file hand-off (integer degrees, conf/255 -- what
+    every real capture delivers), uploaded as the pixel CODES themselves (PMVO.from_u8): the
+    records are decoded on the GPU through the loaders' table, the two codes of a pixel stay resident for the tap gathers
+    (2 B per tap), duplicate tap orientations are dropped exactly.  Timed like the headline loop; per-kernel times and
+    rooflines like kernel_rooflines()."""
     import torch
 
-    from monohair_amd import synth
+    from monohair_amd import _lib, synth
     from monohair_amd.pmvo import PMVO
 
-    scene_q = synth.make_scene(a.views, a.height, a.width, device=dev, seed=0, quantize=True)
-    pm = PMVO.from_planes(recs, scene_q["depth"], scene_q["ori"], scene_q["conf"], scene_q["mask"], device=dev,
-                          patch_size=a.patch, visible_threshold=1, conf_threshold=a.conf_threshold, camera=cams)
+    V, H, W, P = a.views, a.height, a.width, a.patch * a.patch
+    sc = synth.make_scene_codes(V, H, W, device=dev, seed=0)
+    from monohair_amd.camera import cameras_from_list
+
+    camd = cameras_from_list(sc["cams"])
+    pm = PMVO.from_u8(camd, sc["depth"], sc["ori_u8"], sc["conf_u8"], sc["mask_u8"], device=dev, image_size=[H, W],
+                      patch_size=a.patch, visible_threshold=1, conf_threshold=a.conf_threshold)
+    del sc
+    if a.taps_tile:
+        pm.set_option("taps_tile", a.taps_tile)
+    if a.variant:
+        pm.set_option("search_variant", a.variant)
     streams = pm.side_streams(max(1, a.streams))
 
     def step(i):
@@ -573,8 +599,13 @@ def secondary_quantized(a, dev, recs, cams, my):
         step(a.warmup + i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    return {"value": round(a.steps / dt, 3), "unit": "iterations/s", "ms_per_step": round(dt / a.steps * 1e3, 4),
-            "maps": "quantized-8bit"}
+    out = {"value": round(a.steps / dt, 3), "unit": "iterations/s", "ms_per_step": round(dt / a.steps * 1e3, 4),
+           "maps": "8-bit file codes (PMVO.from_u8): 20 B/px decoded records + 2 B/px resident codes for the tap gathers"}
+    try:
+        out.update(kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=True))
+    except Exception as e:
+        out["roofline"] = {"error": repr(e)[:300]}
+    return out
 
 
 def secondary_full_pass(dev, pm, cand, dist):

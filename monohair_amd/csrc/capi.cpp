@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/mh_pmvo.h"
 
@@ -35,6 +36,20 @@ struct mh_ctx {
     void *dog_w = nullptr;    // device MhDogWeights of the difference-of-Gaussians prefilter (csrc/dog.hip)
     MhDogWeightsHost *dog_w_host = nullptr;   // what dog_w holds
     float4 *lut = nullptr;    // [256] pixel-code table of the 8-bit map files
+    // views uploaded as 8-bit file codes keep the codes resident as well (2 B per pixel: orientation | confidence << 8) for
+    // the per-iteration tap gathers of mh_forward_prepare; used when EVERY view was uploaded that way with one table
+    uint16_t *oc = nullptr;           // [V][H][W]
+    void *code_tabs = nullptr;        // MhCodeTabs (csrc/pmvo_project.hip), derived from lut
+    std::vector<unsigned char> code_view;   // per view: uploaded as codes
+    float lut_host[1024];             // the table the resident records and code tables were made with
+    bool lut_set = false, lut_mixed = false;
+    int use_codes = 1;                // option "tap_codes": 0 = always gather the fp32 records (A/B, cross-check)
+    bool codes_ready() const {
+        if (!oc || !code_tabs || !use_codes || lut_mixed || (int)code_view.size() != V) return false;
+        for (unsigned char c : code_view)
+            if (!c) return false;
+        return true;
+    }
     int S = 0;
     int search_variant = 0;
     int topk_order = 0;       // 0: torch.topk's CPU tie order (mh_topk_wave.h); 1: value desc, view asc; 2: mh_topk_order.h
@@ -51,7 +66,9 @@ extern "C" {
 int mh_launch_pack_view(float4 *, float *, const float *, int, const float *, const float *, const float *, int,
                         size_t, hipStream_t);
 int mh_launch_pack_view_u8(float4 *, float *, const float *, int, const uint8_t *, const uint8_t *, const uint8_t *,
-                           const float4 *, size_t, hipStream_t);
+                           const float4 *, size_t, uint16_t *, hipStream_t);
+size_t mh_code_tabs_bytes();
+int mh_launch_code_tabs(const float4 *, void *, hipStream_t);
 int mh_launch_render_depth(const float *, const float *, int, const int32_t *, int, int, int, int, int, void *,
                            unsigned long long *, int32_t *, unsigned int *, float *, int, hipStream_t);
 size_t mh_grid_scratch_bytes_impl(int);
@@ -81,7 +98,7 @@ int mh_launch_topk(const float *, const float *, int, int, int32_t *, float *, i
 int mh_launch_prep_taps(const float *, const float *, const float *, const float *, int, int, float, float4 *,
                         uint8_t *, hipStream_t);
 int mh_launch_project_taps(MhViews, const float *, int, int, float, float *, float *, float *, float *, float4 *,
-                           uint8_t *, int, hipStream_t);
+                           uint8_t *, int, const uint16_t *, const void *, hipStream_t);
 int mh_launch_search(MhViews, const float *, int, int, int, const float *, int, int, float, const float *,
                      const int32_t *, const float *, const float4 *, int32_t *, const uint8_t *, float *, float *,
                      uint8_t *, float *, int32_t *, int32_t *, int, hipStream_t);
@@ -156,6 +173,10 @@ static void free_views(mh_ctx *c) {
     if (c->rec) (void)hipFree(c->rec);
     if (c->mask) (void)hipFree(c->mask);
     if (c->cams) (void)hipFree(c->cams);
+    if (c->oc) (void)hipFree(c->oc);
+    c->oc = nullptr;
+    c->code_view.clear();
+    c->lut_set = c->lut_mixed = false;
     c->rec = nullptr;
     c->mask = nullptr;
     c->cams = nullptr;
@@ -173,6 +194,7 @@ extern "C" void mh_ctx_destroy(mh_ctx *ctx) {
     if (ctx->dog_w) (void)hipFree(ctx->dog_w);
     delete ctx->dog_w_host;
     if (ctx->lut) (void)hipFree(ctx->lut);
+    if (ctx->code_tabs) (void)hipFree(ctx->code_tabs);
     delete ctx;
 }
 
@@ -190,6 +212,7 @@ extern "C" int mh_ctx_alloc_views(mh_ctx *ctx, int V, int H, int W) {
     ctx->V = V;
     ctx->H = H;
     ctx->W = W;
+    ctx->code_view.assign(V, 0);
     return MH_OK;
 }
 
@@ -205,6 +228,7 @@ extern "C" int mh_ctx_set_view(mh_ctx *ctx, int view, const float *cam_host, con
     // pageable host -> device copy of 192 bytes: synchronous w.r.t. the host buffer, ordered on `st`
     MH_HIP(hipMemcpyAsync(ctx->cams + (size_t)view * MH_CAM_STRIDE, cam_host, MH_CAM_STRIDE * sizeof(float),
                           hipMemcpyHostToDevice, st));
+    if ((int)ctx->code_view.size() == ctx->V) ctx->code_view[view] = 0;      // this view has no resident codes (any more)
     return launched(mh_launch_pack_view(ctx->rec + (size_t)view * npix, ctx->mask + (size_t)view * npix, depth,
                                         depth_stride, ori, conf, mask, mask_stride, npix, st),
                     "mh_ctx_set_view");
@@ -221,11 +245,25 @@ extern "C" int mh_ctx_set_view_u8(mh_ctx *ctx, int view, const float *cam_host, 
     const size_t npix = (size_t)ctx->H * ctx->W;
     MH_HIP(hipSetDevice(ctx->device));
     if (!ctx->lut) MH_HIP(hipMalloc(&ctx->lut, 256 * sizeof(float4)));
-    MH_HIP(hipMemcpyAsync(ctx->lut, lut_host, 256 * sizeof(float4), hipMemcpyHostToDevice, st));
+    if (!ctx->code_tabs) MH_HIP(hipMalloc(&ctx->code_tabs, mh_code_tabs_bytes()));
+    if (!ctx->oc) {      // (2 B per pixel next to the 20 B of records; without it the tap gathers simply use the records)
+        if (hipMalloc(&ctx->oc, (size_t)ctx->V * npix * sizeof(uint16_t)) != hipSuccess) ctx->oc = nullptr;
+    }
+    // one table per context: views decoded through DIFFERENT tables cannot share the code tables of the tap gather
+    if (ctx->lut_set && memcmp(ctx->lut_host, lut_host, sizeof ctx->lut_host) != 0) ctx->lut_mixed = true;
+    if (!ctx->lut_set || ctx->lut_mixed) {
+        if (ctx->lut_set) MH_HIP(hipDeviceSynchronize());     // (a pack kernel of another stream may still read the old table)
+        memcpy(ctx->lut_host, lut_host, sizeof ctx->lut_host);
+        ctx->lut_set = true;
+        MH_HIP(hipMemcpyAsync(ctx->lut, ctx->lut_host, 256 * sizeof(float4), hipMemcpyHostToDevice, st));
+        if (int rc = launched(mh_launch_code_tabs(ctx->lut, ctx->code_tabs, st), "mh_ctx_set_view_u8(tables)")) return rc;
+    }
     MH_HIP(hipMemcpyAsync(ctx->cams + (size_t)view * MH_CAM_STRIDE, cam_host, MH_CAM_STRIDE * sizeof(float),
                           hipMemcpyHostToDevice, st));
+    if ((int)ctx->code_view.size() == ctx->V) ctx->code_view[view] = ctx->oc ? 1 : 0;
     return launched(mh_launch_pack_view_u8(ctx->rec + (size_t)view * npix, ctx->mask + (size_t)view * npix, depth,
-                                           depth_stride, ori_u8, conf_u8, mask_u8, ctx->lut, npix, st),
+                                           depth_stride, ori_u8, conf_u8, mask_u8, ctx->lut, npix,
+                                           ctx->oc ? ctx->oc + (size_t)view * npix : nullptr, st),
                     "mh_ctx_set_view_u8");
 }
 
@@ -318,6 +356,10 @@ extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
     }
     if (!strcmp(key, "topk_order")) {
         ctx->topk_order = value;
+        return MH_OK;
+    }
+    if (!strcmp(key, "tap_codes")) {
+        ctx->use_codes = value ? 1 : 0;
         return MH_OK;
     }
     if (!strcmp(key, "taps_tile")) {
@@ -430,7 +472,7 @@ extern "C" int mh_forward_prepare(mh_ctx *ctx, const float *points, int N, int p
     return launched(mh_launch_project_taps(ctx->views(), points, N, patch, conf_threshold, vis, ori, conf, mask,
                                            (float4 *)scratch,
                                            (uint8_t *)scratch + search_count_offset(ctx, N, patch), ctx->taps_tile,
-                                           (hipStream_t)stream),
+                                           ctx->codes_ready() ? ctx->oc : nullptr, ctx->code_tabs, (hipStream_t)stream),
                     "mh_forward_prepare");
 }
 

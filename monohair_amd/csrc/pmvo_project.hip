@@ -30,17 +30,44 @@ __global__ __launch_bounds__(256) void mh_pack_view_u8_kernel(float4 *__restrict
                                                               const uint8_t *__restrict__ ori,
                                                               const uint8_t *__restrict__ conf,
                                                               const uint8_t *__restrict__ mask,
-                                                              const float4 *__restrict__ lut, size_t npix) {
+                                                              const float4 *__restrict__ lut, size_t npix,
+                                                              uint16_t *__restrict__ oc) {
     __shared__ float4 s_lut[256];
     s_lut[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;
     for (; i < npix; i += step) {
-        const float4 o = s_lut[ori[i]];
-        rec[i] = make_float4(o.x, o.y, s_lut[conf[i]].z, depth[i * dstride]);
+        const uint8_t ko = ori[i], kc = conf[i];
+        const float4 o = s_lut[ko];
+        rec[i] = make_float4(o.x, o.y, s_lut[kc].z, depth[i * dstride]);
         maskp[i] = s_lut[mask[i]].w;
+        if (oc) oc[i] = (uint16_t)(ko | (kc << 8));      // the two file codes themselves, kept resident for the tap gathers
     }
+}
+
+// What a tap of an 8-bit map can be, per pixel code (derived once from the loaders' table): the unit orientation exactly as
+// mh_unit2 makes it from the decoded (ori_row, ori_col), the clamped confidence, and the smallest code whose unit
+// orientation has the same bits ("canonical" code: duplicate taps are recognised by it).
+struct MhCodeTabs {
+    float2 unit[256];
+    float conf[256];
+    uint8_t canon[256];
+};
+__global__ __launch_bounds__(256) void mh_code_tabs_kernel(const float4 *__restrict__ lut, MhCodeTabs *__restrict__ t) {
+    __shared__ float2 s_u[256];
+    const int c = threadIdx.x;
+    const float4 e = lut[c];
+    float o0, o1;
+    mh_unit2(e.x, e.y, o0, o1);
+    s_u[c] = make_float2(o0, o1);
+    __syncthreads();
+    int k = c;
+    for (int j = c - 1; j >= 0; --j)
+        if (__float_as_uint(s_u[j].x) == __float_as_uint(o0) && __float_as_uint(s_u[j].y) == __float_as_uint(o1)) k = j;
+    t->unit[c] = make_float2(o0, o1);
+    t->conf[c] = mh_clampf(e.z, 1e-6f, 1.0f);
+    t->canon[c] = (uint8_t)k;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -391,13 +418,13 @@ __global__ __launch_bounds__(256) void mh_project_taps_kernel(MhViews vw, const 
     }
     __syncthreads();
 
-    auto gather = [&](int nl, int p) -> float4 {
-        const int i = p / PATCH - HP, j = p - (p / PATCH) * PATCH - HP;
-        return rec[(size_t)min(max(s_r[nl] + i, 0), H - 1) * W + min(max(s_cc[nl] + j, 0), W - 1)];
-    };
     auto next_visible = [&](int nl) -> int {   // uniform per wave
         while (nl < npts && s_vis[nl] == -1.0f) nl += 4;
         return nl;
+    };
+    auto gather = [&](int nl, int p) -> float4 {
+        const int i = p / PATCH - HP, j = p - (p / PATCH) * PATCH - HP;
+        return rec[(size_t)min(max(s_r[nl] + i, 0), H - 1) * W + min(max(s_cc[nl] + j, 0), W - 1)];
     };
     // The kernel is bound by memory-level parallelism (8192 resident waves x one 784-byte patch gather in flight each at
     // ~3 us of loaded HBM latency = the 2.3 TB/s it reached with a one-point look-ahead): the gathers of the wave's next
@@ -477,6 +504,182 @@ __global__ __launch_bounds__(256) void mh_project_taps_kernel(MhViews vw, const 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The fused front end for maps uploaded as 8-bit FILE CODES (mh_ctx_set_view_u8 -- what every real capture is, SURVEY.md
+// App. A.18): same outputs as mh_project_taps_kernel, organised around what bounds it in this regime.  The fp32 form is a
+// chain of three dependent memory round trips per wave (points -> centre record -> patch gather of the points that passed
+// the depth test) at ~50 % occupancy, 64 % of its wave time parked on them (profiles/r03_8bit_*); its LDS work is 87 %
+// bank-conflict cycles (49 lanes bidding for "first tap with this orientation" on one address).  Here
+//   * a tap is the two CODES of its pixel, 2 bytes (a 7-tap patch row is 14 bytes; the touched part of a view shrinks 8x in
+//     the XCD's L2), so the patch of EVERY point is requested right after the projection, before the depth test is known:
+//     one round trip less on the critical path, 16 patch gathers in flight per wave instead of 3; the patches of points
+//     that turn out invisible are dropped unread (2 B x 49 x ~63 % -- nothing);
+//   * one wave owns 16 points of the tile (lane = point for the projection, lane = tap for the patches): no workgroup
+//     barrier between the phases;
+//   * unit orientation and clamped confidence of a code come from 256-entry LDS tables (no square root / division per tap);
+//   * "the first eligible tap with this orientation" is found on the wave's lane masks: take the first remaining eligible
+//     lane, ballot the lanes with the same canonical code, keep the first, drop the class -- as many steps as the patch
+//     has distinct orientations (2.2 on average on 8-bit maps), no LDS, no atomics, no hash collisions.
+// The list of a (view, point) holds the fp32 form's records in the same order, minus the duplicates that form keeps on a
+// hash collision; the search result is bit-identical either way (a duplicate can never win the strict '<' of PMVO.py:177).
+// ---------------------------------------------------------------------------------------------
+template <int PATCH>
+__global__ __launch_bounds__(256) void mh_project_taps_codes_kernel(MhViews vw, const float *__restrict__ pts, int N,
+                                                                    int tiles, float thr, float *__restrict__ vis,
+                                                                    float *__restrict__ ori, float *__restrict__ conf,
+                                                                    float *__restrict__ mask, float4 *__restrict__ taps,
+                                                                    uint8_t *__restrict__ cnt,
+                                                                    const uint16_t *__restrict__ oc_all,
+                                                                    const MhCodeTabs *__restrict__ tabs) {
+    constexpr int P = PATCH * PATCH, HP = PATCH / 2, NCH = (P + MH_WAVE - 1) / MH_WAVE, PW = 16;
+    __shared__ float2 s_unit[256];
+    __shared__ float s_confc[256];
+    __shared__ uint8_t s_canon[256];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous view ranges
+    const int V = vw.V, H = vw.H, W = vw.W;
+    if (bid >= V * tiles) return;
+    const int v = bid / tiles, tile = bid - v * tiles;
+    const int n0 = tile * MH_PG_TILE + wave * PW;            // this wave's 16 points
+    // the tables travel while the wave projects and gathers; they are needed only when the first patch is decoded
+    const float2 t_unit = tabs->unit[tid];
+    const float t_conf = tabs->conf[tid];
+    const uint8_t t_canon = tabs->canon[tid];
+    const float4 *__restrict__ rec = vw.rec + (size_t)v * H * W;
+    const uint16_t *__restrict__ oc = oc_all + (size_t)v * H * W;
+
+    // lane = point: projection (PMVO.project_points, PMVO.py:378-397)
+    const int n = n0 + lane;
+    const bool mine = lane < PW && n < N;
+    int r = 0, c = 0;
+    float rowf = 0.0f, colf = 0.0f, z = 0.0f;
+    bool oob = true;
+    if (mine) {
+        const float *cam = vw.cams + v * MH_CAM_STRIDE;
+        float u, w;
+        mh_cam_project(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, w, z);
+        mh_ndc_to_pixel(u, w, (float)H, (float)W, rowf, colf);
+        float cr = __builtin_rintf(colf), rr = __builtin_rintf(rowf);
+        oob = !(cr <= (float)(W - 1)) || (cr < 0.0f) || !(rr <= (float)(H - 1)) || (rr < 0.0f);
+        cr = fminf(fmaxf(cr, 0.0f), (float)(W - 1));
+        rr = fminf(fmaxf(rr, 0.0f), (float)(H - 1));
+        r = (int)rr;
+        c = (int)cr;
+    }
+    float4 q0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float mk = 0.0f;
+    if (mine) {
+        q0 = rec[(size_t)r * W + c];
+        if (mask) mk = vw.mask[(size_t)v * H * W + (size_t)r * W + c];
+    }
+    // lane = tap: the patch codes of all 16 points, requested before the depth test is known
+    int di[NCH], dj[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int p = ch * MH_WAVE + lane;
+        di[ch] = p / PATCH - HP;
+        dj[ch] = p - (p / PATCH) * PATCH - HP;
+    }
+    const int npw = min(PW, N - n0);                          // points of this wave (uniform; <= 0: nothing to do)
+    unsigned k[PW][NCH];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        const int rj = __builtin_amdgcn_readlane(r, j), cj = __builtin_amdgcn_readlane(c, j);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            k[j][ch] = 0;
+            if (j < npw && ch * MH_WAVE + lane < P)
+                k[j][ch] = oc[(size_t)min(max(rj + di[ch], 0), H - 1) * W + min(max(cj + dj[ch], 0), W - 1)];
+        }
+    }
+    // per-(view, point) outputs and the depth test (soft visibility, PMVO.py:346-376)
+    float visv = -1.0f;
+    if (mine) {
+        visv = mh_soft_visible(q0.w, (-z / 2.0f) * 255.0f);
+        visv = oob ? -1.0f : visv;
+        const size_t vn = (size_t)v * N + n;
+        vis[vn] = visv;
+        reinterpret_cast<float2 *>(ori)[vn] = make_float2(q0.x, q0.y);
+        conf[vn] = mh_clampf(q0.z, 1e-6f, 1.0f);
+        if (mask) mask[vn] = mk;
+        if (visv == -1.0f) {
+            taps[vn * (P + 1)] = make_float4(__int_as_float(0), visv, 0.0f, 0.0f);
+            cnt[vn] = 0;
+        }
+    }
+    s_unit[tid] = t_unit;
+    s_confc[tid] = t_conf;
+    s_canon[tid] = t_canon;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+        const float vj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(visv), j));
+        if (j < npw && vj != -1.0f) {                         // (uniform)
+        float cc[NCH];
+        unsigned kc[NCH];
+        bool el[NCH];
+        float cmax = -1.0f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            cc[ch] = s_confc[k[j][ch] >> 8];
+            kc[ch] = s_canon[k[j][ch] & 255u];
+            if (ch * MH_WAVE + lane < P) cmax = fmaxf(cmax, cc[ch]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o));
+        const bool hc = cmax > thr;
+        unsigned long long rem[NCH], keep[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int p = ch * MH_WAVE + lane;
+            el[ch] = (p < P) && ((p == 0) || (hc ? (cc[ch] > thr) : true));
+            rem[ch] = __ballot(el[ch]);
+            keep[ch] = 0ull;
+        }
+        // first eligible tap of every distinct (canonical) orientation code, in tap order
+        while (true) {
+            int c0 = -1;
+#pragma unroll
+            for (int ch = NCH - 1; ch >= 0; --ch)
+                if (rem[ch]) c0 = ch;
+            if (c0 < 0) break;
+            unsigned long long rsel = rem[0];
+            unsigned ksel = kc[0];
+#pragma unroll
+            for (int ch = 1; ch < NCH; ++ch)
+                if (c0 == ch) rsel = rem[ch], ksel = kc[ch];
+            const int l0 = __builtin_ctzll(rsel);
+            const unsigned code = (unsigned)__builtin_amdgcn_readlane((int)ksel, l0);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const unsigned long long m = __ballot(el[ch] && kc[ch] == code);
+                rem[ch] &= ~m;
+                if (ch == c0) keep[ch] |= 1ull << l0;
+            }
+        }
+        const size_t vn = (size_t)v * N + n0 + j;
+        float4 *__restrict__ out = taps + vn * (P + 1);
+        int base = 0;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const unsigned long long m = keep[ch];
+            if ((m >> lane) & 1ull) {
+                const float2 o = s_unit[k[j][ch] & 255u];
+                out[1 + base + __popcll(m & ((1ull << lane) - 1ull))] = make_float4(o.x, o.y, cc[ch], 0.0f);
+            }
+            base += __popcll(m);
+        }
+        if (lane == 0) {
+            const float rfj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowf), j));
+            const float cfj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(colf), j));
+            out[0] = make_float4(__int_as_float(base), vj, rfj, cfj);
+            cnt[vn] = (uint8_t)base;
+        }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers (called from capi.cpp)
 // ---------------------------------------------------------------------------------------------
@@ -491,10 +694,17 @@ extern "C" int mh_launch_pack_view(float4 *rec, float *maskp, const float *depth
 
 extern "C" int mh_launch_pack_view_u8(float4 *rec, float *maskp, const float *depth, int dstride, const uint8_t *ori,
                                       const uint8_t *conf, const uint8_t *mask, const float4 *lut, size_t npix,
-                                      hipStream_t st) {
+                                      uint16_t *oc, hipStream_t st) {
     const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
     hipLaunchKernelGGL(mh_pack_view_u8_kernel, dim3(blocks), dim3(256), 0, st, rec, maskp, depth, dstride, ori, conf,
-                       mask, lut, npix);
+                       mask, lut, npix, oc);
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t mh_code_tabs_bytes() { return sizeof(MhCodeTabs); }
+
+extern "C" int mh_launch_code_tabs(const float4 *lut, void *tabs, hipStream_t st) {
+    hipLaunchKernelGGL(mh_code_tabs_kernel, dim3(1), dim3(256), 0, st, lut, (MhCodeTabs *)tabs);
     return (int)hipGetLastError();
 }
 
@@ -564,22 +774,24 @@ extern "C" int mh_launch_prep_taps(const float *ori_patch, const float *conf_pat
 
 extern "C" int mh_launch_project_taps(MhViews vw, const float *pts, int N, int patch, float thr, float *vis,
                                       float *ori, float *conf, float *mask, float4 *taps, uint8_t *cnt, int tile,
-                                      hipStream_t st) {
+                                      const uint16_t *oc, const void *tabs_v, hipStream_t st) {
+    const MhCodeTabs *tabs = (const MhCodeTabs *)tabs_v;
+    const bool codes = oc && tabs;
     if (patch * patch > MH_PREP_PMAX) return -1;
-    if (tile != 16 && tile != 32) tile = 64;
+    if (codes || (tile != 16 && tile != 32)) tile = 64;       // (the code form always works on 64-point tiles)
     const int tiles = (N + tile - 1) / tile;
     const dim3 grid((vw.V * tiles + 7) & ~7), block(256);
+#define MH_PT_LAUNCH(PS, TL)                                                                                        \
+    hipLaunchKernelGGL((mh_project_taps_kernel<PS, TL>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, conf, mask, \
+                       taps, cnt)
 #define MH_PT_CASE(PS)                                                                                             \
     case PS:                                                                                                       \
-        if (tile == 64)                                                                                            \
-            hipLaunchKernelGGL((mh_project_taps_kernel<PS, 64>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori,  \
-                               conf, mask, taps, cnt);                                                             \
-        else if (tile == 32)                                                                                       \
-            hipLaunchKernelGGL((mh_project_taps_kernel<PS, 32>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori,  \
-                               conf, mask, taps, cnt);                                                             \
-        else                                                                                                       \
-            hipLaunchKernelGGL((mh_project_taps_kernel<PS, 16>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori,  \
-                               conf, mask, taps, cnt);                                                             \
+        if (codes)                                                                                                 \
+            hipLaunchKernelGGL((mh_project_taps_codes_kernel<PS>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, \
+                               conf, mask, taps, cnt, oc, tabs);                                                   \
+        else if (tile == 64) MH_PT_LAUNCH(PS, 64);                                                                 \
+        else if (tile == 32) MH_PT_LAUNCH(PS, 32);                                                                 \
+        else MH_PT_LAUNCH(PS, 16);                                                                                 \
         break;
     switch (patch) {
         MH_PT_CASE(1)
@@ -591,6 +803,7 @@ extern "C" int mh_launch_project_taps(MhViews vw, const float *pts, int N, int p
         default:
             return -1;
     }
+#undef MH_PT_LAUNCH
 #undef MH_PT_CASE
     return (int)hipGetLastError();
 }

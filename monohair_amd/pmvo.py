@@ -78,11 +78,13 @@ class PMVO:
 
     @classmethod
     def from_u8(cls, camera, depths, ori_u8, conf_u8, mask_u8, device="cuda:0", image_size=None, patch_size=5,
-                visible_threshold=1, conf_threshold=0.4, lut=None):
+                visible_threshold=1, conf_threshold=0.4, lut=None, records=None):
         """The constructor for maps kept as their 8-bit pixel codes (pmvo_utils.load_maps_u8 or a maps pack):
         dicts view -> uint8 [H,W] for orientation / confidence / mask (or [V,H,W] arrays in view order), depth
         float32 [H,W] or [H,W,3]; numpy arrays or torch tensors (device tensors are used in place).  Decoded on the GPU through the 256-entry table of the loaders
-        (pmvo_utils.map_code_lut), so the resident records equal those of PMVO(camera, <decoded float maps>)."""
+        (pmvo_utils.map_code_lut), so the resident records equal those of PMVO(camera, <decoded float maps>).  The two codes of
+        a pixel (orientation, confidence) stay resident as well, 2 B per pixel: the fused front end of forward() gathers a
+        patch tap as those 2 bytes instead of a 16-byte record (option "tap_codes", default on; same results)."""
         from .pmvo_utils import map_code_lut
 
         self = cls.__new__(cls)
@@ -96,7 +98,7 @@ class PMVO:
         self.camera_dict = camera
         self.camera_key = keys
         self.camera = [camera[k] for k in keys]
-        recs = camera_records(camera)
+        recs = camera_records(camera) if records is None else records      # (records: [V,48] override, parity tests)
         lut = np.ascontiguousarray(map_code_lut() if lut is None else lut, dtype=np.float32)
         assert lut.shape == (256, 4)
         self._alloc(len(keys), H, W)
@@ -137,6 +139,8 @@ class PMVO:
         self._side = 2 * (self.patch_size // 2) + 1
         self.visible_threshold = visible_threshold
         self.conf_threshold = conf_threshold
+        self._stage = {}            # pinned upload rings of _upload_points, per launch stream
+        self._scratch_need = {}     # N -> bytes of the search scratch (constant per context)
         self._L = _lib.lib()
         h = ctypes.c_void_p()
         _lib.check(self._L.mh_ctx_create(self.device.index or 0, ctypes.byref(h)), "mh_ctx_create")
@@ -179,8 +183,45 @@ class PMVO:
         (`torch.from_numpy(points).type(torch.float).to(device)`, PMVO.py:40): same rounding, half the H2D bytes and no
         cast kernel on the stream."""
         if isinstance(points, np.ndarray):
-            points = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32))
+            return self._upload_points(points)
         return points.to(self.device).type(torch.float).contiguous()
+
+    def _upload_points(self, points, stream=None):
+        """Host numpy [N,3] -> float32 device tensor through a small ring of PINNED staging buffers per launch stream and
+        an asynchronous copy.  `tensor.to(device)` from pageable memory blocks the host for ~0.2 ms per call (staging +
+        wait) -- as long as a whole iteration takes on 8-bit maps, which made the loop of `optimize` host-bound there.
+        The float64 -> float32 cast happens in the copy into the staging buffer (numpy's rounding = the reference's
+        `.type(torch.float)`, PMVO.py:40)."""
+        n = int(points.shape[0])
+        if n == 0:
+            return torch.empty((0, 3), dtype=torch.float32, device=self.device)
+        cs = torch.cuda.current_stream(self.device) if stream is None else stream
+        ring = self._stage.get(cs.cuda_stream)
+        if ring is None:
+            ring = self._stage[cs.cuda_stream] = {"slots": [], "i": 0}
+        # slots are used in ring order, so only the oldest can be free (copies of one stream complete in order).  If its copy
+        # is still pending the host is running ahead of a GPU-bound loop: take one more slot (up to 32 per stream, 3 MB), and
+        # only then wait -- the host does not block in the steady state
+        slots = ring["slots"]
+        slot = slots[ring["i"] % len(slots)] if slots else None
+        if slot is not None and (slot[1] is None or slot[1].query()):
+            ring["i"] += 1
+        elif len(slots) < 32:
+            slot = [torch.empty((max(n, 8192), 3), dtype=torch.float32, pin_memory=True), None]
+            slots.insert(ring["i"] % len(slots) if slots else 0, slot)      # (in front of the oldest: ring order is kept)
+            ring["i"] += 1
+        else:
+            ring["i"] += 1
+            slot[1].synchronize()
+        if slot[0].shape[0] < n:
+            slot[0] = torch.empty((n, 3), dtype=torch.float32, pin_memory=True)
+        np.copyto(slot[0].numpy()[:n], points, casting="same_kind")
+        dev = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        dev.copy_(slot[0][:n], non_blocking=True)
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        slot[1].record(cs)
+        return dev
 
     # ------------------------------------------------------------------ reference methods
     def Compute_Visible_and_Ori(self, points):
@@ -218,12 +259,12 @@ class PMVO:
         self._materialise_patches()
         return self._Conf_patch
 
-    def _topk32(self):
+    def _topk32(self, stp=None):
         V, N = self.visible.shape
         idx = torch.empty((20, N), dtype=torch.int32, device=self.device)
         val = torch.empty((20, N), dtype=torch.float32, device=self.device)
         _lib.check(self._L.mh_topk_views(self._ctx, _lib.ptr(self.visible), _lib.ptr(self.Conf), N, _lib.ptr(idx),
-                                         _lib.ptr(val), _lib.stream_ptr()), "mh_topk_views")
+                                         _lib.ptr(val), _lib.stream_ptr() if stp is None else stp), "mh_topk_views")
         return idx, val
 
     def Find_max_conf_from_visible_view(self):
@@ -358,11 +399,14 @@ class PMVO:
             self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(n)]
         return self._side_streams[:n]
 
-    def _get_scratch(self, N):
+    def _get_scratch(self, N, key=None):
         """Tap-list scratch of the search, one buffer per launch stream (chunks of `optimize` are independent and
         may be in flight on different streams)."""
-        need = int(self._L.mh_search_scratch_bytes(self._ctx, N, self._side))
-        key = torch.cuda.current_stream().cuda_stream
+        need = self._scratch_need.get(N)
+        if need is None:
+            need = self._scratch_need[N] = int(self._L.mh_search_scratch_bytes(self._ctx, N, self._side))
+        if key is None:
+            key = torch.cuda.current_stream().cuda_stream
         if self._scratch is None:
             self._scratch = {}
         buf = self._scratch.get(key)
@@ -393,8 +437,10 @@ class PMVO:
         the tap preparation as separate kernels through the materialised patch tensors (same results)."""
         ranks = list(self.RANKS)
         f = dict(dtype=torch.float32, device=self.device)
+        cs = torch.cuda.current_stream(self.device)          # looked up once: ~8 us of Python per call
+        stp = ctypes.c_void_p(cs.cuda_stream)
         if fused:
-            points = self._dev_points(points)
+            points = self._upload_points(points, cs) if isinstance(points, np.ndarray) else self._dev_points(points)
             V, N = self.num_view, points.shape[0]
             self.visible = torch.empty((V, N), **f)
             self.Ori = torch.empty((V, N, 2), **f)
@@ -402,18 +448,18 @@ class PMVO:
             self.mask = torch.empty((V, N), **f)
             self._Ori_patch = self._Conf_patch = self._pixf = None
             self._points = points
-            scratch, need = self._get_scratch(N)
+            scratch, need = self._get_scratch(N, cs.cuda_stream)
             _lib.check(self._L.mh_forward_prepare(self._ctx, _lib.ptr(points), N, self._side,
                                                   float(self.conf_threshold), _lib.ptr(self.visible),
                                                   _lib.ptr(self.Ori), _lib.ptr(self.Conf), _lib.ptr(self.mask),
-                                                  _lib.ptr(scratch), need, _lib.stream_ptr()), "mh_forward_prepare")
+                                                  _lib.ptr(scratch), need, stp), "mh_forward_prepare")
         else:
             self.Compute_Visible_and_Ori(points)
             points = self._points
             N = points.shape[0]
-            scratch, need = self._get_scratch(N)
+            scratch, need = self._get_scratch(N, cs.cuda_stream)
         if base_view is None:
-            bidx32, bval = self._topk32()          # int32 end to end: no int64 round trip on the hot path
+            bidx32, bval = self._topk32(stp)       # int32 end to end: no int64 round trip on the hot path
         else:
             bidx32 = torch.as_tensor(base_view[0]).to(self.device).to(torch.int32).contiguous()
             bval = torch.as_tensor(base_view[1]).to(self.device).type(torch.float).contiguous()
@@ -428,14 +474,14 @@ class PMVO:
                 self._ctx, _lib.ptr(points), N, self._side, float(self.conf_threshold), len(ranks),
                 ranks[1] - ranks[0], _lib.ptr(self.Ori), _lib.ptr(bidx32), _lib.ptr(bval), _lib.ptr(scratch),
                 _lib.ptr(line_ori), _lib.ptr(min_loss), _lib.ptr(hc), _lib.ptr(bs), _lib.ptr(br), _lib.ptr(bi),
-                _lib.stream_ptr()), "mh_search_prepared")
+                stp), "mh_search_prepared")
         else:
             _lib.check(self._L.mh_search_forward(
                 self._ctx, _lib.ptr(points), N, self._side, float(self.conf_threshold), len(ranks),
                 ranks[1] - ranks[0], _lib.ptr(self.visible), _lib.ptr(self.Ori), _lib.ptr(self._pixf),
                 _lib.ptr(self._Ori_patch), _lib.ptr(self._Conf_patch), _lib.ptr(bidx32), _lib.ptr(bval),
                 _lib.ptr(scratch), need, _lib.ptr(line_ori), _lib.ptr(min_loss), _lib.ptr(hc), _lib.ptr(bs),
-                _lib.ptr(br), _lib.ptr(bi), _lib.stream_ptr()), "mh_search_forward")
+                _lib.ptr(br), _lib.ptr(bi), stp), "mh_search_forward")
         out = (points, line_ori, min_loss, hc)
         if extras:
             return out + (dict(best_sample=bs, best_rank=br, best_s=bi, base_idx=bidx32.long(), base_val=bval),)

@@ -139,6 +139,25 @@ def make_scene(V, H, W, device="cpu", seed=0, scale=1.7, rings=1, quantize=False
     return dict(cams=cams, depth=depth, ori=ori, conf=conf, mask=mask, image_size=[H, W])
 
 
+def make_scene_codes(V, H, W, device="cpu", seed=0, scale=1.7, rings=1):
+    """The same views as their 8-bit FILE CODES (what a capture's best_ori/, conf/ and hair_mask/ images hold, SURVEY.md
+    Appendix A.18): dict(cams, depth [V,H,W] float32, ori_u8 / conf_u8 / mask_u8 [V,H,W] uint8) for PMVO.from_u8.
+    Codes as write_capture() below writes them: orientation in integer degrees, floor(conf*255 + 0.5), mask 0 / 255."""
+    cams = make_cameras(V, H, W, scale=scale, rings=rings)
+    depth = torch.empty((V, H, W), dtype=torch.float32, device=device)
+    k8 = torch.empty((V, H, W), dtype=torch.uint8, device=device)
+    c8 = torch.empty((V, H, W), dtype=torch.uint8, device=device)
+    m8 = torch.empty((V, H, W), dtype=torch.uint8, device=device)
+    for i, cam in enumerate(cams):
+        d, o, c, m = render_view(cam, i, H, W, device=device, seed=seed, quantize=False)
+        ang = torch.atan2(-o[..., 0].double(), o[..., 1].double()) * (180.0 / math.pi)
+        depth[i] = d
+        k8[i] = torch.remainder(torch.round(ang), 180.0).to(torch.uint8)
+        c8[i] = torch.floor(c.double() * 255.0 + 0.5).clamp(0, 255).to(torch.uint8)
+        m8[i] = (m * 255).to(torch.uint8)
+    return dict(cams=cams, depth=depth, ori_u8=k8, conf_u8=c8, mask_u8=m8, image_size=[H, W])
+
+
 def scene_to_reference_dicts(scene):
     """Reference-layout host dicts as PMVO.__init__ takes them (PMVO.py:14-26):
     depths[k] [H,W,3], Ori[k] [H,W,2], Conf[k] [H,W], masks[k] [H,W,3] (numpy)."""

@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--height", type=int, default=1920)
 ap.add_argument("--width", type=int, default=1080)
 ap.add_argument("--reps", type=int, default=10)
-ap.add_argument("--variant", default="mfma")
+ap.add_argument("--variant", default="mfma2")
 ap.add_argument("--stage", action="store_true", help="time mh_gabor_view (uint8 image -> DoG -> bank -> codes) instead")
 a = ap.parse_args()
 rng = np.random.default_rng(0)
