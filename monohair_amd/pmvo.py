@@ -186,6 +186,23 @@ class PMVO:
             return self._upload_points(points)
         return points.to(self.device).type(torch.float).contiguous()
 
+    def upload_all_points(self, points):
+        """One asynchronous upload of a whole [M,3] host array (float32 cast on the host, PMVO.py:40) through one pinned
+        staging buffer kept on the object; the drivers then hand device slices to forward()."""
+        m = int(points.shape[0])
+        if m == 0:
+            return torch.empty((0, 3), dtype=torch.float32, device=self.device)
+        stg = getattr(self, "_stage_all", None)
+        if stg is not None and stg[1] is not None:
+            stg[1].synchronize()
+        if stg is None or stg[0].shape[0] < m:
+            stg = self._stage_all = [torch.empty((m, 3), dtype=torch.float32, pin_memory=True), torch.cuda.Event()]
+        np.copyto(stg[0].numpy()[:m], points, casting="same_kind")
+        dev = torch.empty((m, 3), dtype=torch.float32, device=self.device)
+        dev.copy_(stg[0][:m], non_blocking=True)
+        stg[1].record(torch.cuda.current_stream(self.device))
+        return dev
+
     def _upload_points(self, points, stream=None):
         """Host numpy [N,3] -> float32 device tensor through a small ring of PINNED staging buffers per launch stream and
         an asynchronous copy.  `tensor.to(device)` from pageable memory blocks the host for ~0.2 ms per call (staging +
@@ -430,11 +447,13 @@ class PMVO:
             nvalid = torch.clamp(last, min=1)
         return cnt, nvalid
 
-    def forward(self, points, base_view=None, extras=False, fused=True):
+    def forward(self, points, base_view=None, extras=False, fused=True, out=None):
         """PMVO.py:39-78.  points: numpy [N,3].  Returns (points, line_ori [N,3], min_loss [N],
         high_conf [N] bool) on the device.  base_view=(idx [20,N], val [20,N]) injects a base-view ranking
         (parity tests: torch.topk's tie order is unspecified).  fused=False runs Compute_Visible_and_Ori and
-        the tap preparation as separate kernels through the materialised patch tensors (same results)."""
+        the tap preparation as separate kernels through the materialised patch tensors (same results).
+        out=(line_ori [N,3] float32, min_loss [N] float32, high_conf [N] bool): contiguous device tensors the search
+        writes into (the driver `optimize` passes slices of one result buffer: no per-chunk concatenation)."""
         ranks = list(self.RANKS)
         f = dict(dtype=torch.float32, device=self.device)
         cs = torch.cuda.current_stream(self.device)          # looked up once: ~8 us of Python per call
@@ -463,9 +482,14 @@ class PMVO:
         else:
             bidx32 = torch.as_tensor(base_view[0]).to(self.device).to(torch.int32).contiguous()
             bval = torch.as_tensor(base_view[1]).to(self.device).type(torch.float).contiguous()
-        line_ori = torch.empty((N, 3), **f)
-        min_loss = torch.empty((N,), **f)
-        hc = torch.empty((N,), dtype=torch.bool, device=self.device)      # the kernel writes 0/1 bytes
+        if out is not None:
+            line_ori, min_loss, hc = out
+            assert line_ori.shape == (N, 3) and min_loss.shape == (N,) and hc.shape == (N,) and hc.dtype == torch.bool
+            assert line_ori.is_contiguous() and min_loss.is_contiguous() and hc.is_contiguous() and line_ori.is_cuda
+        else:
+            line_ori = torch.empty((N, 3), **f)
+            min_loss = torch.empty((N,), **f)
+            hc = torch.empty((N,), dtype=torch.bool, device=self.device)      # the kernel writes 0/1 bytes
         bs = torch.empty((N, 3), **f) if extras else None
         br = torch.empty((N,), dtype=torch.int32, device=self.device) if extras else None
         bi = torch.empty((N,), dtype=torch.int32, device=self.device) if extras else None
@@ -615,7 +639,20 @@ def optimize(points, pmvo, args):
 
     num_sub_p = 5000
     step = points.shape[0] // num_sub_p + 1
-    chunks = [points[i * num_sub_p:(i + 1) * num_sub_p] for i in range(step)]
+    # the candidate points go to the device ONCE (3.4 MB at the headline size); a chunk is a slice of that tensor.  (One
+    # pageable `.to(device)` per chunk, as the reference does it, blocks the host for ~0.2 ms each.)
+    pts_np = points if isinstance(points, np.ndarray) else torch.as_tensor(points).detach().cpu().numpy()
+    dev_all = pmvo.upload_all_points(pts_np)
+    chunks = [dev_all[i * num_sub_p:(i + 1) * num_sub_p] for i in range(step)]
+    # select_p.npy is the float32 copy of the input (PMVO.py:40,575): it is written while the GPU works
+    from concurrent.futures import ThreadPoolExecutor
+
+    pool = ThreadPoolExecutor(4)
+    select_points = np.ascontiguousarray(pts_np, dtype=np.float32)
+    early = None
+    if mdist.rank() == 0:
+        os.makedirs(args.save_root, exist_ok=True)
+        early = pool.submit(np.save, args.save_root + "/select_p.npy", select_points)
 
     # consecutive chunks are independent: they rotate over three HIP streams so that the tail of one chunk's search
     # kernel (workgroups of points that see many views) overlaps the front end and the head of the next chunks (two
@@ -623,36 +660,52 @@ def optimize(points, pmvo, args):
     streams = pmvo.side_streams(3)     # kept on the object: their tap-list scratch (1.2 GB each) is reused
     counter = [0]
     main = torch.cuda.current_stream()
+    M = dev_all.shape[0]
+    if mdist.world() == 1:
+        # one rank: every chunk's search writes straight into its slice of three result buffers; three copies to the
+        # host at the end
+        o_all = torch.empty((M, 3), dtype=torch.float32, device=pmvo.device)
+        l_all = torch.empty((M,), dtype=torch.float32, device=pmvo.device)
+        h_all = torch.empty((M,), dtype=torch.bool, device=pmvo.device)
     for st in streams:
-        st.wait_stream(main)          # whatever produced the maps / points has finished
-
-    def work(sub):
-        st = streams[counter[0] % len(streams)]
-        counter[0] += 1
-        with torch.cuda.stream(st):
-            _, o, l, h = pmvo.forward(sub)
-            # (the points forward() returns are the float32 copy of its input: they do not travel back)
-            out = torch.cat([o, l[:, None], h[:, None].to(torch.float32)], 1)
-        out.record_stream(main)
-        return out
+        st.wait_stream(main)          # whatever produced the maps / points (and last used the buffers) has finished
 
     def join():                        # results are read on the main stream: join the side streams first
         for st in streams:
             main.wait_stream(st)
 
-    res = mdist.map_chunks(chunks, work, pmvo.device,
-                           empty=lambda: torch.empty((0, 5), dtype=torch.float32, device=pmvo.device), after=join)
-    res = torch.cat(res, 0).cpu().numpy()
-    pts_np = points if isinstance(points, np.ndarray) else torch.as_tensor(points).detach().cpu().numpy()
-    select_points = np.ascontiguousarray(pts_np[:res.shape[0]], dtype=np.float32)      # PMVO.py:40: .type(torch.float)
-    select_ori, min_loss = res[:, 0:3], res[:, 3]
-    high_conf_index = res[:, 4] > 0.5
+    if mdist.world() == 1:
+        for i, sub in enumerate(chunks):
+            if len(sub) == 0:
+                continue
+            a, b = i * num_sub_p, i * num_sub_p + len(sub)
+            with torch.cuda.stream(streams[i % len(streams)]):
+                pmvo.forward(sub, out=(o_all[a:b], l_all[a:b], h_all[a:b]))
+        join()
+        select_ori, min_loss, high_conf_index = o_all.cpu().numpy(), l_all.cpu().numpy(), h_all.cpu().numpy()
+    else:
+        def work(sub):
+            st = streams[counter[0] % len(streams)]
+            counter[0] += 1
+            with torch.cuda.stream(st):
+                _, o, l, h = pmvo.forward(sub)
+                # (the points forward() returns are the float32 copy of its input: they do not travel back)
+                out = torch.cat([o, l[:, None], h[:, None].to(torch.float32)], 1)
+            out.record_stream(main)
+            return out
+
+        res = mdist.map_chunks(chunks, work, pmvo.device,
+                               empty=lambda: torch.empty((0, 5), dtype=torch.float32, device=pmvo.device), after=join)
+        res = torch.cat(res, 0).cpu().numpy()
+        select_ori, min_loss = res[:, 0:3], res[:, 3]
+        high_conf_index = res[:, 4] > 0.5
+    assert len(min_loss) == len(select_points)
     if mdist.rank() == 0:
-        os.makedirs(args.save_root, exist_ok=True)
-        np.save(args.save_root + "/select_p.npy", np.ascontiguousarray(select_points))
-        np.save(args.save_root + "/select_o.npy", np.ascontiguousarray(select_ori))
-        np.save(args.save_root + "/min_loss.npy", np.ascontiguousarray(min_loss))
-        np.save(args.save_root + "/high_conf_index.npy", high_conf_index)
+        jobs = (("select_o", select_ori), ("min_loss", min_loss), ("high_conf_index", high_conf_index))
+        # the files are written side by side (numpy releases the GIL in write)
+        list(pool.map(lambda j: np.save(args.save_root + "/%s.npy" % j[0], np.ascontiguousarray(j[1])), jobs))
+        early.result()
+    pool.shutdown()
     mdist.barrier()
     return select_points, select_ori, min_loss, high_conf_index
 
