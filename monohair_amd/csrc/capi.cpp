@@ -68,6 +68,18 @@ int mh_launch_pack_view(float4 *, float *, const float *, int, const float *, co
 int mh_launch_pack_view_u8(float4 *, float *, const float *, int, const uint8_t *, const uint8_t *, const uint8_t *,
                            const float4 *, size_t, uint16_t *, hipStream_t);
 size_t mh_code_tabs_bytes();
+int mh_preload_pmvo_project();
+int mh_preload_pmvo_search();
+int mh_preload_pmvo_filter();
+int mh_preload_consensus();
+int mh_preload_gabor();
+int mh_preload_hairgrow();
+int mh_preload_knn();
+int mh_preload_raster();
+int mh_preload_sortgroup();
+int mh_preload_pmvo_pieces();
+int mh_preload_dog();
+
 int mh_launch_code_tabs(const float4 *, void *, hipStream_t);
 int mh_launch_render_depth(const float *, const float *, int, const int32_t *, int, int, int, int, int, void *,
                            unsigned long long *, int32_t *, unsigned int *, float *, int, hipStream_t);
@@ -165,6 +177,16 @@ extern "C" int mh_ctx_create(int device_id, mh_ctx **out) {
     mh_ctx *c = new (std::nothrow) mh_ctx();
     if (!c) return fail(MH_ERR_NOMEM, "mh_ctx_create: out of host memory");
     c->device = device_id;
+    // the code objects of the library go onto the device now (HIP would load each translation unit's on the first launch
+    // of one of its kernels -- in the middle of the first pass's stages); a failure here only means they load lazily
+    if (hipSetDevice(device_id) == hipSuccess) {
+        int (*const preload[])() = {mh_preload_pmvo_project, mh_preload_pmvo_search, mh_preload_pmvo_filter,
+                                    mh_preload_consensus,    mh_preload_gabor,       mh_preload_hairgrow,
+                                    mh_preload_knn,          mh_preload_raster,      mh_preload_sortgroup,
+                                    mh_preload_pmvo_pieces,  mh_preload_dog};
+        for (auto f : preload) (void)f();
+        (void)hipGetLastError();
+    }
     *out = c;
     return MH_OK;
 }

@@ -291,3 +291,10 @@ extern "C" int mh_launch_medoid_segmented(const float *ori, const int32_t *seg_s
     }
     return (int)hipGetLastError();
 }
+
+// forces this translation unit's code object onto the device (HIP loads a fat binary on the first use of one of its kernels:
+// 2-20 ms each, which a one-shot pass would pay in the middle of its stages); called from mh_ctx_create
+extern "C" int mh_preload_consensus() {
+    hipFuncAttributes a;
+    return (int)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&mh_medoid_kernel<false>));
+}

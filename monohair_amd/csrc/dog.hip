@@ -131,3 +131,10 @@ extern "C" int mh_launch_dog(const void *img, int in_kind, int H, int W, const v
     hipLaunchKernelGGL(mh_dog_horz_kernel, gh, dim3(256), 0, st, ylo, yhi, H, W, wt, out64, out32);
     return (int)hipGetLastError();
 }
+
+// forces this translation unit's code object onto the device (HIP loads a fat binary on the first use of one of its kernels:
+// 2-20 ms each, which a one-shot pass would pay in the middle of its stages); called from mh_ctx_create
+extern "C" int mh_preload_dog() {
+    hipFuncAttributes a;
+    return (int)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&mh_dog_horz_kernel));
+}

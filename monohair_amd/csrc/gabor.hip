@@ -684,3 +684,10 @@ extern "C" int mh_launch_gabor_bank(const float *bankT, const float *bankQ, cons
     hipLaunchKernelGGL(mh_gabor_finish_kernel, dim3(blocks), dim3(256), 0, st, var, maxbits, npix, conf, orient, k8, c8);
     return (int)hipGetLastError();
 }
+
+// forces this translation unit's code object onto the device (HIP loads a fat binary on the first use of one of its kernels:
+// 2-20 ms each, which a one-shot pass would pay in the middle of its stages); called from mh_ctx_create
+extern "C" int mh_preload_gabor() {
+    hipFuncAttributes a;
+    return (int)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&mh_gabor_build_kernel));
+}

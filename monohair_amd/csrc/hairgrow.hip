@@ -196,3 +196,10 @@ extern "C" int mh_launch_strands_compact(const float *rows, const int32_t *first
                        packed);
     return (int)hipGetLastError();
 }
+
+// forces this translation unit's code object onto the device (HIP loads a fat binary on the first use of one of its kernels:
+// 2-20 ms each, which a one-shot pass would pay in the middle of its stages); called from mh_ctx_create
+extern "C" int mh_preload_hairgrow() {
+    hipFuncAttributes a;
+    return (int)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&mh_trace_seeds_kernel));
+}

@@ -246,3 +246,10 @@ extern "C" int mh_launch_prj_loss(const float *D, const float *ori_patch, const 
                        conf_patch, vis, V, N, S, P, thr, loss, index, hc, all_loss);
     return (int)hipGetLastError();
 }
+
+// forces this translation unit's code object onto the device (HIP loads a fat binary on the first use of one of its kernels:
+// 2-20 ms each, which a one-shot pass would pay in the middle of its stages); called from mh_ctx_create
+extern "C" int mh_preload_pmvo_pieces() {
+    hipFuncAttributes a;
+    return (int)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&mh_project_points_kernel));
+}

@@ -1382,3 +1382,10 @@ extern "C" int mh_launch_refine_loss(MhViews vw, const float *pts, const float *
                        vis, ori_patch, conf_patch, loss, hc);
     return (int)hipGetLastError();
 }
+
+// forces this translation unit's code object onto the device (HIP loads a fat binary on the first use of one of its kernels:
+// 2-20 ms each, which a one-shot pass would pay in the middle of its stages); called from mh_ctx_create
+extern "C" int mh_preload_pmvo_search() {
+    hipFuncAttributes a;
+    return (int)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&mh_search_order_kernel));
+}

@@ -191,3 +191,10 @@ extern "C" int mh_launch_voxel_group(const void *pts, int pts_f64, const float *
         hipLaunchKernelGGL(mh_gather3_canon_kernel, dim3(nb), dim3(256), 0, st, ori, order, n, ori_sorted);
     return (int)hipGetLastError();
 }
+
+// forces this translation unit's code object onto the device (HIP loads a fat binary on the first use of one of its kernels:
+// 2-20 ms each, which a one-shot pass would pay in the middle of its stages); called from mh_ctx_create
+extern "C" int mh_preload_sortgroup() {
+    hipFuncAttributes a;
+    return (int)hipFuncGetAttributes(&a, reinterpret_cast<const void *>(&mh_cell_key_kernel));
+}
