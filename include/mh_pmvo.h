@@ -334,10 +334,12 @@ int mh_mat_write_sparse(const char *path, const void *prefix, size_t prefix_byte
 
 /* Tuning knobs for A/B runs and cross-checks; every setting computes the same results (except "topk_order" 1, which
  * returns tied confidences in view order).
- *   "search_variant": 0 = default (6 when the list-length array of mh_forward_prepare is available);
- *       6 / 7 mh_search3_kernel (tap lists staged in LDS) in work order / natural order; 1 / 2 mh_search2_kernel (broadcast
- *       vector tap loads) in work order / natural order; 3 / 4 the same with scalar tap loads; 5 = 1 with the loop over all
- *       views; 64, 128, 192, 256, 320, 1128, 1256, 2256: round 1's kernel with that many threads per point.
+ *   "search_variant": 0 = default: mh_search3_kernel (tap lists staged in LDS), points in descending order of work;
+ *       7: the same with the points in their natural order (A/B); 1256: the portable mh_search_kernel, the cross-check
+ *       of the shipped kernel (also what runs when the caller has no list lengths).  Same results.
+ *   "tap_codes": 1 (default) = contexts whose views were ALL uploaded with mh_ctx_set_view_u8 gather a patch tap as the
+ *       two resident 8-bit codes of its pixel (mh_project_taps_codes_kernel); 0 = always the decoded records.
+ *   "gabor_variant": 3 (default) mh_gabor_mfma2_kernel; 1 the first FP32-MFMA form; 0 / 2 the direct v_pk_fma forms.
  *   "topk_order": see mh_topk_views.   "taps_tile": points per workgroup of the tap preparation (64 / 32 / 16).
  *   "gabor_variant": 0 v_pk_fma, 1 FP32-MFMA im2col (default), 2 v_pk_fma with a split bank.
  *   "line_rule" (mh_render_strands): 0 = OpenGL's diamond-exit rule (default), 1 = the pixel that holds a segment's end

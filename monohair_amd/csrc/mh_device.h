@@ -45,30 +45,6 @@ __device__ __forceinline__ void mh_cam_project(const float *__restrict__ cam, fl
     v = q1 / c2;
 }
 
-// n0/d and n1/d, bit-identical to IEEE-754 division for operands in the normal range: this is the very
-// instruction sequence LLVM expands an f32 fdiv to on gfx9 (v_rcp_f32, two Newton steps on the reciprocal,
-// quotient, two residual corrections) minus the v_div_scale / v_div_fixup range handling, which is the
-// identity unless an operand or the quotient is (nearly) denormal or the exponents differ by >= 96 -- never
-// the case for camera-space depths and pixel distances.  Sharing the refined reciprocal saves ~40 % of the
-// instructions of two separate divisions.  (tests: the kernels using it stay bit-exact against the CPU oracle,
-// which divides with the host's IEEE division.)
-__device__ __forceinline__ void mh_div2(float n0, float n1, float d, float &q0, float &q1) {
-    float r = __builtin_amdgcn_rcpf(d);
-    const float nd = -d;
-    float e = mh_fma(nd, r, 1.0f);
-    r = mh_fma(e, r, r);
-    float a = n0 * r;
-    float ea = mh_fma(nd, a, n0);
-    a = mh_fma(ea, r, a);
-    ea = mh_fma(nd, a, n0);
-    q0 = mh_fma(ea, r, a);
-    float b = n1 * r;
-    float eb = mh_fma(nd, b, n1);
-    b = mh_fma(eb, r, b);
-    eb = mh_fma(nd, b, n1);
-    q1 = mh_fma(eb, r, b);
-}
-
 // ndc -> unrounded pixel (PMVO.py:380-382, Camera_utils.py:67-69)
 __device__ __forceinline__ void mh_ndc_to_pixel(float u, float v, float Hf, float Wf, float &row, float &col) {
     col = ((-u + 1.0f) / 2.0f) * Wf;
@@ -106,42 +82,19 @@ __device__ __forceinline__ void mh_unit2(float x0, float x1, float &o0, float &o
     o1 = x1 / nrm;
 }
 
-// same results as mh_pixel_of / mh_unit2 with the two divisions by a common denominator fused (mh_div2)
-__device__ __forceinline__ void mh_pixel_of_fast(const float *__restrict__ cam, float X0, float X1, float X2,
-                                                 float Hf, float Wf, float &row, float &col) {
-    float c0 = cam[0] * X0;
-    c0 = mh_fma(cam[1], X1, c0);
-    c0 = mh_fma(cam[2], X2, c0);
-    c0 = mh_fma(cam[3], 1.0f, c0);
-    float c1 = cam[4] * X0;
-    c1 = mh_fma(cam[5], X1, c1);
-    c1 = mh_fma(cam[6], X2, c1);
-    c1 = mh_fma(cam[7], 1.0f, c1);
-    float c2 = cam[8] * X0;
-    c2 = mh_fma(cam[9], X1, c2);
-    c2 = mh_fma(cam[10], X2, c2);
-    c2 = mh_fma(cam[11], 1.0f, c2);
-    const float q0 = mh_fma(cam[18], c2, cam[16] * c0);
-    const float q1 = mh_fma(cam[22], c2, cam[21] * c1);
-    float u, v;
-    mh_div2(q0, q1, c2, u, v);
-    mh_ndc_to_pixel(u, v, Hf, Wf, row, col);
-}
-
-__device__ __forceinline__ void mh_unit2_fast(float x0, float x1, float &o0, float &o1) {
-    float s = x0 * x0;
-    s = mh_fma(x1, x1, s);
-    float nrm = __builtin_sqrtf(s);
-    nrm = (nrm < 1e-8f) ? 1e-8f : nrm;
-    mh_div2(x0, x1, nrm, o0, o1);
-}
-
 // ---- two items at a time: the same operations, element by element, on 64-bit register pairs, so that the fma
 // chains become v_pk_fma_f32 (two single-rounded fp32 FMAs per issue slot) -- bit-identical to the scalar forms.
 typedef float mh_v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ mh_v2f mh_fma2(mh_v2f a, mh_v2f b, mh_v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ mh_v2f mh_splat(float x) { return mh_v2f{x, x}; }
 
+// n0/d and n1/d for two items (element-wise on register pairs), bit-identical to IEEE-754 division for operands in the normal range: this is the very
+// instruction sequence LLVM expands an f32 fdiv to on gfx9 (v_rcp_f32, two Newton steps on the reciprocal,
+// quotient, two residual corrections) minus the v_div_scale / v_div_fixup range handling, which is the
+// identity unless an operand or the quotient is (nearly) denormal or the exponents differ by >= 96 -- never
+// the case for camera-space depths and pixel distances.  Sharing the refined reciprocal saves ~40 % of the
+// instructions of two separate divisions.  (tests: the kernels using it stay bit-exact against the CPU oracle,
+// which divides with the host's IEEE division.)
 __device__ __forceinline__ void mh_div2x2(mh_v2f n0, mh_v2f n1, mh_v2f d, mh_v2f &q0, mh_v2f &q1) {
     mh_v2f r = mh_v2f{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
     const mh_v2f nd = -d;
@@ -159,7 +112,8 @@ __device__ __forceinline__ void mh_div2x2(mh_v2f n0, mh_v2f n1, mh_v2f d, mh_v2f
     q1 = mh_fma2(eb, r, b);
 }
 
-// pixel (row, col) of two world points in one view (mh_pixel_of_fast, pairwise)
+// pixel (row, col) of two world points in one view: mh_pixel_of with the two divisions by the common denominator
+// sharing one refined reciprocal (mh_div2x2)
 __device__ __forceinline__ void mh_pixel_of_fast2(const float *__restrict__ cam, mh_v2f X0, mh_v2f X1, mh_v2f X2,
                                                   float Hf, float Wf, mh_v2f &row, mh_v2f &col) {
     mh_v2f c0 = mh_splat(cam[0]) * X0;

@@ -49,7 +49,12 @@ __device__ __forceinline__ float mh_one_minus_abs(float x) {
     return r;
 }
 
-template <int K, int T, int FAST>
+// mh_search_kernel -- the PORTABLE form of the fused loss search: plain C++ loops over views and taps, the compiler's
+// schedule, tap lists read from the scratch records.  It is the cross-check of the shipped mh_search3_kernel (every test that
+// compares the search with the oracle runs both: search_variant 1256) and what runs when no list lengths are available.
+// (Rounds 1-2 carried this kernel's hand-shaped FAST forms and mh_search2_kernel as variants; they are gone: three
+// generations of one arithmetic contract were two too many to keep in step.)
+template <int K, int T>
 __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *__restrict__ offs, int S, int nrank,
                                                       int rank_step, const float *__restrict__ pts, int N, int P1,
                                                       float thr, const float *__restrict__ ori_c,
@@ -100,119 +105,7 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
         const int ntap = __float_as_int(hdr.x);
         const float *__restrict__ cam = vw.cams + v * MH_CAM_STRIDE;
         const float4 t0 = rec[1];
-        if constexpr (FAST && (K % 2 == 0)) {
-            // Hand-shaped tap loop.  Items are processed in pairs: the unit directions of two items sit in one
-            // 64-bit register pair per component, so the two products and the sum of the cosine are
-            // v_pk_mul_f32 / v_pk_add_f32 (separately rounded, no fma -- same bits as the scalar form), 1-|x| is one
-            // v_sub_f32 with the abs source modifier, and the running minimum is a compare into an SGPR mask plus
-            // two selects: 23 VALU instructions per tap per 4 items instead of the 27 of the portable loop below.
-            mh_v2f DX[K / 2], DY[K / 2];
-            float ML[K], BC[K];
-#pragma unroll
-            for (int jp = 0; jp < K / 2; ++jp) {
-                mh_v2f row, col;
-                mh_pixel_of_fast2(cam, mh_v2f{X0[2 * jp], X0[2 * jp + 1]}, mh_v2f{X1[2 * jp], X1[2 * jp + 1]},
-                                  mh_v2f{X2[2 * jp], X2[2 * jp + 1]}, Hf, Wf, row, col);
-                mh_unit2_fast2(row - mh_splat(hdr.z), col - mh_splat(hdr.w), DX[jp], DY[jp]);
-                const mh_v2f cs = mh_v2f{t0.x, t0.x} * DX[jp] + mh_v2f{t0.y, t0.y} * DY[jp];
-                ML[2 * jp] = mh_one_minus_abs(cs.x);
-                ML[2 * jp + 1] = mh_one_minus_abs(cs.y);
-                BC[2 * jp] = BC[2 * jp + 1] = t0.z;
-            }
-            // The tap loop is software-pipelined by hand in groups of GRP taps: the loads of the next group are issued
-            // before the current group is computed, so the load latency hides behind GRP*22 VALU instructions even
-            // with a single wave on the SIMD.  The records travel as wave-uniform VECTOR loads (every lane gets a
-            // copy): vmcnt lets the wave wait for one group while the next is in flight, whereas scalar loads can
-            // only be waited for all together (lgkmcnt(0)) -- measured 1155 vs 926 iterations/s.  The explicit
-            // s_waitcnt below is what keeps the backend from turning them into scalar loads.  (The list is padded: reading
-            // up to 2*GRP records past `ntap` stays inside the scratch buffer and the values are never used.)
-            constexpr int GRP = 4;
-            auto process = [&](const float4 (&g)[GRP], int t) {
-#pragma unroll
-                for (int u = 0; u < GRP; ++u) {
-                    if (t + u < ntap) {   // uniform
-                        const float4 tp = g[u];
-                        float l[K];
-                        if constexpr (FAST == 2 && K == 4) {
-                            // The tap record is wave-uniform and sits in a register pair {ox, oy}: v_pk_mul_f32
-                            // broadcasts one half of it (op_sel), no splat copies.  The four compares go to four SGPR
-                            // masks BEFORE the eight selects: gfx950 needs 2 wait states between a VALU write of an
-                            // SGPR/VCC and a VALU read of it, which the compiler's one-VCC-at-a-time code pays as an
-                            // s_nop after every compare.
-                            const unsigned long long xy =
-                                ((unsigned long long)__float_as_uint(tp.y) << 32) | __float_as_uint(tp.x);
-#pragma unroll
-                            for (int jp = 0; jp < 2; ++jp) {
-                                mh_v2f px, py;
-                                asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(px) : "v"(xy), "v"(DX[jp]));
-                                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]"
-                                    : "=v"(py)
-                                    : "v"(xy), "v"(DY[jp]));
-                                const mh_v2f cs = px + py;
-                                l[2 * jp] = mh_one_minus_abs(cs.x);
-                                l[2 * jp + 1] = mh_one_minus_abs(cs.y);
-                            }
-                            unsigned long long m0, m1, m2, m3;
-                            asm("v_cmp_lt_f32_e64 %[m0], %[l0], %[a0]\n\t"
-                                "v_cmp_lt_f32_e64 %[m1], %[l1], %[a1]\n\t"
-                                "v_cmp_lt_f32_e64 %[m2], %[l2], %[a2]\n\t"
-                                "v_cmp_lt_f32_e64 %[m3], %[l3], %[a3]\n\t"
-                                "v_cndmask_b32_e64 %[a0], %[a0], %[l0], %[m0]\n\t"
-                                "v_cndmask_b32_e64 %[a1], %[a1], %[l1], %[m1]\n\t"
-                                "v_cndmask_b32_e64 %[a2], %[a2], %[l2], %[m2]\n\t"
-                                "v_cndmask_b32_e64 %[a3], %[a3], %[l3], %[m3]\n\t"
-                                "v_cndmask_b32_e64 %[b0], %[b0], %[cf], %[m0]\n\t"
-                                "v_cndmask_b32_e64 %[b1], %[b1], %[cf], %[m1]\n\t"
-                                "v_cndmask_b32_e64 %[b2], %[b2], %[cf], %[m2]\n\t"
-                                "v_cndmask_b32_e64 %[b3], %[b3], %[cf], %[m3]"
-                                : [a0] "+v"(ML[0]), [a1] "+v"(ML[1]), [a2] "+v"(ML[2]), [a3] "+v"(ML[3]),
-                                  [b0] "+v"(BC[0]), [b1] "+v"(BC[1]), [b2] "+v"(BC[2]), [b3] "+v"(BC[3]),
-                                  [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)
-                                : [l0] "v"(l[0]), [l1] "v"(l[1]), [l2] "v"(l[2]), [l3] "v"(l[3]), [cf] "v"(tp.z));
-                        } else {
-                            const mh_v2f ox2 = mh_v2f{tp.x, tp.x}, oy2 = mh_v2f{tp.y, tp.y};
-#pragma unroll
-                            for (int jp = 0; jp < K / 2; ++jp) {
-                                const mh_v2f cs = ox2 * DX[jp] + oy2 * DY[jp];
-                                l[2 * jp] = mh_one_minus_abs(cs.x);
-                                l[2 * jp + 1] = mh_one_minus_abs(cs.y);
-                            }
-                            // compare into an SGPR mask, two selects: measured 10 cycles per update against 12 for
-                            // the v_cmpx + v_pk_mov_b32 + EXEC-restore form (tools/ubench/valu.hip)
-#pragma unroll
-                            for (int j = 0; j < K; ++j) {
-                                const bool upd = l[j] < ML[j];
-                                ML[j] = upd ? l[j] : ML[j];
-                                BC[j] = upd ? tp.z : BC[j];
-                            }
-                        }
-                    }
-                }
-            };
-            float4 ga[GRP], gb[GRP];   // ping-pong groups (no register copies between trips)
-#pragma unroll
-            for (int u = 0; u < GRP; ++u) ga[u] = rec[2 + u];
-            for (int t = 1; t < ntap;) {
-                __builtin_amdgcn_s_waitcnt(0xc07f);   // (see above: keeps the record loads on the vector path)
-#pragma unroll
-                for (int u = 0; u < GRP; ++u) gb[u] = rec[1 + t + GRP + u];
-                process(ga, t);
-                t += GRP;
-                if (t >= ntap) break;
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-#pragma unroll
-                for (int u = 0; u < GRP; ++u) ga[u] = rec[1 + t + GRP + u];
-                process(gb, t);
-                t += GRP;
-            }
-#pragma unroll
-            for (int j = 0; j < K; ++j) {
-                const float w = BC[j];   // (vis != -1) * best_conf
-                num[j].a0 = num[j].a0 + ML[j] * w;
-                den[j].a0 = den[j].a0 + w;
-                cnt[j] += (w > 0.0f) ? 1 : 0;
-            }
-        } else {
+        {
             float dx[K], dy[K], ml[K], bc[K];
 #pragma unroll
             for (int j = 0; j < K; ++j) {
@@ -332,27 +225,17 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
 }
 
 // ---------------------------------------------------------------------------------------------
-// mh_search2_kernel -- the shipped search (round 2).  Same arithmetic, operation for operation, as mh_search_kernel;
-// what changed is how the work is laid out on the machine (tools/ubench/valu2.hip, valu3.hip give the issue costs):
-//   * the tap body uses plain v_mul/v_mul/v_add/v_sub (full-rate VALU operations, ~2 cycles per wave-instruction)
-//     instead of v_pk_mul/v_pk_add: packed fp32 operations go through the half-rate path together with v_cmp /
-//     v_cndmask and do not overlap with them, the full-rate ones do (82 -> 69 cycles per tap per 4 items);
-//   * candidates of base-view ranks that can never be taken are not evaluated: ranks > 0 only replace the best-so-far
-//     when base_view_conf[rank] > 0 (PMVO.py:64), and the ranking is sorted by that value, so the usable ranks are a
-//     prefix; a point seen by few views costs proportionally less (exact: those losses are never read);
-//   * every wave evaluates only the item slices it has (900 items = 15 wave-slices, not 16);
-//   * workgroups take the points in descending order of work (order[], mh_search_order_kernel), so the tail of the
-//     launch is made of cheap points.
+// Building blocks of the shipped search (mh_search3_kernel below).  What rounds 1-2 measured about the tap body
+// (tools/ubench/valu2.hip, valu3.hip): plain v_mul/v_mul/v_add/v_sub are full-rate VALU operations (~2 cycles per
+// wave-instruction) and overlap with the half-rate v_cmp / v_cndmask, the packed v_pk_mul/v_pk_add do not (82 -> 69 cycles
+// per tap per 4 items); candidates of base-view ranks that can never be taken are not evaluated (ranks > 0 only replace the
+// best-so-far when base_view_conf[rank] > 0, PMVO.py:64, and the ranking is sorted by that value, so the usable ranks are a
+// prefix); every wave evaluates only the item slices it has (900 items = 15 wave-slices, not 16); workgroups take the points
+// in descending order of work (order[], mh_search_order_kernel), so the tail of the launch is made of cheap points.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float mh_vmul(float a, float b) {
     float r;
     asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-// the same with the first factor in an SGPR (a wave-uniform tap value that came through the scalar cache)
-__device__ __forceinline__ float mh_vmul_s(float a, float b) {
-    float r;
-    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(r) : "s"(a), "v"(b));
     return r;
 }
 __device__ __forceinline__ float mh_vadd(float a, float b) {
@@ -418,285 +301,12 @@ __device__ __forceinline__ void mh_tap_update(float (&ML)[KA], float (&BC)[KA], 
     }
 }
 
-// One wave's share of a point: KA item slices (item = j*T + tid), all views, per-sample loss and "positive" flag into LDS
-template <int KA, int T, int LD>
-__device__ __forceinline__ void mh_search_slices(const MhViews &vw, const float *__restrict__ offs, int S, int rank_step,
-                                                 float P0, float P1x, float P2, int n, int N, int P1, float thr,
-                                                 const float *__restrict__ ori_c, const int32_t *__restrict__ base_idx,
-                                                 const float4 *__restrict__ taps, const uint8_t *__restrict__ vcnt,
-                                                 int nact, int tid, float *s_loss, uint8_t *s_pos) {
-    const int V = vw.V;
-    const float Hf = (float)vw.H, Wf = (float)vw.W;
-    float X0[KA], X1[KA], X2[KA];
-    MhCascV num[KA], den[KA];
-    int cnt[KA];
-#pragma unroll
-    for (int j = 0; j < KA; ++j) {
-        int it = j * T + tid;
-        it = it < nact ? it : 0;
-        const int r = it / S, s = it - r * S;
-        const int b = base_idx[(size_t)(r * rank_step) * N + n];
-        const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
-        mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[s], X0[j], X1[j], X2[j]);
-        num[j] = den[j] = MhCascV{0.0f, 0.0f, 0.0f};
-        cnt[j] = 0;
-    }
-    // The views that see the point, as a wave-uniform bit mask (64 views at a time) from the compact [V,N] array of tap-list
-    // lengths the preparation kernel leaves (0 = not visible): the loop visits only those -- no dependent header load and
-    // branch for the ~64 % of the views that do not see the point -- and the header of the NEXT visible view is requested
-    // before the current view is worked on.  The cascade of the weighted sums is flushed at the same view indices as
-    // before (every multiple of 16 below V, visible or not).
-    int nf = 16;
-    auto flush_upto = [&](int v) {
-        while (nf <= v) {
-#pragma unroll
-            for (int j = 0; j < KA; ++j) {
-                mh_cascv_flush(num[j], nf);
-                mh_cascv_flush(den[j], nf);
-            }
-            nf += 16;
-        }
-    };
-    auto one_view = [&](int v, const float4 hdr) {
-        const float4 *__restrict__ rec0 = taps + ((size_t)v * N + n) * P1;
-        if (hdr.y == -1.0f) return;   // uniform: point not visible in this view, weight 0
-        const int ntap = __float_as_int(hdr.x);
-        const float *__restrict__ cam = vw.cams + v * MH_CAM_STRIDE;
-        // LD == 0: the tap records travel as wave-uniform VECTOR loads (every lane gets a copy; the address is made
-        // opaque so that the backend cannot move them to the scalar cache); LD == 1: scalar loads, the tap values are
-        // SGPR operands of the multiplies
-        const float4 *__restrict__ rec = rec0;
-        if constexpr (LD == 0) {
-            unsigned zl;
-            asm("v_mov_b32_e32 %0, 0" : "=v"(zl));
-            rec = rec0 + zl;
-        }
-        const float4 t0 = rec[1];
-        float DX[KA], DY[KA], ML[KA], BC[KA];
-#pragma unroll
-        for (int jp = 0; jp < KA / 2; ++jp) {
-            mh_v2f row, col, dx, dy;
-            mh_pixel_of_fast2(cam, mh_v2f{X0[2 * jp], X0[2 * jp + 1]}, mh_v2f{X1[2 * jp], X1[2 * jp + 1]},
-                              mh_v2f{X2[2 * jp], X2[2 * jp + 1]}, Hf, Wf, row, col);
-            mh_unit2_fast2(row - mh_splat(hdr.z), col - mh_splat(hdr.w), dx, dy);
-            DX[2 * jp] = dx.x;
-            DX[2 * jp + 1] = dx.y;
-            DY[2 * jp] = dy.x;
-            DY[2 * jp + 1] = dy.y;
-        }
-        if constexpr (KA & 1) {
-            // the odd item goes through the pairwise form too (a duplicated lane pair): identical operations
-            mh_v2f row, col, dx, dy;
-            mh_pixel_of_fast2(cam, mh_splat(X0[KA - 1]), mh_splat(X1[KA - 1]), mh_splat(X2[KA - 1]), Hf, Wf, row, col);
-            mh_unit2_fast2(row - mh_splat(hdr.z), col - mh_splat(hdr.w), dx, dy);
-            DX[KA - 1] = dx.x;
-            DY[KA - 1] = dy.x;
-        }
-#pragma unroll
-        for (int j = 0; j < KA; ++j) {
-            if constexpr (LD == 0) ML[j] = mh_one_minus_abs(mh_vadd(mh_vmul(t0.x, DX[j]), mh_vmul(t0.y, DY[j])));
-            else ML[j] = mh_one_minus_abs(mh_vadd(mh_vmul_s(t0.x, DX[j]), mh_vmul_s(t0.y, DY[j])));
-            BC[j] = t0.z;
-        }
-        // tap records travel as wave-uniform VECTOR loads in ping-pong groups of four (see mh_search_kernel)
-        constexpr int GRP = 4;
-        auto process = [&](const float4 (&g)[GRP], int t) {
-#pragma unroll
-            for (int u = 0; u < GRP; ++u) {
-                if (t + u < ntap) {   // uniform
-                    const float4 tp = g[u];
-                    float l[KA];
-#pragma unroll
-                    for (int j = 0; j < KA; ++j) {
-                        if constexpr (LD == 0) l[j] = mh_one_minus_abs(mh_vadd(mh_vmul(tp.x, DX[j]), mh_vmul(tp.y, DY[j])));
-                        else l[j] = mh_one_minus_abs(mh_vadd(mh_vmul_s(tp.x, DX[j]), mh_vmul_s(tp.y, DY[j])));
-                    }
-                    mh_tap_update<KA>(ML, BC, l, tp.z);
-                }
-            }
-        };
-        float4 ga[GRP], gb[GRP];
-#pragma unroll
-        for (int u = 0; u < GRP; ++u) ga[u] = rec[2 + u];
-        for (int t = 1; t < ntap;) {
-#pragma unroll
-            for (int u = 0; u < GRP; ++u) gb[u] = rec[1 + t + GRP + u];
-            process(ga, t);
-            t += GRP;
-            if (t >= ntap) break;
-#pragma unroll
-            for (int u = 0; u < GRP; ++u) ga[u] = rec[1 + t + GRP + u];
-            process(gb, t);
-            t += GRP;
-        }
-#pragma unroll
-        for (int j = 0; j < KA; ++j) {
-            const float w = BC[j];   // (vis != -1) * best_conf
-            num[j].a0 = num[j].a0 + ML[j] * w;
-            den[j].a0 = den[j].a0 + w;
-            cnt[j] += (w > 0.0f) ? 1 : 0;
-        }
-    };
-    const int lane = tid & 63;
-    for (int vb = 0; vb < V; vb += 64) {
-        unsigned long long vm;
-        if (vcnt) {
-            const int vv = vb + lane;
-            vm = __ballot(vv < V && vcnt[(size_t)vv * N + n] != 0);
-        } else {
-            vm = (V - vb >= 64) ? ~0ull : ((1ull << (V - vb)) - 1ull);
-        }
-        if (!vm) continue;
-        int v = vb + (int)__builtin_ctzll(vm);
-        vm &= vm - 1;
-        float4 hdr = taps[((size_t)v * N + n) * P1];
-        for (;;) {
-            int vnext = -1;
-            float4 hdr_n = hdr;
-            if (vm) {
-                vnext = vb + (int)__builtin_ctzll(vm);
-                vm &= vm - 1;
-                hdr_n = taps[((size_t)vnext * N + n) * P1];
-            }
-            flush_upto(v);
-            one_view(v, hdr);
-            if (vnext < 0) break;
-            v = vnext;
-            hdr = hdr_n;
-        }
-    }
-    flush_upto(V - 1);
-#pragma unroll
-    for (int j = 0; j < KA; ++j) {
-        const int it = j * T + tid;
-        if (it < nact) {
-            const float dn = mh_cascv_done(den[j]);
-            const float nm = mh_cascv_done(num[j]);
-            const float ratio = dn / (float)cnt[j];
-            s_pos[it] = (ratio > thr) ? 1 : 0;
-            s_loss[it] = nm / dn;
-        }
-    }
-}
-
-template <int T, int LD>
-__global__ __launch_bounds__(T) void mh_search2_kernel(MhViews vw, const float *__restrict__ offs, int S, int nrank,
-                                                       int rank_step, const float *__restrict__ pts, int N, int P1,
-                                                       float thr, const float *__restrict__ ori_c,
-                                                       const int32_t *__restrict__ base_idx,
-                                                       const float *__restrict__ base_val,
-                                                       const float4 *__restrict__ taps,
-                                                       const uint8_t *__restrict__ vcnt,
-                                                       const int32_t *__restrict__ order, float *__restrict__ line_ori,
-                                                       float *__restrict__ min_loss, uint8_t *__restrict__ high_conf,
-                                                       float *__restrict__ best_sample, int32_t *__restrict__ best_rank,
-                                                       int32_t *__restrict__ best_s) {
-    __shared__ float s_loss[MH_MAX_ITEMS];
-    __shared__ uint8_t s_pos[MH_MAX_ITEMS];
-    __shared__ float s_rl[MH_MAX_RANKS];
-    __shared__ int s_ri[MH_MAX_RANKS];
-    __shared__ int s_rh[MH_MAX_RANKS];
-
-    const int tid = threadIdx.x;
-    const int n = order ? order[blockIdx.x] : (int)blockIdx.x;
-    const float P0 = pts[3 * n], P1x = pts[3 * n + 1], P2 = pts[3 * n + 2];
-    // usable base-view ranks: rank 0 always, rank r > 0 only if base_view_conf[r] > 0 (PMVO.py:57-64); keep every rank up
-    // to the last usable one
-    int nvalid = 1;
-    for (int r = 1; r < nrank; ++r)
-        if (base_val[(size_t)(r * rank_step) * N + n] > 0.0f) nvalid = r + 1;
-    const int nact = nvalid * S;
-    const int wave0 = tid & ~63;   // first item of this wave in slice 0
-    int ka = 0;
-    for (int j = 0; j < 4; ++j) ka += (j * T + wave0 < nact) ? 1 : 0;
-#define MH_S2_ARGS vw, offs, S, rank_step, P0, P1x, P2, n, N, P1, thr, ori_c, base_idx, taps, vcnt, nact, tid, s_loss, s_pos
-    if (ka == 4) mh_search_slices<4, T, LD>(MH_S2_ARGS);
-    else if (ka == 3) mh_search_slices<3, T, LD>(MH_S2_ARGS);
-    else if (ka == 2) mh_search_slices<2, T, LD>(MH_S2_ARGS);
-    else if (ka == 1) mh_search_slices<1, T, LD>(MH_S2_ARGS);
-#undef MH_S2_ARGS
-    __syncthreads();
-
-    // ---- per rank: low-confidence escape hatch, min / argmin over the S samples (PMVO.py:199-206)
-    const int wave = tid >> 6, lane = tid & 63, nwaves = T >> 6;
-    for (int r = wave; r < nvalid; r += nwaves) {
-        int npos = 0;
-        for (int s0 = 0; s0 < S; s0 += MH_WAVE) {
-            const int s = s0 + lane;
-            npos += __popcll(__ballot(s < S && s_pos[r * S + s]));
-        }
-        const bool low = npos < 5;
-        float bl = 0.0f;
-        int bi = 0x7fffffff;
-        for (int s = lane; s < S; s += MH_WAVE) {
-            float l = s_loss[r * S + s];
-            if (!low && !s_pos[r * S + s]) l = 1.0f;
-            if (bi == 0x7fffffff || mh_min_better(l, s, bl, bi)) {
-                bl = l;
-                bi = s;
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ol = __shfl_xor(bl, o);
-            const int oi = __shfl_xor(bi, o);
-            if (oi != 0x7fffffff && (bi == 0x7fffffff || mh_min_better(ol, oi, bl, bi))) {
-                bl = ol;
-                bi = oi;
-            }
-        }
-        if (lane == 0) {
-            s_rl[r] = bl;
-            s_ri[r] = bi;
-            s_rh[r] = s_pos[r * S + bi];
-        }
-    }
-    __syncthreads();
-
-    // ---- best candidate across base-view ranks (PMVO.py:57-70) and the 3D direction (:73-74)
-    if (tid == 0) {
-        const float Hf = (float)vw.H, Wf = (float)vw.W;
-        float ml = s_rl[0];
-        int br = 0, bs = s_ri[0], hc = s_rh[0];
-        for (int r = 1; r < nvalid; ++r) {
-            const float l = s_rl[r];
-            if ((l < ml) && (base_val[(size_t)(r * rank_step) * N + n] > 0.0f)) {
-                ml = l;
-                br = r;
-                bs = s_ri[r];
-                hc = s_rh[r];
-            }
-        }
-        const int b = base_idx[(size_t)(br * rank_step) * N + n];
-        const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
-        float B0, B1, B2;
-        mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[bs], B0, B1, B2);
-        const float d0 = B0 - P0, d1 = B1 - P1x, d2 = B2 - P2;
-        float s2 = d0 * d0;
-        s2 = mh_fma(d1, d1, s2);
-        s2 = mh_fma(d2, d2, s2);
-        const float nrm = __builtin_sqrtf(s2);
-        line_ori[3 * n] = d0 / nrm;
-        line_ori[3 * n + 1] = d1 / nrm;
-        line_ori[3 * n + 2] = d2 / nrm;
-        min_loss[n] = ml;
-        high_conf[n] = (uint8_t)hc;
-        if (best_sample) {
-            best_sample[3 * n] = B0;
-            best_sample[3 * n + 1] = B1;
-            best_sample[3 * n + 2] = B2;
-        }
-        if (best_rank) best_rank[n] = br;
-        if (best_s) best_s[n] = bs;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// mh_search3_kernel -- mh_search2_kernel with the tap lists of the point STAGED IN LDS.  Same arithmetic in the same order;
-// what changes is where the wave-uniform tap records come from:
-//   * mh_search2 reads them with broadcast vector loads: every one of the 4 waves of the workgroup loads every tap record
-//     of every visible view (20.9 M wave-level loads per launch, 768 B of register return each through the CU's one
-//     vector-memory path), and the first two loads of a view (first tap, first group) are waited for at full L2 latency;
+// mh_search3_kernel -- the shipped search: the arithmetic of mh_search_kernel in the same order, laid out for the machine.
+// Where the wave-uniform tap records come from:
+//   * round 2's first form read them with broadcast vector loads: every one of the 4 waves of the workgroup loaded every tap
+//     record of every visible view (20.9 M wave-level loads per launch, 768 B of register return each through the CU's one
+//     vector-memory path), and the first two loads of a view (first tap, first group) were waited for at full L2 latency;
 //   * here the 256 threads copy the lists of the visible views into LDS once (coalesced 16-B loads, one copy per
 //     workgroup instead of four), one barrier, and the tap loop reads them back with same-address ds_read (broadcast, no
 //     bank conflict, ~100 cycles of latency that the ping-pong groups cover).  Lists that do not fit (MH_S3_CAP records)
@@ -1276,71 +886,33 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
                                 int32_t *best_rank, int32_t *best_s, int variant, hipStream_t st) {
     const int nitems = nrank * S;
     if (nitems > MH_MAX_ITEMS || nrank > MH_MAX_RANKS || nitems < 1) return -1;
-#define MH_SEARCH_LAUNCH_F(KK, TT, FF)                                                                                   \
-    hipLaunchKernelGGL((mh_search_kernel<KK, TT, FF>), dim3(N), dim3(TT), 0, st, vw, offs, S, nrank, rank_step, pts, N, \
-                       P1, thr, ori_c, base_idx, base_val, taps, line_ori, min_loss, high_conf, best_sample,        \
-                       best_rank, best_s)
-#define MH_SEARCH_LAUNCH(KK, TT) MH_SEARCH_LAUNCH_F(KK, TT, 0)
-    // variant 0: mh_search2_kernel (256 threads, up to 4 item slices) when the items fit, ordered by work;
-    // 2: the same without the work order (A/B); the others: earlier forms kept for A/B and cross-checks
-    if (variant == 0) variant = (nitems <= 64) ? 64 : (nitems <= 1024 ? (cnt ? 6 : 1) : 256);
-    if (variant >= 1 && variant <= 7) {
-        // 6: mh_search3_kernel (tap lists staged in LDS), ordered by work -- the shipped form; 7: the same in natural order;
-        // 1: mh_search2_kernel (broadcast vector tap loads), ordered; 2: natural order; 3/4: scalar tap loads; 5: variant 1
-        // with the loop over ALL views instead of the visible-view mask (A/B)
-        if (nitems > 1024) return -1;
-        if ((variant == 6 || variant == 7) && !cnt) return -1;
+    // variant 0 (default): mh_search3_kernel, workgroups in descending order of work; 7: the same in natural order (A/B);
+    // 1256: the portable mh_search_kernel (cross-check) -- also what runs when the caller has no list lengths
+    if (variant == 0) variant = cnt ? 6 : 1256;
+    if (variant == 6 || variant == 7) {
+        if (!cnt) return -1;
         const int32_t *ord = nullptr;
-        if ((variant == 1 || variant == 3 || variant == 5 || variant == 6) && order && cnt && N > 1) {
+        if (variant == 6 && order && N > 1) {
             hipLaunchKernelGGL(mh_search_work_kernel, dim3((N + 3) / 4), dim3(256), 0, st, cnt, vw.V, N, P1, base_val,
                                nrank, rank_step, S, 256, order);
             hipLaunchKernelGGL(mh_search_order_kernel, dim3(1), dim3(1024), 0, st, N, order);
             ord = order + N;
         }
-        const uint8_t *vc = (variant == 5) ? nullptr : cnt;
-        if (variant >= 6 && vw.V > 256)
+        if (vw.V > 256)
             hipLaunchKernelGGL((mh_search3_kernel<256, true>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts,
                                N, P1, thr, ori_c, base_idx, base_val, taps, cnt, ord, line_ori, min_loss, high_conf,
                                best_sample, best_rank, best_s);
-        else if (variant >= 6)
+        else
             hipLaunchKernelGGL((mh_search3_kernel<256, false>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step,
                                pts, N, P1, thr, ori_c, base_idx, base_val, taps, cnt, ord, line_ori, min_loss, high_conf,
                                best_sample, best_rank, best_s);
-        else if (variant <= 2 || variant == 5)
-            hipLaunchKernelGGL((mh_search2_kernel<256, 0>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts,
-                               N, P1, thr, ori_c, base_idx, base_val, taps, vc, ord, line_ori, min_loss, high_conf,
-                               best_sample, best_rank, best_s);
-        else
-            hipLaunchKernelGGL((mh_search2_kernel<256, 1>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts,
-                               N, P1, thr, ori_c, base_idx, base_val, taps, vc, ord, line_ori, min_loss, high_conf,
-                               best_sample, best_rank, best_s);
-    } else if (variant == 64) {
-        if (nitems <= 64) MH_SEARCH_LAUNCH(1, 64);
-        else if (nitems <= 512) MH_SEARCH_LAUNCH(8, 64);
-        else if (nitems <= 960) MH_SEARCH_LAUNCH(15, 64);
-        else MH_SEARCH_LAUNCH(16, 64);
-    } else if (variant == 128) {
-        MH_SEARCH_LAUNCH(8, 128);
-    } else if (variant == 192) {
-        if (nitems <= 960) MH_SEARCH_LAUNCH(5, 192);
-        else MH_SEARCH_LAUNCH(6, 192);
-    } else if (variant == 256) {    // round 1's shipped form: packed multiplies, all ranks, natural order
-        MH_SEARCH_LAUNCH_F(4, 256, 2);
-    } else if (variant == 2256) {   // compiler-scheduled tap body (pre hand-ordered compare/select block)
-        MH_SEARCH_LAUNCH_F(4, 256, 1);
-    } else if (variant == 1256) {   // portable loop, for A/B and cross-checks
-        MH_SEARCH_LAUNCH(4, 256);
-    } else if (variant == 1128) {
-        MH_SEARCH_LAUNCH_F(8, 128, 1);
-    } else if (variant == 320) {
-        if (nitems <= 320) MH_SEARCH_LAUNCH(1, 320);
-        else if (nitems <= 960) MH_SEARCH_LAUNCH(3, 320);
-        else MH_SEARCH_LAUNCH(4, 320);
+    } else if (variant == 1256) {
+        hipLaunchKernelGGL((mh_search_kernel<4, 256>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts, N, P1,
+                           thr, ori_c, base_idx, base_val, taps, line_ori, min_loss, high_conf, best_sample, best_rank,
+                           best_s);
     } else {
         return -1;
     }
-#undef MH_SEARCH_LAUNCH
-#undef MH_SEARCH_LAUNCH_F
     return (int)hipGetLastError();
 }
 
