@@ -105,6 +105,40 @@ def all_gather_views(local, n_views, shape, dtype, device):
     return out
 
 
+def refine_sharded():
+    """Does `refine` shard its per-point stages over the ranks?  Default: yes under the nccl backend (one small in-place
+    all_gather per 5000-point chunk of the smoothing loop is cheap on RCCL), no under gloo (every exchange would be a device
+    -> host -> device round trip); MH_REFINE_SHARD=1 / 0 forces it either way (the tests force it under gloo)."""
+    import os
+
+    d = _dist()
+    if not d or world() == 1:
+        return False
+    env = os.environ.get("MH_REFINE_SHARD")
+    if env is not None:
+        return env == "1"
+    return d.get_backend() == "nccl"
+
+
+def all_gather_rows_inplace(buf, lo, s):
+    """buf: device tensor [M] or [M, C] that is IDENTICAL on all ranks except for the rows each rank has just written,
+    rows [lo + rank*s, lo + (rank+1)*s).  Afterwards every rank holds everybody's rows [lo, lo + world*s): one in-place
+    all_gather (sendbuff = recvbuff + rank*count).  Rows of the range that nobody wrote travel too -- they are the same
+    everywhere, so the copy is a no-op on them (buf must be allocated with world*s rows of slack at the end)."""
+    d = _dist()
+    R, r = world(), rank()
+    out = buf[lo:lo + R * s]
+    inp = buf[lo + r * s:lo + (r + 1) * s]
+    assert out.shape[0] == R * s and out.is_contiguous(), "all_gather_rows_inplace: the buffer needs world*s rows of slack"
+    if d.get_backend() == "nccl":
+        d.all_gather_into_tensor(out, inp)
+    else:
+        host = inp.cpu()
+        parts = [torch.empty_like(host) for _ in range(R)]
+        d.all_gather(parts, host)
+        out.copy_(torch.cat(parts, 0).to(buf.device))
+
+
 _COMMS = {}
 _CAPI_BROKEN = []          # non-empty once the hand-bound RCCL path failed to come up on some rank: stay on torch
 

@@ -753,17 +753,41 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         # cores), then the sequentially dependent smoothing loop (chunk k+1 reads the orientations chunk k wrote,
         # PMVO.py:614,640) runs entirely on the device, stream-ordered, without a host round trip per chunk.
         n_all = points.shape[0]
+        sub_num = 5000
+        step = n_all // sub_num + 1
+        # With several ranks (mdist.refine_sharded) every rank owns a fixed slice of EVERY chunk: slice k of a chunk of n
+        # points is rows [lo + k*s, lo + (k+1)*s) with s = ceil(n / ranks).  A point's new orientation depends on the
+        # orientations as they were when its chunk started (the medoid launch reads them before the chunk's write-back,
+        # PMVO.py:614,640), so the slices of a chunk are independent; after the chunk one in-place all_gather per array
+        # makes every rank's copy complete again -- the arrays a rank holds at the start of a chunk are the single-rank
+        # ones, bit for bit.  Neighbour queries are needed for the owned rows only.
+        R, rk = (mdist.world(), mdist.rank()) if mdist.refine_sharded() else (1, 0)
+
+        def own(i):
+            lo, hi = i * sub_num, min((i + 1) * sub_num, n_all)
+            s_ = -(-(hi - lo) // R) if hi > lo else 0
+            return lo, hi, s_, min(lo + rk * s_, hi), min(lo + (rk + 1) * s_, hi)
+
         with stage("refine: knn (surface)", device):
-            index_all = _knn(points, points, 100, device, getattr(args, "knn", "device"), int32=True,
-                             self_query=True, keep_grid=grid_all).contiguous()
+            if R == 1:
+                index_all = _knn(points, points, 100, device, getattr(args, "knn", "device"), int32=True,
+                                 self_query=True, keep_grid=grid_all).contiguous()
+                row_of = [i * sub_num for i in range(step)]
+            else:
+                mine = [np.arange(own(i)[3], own(i)[4]) for i in range(step)]
+                row_of = np.concatenate([[0], np.cumsum([len(m) for m in mine])]).tolist()
+                qidx = np.concatenate(mine) if mine else np.zeros(0, np.int64)
+                index_all = _knn(points, points[qidx], 100, device, getattr(args, "knn", "device"), int32=True,
+                                 keep_grid=grid_all).contiguous()
         T_loop = stage("refine: smoothing loop", device).__enter__()
         pts_dev = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(device)
         with stage("refine: head-top mask", device):      # scalp half of filter_head_points, once for all chunks
             head_top_all = pmvo.head_top_mask_device(pts_dev)
-        ori_dev = torch.from_numpy(ori).to(device).type(torch.float).contiguous()
-        loss_dev = torch.from_numpy(loss).to(device).type(torch.float).contiguous()
-        sub_num = 5000
-        step = n_all // sub_num + 1
+        slack = R * (-(-sub_num // R)) if R > 1 else 0     # rows the in-place exchange may touch past the last chunk
+        ori_dev = torch.zeros((n_all + slack, 3), dtype=torch.float32, device=device)
+        loss_dev = torch.zeros((n_all + slack,), dtype=torch.float32, device=device)
+        ori_dev[:n_all] = torch.from_numpy(ori).to(device).type(torch.float)
+        loss_dev[:n_all] = torch.from_numpy(loss).to(device).type(torch.float)
         # per chunk four launches and no tensor op: medoid over the neighbour rows, the loss of that direction straight
         # from the maps, the head-filter votes, and the tail (-1 / replacement / 0.5) in place
         K = index_all.shape[1]
@@ -773,21 +797,26 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         L, ctx, st = pmvo._L, pmvo._ctx, _lib.stream_ptr()
         off = lambda t, row, width=1: ctypes.c_void_p(t.data_ptr() + row * width * t.element_size())   # noqa: E731
         for i in range(step):
-            lo, hi = i * sub_num, min((i + 1) * sub_num, n_all)
-            n = hi - lo
-            if n <= 0:
+            lo, hi, s_, a, b = own(i)
+            if hi <= lo:
                 continue
-            _lib.check(L.mh_medoid_indexed(ctx, _lib.ptr(ori_dev), off(index_all, lo, K), n, K, _lib.ptr(center), None,
-                                           st), "mh_medoid_indexed")
-            _lib.check(L.mh_refine_loss_maps(ctx, off(pts_dev, lo, 3), _lib.ptr(center), 0.005, 4.0, n,
-                                             pmvo._side, float(pmvo.conf_threshold), _lib.ptr(loss_u), None, st),
-                       "mh_refine_loss_maps")
-            _lib.check(L.mh_filter_points(ctx, off(pts_dev, lo, 3), n, pmvo._side, float(pmvo.conf_threshold),
-                                          float(pmvo.visible_threshold), None, None, None, _lib.ptr(head), st),
-                       "mh_filter_points")
-            _lib.check(L.mh_refine_combine(ctx, _lib.ptr(center), _lib.ptr(loss_u), _lib.ptr(head),
-                                           off(head_top_all, lo), 0.95, off(ori_dev, lo, 3), off(loss_dev, lo), n, st),
-                       "mh_refine_combine")
+            n = b - a
+            if n > 0:
+                _lib.check(L.mh_medoid_indexed(ctx, _lib.ptr(ori_dev), off(index_all, row_of[i], K), n, K,
+                                               _lib.ptr(center), None, st), "mh_medoid_indexed")
+                _lib.check(L.mh_refine_loss_maps(ctx, off(pts_dev, a, 3), _lib.ptr(center), 0.005, 4.0, n,
+                                                 pmvo._side, float(pmvo.conf_threshold), _lib.ptr(loss_u), None, st),
+                           "mh_refine_loss_maps")
+                _lib.check(L.mh_filter_points(ctx, off(pts_dev, a, 3), n, pmvo._side, float(pmvo.conf_threshold),
+                                              float(pmvo.visible_threshold), None, None, None, _lib.ptr(head), st),
+                           "mh_filter_points")
+                _lib.check(L.mh_refine_combine(ctx, _lib.ptr(center), _lib.ptr(loss_u), _lib.ptr(head),
+                                               off(head_top_all, a), 0.95, off(ori_dev, a, 3), off(loss_dev, a), n, st),
+                           "mh_refine_combine")
+            if R > 1:
+                mdist.all_gather_rows_inplace(ori_dev, lo, s_)
+                mdist.all_gather_rows_inplace(loss_dev, lo, s_)
+        ori_dev, loss_dev = ori_dev[:n_all], loss_dev[:n_all]
         ori[:] = ori_dev.cpu().numpy()
         loss[:] = loss_dev.cpu().numpy()
         T_loop.__exit__()
@@ -828,35 +857,53 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     select_filter_unvisible_points = np.zeros((0, 3), np.float32)
     if len(select_points) and len(filter_unvisible_points):
         fu = np.ascontiguousarray(filter_unvisible_points)
-        with stage("refine: knn (shell)", device):
-            if grid_all and grid_all[0].M == len(points):
-                # KDTree(select_points).query(fu) on the grid that already exists for all points: the points kept by
-                # the loss threshold are flagged valid, the indices come back in terms of `points` (order-preserving
-                # compaction: same (distance, index) order), so the medoid reads the full orientation array
-                valid = np.zeros(len(points), np.uint8)
-                valid[index] = 1
-                index_all = grid_all[0].query(fu, 100, int32=True, valid=valid).contiguous()
-                ori_rows = ori
-            else:
-                index_all = _knn(select_points, fu, 100, device, getattr(args, "knn", "device"),
-                                 int32=True).contiguous()
-                ori_rows = select_ori
-        fu_dev = torch.from_numpy(fu.astype(np.float32)).to(device).contiguous()
+        use_grid = bool(grid_all) and grid_all[0].M == len(points)
+        if use_grid:
+            # KDTree(select_points).query(fu) on the grid that already exists for all points: the points kept by the loss
+            # threshold are flagged valid, the indices come back in terms of `points` (order-preserving compaction: same
+            # (distance, index) order), so the medoid reads the full orientation array
+            valid = np.zeros(len(points), np.uint8)
+            valid[index] = 1
+            ori_rows = ori
+        else:
+            ori_rows = select_ori
         sel_ori_dev = torch.from_numpy(np.ascontiguousarray(ori_rows, dtype=np.float32)).to(device)
-        F, K = index_all.shape
-        center = torch.empty((F, 3), dtype=torch.float32, device=device)
-        head = torch.empty((F,), dtype=torch.uint8, device=device)
-        # the points are independent here: one medoid launch and one vote launch for all of them (the reference's
-        # 5000-point chunks only bound its memory)
-        _lib.check(pmvo._L.mh_medoid_indexed(pmvo._ctx, _lib.ptr(sel_ori_dev), _lib.ptr(index_all), F, K,
-                                             _lib.ptr(center), None, _lib.stream_ptr()), "mh_medoid_indexed")
-        _lib.check(pmvo._L.mh_filter_points(pmvo._ctx, _lib.ptr(fu_dev), F, pmvo._side,
-                                            float(pmvo.conf_threshold), float(args.PMVO.visible_threshold), None, None,
-                                            None, _lib.ptr(head), _lib.stream_ptr()), "mh_filter_points")
-        head_top = pmvo.head_top_mask_device(fu_dev).cpu().numpy().astype(bool)
-        keep = ~np.logical_and(head.cpu().numpy().astype(bool), ~head_top)     # not filter_head_points
-        filter_unvisible_ori = center.cpu().numpy()[keep]
-        select_filter_unvisible_points = fu_dev.cpu().numpy()[keep]
+
+        def shell_block(fb):
+            """rows of `fb` -> [n, 4] device tensor: the medoid orientation of the 100 nearest kept points and the keep flag
+            (not filter_head_points).  The points are independent: one medoid launch and one vote launch for all of them
+            (the reference's 5000-point chunks only bound its memory)."""
+            with stage("refine: knn (shell)", device):
+                if use_grid:
+                    idx = grid_all[0].query(fb, 100, int32=True, valid=valid).contiguous()
+                else:
+                    idx = _knn(select_points, fb, 100, device, getattr(args, "knn", "device"), int32=True).contiguous()
+            fb_dev = torch.from_numpy(fb.astype(np.float32)).to(device).contiguous()
+            F, K = idx.shape
+            out = torch.empty((F, 4), dtype=torch.float32, device=device)
+            cen = torch.empty((F, 3), dtype=torch.float32, device=device)
+            hd = torch.empty((F,), dtype=torch.uint8, device=device)
+            _lib.check(pmvo._L.mh_medoid_indexed(pmvo._ctx, _lib.ptr(sel_ori_dev), _lib.ptr(idx), F, K, _lib.ptr(cen), None,
+                                                 _lib.stream_ptr()), "mh_medoid_indexed")
+            _lib.check(pmvo._L.mh_filter_points(pmvo._ctx, _lib.ptr(fb_dev), F, pmvo._side, float(pmvo.conf_threshold),
+                                                float(args.PMVO.visible_threshold), None, None, None, _lib.ptr(hd),
+                                                _lib.stream_ptr()), "mh_filter_points")
+            ht = pmvo.head_top_mask_device(fb_dev)
+            out[:, :3] = cen
+            out[:, 3] = (~(hd.bool() & ~ht.bool())).to(torch.float32)
+            return out
+
+        if mdist.refine_sharded():           # block k of the shell points belongs to rank k; one all_gather of the results
+            W_ = mdist.world()
+            cuts = [(len(fu) * k) // W_ for k in range(W_ + 1)]
+            res = torch.cat(mdist.map_chunks([fu[cuts[k]:cuts[k + 1]] for k in range(W_)], shell_block, device,
+                                             empty=lambda: torch.empty((0, 4), dtype=torch.float32, device=device)), 0)
+        else:
+            res = shell_block(fu)
+        res = res.cpu().numpy()
+        keep = res[:, 3] > 0.5
+        filter_unvisible_ori = np.ascontiguousarray(res[keep, :3])
+        select_filter_unvisible_points = fu.astype(np.float32)[keep]
     T_shell.__exit__()
     if saver is not None:
         saver.join()

@@ -53,25 +53,30 @@ def test_pmvo_cli_end_to_end(tmp_path):
     assert (out / "full" / "Ori3D.mat").exists() and (out / "full" / "coarse.npy").exists()
 
 
-def test_two_ranks_give_the_single_rank_volume_bit_for_bit(tmp_path):
-    """the path shards by points and the voxel fit by disjoint slabs + ONE reduce, so an N-rank run must
-    reproduce the 1-rank outputs bit for bit.  Two ranks share the single test GPU (gloo; RCCL refuses two ranks on
-    one device), which exercises map_chunks, the all_gather and the volume reduce with the real kernels."""
+@pytest.mark.parametrize("ranks,refine_shard,res", [(2, "0", 32), (2, "1", 32), (3, "1", 64)])
+def test_two_ranks_give_the_single_rank_volume_bit_for_bit(tmp_path, ranks, refine_shard, res):
+    """the path shards by points and the voxel fit by disjoint slabs + ONE exchange, so an N-rank run must
+    reproduce the 1-rank outputs bit for bit.  The ranks share the single test GPU (gloo; RCCL refuses two ranks on
+    one device), which exercises map_chunks, the all_gather and the volume exchange with the real kernels.
+    refine_shard "1": refine's smoothing loop and shell stage sharded over the ranks as well (what the nccl backend does by
+    default: every rank owns a slice of every 5000-point chunk, one in-place all_gather per chunk); 3 ranks on the larger
+    case: several chunks, slices that do not divide a chunk."""
     import scipy.io
 
     from monohair_amd import synth
 
     data = tmp_path / "data"
-    synth.write_case(str(data), "synthetic_sphere", V=24, H=240, W=136, res=32)
+    synth.write_case(str(data), "synthetic_sphere", V=24, H=240, W=136, res=res)
     base = ["--yaml=configs/reconstruct/synthetic_sphere", "--data.root=%s" % data, "--data.image_size=[240,136]",
             "--PMVO.patch_size=3"]
     env = dict(os.environ, PYTHONPATH=ROOT)
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "PMVO.py")] + base + ["--name=one"], cwd=ROOT, env=env,
                         stdin=subprocess.DEVNULL, capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-2000:]
-    env2 = dict(env, MH_DIST_BACKEND="gloo", MH_DEVICE_OVERRIDE="0")
-    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                         "--master-addr", "127.0.0.1", "--master-port", "29561", os.path.join(ROOT, "PMVO.py")] + base +
+    env2 = dict(env, MH_DIST_BACKEND="gloo", MH_DEVICE_OVERRIDE="0", MH_REFINE_SHARD=refine_shard)
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+                         "--master-addr", "127.0.0.1", "--master-port", str(29561 + ranks + int(refine_shard)),
+                         os.path.join(ROOT, "PMVO.py")] + base +
                         ["--name=two"], cwd=ROOT, env=env2, stdin=subprocess.DEVNULL, capture_output=True, text=True,
                         timeout=900)
     assert r2.returncode == 0, r2.stdout[-3000:] + r2.stderr[-3000:]
