@@ -60,8 +60,10 @@ def main(argv=None):
                              "pass --infer_inner.run_mvs= to stop after the render stage" % raw)
         import PMVO as pmvo_cli
 
-        keep = [a for a in argv if a.startswith("--yaml=") or a.startswith("--data.") or a.startswith("--name=")
-                or a.startswith("--PMVO.") or a.startswith("--gpu=")]
+        # the second PMVO pass sees every option of this command line (name / seed / output_root / bbox / bust_to_origin /
+        # camera path ... all decide where it finds refine/select_p.npy and with what geometry) except this script's own
+        # switches
+        keep = [a for a in argv if not a.startswith("--infer_inner")]
         pmvo_cli.main(keep + ["--PMVO.infer_inner", "--PMVO.optimize="])
 
 

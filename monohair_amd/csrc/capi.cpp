@@ -567,6 +567,11 @@ extern "C" int mh_refine_loss_maps(mh_ctx *ctx, const float *points, const float
     if (N == 0) return MH_OK;
     if (!points || !dir || !loss || N < 0 || patch < 1 || !(patch & 1))
         return fail(MH_ERR_ARG, "mh_refine_loss_maps: bad arguments");
+    if (patch > 11)
+        return fail(MH_ERR_ARG, "mh_refine_loss_maps: patch side %d is not built in (odd sides 1..11 are; the reference's "
+                                "configurations use 5, 7 and 9) -- use mh_project_gather + mh_refine_loss for larger patches",
+                    patch);
+    if (ctx->V > 512) return fail(MH_ERR_ARG, "mh_refine_loss_maps: %d views exceed the limit of 512", ctx->V);
     return launched(mh_launch_refine_loss_maps(ctx->views(), points, dir, step_mul, step_div, N, patch, conf_threshold,
                                                loss, high_conf, (hipStream_t)stream),
                     "mh_refine_loss_maps");

@@ -123,12 +123,23 @@ def process_options(opt):
         if int(os.environ.get("WORLD_SIZE", "1")) > 1:
             import torch.distributed as tdist
 
-            if not (tdist.is_available() and tdist.is_initialized()):
-                raise RuntimeError("seed: null under torch.distributed needs an initialised process group (the run "
-                                   "name and the candidate jitter are drawn on rank 0); set a seed or init first")
-            box = [suffix, shared_seed]
-            tdist.broadcast_object_list(box, src=0)
-            suffix, shared_seed = box
+            if tdist.is_available() and tdist.is_initialized():
+                box = [suffix, shared_seed]
+                tdist.broadcast_object_list(box, src=0)
+                suffix, shared_seed = box
+            else:
+                # called before init_process_group (tools, tests, infer_inner.get_config): every rank derives the SAME
+                # values from what the launcher gave all of them -- the rendezvous id / port -- instead of failing;
+                # distinct per launch, identical across the ranks of one launch
+                import hashlib
+
+                key = "%s|%s|%s" % (os.environ.get("TORCHELASTIC_RUN_ID", ""), os.environ.get("MASTER_ADDR", ""),
+                                    os.environ.get("MASTER_PORT", ""))
+                h = hashlib.sha256(key.encode()).digest()
+                suffix = "".join(string.ascii_uppercase[b % 26] for b in h[:4])
+                shared_seed = int.from_bytes(h[4:8], "little") % (2 ** 31)
+            # (the numpy stream is re-seeded only here: a single-rank unseeded run keeps numpy's own entropy, as the
+            # reference does; multi-rank runs need the ranks to draw the same candidate jitter)
             np.random.seed(shared_seed)
         opt.name = str(opt.name) + "_" + suffix
     assert isinstance(opt.gpu, int)

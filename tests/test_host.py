@@ -413,3 +413,24 @@ def test_camera_tensor_utilities_equal_the_reference():
         assert np.allclose(camv.numpy(), z["cam%d_camv" % i], rtol=0, atol=1e-6)
         c2w = cam.camera2world(torch.from_numpy(z["cam%d_camv" % i])[:, :3])
         assert np.allclose(c2w.numpy(), z["cam%d_c2w" % i], rtol=0, atol=1e-6)
+
+
+def test_unseeded_options_before_process_group_init_agree_across_ranks(tmp_path, monkeypatch):
+    """seed: null under a multi-rank launcher, options.set() called BEFORE init_process_group (tools, infer_inner): every
+    rank derives the same run-name suffix and numpy seed from the launcher's rendezvous environment instead of failing."""
+    from monohair_amd import options
+
+    (tmp_path / "c.yaml").write_text("seed:\ncpu: true\ngpu: 0\nname: run\n")
+    names, draws = [], []
+    for rank in ("0", "1"):
+        monkeypatch.setenv("WORLD_SIZE", "2")
+        monkeypatch.setenv("RANK", rank)
+        monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+        monkeypatch.setenv("MASTER_PORT", "29999")
+        monkeypatch.setenv("TORCHELASTIC_RUN_ID", "abc")
+        opt = options.set(options.parse_arguments(["--yaml=%s" % (tmp_path / "c")]))
+        names.append(opt.name)
+        draws.append(np.random.rand())
+    assert names[0] == names[1] and names[0].startswith("run_") and len(names[0]) == 8 and draws[0] == draws[1]
+    monkeypatch.setenv("MASTER_PORT", "30000")               # another launch: another suffix
+    assert options.set(options.parse_arguments(["--yaml=%s" % (tmp_path / "c")])).name != names[0]

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 TAG=${1:-r03}
 ARGS=${2:-}
-RX=${3:-"mh_project_taps|mh_topk|mh_search"}
+RX=${3:-"mh_project_taps|mh_project_gather|mh_topk|mh_search"}
 mkdir -p $OUT
 cd /tmp
 CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu --no-secondary --streams 1 $ARGS"
