@@ -439,7 +439,7 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=False):
             "note": "executed = sum over points of (taps of the views that see the point) x (usable base-view ranks) x 90 "
                     "samples, read back from the launch's own work arrays; launch_ms includes the two small ordering "
                     "kernels in front of the search",
-            "valu_issue": prof.get("search_valu_issue") if not codes else None,
+            "valu_issue": prof.get(pre + "search_valu_issue"),
         },
         "roofline_kernels": [
             {"kernel": "mh_project_taps_kernel<%d>" % a.patch, "bound": "hbm", "launch_ms": round(t_taps, 4),
@@ -470,7 +470,7 @@ def load_profile_facts(V, H, W):
         if not t.get("workload", "").startswith("%d views @ %dx%d" % (V, H, W)):
             return {}
         return {"traffic": {k: v.get("traffic_bytes") for k, v in t.items() if isinstance(v, dict) and "traffic_bytes" in v},
-                "search_valu_issue": t.get("search_valu_issue")}
+                "search_valu_issue": t.get("search_valu_issue"), "8bit:search_valu_issue": t.get("8bit:search_valu_issue")}
     except Exception:
         return {}
 
