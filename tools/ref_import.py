@@ -20,8 +20,19 @@ def _stub(name, **attrs):
     return sys.modules[name]
 
 
+PINNED_TORCH = "2.10."        # the goldens under tests/golden/ are outputs of CPU torch of this version
+
+
 def import_reference(gabor=False):
+    import os
+
     import torch
+
+    print("gen_golden: CPU torch %s" % torch.__version__)
+    if not torch.__version__.startswith(PINNED_TORCH) and not os.environ.get("MH_GOLDEN_ANY_TORCH"):
+        raise SystemExit("the golden vectors are pinned to CPU torch %sx: torch.topk's tie order and ATen's summation order "
+                         "are part of what they record (DESIGN.md §5).  This is torch %s; set MH_GOLDEN_ANY_TORCH=1 to "
+                         "regenerate them deliberately with another version." % (PINNED_TORCH, torch.__version__))
 
     sys.dont_write_bytecode = True
     for name in ("cv2", "trimesh", "open3d", "termcolor"):
