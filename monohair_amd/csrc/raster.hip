@@ -210,7 +210,8 @@ extern "C" int mh_launch_render_depth(const float *cam, const float *verts, int 
 //     segment crosses (the pixel whose sample is nearest), one in the column of an end point that lies inside its pixel's
 //     diamond, none for the pixel whose diamond holds the END point; the interpolation parameter of a fragment is GL's
 //     t = (p_r - p_a).(p_b - p_a) / |p_b - p_a|^2 with p_r the fragment's centre (mh_seg_t);
-//     `width` fragments (ctx.line_width = 3, :30) are stacked around it in the minor direction (GL's wide-line rule).
+//     wide lines (ctx.line_width = 3, :30) follow GL's rule: offset by (width-1)/2 in the minor direction, rasterise thin,
+//     replicate each fragment `width` times (mh_setup_seg) -- pinned against a desktop GL, tests/golden/gl_mesa.npz.
 //     Option "line_rule" 1 keeps the end pixel (every diamond touched): what Google SwiftShader draws -- with it and
 //     "raster_subpixel_bits" 4 this rasteriser draws exactly SwiftShader's line pixels (tests/golden/gl_raster.npz,
 //     tools/gen_golden_gl.py);
@@ -269,14 +270,23 @@ struct MhRSeg {
     int i0, i1;         // pixel columns along the major axis that can hold a fragment
 };
 
-__device__ __forceinline__ bool mh_setup_seg(const MhRLVert &a, const MhRLVert &b, int H, int W, int off, MhRSeg &g) {
+// Wide lines (GL 4.6 14.5.2.2): the segment is offset by (width-1)/2 pixels in the minor direction towards smaller WINDOW
+// coordinates, rasterised as a line of width 1, and every fragment becomes a column of `width` fragments going up from there.
+// Window y grows upwards and the rows here grow downwards: an x-major segment moves +(width-1)/2 rows and its column is
+// rows jc-(width-1) .. jc; a y-major one moves -(width-1)/2 columns and its column is jc .. jc+width-1.  Odd widths: a whole-
+// pixel offset, i.e. the symmetric stack around the thin line; even widths: the half-pixel offset changes which pixel the
+// diamond rule picks.  Pinned against Mesa llvmpipe (tests/golden/gl_mesa.npz): width 3 -- the reference's -- within 3
+// pixels of ~3 800 per view, width 1 within 1, width 2 within 2.5 % (Mesa draws even widths as a rectangle).
+__device__ __forceinline__ bool mh_setup_seg(const MhRLVert &a, const MhRLVert &b, int H, int W, int off, int width,
+                                             MhRSeg &g) {
     if (a.x == MH_R_BAD || b.x == MH_R_BAD) return false;
     const int dx = b.x - a.x, dy = b.y - a.y;
+    const int wshift = (width - 1) * (MH_R_SUB / 2);
     g.xmaj = (abs(dx) >= abs(dy)) ? 1 : 0;
     g.A = g.xmaj ? a.x : a.y;
     g.B = g.xmaj ? b.x : b.y;
-    g.ma = g.xmaj ? a.y : a.x;
-    g.mb = g.xmaj ? b.y : b.x;
+    g.ma = g.xmaj ? a.y + wshift : a.x - wshift;
+    g.mb = g.xmaj ? b.y + wshift : b.x - wshift;
     if (g.A == g.B) return false;
     const int lo = min(g.A, g.B), hi = max(g.A, g.B);
     g.i0 = max(-mh_floor_div(MH_R_SUB / 2 - (lo - off), MH_R_SUB), 0);                     // the column that holds the lower end
@@ -352,7 +362,7 @@ __global__ __launch_bounds__(256) void mh_raster_lines_kernel(const MhRLVert *__
     if (s >= Ns) return;
     const MhRLVert a = lv[2 * s], b = lv[2 * s + 1];
     MhRSeg g;
-    if (!mh_setup_seg(a, b, H, W, off, g)) return;
+    if (!mh_setup_seg(a, b, H, W, off, width, g)) return;
     const int nminor = g.xmaj ? H : W;
     for (int i = g.i0; i <= g.i1; ++i) {
         int jc;
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(256) void mh_raster_lines_kernel(const MhRLVert *__
         const float zw = a.zw + t * (b.zw - a.zw);
         if (!(zw >= 0.0f && zw <= 1.0f)) continue;
         const unsigned long long key = ((unsigned long long)__float_as_uint(zw) << 32) | (prim_base + (unsigned)s);
-        const int j0 = jc - (width - 1) / 2;     // `width` fragments stacked in the minor direction (GL's wide lines)
+        const int j0 = g.xmaj ? jc - (width - 1) : jc;     // the column of `width` fragments (see mh_setup_seg)
         for (int k = 0; k < width; ++k) {
             const int j = j0 + k;
             if (j < 0 || j >= nminor) continue;
@@ -373,7 +383,7 @@ __global__ __launch_bounds__(256) void mh_raster_lines_kernel(const MhRLVert *__
 
 __global__ __launch_bounds__(256) void mh_raster_resolve_color_kernel(
     const MhRVert *__restrict__ vt, const int32_t *__restrict__ faces, int Nv, int Nf, const MhRLVert *__restrict__ lv,
-    int H, int W, int off, int rule, int color_option, int depth_option, float clear,
+    int H, int W, int off, int width, int rule, int color_option, int depth_option, float clear,
     const unsigned long long *__restrict__ zbuf, float *__restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)H * W) return;
@@ -399,8 +409,8 @@ __global__ __launch_bounds__(256) void mh_raster_resolve_color_kernel(
             const int s = (int)(prim - (unsigned)Nf);
             const MhRLVert a = lv[2 * s], b = lv[2 * s + 1];
             MhRSeg g;
-            mh_setup_seg(a, b, H, W, off, g);
-            // the fragment of the 1-pixel line in this pixel's column (a wide line stacks `width` copies of it)
+            mh_setup_seg(a, b, H, W, off, width, g);
+            // the fragment of the (offset) 1-pixel line in this pixel's column (a wide line replicates it `width` times)
             const int mi = g.xmaj ? c : r;
             int jc = g.xmaj ? r : c;
             mh_seg_fragment(g, mi, off, rule, jc);
@@ -460,8 +470,8 @@ extern "C" int mh_launch_render_strands(const float *cam, const float *verts, in
                            rule, (unsigned)(Nf > 0 && Nv > 0 ? Nf : 0), zbuf);
     }
     hipLaunchKernelGGL(mh_raster_resolve_color_kernel, dim3((unsigned)(((size_t)H * W + 255) / 256)), dim3(256), 0, st,
-                       vt, faces, Nv, (Nf > 0 && Nv > 0) ? Nf : 0, lv, H, W, off, rule, color_option, depth_option, clear,
-                       zbuf, out);
+                       vt, faces, Nv, (Nf > 0 && Nv > 0) ? Nf : 0, lv, H, W, off, width, rule, color_option, depth_option,
+                       clear, zbuf, out);
     return (int)hipGetLastError();
 }
 

@@ -334,7 +334,15 @@ long ora_render_strands(const float *cam, const float *verts, int Nv, const int3
             const int dx = b->x - a->x, dy = b->y - a->y;
             const int xmaj = abs(dx) >= abs(dy);
             const int A = xmaj ? a->x : a->y, B = xmaj ? b->x : b->y;
-            const int ma = xmaj ? a->y : a->x, mb = xmaj ? b->y : b->x;
+            /* Wide lines (GL 4.6 14.5.2.2): the segment is offset by (width-1)/2 pixels in the minor direction towards
+             * smaller WINDOW coordinates, rasterised as a line of width 1, and every fragment becomes a column of `width`
+             * fragments going up from there.  Window y grows upwards and the rows here grow downwards, so for an x-major
+             * line the offset is +(width-1)/2 rows and the column goes towards smaller rows; for a y-major line it is
+             * -(width-1)/2 columns and the column goes right.  For odd widths the offset is whole pixels -- the symmetric
+             * stack around the thin line; for even widths the half-pixel offset changes which pixel the diamond rule
+             * picks (pinned against Mesa: tests/golden/gl_mesa.npz, widths 1-3). */
+            const int wshift = (width - 1) * 128;
+            const int ma = (xmaj ? a->y + wshift : a->x - wshift), mb = (xmaj ? b->y + wshift : b->x - wshift);
             if (A == B) continue;
             const int lo = A < B ? A : B, hi = A < B ? B : A;
             /* OpenGL's diamond-exit rule (GL 4.6 14.5.1) with the specification's tie-breaking shift: see seg_fragment */
@@ -352,7 +360,7 @@ long ora_render_strands(const float *cam, const float *verts, int Nv, const int3
                                 (float)((long long)(B - A) * (B - A) + (long long)(mb - ma) * (mb - ma));
                 const float zw = a->zw + t * (b->zw - a->zw);
                 if (!(zw >= 0.0f && zw <= 1.0f)) continue;
-                const int j0 = jc - (width - 1) / 2;
+                const int j0 = xmaj ? jc - (width - 1) : jc;       /* the column: rows jc-(width-1) .. jc / columns jc .. jc+width-1 */
                 const float wa = (1.0f - t) * a->iw, wb = t * b->iw;
                 const float den = wa + wb;
                 const float depth = (wa * a->depth + wb * b->depth) / den;

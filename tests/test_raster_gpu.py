@@ -215,3 +215,39 @@ def test_hip_rasterisers_against_real_opengl():
             check_strands_against_gl(draw, z, vi)
     finally:
         bits(8)
+
+
+def test_hip_rasterisers_against_a_desktop_opengl_with_the_references_own_shaders():
+    """tests/golden/gl_mesa.npz: Mesa llvmpipe (OpenGL 4.5 core) compiling the reference's own GLSL, lines at the reference's
+    width 3 -- same checks as the C statement's CPU test (tests/gl_checks.py::check_against_desktop_gl)."""
+    import os
+
+    from conftest import GOLDEN
+    from gl_checks import check_against_desktop_gl
+    from monohair_amd.render import DepthRenderer, StrandRenderer
+
+    z = np.load(os.path.join(GOLDEN, "gl_mesa.npz"))
+    H, W = int(z["H"]), int(z["W"])
+    cams = [dict(file="v%d" % i, pose=z["cam_pose"][i].tolist(), ndc_prj=z["cam_ndc"][i].tolist())
+            for i in range(len(z["cam_pose"]))]
+    rec = camera_records(cameras_from_list(cams))
+
+    def strand_renderer(with_bust):
+        r = StrandRenderer([], z["v1"] if with_bust else np.zeros((0, 3)), z["f1"] if with_bust else np.zeros((0, 3), int), DEV)
+        r.line_pts = torch.from_numpy(z["line_pts"]).to(DEV)
+        r.line_tan = torch.from_numpy(z["line_tan"]).to(DEV)
+        r.nseg = len(z["line_pts"]) // 2
+        return r
+
+    rs = {True: strand_renderer(True), False: strand_renderer(False)}
+    for vi in z["views"]:
+        vi = int(vi)
+
+        def depth_of(v, f):
+            return DepthRenderer([(v, f)], DEV).render(rec[vi], H, W, pixel_center=0.5).cpu().numpy().reshape(H, W)
+
+        def draw(width, copt, dopt, clear, with_bust):
+            return rs[with_bust].render(rec[vi], H, W, copt, dopt, clear, pixel_center=0.5, line_width=width,
+                                        line_rule=0).cpu().numpy()
+
+        check_against_desktop_gl(z, vi, depth_of, draw)

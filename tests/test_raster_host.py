@@ -203,6 +203,35 @@ def test_oracle_rasterisers_against_real_opengl():
         oracle.set_subpixel_bits(8)
 
 
+def test_oracle_rasterisers_against_a_desktop_opengl_with_the_references_own_shaders():
+    """tests/golden/gl_mesa.npz: Mesa llvmpipe (OpenGL 4.5 core) compiling the reference's own GLSL, lines at the reference's
+    width 3 -- the wide-line rule, which SwiftShader could not pin (tests/gl_checks.py::check_against_desktop_gl)."""
+    import os
+
+    from conftest import GOLDEN
+    from gl_checks import check_against_desktop_gl
+
+    z = np.load(os.path.join(GOLDEN, "gl_mesa.npz"))
+    H, W = int(z["H"]), int(z["W"])
+    cams = [dict(file="v%d" % i, pose=z["cam_pose"][i].tolist(), ndc_prj=z["cam_ndc"][i].tolist())
+            for i in range(len(z["cam_pose"]))]
+    rec = camera_records(cameras_from_list(cams))
+    none_v, none_f = np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32)
+    oracle.set_subpixel_bits(8)
+    for vi in z["views"]:
+        vi = int(vi)
+
+        def depth_of(v, f):
+            return oracle.render_depth(rec[vi], v, f, H, W, pixel_center=0.5)[0].reshape(H, W)
+
+        def draw(width, copt, dopt, clear, with_bust):
+            bv, bf = (z["v1"], z["f1"]) if with_bust else (none_v, none_f)
+            return oracle.render_strands(rec[vi], bv, bf, z["line_pts"], z["line_tan"], H, W, 0.5, width, copt, dopt, clear,
+                                         line_rule=0)[0]
+
+        check_against_desktop_gl(z, vi, depth_of, draw)
+
+
 def test_line_rule_known_answers():
     """The fragments of single horizontal segments, start x0 = 5 + f0, end x1 = 12 + f1 (GL window coordinates, pixel
     centres at +0.5).  line_rule 1 = every diamond |dx| + |dy| < 1/2 the closed segment touches -- the columns below are
