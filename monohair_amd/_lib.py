@@ -31,6 +31,7 @@ _SIGS = {
                                vp, vp]),
     "mh_forward_prepare": (ci, [vp, vp, ci, ci, cf, vp, vp, vp, vp, vp, csz, vp]),
     "mh_search_prepared": (ci, [vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "mh_forward": (ci, [vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, vp, vp, csz, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mh_refine_loss": (ci, [vp, vp, vp, cf, cf, ci, ci, cf, vp, vp, vp, vp, vp, vp]),
     "mh_filter_points": (ci, [vp, vp, ci, ci, cf, cf, vp, vp, vp, vp, vp]),
     "mh_project_points": (ci, [vp, ci, vp, ci, vp, vp, vp, vp, vp]),

@@ -519,6 +519,17 @@ extern "C" int mh_search_prepared(mh_ctx *ctx, const float *points, int N, int p
                     "mh_search_prepared");
 }
 
+extern "C" int mh_forward(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank, int rank_step,
+                          float *vis, float *ori, float *conf, float *mask, void *scratch, size_t scratch_bytes,
+                          int32_t *base_idx, float *base_val, float *line_ori, float *min_loss, uint8_t *high_conf,
+                          float *best_sample, int32_t *best_rank, int32_t *best_s, void *stream) {
+    if (int rc = mh_forward_prepare(ctx, points, N, patch, conf_threshold, vis, ori, conf, mask, scratch, scratch_bytes, stream))
+        return rc;
+    if (int rc = mh_topk_views(ctx, vis, conf, N, base_idx, base_val, stream)) return rc;
+    return mh_search_prepared(ctx, points, N, patch, conf_threshold, nrank, rank_step, ori, base_idx, base_val, scratch,
+                              line_ori, min_loss, high_conf, best_sample, best_rank, best_s, stream);
+}
+
 extern "C" int mh_refine_loss(mh_ctx *ctx, const float *points, const float *dir, float step_mul, float step_div,
                               int N, int patch, float conf_threshold, const float *vis, const float *ori_patch,
                               const float *conf_patch, float *loss, uint8_t *high_conf, void *stream) {

@@ -131,7 +131,16 @@ def all_gather_rows_inplace(buf, lo, s):
     inp = buf[lo + r * s:lo + (r + 1) * s]
     assert out.shape[0] == R * s and out.is_contiguous(), "all_gather_rows_inplace: the buffer needs world*s rows of slack"
     if d.get_backend() == "nccl":
-        d.all_gather_into_tensor(out, inp)
+        global _INPLACE_GATHER_OK
+        if _INPLACE_GATHER_OK:
+            try:
+                d.all_gather_into_tensor(out, inp)
+                return
+            except (RuntimeError, ValueError):      # an argument check of this torch build (raised before any traffic, on
+                _INPLACE_GATHER_OK = False          # every rank alike): use a separate receive buffer from now on
+        tmp = torch.empty_like(out)
+        d.all_gather_into_tensor(tmp, inp.clone())
+        out.copy_(tmp)
     else:
         host = inp.cpu()
         parts = [torch.empty_like(host) for _ in range(R)]
@@ -139,6 +148,7 @@ def all_gather_rows_inplace(buf, lo, s):
         out.copy_(torch.cat(parts, 0).to(buf.device))
 
 
+_INPLACE_GATHER_OK = True
 _COMMS = {}
 _CAPI_BROKEN = []          # non-empty once the hand-bound RCCL path failed to come up on some rank: stay on torch
 

@@ -458,6 +458,7 @@ class PMVO:
         f = dict(dtype=torch.float32, device=self.device)
         cs = torch.cuda.current_stream(self.device)          # looked up once: ~8 us of Python per call
         stp = ctypes.c_void_p(cs.cuda_stream)
+        d_ = torch.Tensor.data_ptr          # raw addresses: ctypes converts ints to void* without a wrapper object each
         if fused:
             points = self._upload_points(points, cs) if isinstance(points, np.ndarray) else self._dev_points(points)
             V, N = self.num_view, points.shape[0]
@@ -468,20 +469,11 @@ class PMVO:
             self._Ori_patch = self._Conf_patch = self._pixf = None
             self._points = points
             scratch, need = self._get_scratch(N, cs.cuda_stream)
-            _lib.check(self._L.mh_forward_prepare(self._ctx, _lib.ptr(points), N, self._side,
-                                                  float(self.conf_threshold), _lib.ptr(self.visible),
-                                                  _lib.ptr(self.Ori), _lib.ptr(self.Conf), _lib.ptr(self.mask),
-                                                  _lib.ptr(scratch), need, stp), "mh_forward_prepare")
         else:
             self.Compute_Visible_and_Ori(points)
             points = self._points
             N = points.shape[0]
             scratch, need = self._get_scratch(N, cs.cuda_stream)
-        if base_view is None:
-            bidx32, bval = self._topk32(stp)       # int32 end to end: no int64 round trip on the hot path
-        else:
-            bidx32 = torch.as_tensor(base_view[0]).to(self.device).to(torch.int32).contiguous()
-            bval = torch.as_tensor(base_view[1]).to(self.device).type(torch.float).contiguous()
         if out is not None:
             line_ori, min_loss, hc = out
             assert line_ori.shape == (N, 3) and min_loss.shape == (N,) and hc.shape == (N,) and hc.dtype == torch.bool
@@ -493,19 +485,39 @@ class PMVO:
         bs = torch.empty((N, 3), **f) if extras else None
         br = torch.empty((N,), dtype=torch.int32, device=self.device) if extras else None
         bi = torch.empty((N,), dtype=torch.int32, device=self.device) if extras else None
-        if fused:
-            _lib.check(self._L.mh_search_prepared(
-                self._ctx, _lib.ptr(points), N, self._side, float(self.conf_threshold), len(ranks),
-                ranks[1] - ranks[0], _lib.ptr(self.Ori), _lib.ptr(bidx32), _lib.ptr(bval), _lib.ptr(scratch),
-                _lib.ptr(line_ori), _lib.ptr(min_loss), _lib.ptr(hc), _lib.ptr(bs), _lib.ptr(br), _lib.ptr(bi),
-                stp), "mh_search_prepared")
+        if fused and base_view is None:
+            # the whole iteration in one call: projection / visibility / tap lists, base-view ranking, loss search
+            bidx32 = torch.empty((20, N), dtype=torch.int32, device=self.device)
+            bval = torch.empty((20, N), **f)
+            if N:
+                _lib.check(self._L.mh_forward(
+                    self._ctx, d_(points), N, self._side, float(self.conf_threshold), len(ranks), ranks[1] - ranks[0],
+                    d_(self.visible), d_(self.Ori), d_(self.Conf), d_(self.mask), d_(scratch), need, d_(bidx32), d_(bval),
+                    d_(line_ori), d_(min_loss), d_(hc), _lib.ptr(bs), _lib.ptr(br), _lib.ptr(bi), stp), "mh_forward")
         else:
-            _lib.check(self._L.mh_search_forward(
-                self._ctx, _lib.ptr(points), N, self._side, float(self.conf_threshold), len(ranks),
-                ranks[1] - ranks[0], _lib.ptr(self.visible), _lib.ptr(self.Ori), _lib.ptr(self._pixf),
-                _lib.ptr(self._Ori_patch), _lib.ptr(self._Conf_patch), _lib.ptr(bidx32), _lib.ptr(bval),
-                _lib.ptr(scratch), need, _lib.ptr(line_ori), _lib.ptr(min_loss), _lib.ptr(hc), _lib.ptr(bs),
-                _lib.ptr(br), _lib.ptr(bi), stp), "mh_search_forward")
+            if fused:
+                _lib.check(self._L.mh_forward_prepare(self._ctx, _lib.ptr(points), N, self._side,
+                                                      float(self.conf_threshold), _lib.ptr(self.visible),
+                                                      _lib.ptr(self.Ori), _lib.ptr(self.Conf), _lib.ptr(self.mask),
+                                                      _lib.ptr(scratch), need, stp), "mh_forward_prepare")
+            if base_view is None:
+                bidx32, bval = self._topk32(stp)       # int32 end to end: no int64 round trip on the hot path
+            else:
+                bidx32 = torch.as_tensor(base_view[0]).to(self.device).to(torch.int32).contiguous()
+                bval = torch.as_tensor(base_view[1]).to(self.device).type(torch.float).contiguous()
+            if fused:
+                _lib.check(self._L.mh_search_prepared(
+                    self._ctx, _lib.ptr(points), N, self._side, float(self.conf_threshold), len(ranks),
+                    ranks[1] - ranks[0], _lib.ptr(self.Ori), _lib.ptr(bidx32), _lib.ptr(bval), _lib.ptr(scratch),
+                    _lib.ptr(line_ori), _lib.ptr(min_loss), _lib.ptr(hc), _lib.ptr(bs), _lib.ptr(br), _lib.ptr(bi),
+                    stp), "mh_search_prepared")
+            else:
+                _lib.check(self._L.mh_search_forward(
+                    self._ctx, _lib.ptr(points), N, self._side, float(self.conf_threshold), len(ranks),
+                    ranks[1] - ranks[0], _lib.ptr(self.visible), _lib.ptr(self.Ori), _lib.ptr(self._pixf),
+                    _lib.ptr(self._Ori_patch), _lib.ptr(self._Conf_patch), _lib.ptr(bidx32), _lib.ptr(bval),
+                    _lib.ptr(scratch), need, _lib.ptr(line_ori), _lib.ptr(min_loss), _lib.ptr(hc), _lib.ptr(bs),
+                    _lib.ptr(br), _lib.ptr(bi), stp), "mh_search_forward")
         out = (points, line_ori, min_loss, hc)
         if extras:
             return out + (dict(best_sample=bs, best_rank=br, best_s=bi, base_idx=bidx32.long(), base_val=bval),)
