@@ -66,7 +66,9 @@ def test_visible_and_ori(case):
 def test_topk_is_the_reference_ranking(case):
     """The ranking equals the reference's torch.topk output index for index, tied values included (40-47 % of the points
     of these fixtures have tied positive values in their top 20): topk_oracle.cpp calls the same libstdc++ selection and
-    sort that ATen's CPU kernel calls.  The simpler index-ordered rule agrees wherever values are unique."""
+    sort that ATen's CPU kernel calls.  The simpler index-ordered rule agrees wherever values are unique.
+    (This order is a property of CPU torch -- the goldens are outputs of CPU torch 2.10, tools/ref_import.py pins the version;
+    the reference on CUDA would order ties differently.  DESIGN.md §5.)"""
     meta, z, scene, views = case
     idx, val = oracle.topk_views(z["visible"], z["Conf"], 20)
     assert np.array_equal(val, z["base_val"]) and np.array_equal(idx, z["base_idx"])
