@@ -442,7 +442,8 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=False):
             "valu_issue": prof.get(pre + "search_valu_issue"),
         },
         "roofline_kernels": [
-            {"kernel": "mh_project_taps_kernel<%d>" % a.patch, "bound": "hbm", "launch_ms": round(t_taps, 4),
+            {"kernel": ("mh_project_taps_codes_kernel<%d>" if codes else "mh_project_taps2_kernel<%d>") % a.patch, "bound": "hbm",
+             "launch_ms": round(t_taps, 4),
              "algorithmic_bytes_per_launch": int(taps_in + taps_out),
              "achieved": round((taps_in + taps_out) / (t_taps * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round((taps_in + taps_out) / (t_taps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

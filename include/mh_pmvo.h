@@ -347,7 +347,8 @@ int mh_mat_write_sparse(const char *path, const void *prefix, size_t prefix_byte
  *   "tap_codes": 1 (default) = contexts whose views were ALL uploaded with mh_ctx_set_view_u8 gather a patch tap as the
  *       two resident 8-bit codes of its pixel (mh_project_taps_codes_kernel); 0 = always the decoded records.
  *   "gabor_variant": 3 (default) mh_gabor_mfma2_kernel; 1 the first FP32-MFMA form; 0 / 2 the direct v_pk_fma forms.
- *   "topk_order": see mh_topk_views.   "taps_tile": points per workgroup of the tap preparation (64 / 32 / 16).
+ *   "topk_order": see mh_topk_views.   "taps_tile": 1 (default) mh_project_taps2_kernel; 64 / 32 / 16: the first
+ *       form of the fp32 front end with that many points per workgroup (A/B).
  *   "line_rule" (mh_render_strands): 0 = OpenGL's diamond-exit rule (default), 1 = the pixel that holds a segment's end
  *       point is drawn too (what Google SwiftShader does; changes the image: used to compare with that GL).
  *   "raster_subpixel_bits" (mh_render_depth, mh_render_strands): window positions are snapped to 2^-bits pixel, 4..8,

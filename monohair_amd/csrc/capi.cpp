@@ -53,7 +53,8 @@ struct mh_ctx {
     int S = 0;
     int search_variant = 0;
     int topk_order = 0;       // 0: torch.topk's CPU tie order (mh_topk_wave.h); 1: value desc, view asc; 2: mh_topk_order.h
-    int taps_tile = 64;       // points per workgroup of mh_project_taps_kernel (64 / 32 / 16)
+    int taps_tile = 1;        // fp32 front end: 1 = mh_project_taps2_kernel (a wave owns 16 points; default since round 3);
+                              // 64 / 32 / 16 = points per workgroup of the first form, mh_project_taps_kernel (A/B)
     int line_rule = 0;        // strand renderer: 0 GL's diamond-exit, 1 every touched diamond (SwiftShader)
     int raster_subpixel_bits = 8;   // both rasterisers: window positions snapped to 2^-bits pixel (SwiftShader: 4)
     int gabor_variant = 3;    // 0: v_pk_fma, one pixel/lane; 1: FP32-MFMA im2col, first form; 2: v_pk_fma, split bank;

@@ -683,6 +683,165 @@ __global__ __launch_bounds__(256) void mh_project_taps_codes_kernel(MhViews vw, 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// mh_project_taps2_kernel -- the fused front end for fp32 records in the organisation of the code form above (round 3): one
+// wave owns 16 points of the 64-point tile (lane = point for the projection, lane = tap for the patches), no workgroup
+// barrier between projection and patches, and the 16-byte patch gathers of up to INF visible points are in flight at once
+// instead of three.  Arithmetic, eligibility, duplicate rule (hash table + bit compare) and record layout are those of
+// mh_project_taps_kernel: the tap lists are identical.
+// ---------------------------------------------------------------------------------------------
+template <int PATCH>
+__global__ __launch_bounds__(256) void mh_project_taps2_kernel(MhViews vw, const float *__restrict__ pts, int N, int tiles,
+                                                               float thr, float *__restrict__ vis,
+                                                               float *__restrict__ ori, float *__restrict__ conf,
+                                                               float *__restrict__ mask, float4 *__restrict__ taps,
+                                                               uint8_t *__restrict__ cnt) {
+    constexpr int P = PATCH * PATCH, HP = PATCH / 2, NCH = (P + MH_WAVE - 1) / MH_WAVE, PW = 16;
+    constexpr int INF = NCH == 1 ? 8 : 4;            // points whose patch gathers are in flight together (32 VGPRs)
+    __shared__ float2 s_o[4][MH_PREP_PMAX];
+    __shared__ float s_c[4][MH_PREP_PMAX];
+    __shared__ unsigned char s_el[4][MH_PREP_PMAX];
+    __shared__ unsigned int s_first[4][256];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous view ranges
+    const int V = vw.V, H = vw.H, W = vw.W;
+    if (bid >= V * tiles) return;
+    const int v = bid / tiles, tile = bid - v * tiles;
+    const int n0 = tile * MH_PG_TILE + wave * PW;
+    const float4 *__restrict__ rec = vw.rec + (size_t)v * H * W;
+    const int n = n0 + lane;
+    const bool mine = lane < PW && n < N;
+    int r = 0, c = 0;
+    float rowf = 0.0f, colf = 0.0f, visv = -1.0f;
+    if (mine) {
+        const float *cam = vw.cams + v * MH_CAM_STRIDE;
+        float u, w, z;
+        mh_cam_project(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, w, z);
+        mh_ndc_to_pixel(u, w, (float)H, (float)W, rowf, colf);
+        float cr = __builtin_rintf(colf), rr = __builtin_rintf(rowf);
+        const bool oob = !(cr <= (float)(W - 1)) || (cr < 0.0f) || !(rr <= (float)(H - 1)) || (rr < 0.0f);
+        cr = fminf(fmaxf(cr, 0.0f), (float)(W - 1));
+        rr = fminf(fmaxf(rr, 0.0f), (float)(H - 1));
+        r = (int)rr;
+        c = (int)cr;
+        const float4 q0 = rec[(size_t)r * W + c];
+        visv = mh_soft_visible(q0.w, (-z / 2.0f) * 255.0f);
+        visv = oob ? -1.0f : visv;
+        const size_t vn = (size_t)v * N + n;
+        vis[vn] = visv;
+        reinterpret_cast<float2 *>(ori)[vn] = make_float2(q0.x, q0.y);
+        conf[vn] = mh_clampf(q0.z, 1e-6f, 1.0f);
+        if (mask) mask[vn] = vw.mask[(size_t)v * H * W + (size_t)r * W + c];
+        if (visv == -1.0f) {
+            taps[vn * (P + 1)] = make_float4(__int_as_float(0), visv, 0.0f, 0.0f);
+            cnt[vn] = 0;
+        }
+    }
+    const int npw = min(PW, N - n0);
+    if (npw <= 0) return;
+    const unsigned long long vmask = __ballot(mine && visv != -1.0f);     // bit j: point j of this wave is visible
+    int di[NCH], dj[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int p = ch * MH_WAVE + lane;
+        di[ch] = p / PATCH - HP;
+        dj[ch] = p - (p / PATCH) * PATCH - HP;
+    }
+    unsigned long long todo = vmask;
+    while (todo) {
+        // the next INF visible points: their patches are requested back to back, then processed in turn
+        int pj[INF];
+        float4 q[INF][NCH];
+        unsigned long long t = todo;
+#pragma unroll
+        for (int k = 0; k < INF; ++k) {
+            pj[k] = t ? (int)__builtin_ctzll(t) : -1;
+            t &= t - 1;
+            if (pj[k] >= 0) {
+                const int rj = __builtin_amdgcn_readlane(r, pj[k]), cj = __builtin_amdgcn_readlane(c, pj[k]);
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    q[k][ch] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ch * MH_WAVE + lane < P)
+                        q[k][ch] = rec[(size_t)min(max(rj + di[ch], 0), H - 1) * W + min(max(cj + dj[ch], 0), W - 1)];
+                }
+            }
+        }
+        todo = t;
+#pragma unroll
+        for (int k = 0; k < INF; ++k) {
+            if (pj[k] < 0) continue;
+            const int j = pj[k];
+            const size_t vn = (size_t)v * N + n0 + j;
+            float4 *__restrict__ out = taps + vn * (P + 1);
+            for (int b = lane; b < 256; b += MH_WAVE) s_first[wave][b] = 0xffffffffu;
+            float cmax = -1.0f;
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int p = ch * MH_WAVE + lane;
+                if (p < P) {
+                    const float cc = mh_clampf(q[k][ch].z, 1e-6f, 1.0f);
+                    float o0, o1;
+                    mh_unit2(q[k][ch].x, q[k][ch].y, o0, o1);
+                    s_o[wave][p] = make_float2(o0, o1);
+                    s_c[wave][p] = cc;
+                    cmax = fmaxf(cmax, cc);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o));
+            const bool hc = cmax > thr;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int p = lane; p < P; p += MH_WAVE) {
+                const bool el = (p == 0) || (hc ? (s_c[wave][p] > thr) : true);
+                s_el[wave][p] = el;
+                if (el) {
+                    const float2 o = s_o[wave][p];
+                    const unsigned h = ((__float_as_uint(o.x) * 0x9E3779B1u) ^ (__float_as_uint(o.y) * 0x85EBCA77u)) >> 24;
+                    atomicMin(&s_first[wave][h], (unsigned)p);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int base = 0;
+            for (int p0 = 0; p0 < P; p0 += MH_WAVE) {
+                const int p = p0 + lane;
+                bool el = false;
+                float2 o = make_float2(0.f, 0.f);
+                float cc = 0.f;
+                if (p < P) {
+                    el = s_el[wave][p] != 0;
+                    o = s_o[wave][p];
+                    cc = s_c[wave][p];
+                    if (el) {
+                        const unsigned ox = __float_as_uint(o.x), oy = __float_as_uint(o.y);
+                        const unsigned qf = s_first[wave][((ox * 0x9E3779B1u) ^ (oy * 0x85EBCA77u)) >> 24];
+                        if (qf < (unsigned)p) {
+                            const float2 e = s_o[wave][qf];
+                            if (__float_as_uint(e.x) == ox && __float_as_uint(e.y) == oy) el = false;
+                        }
+                    }
+                }
+                const unsigned long long m = __ballot(el);
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (el) out[1 + pos] = make_float4(o.x, o.y, cc, 0.0f);
+                base += __popcll(m);
+            }
+            const float vjj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(visv), j));
+            const float rfj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowf), j));
+            const float cfj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(colf), j));
+            if (lane == 0) {
+                out[0] = make_float4(__int_as_float(base), vjj, rfj, cfj);
+                cnt[vn] = (uint8_t)base;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host-side launchers (called from capi.cpp)
 // ---------------------------------------------------------------------------------------------
@@ -781,8 +940,10 @@ extern "C" int mh_launch_project_taps(MhViews vw, const float *pts, int N, int p
     const MhCodeTabs *tabs = (const MhCodeTabs *)tabs_v;
     const bool codes = oc && tabs;
     if (patch * patch > MH_PREP_PMAX) return -1;
+    const int form = tile;                                    // 1: mh_project_taps2_kernel (64-point tiles, a wave owns 16)
     if (codes || (tile != 16 && tile != 32)) tile = 64;       // (the code form always works on 64-point tiles)
-    const int tiles = (N + tile - 1) / tile;
+    if (!codes && form == 1) tile = 1;
+    const int tiles = (N + (tile == 1 ? 64 : tile) - 1) / (tile == 1 ? 64 : tile);
     const dim3 grid((vw.V * tiles + 7) & ~7), block(256);
 #define MH_PT_LAUNCH(PS, TL)                                                                                        \
     hipLaunchKernelGGL((mh_project_taps_kernel<PS, TL>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, conf, mask, \
@@ -792,6 +953,9 @@ extern "C" int mh_launch_project_taps(MhViews vw, const float *pts, int N, int p
         if (codes)                                                                                                 \
             hipLaunchKernelGGL((mh_project_taps_codes_kernel<PS>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, \
                                conf, mask, taps, cnt, oc, tabs);                                                   \
+        else if (tile == 1)                                                                                       \
+            hipLaunchKernelGGL((mh_project_taps2_kernel<PS>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, conf, \
+                               mask, taps, cnt);                                                                  \
         else if (tile == 64) MH_PT_LAUNCH(PS, 64);                                                                 \
         else if (tile == 32) MH_PT_LAUNCH(PS, 32);                                                                 \
         else MH_PT_LAUNCH(PS, 16);                                                                                 \

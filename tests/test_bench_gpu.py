@@ -35,7 +35,7 @@ def test_single_gpu_line_and_rooflines_of_the_timed_kernels():
     # frac must be recomputable from the line itself
     assert abs(rf["pair_evals_executed"] * rf["flop_per_pair_eval"] / (rf["launch_ms"] * 1e-3) / 1e12 - rf["achieved"]) < 0.05
     names = [k["kernel"] for k in d["roofline_kernels"]]
-    assert any(n.startswith("mh_project_taps_kernel") for n in names) and any(n.startswith("mh_project_gather") for n in names)
+    assert any(n.startswith("mh_project_taps") for n in names) and any(n.startswith("mh_project_gather") for n in names)
     for k in d["roofline_kernels"]:
         assert abs(k["algorithmic_bytes_per_launch"] / (k["launch_ms"] * 1e-3) / 1e9 - k["achieved"]) < 1.0
     assert "refine_and_volume_s" in d["secondary_full_pass"]

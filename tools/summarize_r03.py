@@ -46,7 +46,7 @@ facts = {"_comment": "facts from rocprofv3 passes (tools/profile_r03.sh, tools/p
          "round": 3, "workload": "60 views @ 1920x1080, 5000 points, patch 7"}
 notes = []
 for tag, pre, kernels in (("r03_main", "", (("mh_project_gather_kernel<7>", "mh_project_gather_kernel<7", 2),
-                                            ("mh_project_taps_kernel<7>", "mh_project_taps_kernel<7", 2),
+                                            ("mh_project_taps_kernel<7>", "mh_project_taps2_kernel<7", 2),
                                             ("mh_search3_kernel<256>", "mh_search3_kernel<256", 2))),
                           ("r03_8bit", "8bit:", (("mh_project_taps_kernel<7>", "mh_project_taps_codes_kernel<7", 1),
                                                  ("mh_project_gather_kernel<7>", "mh_project_gather_kernel<7", 2),
