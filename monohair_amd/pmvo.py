@@ -796,10 +796,14 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         with stage("refine: head-top mask", device):      # scalp half of filter_head_points, once for all chunks
             head_top_all = pmvo.head_top_mask_device(pts_dev)
         slack = R * (-(-sub_num // R)) if R > 1 else 0     # rows the in-place exchange may touch past the last chunk
-        ori_dev = torch.zeros((n_all + slack, 3), dtype=torch.float32, device=device)
-        loss_dev = torch.zeros((n_all + slack,), dtype=torch.float32, device=device)
-        ori_dev[:n_all] = torch.from_numpy(ori).to(device).type(torch.float)
-        loss_dev[:n_all] = torch.from_numpy(loss).to(device).type(torch.float)
+        if slack:
+            ori_dev = torch.zeros((n_all + slack, 3), dtype=torch.float32, device=device)
+            loss_dev = torch.zeros((n_all + slack,), dtype=torch.float32, device=device)
+            ori_dev[:n_all] = torch.from_numpy(ori).to(device).type(torch.float)
+            loss_dev[:n_all] = torch.from_numpy(loss).to(device).type(torch.float)
+        else:       # (one rank: no tensor operation beyond the upload -- first uses of torch kernels cost a one-shot run ~40 ms)
+            ori_dev = torch.from_numpy(ori).to(device).type(torch.float).contiguous()
+            loss_dev = torch.from_numpy(loss).to(device).type(torch.float).contiguous()
         # per chunk four launches and no tensor op: medoid over the neighbour rows, the loss of that direction straight
         # from the maps, the head-filter votes, and the tail (-1 / replacement / 0.5) in place
         K = index_all.shape[1]
@@ -882,9 +886,9 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         sel_ori_dev = torch.from_numpy(np.ascontiguousarray(ori_rows, dtype=np.float32)).to(device)
 
         def shell_block(fb):
-            """rows of `fb` -> [n, 4] device tensor: the medoid orientation of the 100 nearest kept points and the keep flag
-            (not filter_head_points).  The points are independent: one medoid launch and one vote launch for all of them
-            (the reference's 5000-point chunks only bound its memory)."""
+            """rows of `fb` -> device tensors (medoid orientation of the 100 nearest kept points [n,3], head-filter votes [n],
+            head-top mask [n]).  The points are independent: one medoid launch and one vote launch for all of them (the
+            reference's 5000-point chunks only bound its memory)."""
             with stage("refine: knn (shell)", device):
                 if use_grid:
                     idx = grid_all[0].query(fb, 100, int32=True, valid=valid).contiguous()
@@ -892,7 +896,6 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
                     idx = _knn(select_points, fb, 100, device, getattr(args, "knn", "device"), int32=True).contiguous()
             fb_dev = torch.from_numpy(fb.astype(np.float32)).to(device).contiguous()
             F, K = idx.shape
-            out = torch.empty((F, 4), dtype=torch.float32, device=device)
             cen = torch.empty((F, 3), dtype=torch.float32, device=device)
             hd = torch.empty((F,), dtype=torch.uint8, device=device)
             _lib.check(pmvo._L.mh_medoid_indexed(pmvo._ctx, _lib.ptr(sel_ori_dev), _lib.ptr(idx), F, K, _lib.ptr(cen), None,
@@ -901,20 +904,31 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
                                                 float(args.PMVO.visible_threshold), None, None, None, _lib.ptr(hd),
                                                 _lib.stream_ptr()), "mh_filter_points")
             ht = pmvo.head_top_mask_device(fb_dev)
-            out[:, :3] = cen
-            out[:, 3] = (~(hd.bool() & ~ht.bool())).to(torch.float32)
-            return out
+            return cen, hd, ht
 
         if mdist.refine_sharded():           # block k of the shell points belongs to rank k; one all_gather of the results
             W_ = mdist.world()
             cuts = [(len(fu) * k) // W_ for k in range(W_ + 1)]
-            res = torch.cat(mdist.map_chunks([fu[cuts[k]:cuts[k + 1]] for k in range(W_)], shell_block, device,
+
+            def packed(fb):
+                cen, hd, ht = shell_block(fb)
+                out = torch.empty((cen.shape[0], 4), dtype=torch.float32, device=device)
+                out[:, :3] = cen
+                out[:, 3] = (~(hd.bool() & ~ht.bool())).to(torch.float32)
+                return out
+
+            res = torch.cat(mdist.map_chunks([fu[cuts[k]:cuts[k + 1]] for k in range(W_)], packed, device,
                                              empty=lambda: torch.empty((0, 4), dtype=torch.float32, device=device)), 0)
+            res = res.cpu().numpy()
+            keep = res[:, 3] > 0.5
+            centres = res[:, :3]
         else:
-            res = shell_block(fu)
-        res = res.cpu().numpy()
-        keep = res[:, 3] > 0.5
-        filter_unvisible_ori = np.ascontiguousarray(res[keep, :3])
+            # one rank: the three results go to the host as they are (no tensor operation: in a one-shot process every
+            # first use of a torch kernel costs tens of milliseconds of code-object loading)
+            cen, hd, ht = shell_block(fu)
+            keep = ~np.logical_and(hd.cpu().numpy().astype(bool), ~ht.cpu().numpy().astype(bool))     # not filter_head_points
+            centres = cen.cpu().numpy()
+        filter_unvisible_ori = np.ascontiguousarray(centres[keep])
         select_filter_unvisible_points = fu.astype(np.float32)[keep]
     T_shell.__exit__()
     if saver is not None:
