@@ -35,6 +35,44 @@ __device__ __forceinline__ void mh_sample_next(const float *__restrict__ cam, fl
     mh_cam_unproject(cam, nx, ny, z + off, S0, S1, S2);
 }
 
+// mh_sample_next split at what the S samples of one base-view rank have in common (the point's pixel in the base view, the
+// shifted pixel in NDC, the two quotients of mh_cam_unproject) and what is per sample (depth + offset onwards).  Same
+// operations on the same values in the same order, so rank part + item part == mh_sample_next bit for bit; the shipped
+// search evaluates the rank part once per (point, rank) instead of once per item (90 times) and keeps it in LDS.
+// rec[16] = { A, B, z, t0 | t1, t2, Ri0, Ri1 | Ri2 .. Ri5 | Ri6, Ri7, Ri8, - }
+__device__ __forceinline__ void mh_sample_rank(const float *__restrict__ cam, float X0, float X1, float X2, float ori_r,
+                                               float ori_c, float Hf, float Wf, float *__restrict__ rec) {
+    float u, v, z, row, col;
+    mh_cam_project(cam, X0, X1, X2, u, v, z);
+    mh_ndc_to_pixel(u, v, Hf, Wf, row, col);
+    float nx = col + ori_c * 2.0f;
+    float ny = row + ori_r * 2.0f;
+    nx = nx / Wf;
+    ny = ny / Hf;
+    nx = nx * 2.0f - 1.0f;
+    ny = ny * 2.0f - 1.0f;
+    nx = -nx;
+    rec[0] = (nx - cam[18]) / cam[16];
+    rec[1] = (ny - cam[22]) / cam[21];
+    rec[2] = z;
+    rec[3] = cam[3];
+    rec[4] = cam[7];
+    rec[5] = cam[11];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rec[6 + i] = cam[32 + i];
+    rec[15] = 0.0f;
+}
+
+__device__ __forceinline__ void mh_sample_item(const float4 *__restrict__ rec, float off, float &S0, float &S1, float &S2) {
+    const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
+    const float z = a.z + off;
+    const float c0 = a.x * z, c1 = a.y * z;
+    const float d0 = c0 - a.w, d1 = c1 - b.x, d2 = z - b.y;
+    S0 = (b.z * d0 + c.x * d2) + b.w * d1;
+    S1 = (c.y * d0 + c.w * d2) + c.z * d1;
+    S2 = (d.x * d0 + d.z * d2) + d.y * d1;
+}
+
 // torch.min over a row with NaN propagation: NaN beats numbers, first index wins among equals
 __device__ __forceinline__ bool mh_min_better(float al, int ai, float bl, int bi) {
     const bool an = al != al, bn = bl != bl;
@@ -189,6 +227,7 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
 
     // ---- best candidate across base-view ranks (PMVO.py:57-70) and the 3D direction (:73-74)
     if (tid == 0) {
+        const float Hf = (float)vw.H, Wf = (float)vw.W;
         float ml = s_rl[0];
         int br = 0, bs = s_ri[0], hc = s_rh[0];
         for (int r = 1; r < nrank; ++r) {
@@ -336,11 +375,10 @@ struct MhCascS {
 
 template <int KA, int T, bool BIGV>
 __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const float *__restrict__ offs, int S,
-                                                     int rank_step, float P0, float P1x, float P2, int n, int N, int P1,
-                                                     float thr, const float *__restrict__ ori_c,
-                                                     const int32_t *__restrict__ base_idx,
+                                                     int n, int N, int P1, float thr,
                                                      const float4 *__restrict__ taps, const uint8_t *__restrict__ vcnt,
-                                                     int nact, int tid, float *s_loss, uint8_t *s_pos, float4 *s_taps) {
+                                                     int nact, int tid, float *s_loss, uint8_t *s_pos, float4 *s_taps,
+                                                     const float4 *s_rank) {
     constexpr int KN = KA > 0 ? KA : 1;   // a wave without items (KA == 0) only helps to stage the lists
     const int V = vw.V;
     const float Hf = (float)vw.H, Wf = (float)vw.W;
@@ -350,14 +388,13 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
     MhCascS<BIGV> num[KN], den[KN];
     int cnt[KN];
     if constexpr (KA > 0) {
+        const unsigned inv = (1u << 20) / (unsigned)S + 1u;   // it / S for it < 1024 >= S: (it * inv) >> 20 (error < 2^-10 <= 1/S)
 #pragma unroll
         for (int j = 0; j < KA; ++j) {
             int it = j * T + tid;
             it = it < nact ? it : 0;
-            const int r = it / S, s = it - r * S;
-            const int b = base_idx[(size_t)(r * rank_step) * N + n];
-            const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
-            mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[s], X0[j], X1[j], X2[j]);
+            const int r = (int)(((unsigned)it * inv) >> 20), s = it - r * S;
+            mh_sample_item(s_rank + 4 * r, offs[s], X0[j], X1[j], X2[j]);   // (the rank part: mh_search3_kernel's prologue)
             num[j] = den[j] = MhCascS<BIGV>{};
             cnt[j] = 0;
         }
@@ -524,6 +561,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5))) void mh_
     __shared__ float s_rl[MH_MAX_RANKS];
     __shared__ int s_ri[MH_MAX_RANKS];
     __shared__ int s_rh[MH_MAX_RANKS];
+    __shared__ float4 s_rank[MH_MAX_RANKS * 4];   // mh_sample_rank's record of every usable base-view rank
 
     // Wave priority: everything that is not the tap loop -- prologue, staging, the per-view projection, the epilogue -- runs
     // at priority 1, the tap loop at 0.  The tap loops saturate the VALU whatever the arbiter picks; the other phases are
@@ -539,10 +577,18 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5))) void mh_
     for (int r = 1; r < nrank; ++r)
         if (base_val[(size_t)(r * rank_step) * N + n] > 0.0f) nvalid = r + 1;
     const int nact = nvalid * S;
+    // what the S samples of a rank share (mh_sample_rank), once per (point, rank): lane r of the first wave
+    if (tid < nvalid) {
+        const int b = base_idx[(size_t)(tid * rank_step) * N + n];
+        const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
+        mh_sample_rank(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, (float)vw.H, (float)vw.W,
+                       reinterpret_cast<float *>(s_rank + 4 * tid));
+    }
+    __syncthreads();
     const int wave0 = tid & ~63;   // first item of this wave in slice 0
     int ka = 0;
     for (int j = 0; j < 4; ++j) ka += (j * T + wave0 < nact) ? 1 : 0;
-#define MH_S3_ARGS vw, offs, S, rank_step, P0, P1x, P2, n, N, P1, thr, ori_c, base_idx, taps, vcnt, nact, tid, s_loss, s_pos, s_taps
+#define MH_S3_ARGS vw, offs, S, n, N, P1, thr, taps, vcnt, nact, tid, s_loss, s_pos, s_taps, s_rank
     if (ka == 4) mh_search_slices_lds<4, T, BIGV>(MH_S3_ARGS);
     else if (ka == 3) mh_search_slices_lds<3, T, BIGV>(MH_S3_ARGS);
     else if (ka == 2) mh_search_slices_lds<2, T, BIGV>(MH_S3_ARGS);
@@ -589,7 +635,6 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5))) void mh_
 
     // ---- best candidate across base-view ranks (PMVO.py:57-70) and the 3D direction (:73-74)
     if (tid == 0) {
-        const float Hf = (float)vw.H, Wf = (float)vw.W;
         float ml = s_rl[0];
         int br = 0, bs = s_ri[0], hc = s_rh[0];
         for (int r = 1; r < nvalid; ++r) {
@@ -601,10 +646,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5))) void mh_
                 hc = s_rh[r];
             }
         }
-        const int b = base_idx[(size_t)(br * rank_step) * N + n];
-        const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
         float B0, B1, B2;
-        mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[bs], B0, B1, B2);
+        mh_sample_item(s_rank + 4 * br, offs[bs], B0, B1, B2);
         const float d0 = B0 - P0, d1 = B1 - P1x, d2 = B2 - P2;
         float s2 = d0 * d0;
         s2 = mh_fma(d1, d1, s2);
