@@ -65,6 +65,13 @@ int mh_ctx_set_view_u8(mh_ctx *ctx, int view, const float *cam_host, const float
 /* The S depth offsets of PMVO.sample_next_3d_pos (PMVO.py:274-278), host pointer, S <= 256. */
 int mh_ctx_set_depth_offsets(mh_ctx *ctx, const float *offsets_host, int S);
 
+/* Host -> device copy of a points chunk on `stream` (PMVO.py:40, `torch.from_numpy(points).type(torch.float).to(device)`):
+ * a plain hipMemcpyAsync.  `host` should be page-locked for the copy to be asynchronous; the caller keeps it unchanged until the
+ * copy has completed (an event of its own).  Exists because the tensor library's own non-blocking copy from a pinned source
+ * also records an allocator-tracking event per call: 70 -> 55 us of host time per forward() on the 8-bit loop, where the host
+ * has 0.24 ms per iteration to enqueue the next one. */
+int mh_upload_async(mh_ctx *ctx, const void *host, void *device, size_t bytes, void *stream);
+
 /* ---- K3+K4+K5: PMVO.Compute_Visible_and_Ori (PMVO.py:346-376) with project_points (:378-397),
  * the gathers (:482-523) and compute_visible (:525-529).  Any output may be NULL.
  * pixf[V,N,2] = unrounded (row, col) of each point in each view (what Camera.uv2pixel returns,

@@ -108,6 +108,8 @@ int mh_launch_prj_loss(const float *, const float *, const float *, const float 
 int mh_launch_project_gather(MhViews, const float *, int, int, float *, float *, float *, float *, float *, float *,
                              float *, hipStream_t);
 int mh_launch_topk(const float *, const float *, int, int, int32_t *, float *, int, hipStream_t);
+int mh_launch_topk_work(const float *, const float *, int, int, int32_t *, float *, int, const uint8_t *, int32_t *, int, int,
+                        int, int, hipStream_t);
 int mh_launch_prep_taps(const float *, const float *, const float *, const float *, int, int, float, float4 *,
                         uint8_t *, hipStream_t);
 int mh_launch_project_taps(MhViews, const float *, int, int, float, float *, float *, float *, float *, float4 *,
@@ -371,6 +373,13 @@ extern "C" int mh_ctx_set_depth_offsets(mh_ctx *ctx, const float *offsets_host, 
     return MH_OK;
 }
 
+extern "C" int mh_upload_async(mh_ctx *ctx, const void *host, void *device, size_t bytes, void *stream) {
+    if (!ctx || (bytes && (!host || !device))) return fail(MH_ERR_ARG, "mh_upload_async: bad arguments");
+    if (!bytes) return MH_OK;
+    MH_HIP(hipMemcpyAsync(device, host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return MH_OK;
+}
+
 extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return fail(MH_ERR_ARG, "mh_ctx_set_option: bad arguments");
     if (!strcmp(key, "search_variant")) {
@@ -499,10 +508,10 @@ extern "C" int mh_forward_prepare(mh_ctx *ctx, const float *points, int N, int p
                     "mh_forward_prepare");
 }
 
-extern "C" int mh_search_prepared(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank,
-                                  int rank_step, const float *ori, const int32_t *base_idx, const float *base_val,
-                                  void *scratch, float *line_ori, float *min_loss, uint8_t *high_conf,
-                                  float *best_sample, int32_t *best_rank, int32_t *best_s, void *stream) {
+static int search_prepared(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank,
+                           int rank_step, const float *ori, const int32_t *base_idx, const float *base_val,
+                           void *scratch, float *line_ori, float *min_loss, uint8_t *high_conf,
+                           float *best_sample, int32_t *best_rank, int32_t *best_s, int variant, void *stream) {
     if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_search_prepared: views not set");
     if (!ctx->offs) return fail(MH_ERR_STATE, "mh_search_prepared: depth offsets not set");
     if (N == 0) return MH_OK;
@@ -515,9 +524,17 @@ extern "C" int mh_search_prepared(mh_ctx *ctx, const float *points, int N, int p
                                      (const float4 *)scratch,
                                      (int32_t *)((char *)scratch + search_order_offset(ctx, N, patch)),
                                      (const uint8_t *)scratch + search_count_offset(ctx, N, patch), line_ori,
-                                     min_loss, high_conf, best_sample, best_rank, best_s, ctx->search_variant,
+                                     min_loss, high_conf, best_sample, best_rank, best_s, variant,
                                      (hipStream_t)stream),
                     "mh_search_prepared");
+}
+
+extern "C" int mh_search_prepared(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank,
+                                  int rank_step, const float *ori, const int32_t *base_idx, const float *base_val,
+                                  void *scratch, float *line_ori, float *min_loss, uint8_t *high_conf,
+                                  float *best_sample, int32_t *best_rank, int32_t *best_s, void *stream) {
+    return search_prepared(ctx, points, N, patch, conf_threshold, nrank, rank_step, ori, base_idx, base_val, scratch, line_ori,
+                           min_loss, high_conf, best_sample, best_rank, best_s, ctx ? ctx->search_variant : 0, stream);
 }
 
 extern "C" int mh_forward(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank, int rank_step,
@@ -526,9 +543,23 @@ extern "C" int mh_forward(mh_ctx *ctx, const float *points, int N, int patch, fl
                           float *best_sample, int32_t *best_rank, int32_t *best_s, void *stream) {
     if (int rc = mh_forward_prepare(ctx, points, N, patch, conf_threshold, vis, ori, conf, mask, scratch, scratch_bytes, stream))
         return rc;
-    if (int rc = mh_topk_views(ctx, vis, conf, N, base_idx, base_val, stream)) return rc;
-    return mh_search_prepared(ctx, points, N, patch, conf_threshold, nrank, rank_step, ori, base_idx, base_val, scratch,
-                              line_ori, min_loss, high_conf, best_sample, best_rank, best_s, stream);
+    // with the default kernels the ranking kernel also writes the work classes of the search's launch order (it has the
+    // point's ranking in its lanes): one launch less per iteration than the three separate calls
+    const bool fuse_cls = ctx->search_variant == 0 && (ctx->topk_order & 255) == 0 && N > 1 && base_idx && base_val && vis &&
+                          conf && nrank >= 1 && rank_step >= 1 && ctx->V >= MH_TOPK && ctx->offs;
+    if (!fuse_cls) {
+        if (int rc = mh_topk_views(ctx, vis, conf, N, base_idx, base_val, stream)) return rc;
+        return mh_search_prepared(ctx, points, N, patch, conf_threshold, nrank, rank_step, ori, base_idx, base_val, scratch,
+                                  line_ori, min_loss, high_conf, best_sample, best_rank, best_s, stream);
+    }
+    int32_t *order = (int32_t *)((char *)scratch + search_order_offset(ctx, N, patch));
+    const uint8_t *cnt = (const uint8_t *)scratch + search_count_offset(ctx, N, patch);
+    if (int rc = launched(mh_launch_topk_work(vis, conf, ctx->V, N, base_idx, base_val, ctx->topk_order, cnt, order,
+                                              patch * patch + 1, nrank, rank_step, ctx->S, (hipStream_t)stream),
+                          "mh_forward (base-view ranking)"))
+        return rc;
+    return search_prepared(ctx, points, N, patch, conf_threshold, nrank, rank_step, ori, base_idx, base_val, scratch, line_ori,
+                           min_loss, high_conf, best_sample, best_rank, best_s, 8 /* ordered, classes written */, stream);
 }
 
 extern "C" int mh_refine_loss(mh_ctx *ctx, const float *points, const float *dir, float step_mul, float step_div,

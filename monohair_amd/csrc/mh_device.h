@@ -196,3 +196,19 @@ __device__ __forceinline__ void mh_casc_flush(MhCasc &c) {
     c.a1 = c.a1 + c.a0;
     c.a0 = 0.0f;
 }
+
+// Launch order of the search (pmvo_search.hip): the work class of a point, 0 = heaviest.  work = (taps of the views that see
+// the point) x (item slices its usable base-view ranks need); computed by mh_search_work_kernel, or by the base-view ranking
+// kernel of the fused forward, which has the point's ranking in its lanes anyway (MhWorkArgs.cls != nullptr).
+#define MH_ORDER_BUCKETS 1024
+struct MhWorkArgs {
+    const uint8_t *cnt;   // [V,N] tap-list lengths
+    int32_t *cls;         // [N] out: work class (nullptr: not wanted)
+    int P1, nrank, rank_step, S, T;
+};
+__device__ __forceinline__ int mh_work_class(int nt, int nvalid, int V, int P1, int S, int T) {
+    const int maxwork = V * (P1 - 1) * 4;   // taps of all views x 4 slices
+    const int work = nt * ((nvalid * S + T - 1) / T);
+    const int b = (int)(((long long)work * (MH_ORDER_BUCKETS - 1)) / (maxwork > 0 ? maxwork : 1));
+    return MH_ORDER_BUCKETS - 1 - min(max(b, 0), MH_ORDER_BUCKETS - 1);
+}

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64) void mh_topk_torch_kernel(const float *__restri
 template <int R, int W>
 __global__ __launch_bounds__(64 * W) void mh_topk_wave_kernel(const float *__restrict__ vis, const float *__restrict__ conf,
                                                             int V, int N, int32_t *__restrict__ out_idx,
-                                                            float *__restrict__ out_val) {
+                                                            float *__restrict__ out_val, MhWorkArgs wk) {
     __shared__ int s_stack[W][72];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x * W + wave;
@@ -250,11 +250,26 @@ __global__ __launch_bounds__(64 * W) void mh_topk_wave_kernel(const float *__res
         a.i[r] = v;
     }
     a.topk(V, MH_TOPK, s_stack[wave]);
+    float val = 0.0f;
     if (lane < MH_TOPK) {   // MH_TOPK <= 64: the result sits in register 0; the value is read again (keys fold NaN payloads)
         const int v = a.i[0];
         const float vb = vis[(size_t)v * N + n], c = conf[(size_t)v * N + n];
+        val = (vb < 1.0f) ? c * fmaxf(vb, 0.0f) : c;
         out_idx[(size_t)lane * N + n] = v;
-        out_val[(size_t)lane * N + n] = (vb < 1.0f) ? c * fmaxf(vb, 0.0f) : c;
+        out_val[(size_t)lane * N + n] = val;
+    }
+    if (wk.cls) {
+        // the fused forward: the work class of the point for the search's launch order (what mh_search_work_kernel computes
+        // from the same numbers -- this wave has the point's ranking in its lanes already; one launch less per iteration)
+        int nt = 0;
+        for (int v = lane; v < V; v += MH_WAVE) nt += wk.cnt[(size_t)v * N + n];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nt += __shfl_xor(nt, o);
+        const int r = lane / wk.rank_step;
+        const bool usable = lane > 0 && lane < MH_TOPK && r * wk.rank_step == lane && r < wk.nrank && val > 0.0f;
+        const unsigned long long m = __ballot(usable);
+        const int nvalid = m ? (63 - (int)__builtin_clzll(m)) / wk.rank_step + 1 : 1;   // last usable rank + 1
+        if (lane == 0) wk.cls[n] = mh_work_class(nt, nvalid, V, wk.P1, wk.S, wk.T);
     }
 }
 
@@ -894,9 +909,13 @@ extern "C" int mh_launch_project_gather(MhViews vw, const float *pts, int N, int
     return (int)hipGetLastError();
 }
 
-extern "C" int mh_launch_topk(const float *vis, const float *conf, int V, int N, int32_t *out_idx, float *out_val,
-                              int order, hipStream_t st) {
+// wk.cls != nullptr (the fused forward; wave form only): the kernel also writes the work classes of the search's launch order
+extern "C" int mh_launch_topk_work(const float *vis, const float *conf, int V, int N, int32_t *out_idx, float *out_val,
+                                   int order, const uint8_t *cnt, int32_t *cls, int P1, int nrank, int rank_step, int S,
+                                   hipStream_t st) {
     if (V > MH_TOPK_VMAX || V < MH_TOPK) return -1;
+    if (cls && ((order & 255) != 0 || !cnt || rank_step < 1)) return -1;
+    const MhWorkArgs wk{cnt, cls, P1, nrank, rank_step < 1 ? 1 : rank_step, S, 256};
     if ((order & 255) == 1) {   // value descending, view index ascending among equal values (round 1's rule; A/B)
         hipLaunchKernelGGL(mh_topk_kernel, dim3((N + 3) / 4), dim3(256), 0, st, vis, conf, V, N, out_idx, out_val);
     } else if ((order & 255) == 2) {   // torch.topk's CPU order, literal per-lane form (cross-check of the wave form)
@@ -911,9 +930,9 @@ extern "C" int mh_launch_topk(const float *vis, const float *conf, int V, int N,
         const dim3 grid((N + W - 1) / W), block(64 * W);
 #define MH_TKW(RR)                                                                                                    \
     do {                                                                                                              \
-        if (W == 4) hipLaunchKernelGGL((mh_topk_wave_kernel<RR, 4>), grid, block, 0, st, vis, conf, V, N, out_idx, out_val); \
-        else if (W == 8) hipLaunchKernelGGL((mh_topk_wave_kernel<RR, 8>), grid, block, 0, st, vis, conf, V, N, out_idx, out_val); \
-        else hipLaunchKernelGGL((mh_topk_wave_kernel<RR, 16>), grid, block, 0, st, vis, conf, V, N, out_idx, out_val); \
+        if (W == 4) hipLaunchKernelGGL((mh_topk_wave_kernel<RR, 4>), grid, block, 0, st, vis, conf, V, N, out_idx, out_val, wk); \
+        else if (W == 8) hipLaunchKernelGGL((mh_topk_wave_kernel<RR, 8>), grid, block, 0, st, vis, conf, V, N, out_idx, out_val, wk); \
+        else hipLaunchKernelGGL((mh_topk_wave_kernel<RR, 16>), grid, block, 0, st, vis, conf, V, N, out_idx, out_val, wk); \
     } while (0)
         if (V <= 64) MH_TKW(1);
         else if (V <= 128) MH_TKW(2);
@@ -923,6 +942,11 @@ extern "C" int mh_launch_topk(const float *vis, const float *conf, int V, int N,
 #undef MH_TKW
     }
     return (int)hipGetLastError();
+}
+
+extern "C" int mh_launch_topk(const float *vis, const float *conf, int V, int N, int32_t *out_idx, float *out_val,
+                              int order, hipStream_t st) {
+    return mh_launch_topk_work(vis, conf, V, N, out_idx, out_val, order, nullptr, nullptr, 0, 0, 1, 0, st);
 }
 
 extern "C" int mh_launch_prep_taps(const float *ori_patch, const float *conf_patch, const float *vis,

@@ -673,7 +673,6 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5))) void mh_
 // mh_search_order_kernel: one workgroup -- histogram of the MH_ORDER_BUCKETS classes, exclusive scan, scatter of the
 // point indices into order[N..2N).  The order inside a class is whatever the atomics give: it only decides WHEN a
 // point is processed, never what is computed for it.
-#define MH_ORDER_BUCKETS 1024
 __global__ __launch_bounds__(256) void mh_search_work_kernel(const uint8_t *__restrict__ cnt, int V, int N, int P1,
                                                              const float *__restrict__ base_val, int nrank,
                                                              int rank_step, int S, int T, int32_t *__restrict__ order) {
@@ -688,12 +687,7 @@ __global__ __launch_bounds__(256) void mh_search_work_kernel(const uint8_t *__re
     const bool usable = lane > 0 && lane < nrank && base_val[(size_t)(lane * rank_step) * N + n] > 0.0f;
     const unsigned long long m = __ballot(usable);
     const int nvalid = m ? (64 - __builtin_clzll(m)) : 1;   // last usable rank + 1
-    if (lane == 0) {
-        const int maxwork = V * (P1 - 1) * 4;   // taps of all views x 4 slices
-        const int work = nt * ((nvalid * S + T - 1) / T);
-        int b = (int)(((long long)work * (MH_ORDER_BUCKETS - 1)) / (maxwork > 0 ? maxwork : 1));
-        order[n] = MH_ORDER_BUCKETS - 1 - min(max(b, 0), MH_ORDER_BUCKETS - 1);
-    }
+    if (lane == 0) order[n] = mh_work_class(nt, nvalid, V, P1, S, T);
 }
 
 __global__ __launch_bounds__(1024) void mh_search_order_kernel(int N, int32_t *__restrict__ order) {
@@ -931,13 +925,15 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
     if (nitems > MH_MAX_ITEMS || nrank > MH_MAX_RANKS || nitems < 1) return -1;
     // variant 0 (default): mh_search3_kernel, workgroups in descending order of work; 7: the same in natural order (A/B);
     // 1256: the portable mh_search_kernel (cross-check) -- also what runs when the caller has no list lengths
+    // (8: as 0, the work classes are in order[0..N) already -- the fused forward lets the ranking kernel write them)
     if (variant == 0) variant = cnt ? 6 : 1256;
-    if (variant == 6 || variant == 7) {
+    if (variant == 6 || variant == 7 || variant == 8) {
         if (!cnt) return -1;
         const int32_t *ord = nullptr;
-        if (variant == 6 && order && N > 1) {
-            hipLaunchKernelGGL(mh_search_work_kernel, dim3((N + 3) / 4), dim3(256), 0, st, cnt, vw.V, N, P1, base_val,
-                               nrank, rank_step, S, 256, order);
+        if (variant != 7 && order && N > 1) {
+            if (variant == 6)
+                hipLaunchKernelGGL(mh_search_work_kernel, dim3((N + 3) / 4), dim3(256), 0, st, cnt, vw.V, N, P1, base_val,
+                                   nrank, rank_step, S, 256, order);
             hipLaunchKernelGGL(mh_search_order_kernel, dim3(1), dim3(1024), 0, st, N, order);
             ord = order + N;
         }

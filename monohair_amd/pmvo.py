@@ -204,7 +204,7 @@ class PMVO:
         return dev
 
     def _upload_points(self, points, stream=None):
-        """Host numpy [N,3] -> float32 device tensor through a small ring of PINNED staging buffers per launch stream and
+        """Host numpy [N,3] -> float32 device tensor through a ring of PINNED staging slots per launch stream and
         an asynchronous copy.  `tensor.to(device)` from pageable memory blocks the host for ~0.2 ms per call (staging +
         wait) -- as long as a whole iteration takes on 8-bit maps, which made the loop of `optimize` host-bound there.
         The float64 -> float32 cast happens in the copy into the staging buffer (numpy's rounding = the reference's
@@ -214,31 +214,33 @@ class PMVO:
             return torch.empty((0, 3), dtype=torch.float32, device=self.device)
         cs = torch.cuda.current_stream(self.device) if stream is None else stream
         ring = self._stage.get(cs.cuda_stream)
-        if ring is None:
-            ring = self._stage[cs.cuda_stream] = {"slots": [], "i": 0}
-        # slots are used in ring order, so only the oldest can be free (copies of one stream complete in order).  If its copy
-        # is still pending the host is running ahead of a GPU-bound loop: take one more slot (up to 32 per stream, 3 MB), and
-        # only then wait -- the host does not block in the steady state
-        slots = ring["slots"]
-        slot = slots[ring["i"] % len(slots)] if slots else None
-        if slot is not None and (slot[1] is None or slot[1].query()):
-            ring["i"] += 1
-        elif len(slots) < 32:
-            slot = [torch.empty((max(n, 8192), 3), dtype=torch.float32, pin_memory=True), None]
-            slots.insert(ring["i"] % len(slots) if slots else 0, slot)      # (in front of the oldest: ring order is kept)
-            ring["i"] += 1
-        else:
-            ring["i"] += 1
-            slot[1].synchronize()
-        if slot[0].shape[0] < n:
-            slot[0] = torch.empty((n, 3), dtype=torch.float32, pin_memory=True)
-        np.copyto(slot[0].numpy()[:n], points, casting="same_kind")
+        if ring is None or ring["cap"] < n:
+            # ONE pinned slab of 32 slots per launch stream (3 MB), allocated on the stream's first call (a ring that grew
+            # slot by slot paid a pinned allocation -- milliseconds, and it drains the device -- up to 32 times per stream
+            # during the first few hundred iterations of a loop)
+            cap = max(n, 8192)
+            slab = torch.empty((self._STAGE_SLOTS, cap, 3), dtype=torch.float32, pin_memory=True)
+            ring = self._stage[cs.cuda_stream] = {"cap": cap, "slab": slab, "np": slab.numpy(), "i": 0,
+                                                  "ptr": slab.data_ptr(), "ev": [None] * self._STAGE_SLOTS}
+        # slots are used in ring order (copies of one stream complete in order); a slot whose copy is still pending means the
+        # host is 32 iterations ahead of a GPU-bound loop: only then does it wait
+        k = ring["i"] % self._STAGE_SLOTS
+        ring["i"] += 1
+        ev = ring["ev"][k]
+        if ev is None:
+            ev = ring["ev"][k] = torch.cuda.Event()
+        elif not ev.query():
+            ev.synchronize()
+        np.copyto(ring["np"][k, :n], points, casting="same_kind")
         dev = torch.empty((n, 3), dtype=torch.float32, device=self.device)
-        dev.copy_(slot[0][:n], non_blocking=True)
-        if slot[1] is None:
-            slot[1] = torch.cuda.Event()
-        slot[1].record(cs)
+        # (not `dev.copy_(pinned, non_blocking=True)`: that also records an allocator-tracking event per call -- 70 -> 55 us of
+        # host time per forward())
+        _lib.check(self._L.mh_upload_async(self._ctx, ring["ptr"] + k * ring["cap"] * 12, dev.data_ptr(), n * 12,
+                                           cs.cuda_stream), "mh_upload_async")
+        ev.record(cs)
         return dev
+
+    _STAGE_SLOTS = 32
 
     # ------------------------------------------------------------------ reference methods
     def Compute_Visible_and_Ori(self, points):
