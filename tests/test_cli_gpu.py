@@ -53,14 +53,15 @@ def test_pmvo_cli_end_to_end(tmp_path):
     assert (out / "full" / "Ori3D.mat").exists() and (out / "full" / "coarse.npy").exists()
 
 
-@pytest.mark.parametrize("ranks,refine_shard,res", [(2, "0", 32), (2, "1", 32), (3, "1", 64)])
+@pytest.mark.parametrize("ranks,refine_shard,res", [(2, "0", 32), (2, "1", 32), (3, "1", 64), (8, "1", 64)])
 def test_two_ranks_give_the_single_rank_volume_bit_for_bit(tmp_path, ranks, refine_shard, res):
     """the path shards by points and the voxel fit by disjoint slabs + ONE exchange, so an N-rank run must
     reproduce the 1-rank outputs bit for bit.  The ranks share the single test GPU (gloo; RCCL refuses two ranks on
     one device), which exercises map_chunks, the all_gather and the volume exchange with the real kernels.
     refine_shard "1": refine's smoothing loop and shell stage sharded over the ranks as well (what the nccl backend does by
     default: every rank owns a slice of every 5000-point chunk, one in-place all_gather per chunk); 3 ranks on the larger
-    case: several chunks, slices that do not divide a chunk."""
+    case: several chunks, slices that do not divide a chunk; 8 ranks: the rank count of BASELINE.json's multi-GPU
+    configurations (more ranks than chunks in some stages, eight x-slabs of the volume)."""
     import scipy.io
 
     from monohair_amd import synth

@@ -124,7 +124,7 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
+@pytest.mark.parametrize("nranks", [2, 3, 8])
 def test_multi_rank_branches_on_one_gpu_through_the_rccl_stand_in(tmp_path, nranks):
     from conftest import fake_rccl_lib
 
