@@ -268,3 +268,32 @@ def test_topk_tie_order_is_torchs_on_adversarial_columns():
             assert np.array_equal(oi.cpu().numpy(), want_i), (V, order)
             assert np.array_equal(ov.cpu().numpy(), want_v, equal_nan=True), (V, order)
         L.mh_ctx_destroy(ctx)
+
+
+def test_upload_ring_wraps_and_changes_size_with_many_calls_in_flight():
+    """forward() uploads its host chunk through a ring of 32 pinned slots per launch stream and mh_upload_async: more calls
+    than slots without a synchronisation in between (the ring wraps while copies are in flight), chunk sizes that change from
+    call to call and one that exceeds the slab (re-allocation) must all read the right points: every result is compared with
+    the same call made on a device tensor."""
+    from monohair_amd import _lib, synth
+
+    scene, pm, views = build(24, 96, 80, 3)
+    cand = synth.candidate_points(res=32, seed=1)
+    rng = np.random.default_rng(0)
+    sizes = [int(rng.integers(1, 300)) for _ in range(80)] + [9000] + [17, 230]
+    sizes[40] = 0
+    chunks = [np.ascontiguousarray(cand[rng.choice(len(cand), n, replace=n > len(cand))]) for n in sizes]   # float64 in
+    st = pm.side_streams(2)
+    outs = []
+    for i, c in enumerate(chunks):                              # no synchronisation: 83 calls over 2 x 32 slots
+        with torch.cuda.stream(st[i % 2]):
+            outs.append(pm.forward(c)[1:])
+    torch.cuda.synchronize()
+    for c, (o, l, h) in zip(chunks, outs):
+        d = torch.from_numpy(c.astype(np.float32)).to(DEV)
+        _, o2, l2, h2 = pm.forward(d)
+        assert torch.equal(o, o2) or (torch.isnan(o) == torch.isnan(o2)).all() and torch.equal(torch.nan_to_num(o), torch.nan_to_num(o2))
+        assert np.array_equal(l.cpu().numpy(), l2.cpu().numpy(), equal_nan=True) and torch.equal(h, h2)
+    L = _lib.lib()
+    assert L.mh_upload_async(pm._ctx, None, None, 16, None) != 0 and b"mh_upload_async" in L.mh_last_error()
+    assert L.mh_upload_async(pm._ctx, None, None, 0, None) == 0
