@@ -186,22 +186,34 @@ class PMVO:
             return self._upload_points(points)
         return points.to(self.device).type(torch.float).contiguous()
 
-    def upload_all_points(self, points):
+    def upload_all_points(self, points, head=0, after_head=None):
         """One asynchronous upload of a whole [M,3] host array (float32 cast on the host, PMVO.py:40) through one pinned
-        staging buffer kept on the object; the drivers then hand device slices to forward()."""
+        staging buffer kept on the object; the drivers then hand device slices to forward().
+        head > 0: rows [0, head) are converted and copied first, `after_head(dev)` is called (the driver launches the first
+        chunks there), then the rest is converted and copied -- the host-side conversion of a large float64 array (1 ms per
+        300 k points) then runs while the GPU already works.  Returns (device tensor, float32 host view of the staged rows --
+        valid until the next call)."""
         m = int(points.shape[0])
         if m == 0:
-            return torch.empty((0, 3), dtype=torch.float32, device=self.device)
+            return torch.empty((0, 3), dtype=torch.float32, device=self.device), np.zeros((0, 3), np.float32)
         stg = getattr(self, "_stage_all", None)
         if stg is not None and stg[1] is not None:
             stg[1].synchronize()
         if stg is None or stg[0].shape[0] < m:
             stg = self._stage_all = [torch.empty((m, 3), dtype=torch.float32, pin_memory=True), torch.cuda.Event()]
-        np.copyto(stg[0].numpy()[:m], points, casting="same_kind")
+        host = stg[0].numpy()[:m]
         dev = torch.empty((m, 3), dtype=torch.float32, device=self.device)
-        dev.copy_(stg[0][:m], non_blocking=True)
-        stg[1].record(torch.cuda.current_stream(self.device))
-        return dev
+        cs = torch.cuda.current_stream(self.device)
+        head = min(max(int(head), 0), m) if after_head is not None else 0
+        for part, (lo, hi) in enumerate(((0, head), (head, m))):
+            if hi > lo:
+                np.copyto(host[lo:hi], points[lo:hi], casting="same_kind")
+                _lib.check(self._L.mh_upload_async(self._ctx, stg[0].data_ptr() + lo * 12, dev.data_ptr() + lo * 12,
+                                                   (hi - lo) * 12, cs.cuda_stream), "mh_upload_async")
+            if part == 0 and after_head is not None:
+                after_head(dev)
+        stg[1].record(cs)
+        return dev, host
 
     def _upload_points(self, points, stream=None):
         """Host numpy [N,3] -> float32 device tensor through a ring of PINNED staging slots per launch stream and
@@ -656,17 +668,11 @@ def optimize(points, pmvo, args):
     # the candidate points go to the device ONCE (3.4 MB at the headline size); a chunk is a slice of that tensor.  (One
     # pageable `.to(device)` per chunk, as the reference does it, blocks the host for ~0.2 ms each.)
     pts_np = points if isinstance(points, np.ndarray) else torch.as_tensor(points).detach().cpu().numpy()
-    dev_all = pmvo.upload_all_points(pts_np)
-    chunks = [dev_all[i * num_sub_p:(i + 1) * num_sub_p] for i in range(step)]
-    # select_p.npy is the float32 copy of the input (PMVO.py:40,575): it is written while the GPU works
+    # ONE float64 -> float32 conversion (numpy's rounding = the reference's `.type(torch.float)`, PMVO.py:40), in the pinned
+    # staging buffer: the result is both what is uploaded and select_p.npy (PMVO.py:575)
     from concurrent.futures import ThreadPoolExecutor
 
     pool = ThreadPoolExecutor(4)
-    select_points = np.ascontiguousarray(pts_np, dtype=np.float32)
-    early = None
-    if mdist.rank() == 0:
-        os.makedirs(args.save_root, exist_ok=True)
-        early = pool.submit(np.save, args.save_root + "/select_p.npy", select_points)
 
     # consecutive chunks are independent: they rotate over three HIP streams so that the tail of one chunk's search
     # kernel (workgroups of points that see many views) overlaps the front end and the head of the next chunks (two
@@ -674,30 +680,51 @@ def optimize(points, pmvo, args):
     streams = pmvo.side_streams(3)     # kept on the object: their tap-list scratch (1.2 GB each) is reused
     counter = [0]
     main = torch.cuda.current_stream()
-    M = dev_all.shape[0]
+    M = int(pts_np.shape[0])
     if mdist.world() == 1:
         # one rank: every chunk's search writes straight into its slice of three result buffers; three copies to the
         # host at the end
         o_all = torch.empty((M, 3), dtype=torch.float32, device=pmvo.device)
         l_all = torch.empty((M,), dtype=torch.float32, device=pmvo.device)
         h_all = torch.empty((M,), dtype=torch.bool, device=pmvo.device)
-    for st in streams:
-        st.wait_stream(main)          # whatever produced the maps / points (and last used the buffers) has finished
 
     def join():                        # results are read on the main stream: join the side streams first
         for st in streams:
             main.wait_stream(st)
 
-    if mdist.world() == 1:
-        for i, sub in enumerate(chunks):
-            if len(sub) == 0:
+    def launch(dev_all, lo_chunk, hi_chunk):
+        for st in streams:
+            st.wait_stream(main)      # the copy of these rows (and whatever produced the maps) has been enqueued on `main`
+        for i in range(lo_chunk, hi_chunk):
+            a, b = i * num_sub_p, min((i + 1) * num_sub_p, M)
+            if b <= a:
                 continue
-            a, b = i * num_sub_p, i * num_sub_p + len(sub)
             with torch.cuda.stream(streams[i % len(streams)]):
-                pmvo.forward(sub, out=(o_all[a:b], l_all[a:b], h_all[a:b]))
+                pmvo.forward(dev_all[a:b], out=(o_all[a:b], l_all[a:b], h_all[a:b]))
+
+    nhead = len(streams)               # chunks launched before the rest of the points is converted and copied
+    if mdist.world() == 1:
+        dev_all, select_points = pmvo.upload_all_points(pts_np, head=nhead * num_sub_p,
+                                                        after_head=lambda d: launch(d, 0, nhead))
+    else:
+        dev_all, select_points = pmvo.upload_all_points(pts_np)
+    if mdist.world() == 1:
+        launch(dev_all, nhead, step)
+    # select_p.npy is the float32 copy of the input (PMVO.py:40,575): copied out of the staging buffer (which the next call
+    # reuses) and written while the GPU works
+    select_points = select_points.copy()
+    early = None
+    if mdist.rank() == 0:
+        os.makedirs(args.save_root, exist_ok=True)
+        early = pool.submit(np.save, args.save_root + "/select_p.npy", select_points)
+    if mdist.world() == 1:
         join()
         select_ori, min_loss, high_conf_index = o_all.cpu().numpy(), l_all.cpu().numpy(), h_all.cpu().numpy()
     else:
+        for st in streams:
+            st.wait_stream(main)
+        chunks = [dev_all[i * num_sub_p:(i + 1) * num_sub_p] for i in range(step)]
+
         def work(sub):
             st = streams[counter[0] % len(streams)]
             counter[0] += 1
