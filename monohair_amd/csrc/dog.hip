@@ -57,19 +57,49 @@ __global__ __launch_bounds__(256) void mh_dog_vert_kernel(const void *__restrict
     }
     __syncthreads();
     if (x0 + lane >= W) return;
+    // a lane produces its 8 rows in two blocks of 4: the 4 outputs of a block share their inputs (per group of 4 taps: 7 + 7
+    // rows and 4 weights from LDS instead of 4 x 4 x 3 reads -- the pass is LDS-bound), each output keeps its own accumulator
+    // and runs scipy's sequence tmp = x[l]*w[r]; tmp += (x[l+j] + x[l-j]) * w[j+r], j = -r .. -1
+    const int rem = r1 & 3;
 #pragma unroll 1
-    for (int q = 0; q < MH_DG_VT_ROWS / 4; ++q) {
-        const int ry = wave * (MH_DG_VT_ROWS / 4) + q;          // row of the tile this lane produces now
+    for (int blk = 0; blk < MH_DG_VT_ROWS / 16; ++blk) {
+        const int ry = wave * (MH_DG_VT_ROWS / 4) + 4 * blk;    // first row of the block in the tile
         if (y0 + ry >= H) break;
         const double *__restrict__ c = tile + (size_t)(ry + R) * MH_DG_VT_COLS + lane;
-        double a0 = c[0] * sw[0][r0];
-        for (int j = -r0; j < 0; ++j) a0 = a0 + (c[j * MH_DG_VT_COLS] + c[-j * MH_DG_VT_COLS]) * sw[0][j + r0];
-        double a1 = c[0] * sw[1][r1];
-#pragma unroll 4
-        for (int j = -r1; j < 0; ++j) a1 = a1 + (c[j * MH_DG_VT_COLS] + c[-j * MH_DG_VT_COLS]) * sw[1][j + r1];
-        const size_t o = (size_t)(y0 + ry) * W + x0 + lane;
-        ylo[o] = a0;
-        yhi[o] = a1;
+        double a0[4], a1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double *__restrict__ cq = c + q * MH_DG_VT_COLS;
+            double t = cq[0] * sw[0][r0];
+            for (int j = -r0; j < 0; ++j) t = t + (cq[j * MH_DG_VT_COLS] + cq[-j * MH_DG_VT_COLS]) * sw[0][j + r0];
+            a0[q] = t;
+            double u = cq[0] * sw[1][r1];
+            for (int j = -r1; j < -r1 + rem; ++j) u = u + (cq[j * MH_DG_VT_COLS] + cq[-j * MH_DG_VT_COLS]) * sw[1][j + r1];
+            a1[q] = u;
+        }
+#pragma unroll 1
+        for (int j0 = -r1 + rem; j0 < 0; j0 += 4) {
+            double lo[7], hi[7], w[4];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                lo[i] = c[(j0 + i) * MH_DG_VT_COLS];            // rows l0 + j0 .. l0 + j0 + 6
+                hi[i] = c[(-j0 - 3 + i) * MH_DG_VT_COLS];       // rows l0 - j0 - 3 .. l0 - j0 + 3
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[t] = sw[1][j0 + t + r1];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a1[q] = a1[q] + (lo[q + t] + hi[q - t + 3]) * w[t];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (y0 + ry + q < H) {
+                const size_t o = (size_t)(y0 + ry + q) * W + x0 + lane;
+                ylo[o] = a0[q];
+                yhi[o] = a1[q];
+            }
+        }
     }
 }
 
