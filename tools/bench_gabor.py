@@ -17,6 +17,7 @@ ap.add_argument("--width", type=int, default=1080)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--variant", default="mfma2")
 ap.add_argument("--stage", action="store_true", help="time mh_gabor_view (uint8 image -> DoG -> bank -> codes) instead")
+ap.add_argument("--streams", type=int, default=1, help="--stage: views rotate over this many HIP streams (wall clock)")
 a = ap.parse_args()
 rng = np.random.default_rng(0)
 r, c = np.meshgrid(np.arange(a.height), np.arange(a.width), indexing="ij")
@@ -33,7 +34,20 @@ if a.stage:
     gab.view(g8)
     torch.cuda.synchronize()
     runs = []
+    sts = [torch.cuda.Stream() for _ in range(a.streams)]
+    for st in sts:
+        with torch.cuda.stream(st):
+            gab.view(g8)
+    torch.cuda.synchronize()
     for _ in range(4):
+        if a.streams > 1:           # views are independent: rotate them over the streams, wall clock around the batch
+            t0 = time.perf_counter()
+            for k in range(a.reps * 2):
+                with torch.cuda.stream(sts[k % a.streams]):
+                    gab.view(g8)
+            torch.cuda.synchronize()
+            runs.append((time.perf_counter() - t0) * 1e3 / (a.reps * 2))
+            continue
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(a.reps):
