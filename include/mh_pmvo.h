@@ -121,7 +121,9 @@ int mh_search_prepared(mh_ctx *ctx, const float *points, int N, int patch, float
                        int32_t *best_rank, int32_t *best_s, void *stream);
 /* PMVO.forward (PMVO.py:39-78) in ONE call: mh_forward_prepare + mh_topk_views + mh_search_prepared on the same stream
  * (base_idx [20,N] int32 and base_val [20,N] receive the ranking).  What monohair_amd.pmvo.PMVO.forward calls: on 8-bit
- * maps an iteration is 0.26 ms of GPU work, so every host-side call per iteration counts. */
+ * maps an iteration is 0.24 ms of GPU work, so every host-side call per iteration counts.  With the default kernels the
+ * ranking kernel also writes the work classes of the search's launch order (one launch less than the three calls; same
+ * results -- the order only decides WHEN a point is processed). */
 int mh_forward(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank, int rank_step,
                float *vis, float *ori, float *conf, float *mask, void *scratch, size_t scratch_bytes, int32_t *base_idx,
                float *base_val, float *line_ori, float *min_loss, uint8_t *high_conf, float *best_sample,
