@@ -308,7 +308,7 @@ def main():
     if not a.no_secondary and world == 1:
         if not a.quantize:
             try:
-                out["secondary_8bit_maps"] = secondary_quantized(a, dev, recs, cams, my)
+                out["secondary_8bit_maps"] = secondary_quantized(a, dev, recs, cams, my, cand)
             except Exception as e:   # a secondary number must never cost the headline line
                 out["secondary_8bit_maps"] = {"error": repr(e)[:200]}
         try:
@@ -563,7 +563,7 @@ def secondary_volume_reduce(dev, backend):
     return res
 
 
-def secondary_quantized(a, dev, recs, cams, my):
+def secondary_quantized(a, dev, recs, cams, my, cand=None):
     """The same iteration on maps that went through the reference's 8-bit file hand-off (integer degrees, conf/255 -- what
     every real capture delivers), uploaded as the pixel CODES themselves (PMVO.from_u8): the
     records are decoded on the GPU through the loaders' table, the two codes of a pixel stay resident for the tap gathers
@@ -614,6 +614,15 @@ def secondary_quantized(a, dev, recs, cams, my):
         out.update(kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=True))
     except Exception as e:
         out["roofline"] = {"error": repr(e)[:300]}
+    if cand is not None:
+        # the whole exterior pass on these maps -- what a real capture's run of PMVO.py costs after the maps are loaded
+        try:
+            fp = secondary_full_pass(dev, pm, cand, None)
+            out["full_pass"] = {k: fp[k] for k in ("value", "value_is", "steady_total_s", "filter_s", "optimize_s",
+                                                   "refine_and_volume_s", "optimize_ms_per_iteration", "surface_points",
+                                                   "iterations", "unit") if k in fp}
+        except Exception as e:
+            out["full_pass"] = {"error": repr(e)[:200]}
     return out
 
 

@@ -144,7 +144,8 @@ int mh_refine_loss_maps(mh_ctx *ctx, const float *points, const float *dir, floa
 
 /* The tail of one chunk of refine's smoothing loop (PMVO.py:91-92, 631-642), in place on slices of the global arrays:
  * update = head_filter && !head_top ? -1 : loss_u;  ori <- center where |cos(center, ori)| < replace_threshold;
- * loss_out = update == -1 ? 0.5 : update. */
+ * loss_out = update == -1 ? 0.5 : update.  ori may be NULL (loss only: the single-rank loop applies the replacement with
+ * mh_replace_dissimilar inside its dependent chain and evaluates the losses of many chunks in one launch beside it). */
 int mh_refine_combine(mh_ctx *ctx, const float *center, const float *loss_u, const unsigned char *head_filter,
                       const unsigned char *head_top, float replace_threshold, float *ori /*[N,3] in/out*/,
                       float *loss_out, int N, void *stream);

@@ -624,7 +624,7 @@ extern "C" int mh_refine_combine(mh_ctx *ctx, const float *center, const float *
                                  const uint8_t *head_top, float replace_threshold, float *ori, float *loss_out, int N,
                                  void *stream) {
     if (N == 0) return MH_OK;
-    if (!ctx || !center || !loss_u || !head_filter || !head_top || !ori || !loss_out || N < 0)
+    if (!ctx || !center || !loss_u || !head_filter || !head_top || !loss_out || N < 0)   // (ori may be NULL: loss only)
         return fail(MH_ERR_ARG, "mh_refine_combine: bad arguments");
     return launched(mh_launch_refine_combine(center, loss_u, head_filter, head_top, replace_threshold, ori, loss_out, N,
                                              (hipStream_t)stream),

@@ -891,6 +891,8 @@ __global__ __launch_bounds__(256) void mh_refine_combine_kernel(const float *__r
     if (n >= N) return;
     const bool filt = head[n] && !head_top[n];
     const float ul = filt ? -1.0f : loss_u[n];
+    loss_out[n] = (ul == -1.0f) ? 0.5f : ul;
+    if (!ori) return;   // (the replacement was applied already: mh_replace_dissimilar in the chain of the smoothing loop)
     float c[3], o[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -911,7 +913,6 @@ __global__ __launch_bounds__(256) void mh_refine_combine_kernel(const float *__r
 #pragma unroll
         for (int k = 0; k < 3; ++k) ori[3 * n + k] = c[k];
     }
-    loss_out[n] = (ul == -1.0f) ? 0.5f : ul;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -841,7 +841,45 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         head = torch.empty((sub_num,), dtype=torch.uint8, device=device)
         L, ctx, st = pmvo._L, pmvo._ctx, _lib.stream_ptr()
         off = lambda t, row, width=1: ctypes.c_void_p(t.data_ptr() + row * width * t.element_size())   # noqa: E731
-        for i in range(step):
+        if R == 1:
+            # One rank.  Only the ORIENTATIONS chain from chunk to chunk (chunk k+1's medoids read what chunk k replaced,
+            # PMVO.py:614,640): medoid -> replacement rule, 2 small launches per chunk on the main stream.  The loss of a
+            # chunk's medoid directions (PMVO.py:619-623) and the head-filter votes feed nothing in later chunks, so they
+            # run beside the chain on a second stream -- the votes of all points in one launch, the losses in groups of
+            # eight chunks as soon as their medoids exist -- and one launch writes every loss at the end.  Same kernels on
+            # the same values as the four-launches-per-chunk form the sharded path keeps (tests compare the two bit for bit).
+            main = torch.cuda.current_stream(device)
+            side = pmvo.side_streams(1)[0]
+            centers = torch.empty((n_all, 3), dtype=torch.float32, device=device)
+            loss_all = torch.empty((n_all,), dtype=torch.float32, device=device)
+            head_all = torch.empty((n_all,), dtype=torch.uint8, device=device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                st2 = _lib.stream_ptr()
+                _lib.check(L.mh_filter_points(ctx, _lib.ptr(pts_dev), n_all, pmvo._side, float(pmvo.conf_threshold),
+                                              float(pmvo.visible_threshold), None, None, None, _lib.ptr(head_all), st2),
+                           "mh_filter_points")
+            GROUP, g0 = 8, 0
+            for i in range(step):
+                lo, hi = i * sub_num, min((i + 1) * sub_num, n_all)
+                if hi > lo:
+                    _lib.check(L.mh_medoid_indexed(ctx, _lib.ptr(ori_dev), off(index_all, lo, K), hi - lo, K,
+                                                   off(centers, lo, 3), None, st), "mh_medoid_indexed")
+                    _lib.check(L.mh_replace_dissimilar(ctx, off(centers, lo, 3), off(ori_dev, lo, 3), 0.95, hi - lo, st),
+                               "mh_replace_dissimilar")
+                if ((i + 1) % GROUP == 0 or i == step - 1) and hi > g0:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    _lib.check(L.mh_refine_loss_maps(ctx, off(pts_dev, g0, 3), off(centers, g0, 3), 0.005, 4.0, hi - g0,
+                                                     pmvo._side, float(pmvo.conf_threshold), off(loss_all, g0), None, st2),
+                               "mh_refine_loss_maps")
+                    g0 = hi
+            main.wait_stream(side)
+            _lib.check(L.mh_refine_combine(ctx, _lib.ptr(centers), _lib.ptr(loss_all), _lib.ptr(head_all),
+                                           _lib.ptr(head_top_all), 0.95, None, _lib.ptr(loss_dev), n_all, st),
+                       "mh_refine_combine")
+        for i in range(step if R > 1 else 0):
             lo, hi, s_, a, b = own(i)
             if hi <= lo:
                 continue
