@@ -348,6 +348,19 @@ int mh_volume_gather(mh_ctx *ctx, void *comm, int rank, int nranks, int root, co
  * destination range.  Host pointers only; no GPU involved. */
 int mh_mat_write_sparse(const char *path, const void *prefix, size_t prefix_bytes, size_t payload_bytes,
                         const long long *elem_index, const double *values, size_t n, int threads);
+/* The same file in steps (open -> touch -> store -> close): `touch` makes the pages of the given elements resident without
+ * changing them, so a background thread can take the page faults of the zero-filled mapping (16-19 ms for the two volume files
+ * of a pass) early -- with every candidate point's voxel, a superset of what can become occupied -- while the GPU still works;
+ * `store` writes the occupied elements (later entries win).  The finished file is byte for byte what mh_mat_write_sparse and
+ * scipy's dense savemat write (PMVO.py:753-764). */
+int mh_mat_sparse_open(const char *path, const void *prefix, size_t prefix_bytes, size_t payload_bytes, void **handle);
+int mh_mat_sparse_touch(void *handle, const long long *elem_index, size_t n);
+int mh_mat_sparse_store(void *handle, const long long *elem_index, const double *values, size_t n);
+/* store from the voxel list of the fit: vox [G,3] (x,y,z) -> element y + Y*(x + X*z) (+ c*X*Y*Z for channel c of Ori);
+ * ori == NULL writes 1.0 (Occ), else ori [G,3] float32 (ori_is_f64 = 0) or float64; later rows win */
+int mh_mat_sparse_store_voxels(void *handle, const long long *vox, const void *ori, int ori_is_f64, size_t G, int X, int Y,
+                               int Z);
+int mh_mat_sparse_close(void *handle);
 
 /* Tuning knobs for A/B runs and cross-checks; every setting computes the same results (except "topk_order" 1, which
  * returns tied confidences in view order).

@@ -70,6 +70,11 @@ _SIGS = {
     "mh_render_strands_scratch_bytes": (csz, [ci, ci, ci, ci, ci]),
     "mh_render_strands": (ci, [vp, vp, vp, ci, vp, ci, vp, vp, ci, ci, ci, cf, ci, ci, ci, cf, vp, csz, vp, vp]),
     "mh_mat_write_sparse": (ci, [ctypes.c_char_p, vp, csz, csz, vp, vp, csz, ci]),
+    "mh_mat_sparse_open": (ci, [ctypes.c_char_p, vp, csz, csz, ctypes.POINTER(vp)]),
+    "mh_mat_sparse_touch": (ci, [vp, vp, csz]),
+    "mh_mat_sparse_store": (ci, [vp, vp, vp, csz]),
+    "mh_mat_sparse_store_voxels": (ci, [vp, vp, vp, ci, csz, ci, ci, ci]),
+    "mh_mat_sparse_close": (ci, [vp]),
     "mh_gabor_bank": (ci, [vp, vp, ci, ci, vp, vp, vp, vp]),
     "mh_gabor_set_bank": (ci, [vp, vp]),
     "mh_dog_scratch_bytes": (csz, [ci, ci]),

@@ -1201,3 +1201,95 @@ extern "C" int mh_mat_write_sparse(const char *path, const void *prefix, size_t 
     if (!ok) return fail(MH_ERR_STATE, "mh_mat_write_sparse: writing %s failed", path);
     return MH_OK;
 }
+
+// The same file in steps, so that the page faults of the zero-filled mapping (4 KB of page cache to clear per touched page:
+// 16-19 ms for the two volume files of a pass) can be taken by a background thread while the GPU still works:
+//   open  -> creates the file, writes the prefix, maps it;
+//   touch -> makes the pages of the given elements resident without changing their contents (reads the element and writes it
+//            back: call it BEFORE store, not beside it), each page once -- called early with a superset of the voxels that
+//            can become occupied (every candidate point's voxel);
+//   store -> the occupied elements, later entries win;   close -> unmap, close.
+struct MhMatSparse {
+    int fd;
+    char *map;
+    size_t total, prefix_bytes, nelem;
+};
+
+extern "C" int mh_mat_sparse_open(const char *path, const void *prefix, size_t prefix_bytes, size_t payload_bytes,
+                                  void **handle) {
+    if (!path || !handle || (!prefix && prefix_bytes) || (payload_bytes & 7) || (prefix_bytes & 7))
+        return fail(MH_ERR_ARG, "mh_mat_sparse_open: bad arguments");
+    *handle = nullptr;
+    const int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return fail(MH_ERR_STATE, "mh_mat_sparse_open: cannot create %s", path);
+    const size_t total = prefix_bytes + payload_bytes;
+    void *m = MAP_FAILED;
+    if ((size_t)write(fd, prefix, prefix_bytes) == prefix_bytes && ftruncate(fd, (off_t)total) == 0 && total)
+        m = mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (m == MAP_FAILED) {
+        close(fd);
+        return fail(MH_ERR_STATE, "mh_mat_sparse_open: writing %s failed", path);
+    }
+    *handle = new MhMatSparse{fd, (char *)m, total, prefix_bytes, payload_bytes / 8};
+    return MH_OK;
+}
+
+extern "C" int mh_mat_sparse_touch(void *handle, const long long *elem_index, size_t n) {
+    MhMatSparse *h = (MhMatSparse *)handle;
+    if (!h || (n && !elem_index)) return fail(MH_ERR_ARG, "mh_mat_sparse_touch: bad arguments");
+    std::vector<bool> seen((h->total >> 12) + 1, false);
+    for (size_t i = 0; i < n; ++i) {
+        if (elem_index[i] < 0 || (size_t)elem_index[i] >= h->nelem) continue;      // (a hint: out-of-range entries are skipped)
+        const size_t byte = h->prefix_bytes + (size_t)elem_index[i] * 8;
+        if (seen[byte >> 12]) continue;
+        seen[byte >> 12] = true;
+        volatile unsigned long long *q = (volatile unsigned long long *)(h->map + byte);
+        *q = *q;      // a WRITE fault (a read would map the shared zero page); the value stays -- touch precedes store
+    }
+    return MH_OK;
+}
+
+extern "C" int mh_mat_sparse_store(void *handle, const long long *elem_index, const double *values, size_t n) {
+    MhMatSparse *h = (MhMatSparse *)handle;
+    if (!h || (n && (!elem_index || !values))) return fail(MH_ERR_ARG, "mh_mat_sparse_store: bad arguments");
+    for (size_t i = 0; i < n; ++i)
+        if (elem_index[i] < 0 || (size_t)elem_index[i] >= h->nelem)
+            return fail(MH_ERR_ARG, "mh_mat_sparse_store: element %zu out of range", i);
+    char *payload = h->map + h->prefix_bytes;
+    for (size_t i = 0; i < n; ++i) memcpy(payload + (size_t)elem_index[i] * 8, &values[i], 8);
+    return MH_OK;
+}
+
+// store straight from the voxel list of the fit: vox [G,3] (x, y, z), element (y + Y*(x + X*z)) [+ c*X*Y*Z for the three
+// orientation channels of Ori]; ori == NULL writes 1.0 (Occ).  Later rows win, as the reference's fancy assignments do.
+extern "C" int mh_mat_sparse_store_voxels(void *handle, const long long *vox, const void *ori, int ori_is_f64, size_t G, int X,
+                                          int Y, int Z) {
+    MhMatSparse *h = (MhMatSparse *)handle;
+    const size_t plane = (size_t)X * Y * Z;
+    if (!h || (G && !vox) || X < 1 || Y < 1 || Z < 1 || h->nelem != plane * (ori ? 3 : 1))
+        return fail(MH_ERR_ARG, "mh_mat_sparse_store_voxels: bad arguments");
+    for (size_t g = 0; g < G; ++g)
+        if (vox[3 * g] < 0 || vox[3 * g] >= X || vox[3 * g + 1] < 0 || vox[3 * g + 1] >= Y || vox[3 * g + 2] < 0 ||
+            vox[3 * g + 2] >= Z)
+            return fail(MH_ERR_ARG, "mh_mat_sparse_store_voxels: voxel %zu outside the grid", g);
+    double *payload = (double *)(h->map + h->prefix_bytes);
+    for (size_t g = 0; g < G; ++g) {
+        const size_t lin = (size_t)vox[3 * g + 1] + (size_t)Y * ((size_t)vox[3 * g] + (size_t)X * (size_t)vox[3 * g + 2]);
+        if (!ori) {
+            payload[lin] = 1.0;
+        } else {
+            for (int c = 0; c < 3; ++c)
+                payload[lin + c * plane] = ori_is_f64 ? ((const double *)ori)[3 * g + c] : (double)((const float *)ori)[3 * g + c];
+        }
+    }
+    return MH_OK;
+}
+
+extern "C" int mh_mat_sparse_close(void *handle) {
+    MhMatSparse *h = (MhMatSparse *)handle;
+    if (!h) return MH_OK;
+    munmap(h->map, h->total);
+    close(h->fd);
+    delete h;
+    return MH_OK;
+}

@@ -788,6 +788,13 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     grid_resolution = U.GRID_RESOLUTION if grid_resolution is None else np.asarray(grid_resolution).astype(np.int32)
     is_root = mdist.rank() == 0
     grid_all = []          # the spatial index of ALL points (device k-NN), reused for the shell query below
+    # Ori3D.mat / Occ3D.mat are created NOW and their pages made resident in the background (every point that can end up in the
+    # volume is known: the surface points and the shell candidates); the occupied elements are stored at the end
+    mat_writer = None
+    if is_root and os.path.isdir(getattr(args, "save_path", "") or ""):
+        cands = [np.asarray(p_)[:, :3] for p_ in (points, filter_unvisible_points) if p_ is not None and len(p_)]
+        mat_writer = U.SparseMatWriter(args.save_path, grid_resolution, np.concatenate(cands, 0) if cands else None,
+                                       voxel_min, voxel_size)
     if not genrate_ori_only:
         print("filter nosiy points...")
         # Neighbour indices and the head-top mask depend on the points only: ONE host query for all chunks (all
@@ -1026,7 +1033,10 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
             np.save(os.path.join(args.save_path, "coarse.npy"), un_visible_points)
             np.save(os.path.join(args.save_path, "coarse_ori.npy"), unvisible_ori)
         with stage("refine: Ori3D/Occ3D.mat", device):
-            U.save_ori_occ_mat_sparse(args.save_path, grid_resolution, vox, vori)
+            if mat_writer is not None:
+                mat_writer.finish(vox, vori)
+            else:
+                U.save_ori_occ_mat_sparse(args.save_path, grid_resolution, vox, vori)
     mdist.barrier()
     if not return_dense:
         return None

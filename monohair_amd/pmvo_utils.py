@@ -526,6 +526,118 @@ def save_ori_occ_mat_sparse(path, grid_resolution, voxels, ori, threads=1):
         list(pool.map(lambda j: write(*j), jobs))
 
 
+class SparseMatWriter:
+    """Ori3D.mat / Occ3D.mat of save_ori_occ_mat_sparse written in two phases: the constructor creates and maps both files
+    and -- on a background thread per file -- makes the pages resident that the voxels of `candidate_points` fall on (every
+    point that can end up in the volume: the page faults of the zero-filled mappings, 16-19 ms per pass, are taken while the
+    GPU works on the rest of refine); finish(voxels, ori) stores the occupied elements and closes.  Same bytes as
+    save_ori_occ_mat_sparse."""
+
+    def __init__(self, path, grid_resolution, candidate_points=None, voxel_min=VOXEL_MIN, voxel_size=VOXEL_SIZE):
+        import ctypes
+        import threading
+
+        self.X, self.Y, self.Z = (int(v) for v in grid_resolution)
+        X, Y, Z = self.X, self.Y, self.Z
+        self._L = _lib.lib()
+        self._files = [None, None]
+        self._error = []          # errors of the pre-fault hint (they cost time, not correctness)
+        self._fatal = []          # errors of creating the files: re-raised by finish()
+
+        def one_file(k, fname, name, dims, lin):
+            try:
+                prefix, ndata = _mat5_prefix(name, dims)
+                h = ctypes.c_void_p()
+                # (creating the file truncates an existing one: releasing a previous run's 100-300 MB of page cache takes
+                # tens of milliseconds -- also on this thread)
+                _lib.check(self._L.mh_mat_sparse_open(os.path.join(path, fname).encode(), prefix, len(prefix), ndata,
+                                                      ctypes.byref(h)), "mh_mat_sparse_open")
+                self._files[k] = h
+            except BaseException as e:
+                self._fatal.append(e)
+                return
+            try:
+                if lin is not None and len(lin):
+                    idx = lin if k == 0 else (lin[None, :] + (Y * X * Z) * np.arange(3, dtype=np.int64)[:, None]).reshape(-1)
+                    idx = np.ascontiguousarray(idx, dtype=np.int64)
+                    self._L.mh_mat_sparse_touch(h, idx.ctypes.data_as(ctypes.c_void_p), len(idx))
+            except BaseException as e:
+                self._error.append(e)
+
+        def both():
+            lin = None
+            try:
+                if candidate_points is not None and len(candidate_points):
+                    pts = np.array(candidate_points, dtype=np.float64, copy=True)       # (p2v flips its argument in place)
+                    x, y, z = p2v(pts, np.asarray(voxel_min, dtype=np.float64), voxel_size, (X, Y, Z))
+                    lin = np.unique(y.astype(np.int64) + Y * (x.astype(np.int64) + X * z.astype(np.int64)))
+            except BaseException as e:
+                self._error.append(e)
+            t2 = threading.Thread(target=one_file, args=(1, "Ori3D.mat", "Ori", (Y, X, 3 * Z), lin))
+            t2.start()
+            one_file(0, "Occ3D.mat", "Occ", (Y, X, Z), lin)
+            t2.join()
+
+        t = threading.Thread(target=both, daemon=True)
+        t.start()
+        self._threads = [t]
+
+    def finish(self, voxels, ori):
+        import ctypes
+        import threading
+
+        for t in self._threads:
+            t.join()
+        if self._fatal:
+            self.abort()
+            raise self._fatal[0]
+        X, Y, Z = self.X, self.Y, self.Z
+        v = np.ascontiguousarray(np.asarray(voxels).reshape(-1, 3), dtype=np.int64)
+        o = np.asarray(ori).reshape(-1, 3)
+        if o.dtype != np.float32:                    # (float32 orientations convert exactly; anything else goes as float64)
+            o = o.astype(np.float64)
+        o = np.ascontiguousarray(o)
+        jobs = ((self._files[0], None), (self._files[1], o))
+
+        def store(h, val):
+            try:
+                _lib.check(self._L.mh_mat_sparse_store_voxels(
+                    h, v.ctypes.data_as(ctypes.c_void_p), None if val is None else val.ctypes.data_as(ctypes.c_void_p),
+                    int(val is not None and val.dtype == np.float64), len(v), X, Y, Z), "mh_mat_sparse_store_voxels")
+            finally:
+                self._L.mh_mat_sparse_close(h)
+
+        self._files = []
+        err = []
+
+        def guarded(j):
+            try:
+                store(*j)
+            except BaseException as e:
+                err.append(e)
+
+        t2 = threading.Thread(target=guarded, args=(jobs[1],))
+        t2.start()                                    # ctypes releases the GIL during the calls
+        guarded(jobs[0])
+        t2.join()
+        if err:
+            raise err[0]
+
+    def abort(self):
+        for t in self._threads:
+            t.join()
+        for h in self._files:
+            if h is not None:
+                self._L.mh_mat_sparse_close(h)
+        self._files = []
+
+    def __del__(self):          # refine left early (an exception): the mappings do not outlive the object
+        try:
+            self.abort()
+        except Exception:
+            pass
+
+
 def merge_inner_points(voxels, ori, coarse_data, unvisible_index, voxel_min=VOXEL_MIN, voxel_size=VOXEL_SIZE,
                        grid_resolution=GRID_RESOLUTION):
     """The infer_inner merge of refine (PMVO.py:733-751): rows of DeepMVSHair's ours/raw.npy (N x 7: xyz, orientation,

@@ -295,6 +295,37 @@ def test_sparse_mat_writer_equals_savemat(tmp_path):
     assert scipy.io.loadmat(a / "Occ3D.mat")["Occ"].sum() == 0
 
 
+def test_two_phase_mat_writer_gives_the_same_bytes(tmp_path):
+    """SparseMatWriter (files created and their pages made resident early by a background thread, occupied elements stored at
+    the end -- what refine() uses) writes byte for byte what save_ori_occ_mat_sparse writes, whether the pre-fault hint
+    covers the occupied voxels, misses them (points elsewhere / out of the grid) or is absent."""
+    from monohair_amd import pmvo_utils as U
+
+    rng = np.random.default_rng(1)
+    g = [40, 36, 28]
+    vmin, vs = np.array([-0.05, -0.045, -0.035]), 0.0025
+    pts = rng.uniform(-0.05, 0.05, size=(800, 3))
+    x, y, z = U.p2v(pts.copy(), vmin, vs, g)
+    v = np.stack([x, y, z], 1).astype(np.int64)
+    v[-7:] = v[:7]
+    o = rng.normal(size=(len(v), 3)).astype(np.float32)
+    ref = tmp_path / "ref"
+    ref.mkdir()
+    U.save_ori_occ_mat_sparse(str(ref), g, v, o)
+    far = rng.uniform(5, 6, size=(50, 3))
+    for k, hint in enumerate((pts, np.concatenate([pts[:100], far]), far, None, np.zeros((0, 3)))):
+        d = tmp_path / ("two%d" % k)
+        d.mkdir()
+        w = U.SparseMatWriter(str(d), g, hint, vmin, vs)
+        w.finish(v, o)
+        assert not w._error
+        for f in ("Ori3D.mat", "Occ3D.mat"):
+            assert open(d / f, "rb").read() == open(ref / f, "rb").read(), (k, f)
+    w = U.SparseMatWriter(str(tmp_path / "two0"), g, pts, vmin, vs)       # left early: closes without writing elements
+    w.abort()
+    assert os.path.getsize(tmp_path / "two0" / "Occ3D.mat") == os.path.getsize(ref / "Occ3D.mat")
+
+
 def test_camera_tensor_utilities_match_the_oracle():
     """Camera.projection / uv2pixel / pixel2uv / reprojection / camera2world (the reference's torch utilities,
     Camera_utils.py:38-116) on CPU tensors reproduce the oracle's restatement of the same formulas bit for bit."""
