@@ -1237,12 +1237,19 @@ extern "C" int mh_mat_sparse_open(const char *path, const void *prefix, size_t p
 extern "C" int mh_mat_sparse_touch(void *handle, const long long *elem_index, size_t n) {
     MhMatSparse *h = (MhMatSparse *)handle;
     if (!h || (n && !elem_index)) return fail(MH_ERR_ARG, "mh_mat_sparse_touch: bad arguments");
-    std::vector<bool> seen((h->total >> 12) + 1, false);
+    // pages in ASCENDING order, each once (the block allocation of a sparse file is cheaper front to back than in the order
+    // the points happen to come in: 3-5 ms instead of 6-11 for the two files of a pass)
+    const size_t npage = (h->total >> 12) + 1;
+    std::vector<bool> want(npage, false);
     for (size_t i = 0; i < n; ++i) {
         if (elem_index[i] < 0 || (size_t)elem_index[i] >= h->nelem) continue;      // (a hint: out-of-range entries are skipped)
-        const size_t byte = h->prefix_bytes + (size_t)elem_index[i] * 8;
-        if (seen[byte >> 12]) continue;
-        seen[byte >> 12] = true;
+        want[(h->prefix_bytes + (size_t)elem_index[i] * 8) >> 12] = true;
+    }
+    for (size_t pg = 0; pg < npage; ++pg) {
+        if (!want[pg]) continue;
+        size_t byte = pg << 12;
+        if (byte < h->prefix_bytes) byte = h->prefix_bytes;      // (prefix and total are multiples of 8)
+        if (byte + 8 > h->total) continue;
         volatile unsigned long long *q = (volatile unsigned long long *)(h->map + byte);
         *q = *q;      // a WRITE fault (a read would map the shared zero page); the value stays -- touch precedes store
     }
