@@ -542,6 +542,7 @@ class SparseMatWriter:
         X, Y, Z = self.X, self.Y, self.Z
         self._L = _lib.lib()
         self._files = [None, None]
+        self._names = [None, None]
         self._error = []          # errors of the pre-fault hint (they cost time, not correctness)
         self._fatal = []          # errors of creating the files: re-raised by finish()
 
@@ -551,9 +552,12 @@ class SparseMatWriter:
                 h = ctypes.c_void_p()
                 # (creating the file truncates an existing one: releasing a previous run's 100-300 MB of page cache takes
                 # tens of milliseconds -- also on this thread)
-                _lib.check(self._L.mh_mat_sparse_open(os.path.join(path, fname).encode(), prefix, len(prefix), ndata,
-                                                      ctypes.byref(h)), "mh_mat_sparse_open")
+                # under a temporary name, renamed when the elements are in: a pass that fails half-way leaves the files of
+                # an earlier run alone
+                _lib.check(self._L.mh_mat_sparse_open((os.path.join(path, fname) + self._TMP).encode(), prefix,
+                                                      len(prefix), ndata, ctypes.byref(h)), "mh_mat_sparse_open")
                 self._files[k] = h
+                self._names[k] = os.path.join(path, fname)
             except BaseException as e:
                 self._fatal.append(e)
                 return
@@ -582,6 +586,8 @@ class SparseMatWriter:
         t = threading.Thread(target=both, daemon=True)
         t.start()
         self._threads = [t]
+
+    _TMP = ".writing"
 
     def finish(self, voxels, ori):
         import ctypes
@@ -617,6 +623,7 @@ class SparseMatWriter:
                 _lib.check(self._L.mh_mat_sparse_store_voxels(
                     h, v.ctypes.data_as(ctypes.c_void_p), None if val is None else val.ctypes.data_as(ctypes.c_void_p),
                     int(val is not None and val.dtype == np.float64), len(v), X, Y, Z), "mh_mat_sparse_store_voxels")
+                os.replace(self._names[k] + self._TMP, self._names[k])
             except BaseException as e:
                 err.append(e)
             stored[k].set()
@@ -638,9 +645,13 @@ class SparseMatWriter:
     def abort(self):
         for t in self._threads:
             t.join()
-        for h in self._files:
+        for k, h in enumerate(self._files):
             if h is not None:
                 self._L.mh_mat_sparse_close(h)
+                try:
+                    os.remove(self._names[k] + self._TMP)
+                except OSError:
+                    pass
         self._files = []
 
     def __del__(self):          # refine left early (an exception): the mappings do not outlive the object

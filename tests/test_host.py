@@ -319,11 +319,13 @@ def test_two_phase_mat_writer_gives_the_same_bytes(tmp_path):
         w = U.SparseMatWriter(str(d), g, hint, vmin, vs)
         w.finish(v, o)
         assert not w._error
-        for f in ("Ori3D.mat", "Occ3D.mat"):
-            assert open(d / f, "rb").read() == open(ref / f, "rb").read(), (k, f)
-    w = U.SparseMatWriter(str(tmp_path / "two0"), g, pts, vmin, vs)       # left early: closes without writing elements
+        for f in ("Ori3D.mat", "Occ3D.mat"):       # (the first 116 bytes are the header text with the creation time)
+            assert open(d / f, "rb").read()[116:] == open(ref / f, "rb").read()[116:], (k, f)
+    w = U.SparseMatWriter(str(tmp_path / "two0"), g, pts, vmin, vs)       # left early: the files of the earlier run stay
     w.abort()
-    assert os.path.getsize(tmp_path / "two0" / "Occ3D.mat") == os.path.getsize(ref / "Occ3D.mat")
+    assert sorted(os.listdir(tmp_path / "two0")) == ["Occ3D.mat", "Ori3D.mat"]
+    for f in ("Ori3D.mat", "Occ3D.mat"):
+        assert open(tmp_path / "two0" / f, "rb").read()[116:] == open(ref / f, "rb").read()[116:]
 
 
 def test_camera_tensor_utilities_match_the_oracle():
