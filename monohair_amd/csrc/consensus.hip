@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void mh_medoid_kernel(const float *__restrict_
     __shared__ float s_bv[4];
     __shared__ int s_bi[4];
     const int g = blockIdx.x, tid = threadIdx.x;
+    const int nt = (int)blockDim.x;   // 256, or 128 for the dense groups of up to 128 members (the 100 neighbours of refine)
     const int begin = seg_start ? seg_start[g] : g * K_dense;
     const int K = seg_start ? (seg_start[g + 1] - begin) : K_dense;
     if (K <= 0 || (K >= 512) != BIG) return;   // the other launch takes this group
@@ -139,9 +140,9 @@ __global__ __launch_bounds__(256) void mh_medoid_kernel(const float *__restrict_
     float bv = 0.0f;
     int bi = 0x7fffffff;
     if (K <= MH_MEDOID_MAXK) {
-        for (int k = tid; k < K; k += 256) unit_of(k, s_u[3 * k], s_u[3 * k + 1], s_u[3 * k + 2]);
+        for (int k = tid; k < K; k += nt) unit_of(k, s_u[3 * k], s_u[3 * k + 1], s_u[3 * k + 2]);
         __syncthreads();
-        for (int k = tid; k < K; k += 256) {
+        for (int k = tid; k < K; k += nt) {
             const float a0 = s_u[3 * k], a1 = s_u[3 * k + 1], a2 = s_u[3 * k + 2];
             auto x = [&](int j) {
                 return __builtin_fabsf((a0 * s_u[3 * j] + a1 * s_u[3 * j + 1]) + a2 * s_u[3 * j + 2]);
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void mh_medoid_kernel(const float *__restrict_
         // a group that does not fit in LDS (never the case for the 2.5 mm voxels of a real capture): the units are
         // staged MH_MEDOID_MAXK (= 128 rows of 32) at a time, every lane carries the accumulators of its candidate
         if constexpr (BIG) {
-            for (int kb = 0; kb < K; kb += 256) {
+            for (int kb = 0; kb < K; kb += nt) {
                 const int k = kb + tid;
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f;
                 if (k < K) unit_of(k, a0, a1, a2);
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void mh_medoid_kernel(const float *__restrict_
                 for (int j0 = 0; j0 < K; j0 += MH_MEDOID_MAXK) {
                     const int nj = min(MH_MEDOID_MAXK, K - j0);
                     __syncthreads();
-                    for (int j = tid; j < nj; j += 256) unit_of(j0 + j, s_u[3 * j], s_u[3 * j + 1], s_u[3 * j + 2]);
+                    for (int j = tid; j < nj; j += nt) unit_of(j0 + j, s_u[3 * j], s_u[3 * j + 1], s_u[3 * j + 2]);
                     __syncthreads();
                     auto x = [&](int j) {
                         const int q = j - j0;
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void mh_medoid_kernel(const float *__restrict_
     }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < (nt >> 6); ++w)
             if (s_bi[w] != 0x7fffffff && (bi == 0x7fffffff || mh_arg_better(s_bv[w], s_bi[w], bv, bi))) {
                 bv = s_bv[w];
                 bi = s_bi[w];
@@ -268,9 +269,10 @@ extern "C" int mh_launch_replace_dissimilar(const float *center, float *ori, flo
 extern "C" int mh_launch_medoid_dense(const float *ori, const int32_t *index, int G, int K, float *out, int32_t *out_index,
                                       hipStream_t st) {
     const int kl = K < MH_MEDOID_MAXK ? K : MH_MEDOID_MAXK;
+    // (a lane owns a candidate: with 100 neighbours a 256-thread workgroup has two waves that only wait at the barriers)
     if (K < 512)
-        hipLaunchKernelGGL(mh_medoid_kernel<false>, dim3(G), dim3(256), (size_t)kl * 3 * sizeof(float), st, ori, nullptr,
-                           K, out, out_index, index);
+        hipLaunchKernelGGL(mh_medoid_kernel<false>, dim3(G), dim3(K <= 128 ? 128 : 256), (size_t)kl * 3 * sizeof(float), st,
+                           ori, nullptr, K, out, out_index, index);
     else
         hipLaunchKernelGGL(mh_medoid_kernel<true>, dim3(G), dim3(256), (size_t)kl * 3 * sizeof(float), st, ori, nullptr,
                            K, out, out_index, index);
