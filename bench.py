@@ -53,7 +53,6 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs")
     ap.add_argument("--variant", type=int, default=0)
-    ap.add_argument("--taps-tile", type=int, default=0, help="points per workgroup of the tap-preparation kernel (A/B)")
     ap.add_argument("--topk-order", type=int, default=-1, help="0 torch.topk's tie order (default), 1 index order (A/B)")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the independent iterations alternate on (as monohair_amd.pmvo.optimize does)")
@@ -159,8 +158,6 @@ def main():
                               patch_size=a.patch, visible_threshold=1, conf_threshold=a.conf_threshold, camera=cams)
     if a.variant:
         pm.set_option("search_variant", a.variant)
-    if a.taps_tile:
-        pm.set_option("taps_tile", a.taps_tile)
     if a.topk_order >= 0:
         pm.set_option("topk_order", a.topk_order)
 
@@ -221,10 +218,13 @@ def main():
     # --- timed region: exactly K steps
     barrier()
     t0 = time.perf_counter()
+    last = None
     for i in range(a.steps):
-        step(a.warmup + i)
+        last = step(a.warmup + i)       # (the outputs of the LAST timed step stay alive: cpu_baseline checks them)
     barrier()
     dt = time.perf_counter() - t0
+    last_chunk = my[(a.warmup + a.steps - 1) % len(my)]
+    timed_region_s = dt
     per_rank = [a.steps / dt]
     if dist is not None:
         # (both ends of every rank's interval are barriers, so the per-rank figures differ only by how early a rank left
@@ -247,6 +247,7 @@ def main():
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": round(ms, 4),
+        "timed_region_s": round(dt, 5),
         "per_rank_iterations_per_s": [round(v, 2) for v in per_rank],
         "higher_is_better": True,
         "scaling": "weak",
@@ -293,6 +294,10 @@ def main():
             out["secondary_full_pass"] = secondary_full_pass(dev, pm, cand, dist)
         except Exception as e:
             out["secondary_full_pass"] = {"error": repr(e)[:300]}
+        try:
+            out["secondary_gabor_sharded"] = secondary_gabor_sharded(a, dev, dist, backend)
+        except Exception as e:
+            out["secondary_gabor_sharded"] = {"error": repr(e)[:300]}
         wd.cancel()
     if rank != 0:
         if dist is not None:
@@ -323,11 +328,17 @@ def main():
             out["secondary_gabor_stage"] = secondary_gabor_stage(a, dev)
         except Exception as e:
             out["secondary_gabor_stage"] = {"error": repr(e)[:200]}
+        try:       # the N = 1 point of the view-sharded Gabor curve (the same leg runs on all ranks at N > 1)
+            out["secondary_gabor_sharded"] = secondary_gabor_sharded(a, dev, None, backend)
+        except Exception as e:
+            out["secondary_gabor_sharded"] = {"error": repr(e)[:200]}
     # last: its 128 OpenMP workers keep spinning for a while after the parallel region and would slow the host side
     # of the secondary legs
     if not a.no_cpu and world == 1:      # the CPU leg runs on rank 0 at N=1 only
         try:
-            out["cpu_baseline"] = cpu_baseline(a, scene, recs, my[0], ms)
+            out["cpu_baseline"], out["parity_check"] = cpu_baseline(a, scene, recs, last_chunk, ms, last)
+        except ParityError:
+            raise                        # the timed kernels did not produce the oracle's bits: no line at all
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)[:200]}
     em.emit(out)
@@ -431,6 +442,7 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=False):
             "kernel": "mh_search3_kernel<256>", "bound": "valu",
             "achieved": round(tf, 2), "peak": VALU_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TF, 4),
             "traffic": prof.get("traffic", {}).get(pre + "mh_search3_kernel<256>"),
+            "traffic_source": prof.get("source"), "valu_issue_source": prof.get("source"),
             "launch_ms": round(t_search, 4),
             "pair_evals_executed": int(pairs), "flop_per_pair_eval": FLOP_PER_PAIR,
             "gpair_per_s_executed": round(pairs / (t_search * 1e-3) / 1e9, 1),
@@ -448,6 +460,7 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=False):
              "achieved": round((taps_in + taps_out) / (t_taps * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round((taps_in + taps_out) / (t_taps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
              "traffic": prof.get("traffic", {}).get(pre + "mh_project_taps_kernel<%d>" % a.patch),
+             "traffic_source": prof.get("source"),
              "bytes_model": "in: 12N + V*N*20 + visible*P*%d; out: V*N*20 + V*N*16 + taps*16 + V*N" % (2 if codes else 16),
              "visible_pairs": int(nvis), "taps_written": int(taps_vis)},
             {"kernel": "mh_project_gather_kernel<%d>" % a.patch, "bound": "hbm", "launch_ms": round(t_pg, 4),
@@ -455,12 +468,17 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=False):
              "achieved": round(pg_bytes / (t_pg * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": round(pg_bytes / (t_pg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
              "traffic": prof.get("traffic", {}).get(pre + "mh_project_gather_kernel<%d>" % a.patch),
+             "traffic_source": prof.get("source"),
              "note": "the API form of Compute_Visible_and_Ori (patch tensors materialised, SURVEY.md §8d byte count); "
                      "forward() uses mh_project_taps_kernel instead; launches rotate over %d chunks" % reps},
         ],
         "kernels_ms": {"project_taps": round(t_taps, 4), "topk": round(t_topk, 4),
                        "order+search": round(t_search, 4), "project_gather_api_kernel": round(t_pg, 4)},
     }
+
+
+PROFILE_SOURCE = ("profiles/traffic.json (the builder's rocprofv3 --pmc passes of this command, committed; NOT measured in "
+                  "this run)")
 
 
 def load_profile_facts(V, H, W):
@@ -470,7 +488,8 @@ def load_profile_facts(V, H, W):
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         if not t.get("workload", "").startswith("%d views @ %dx%d" % (V, H, W)):
             return {}
-        return {"traffic": {k: v.get("traffic_bytes") for k, v in t.items() if isinstance(v, dict) and "traffic_bytes" in v},
+        return {"source": PROFILE_SOURCE,
+                "traffic": {k: v.get("traffic_bytes") for k, v in t.items() if isinstance(v, dict) and "traffic_bytes" in v},
                 "search_valu_issue": t.get("search_valu_issue"), "8bit:search_valu_issue": t.get("8bit:search_valu_issue")}
     except Exception:
         return {}
@@ -582,8 +601,6 @@ def secondary_quantized(a, dev, recs, cams, my, cand=None):
     pm = PMVO.from_u8(camd, sc["depth"], sc["ori_u8"], sc["conf_u8"], sc["mask_u8"], device=dev, image_size=[H, W],
                       patch_size=a.patch, visible_threshold=1, conf_threshold=a.conf_threshold)
     del sc
-    if a.taps_tile:
-        pm.set_option("taps_tile", a.taps_tile)
     if a.variant:
         pm.set_option("search_variant", a.variant)
     streams = pm.side_streams(max(1, a.streams))
@@ -755,7 +772,75 @@ def secondary_gabor(a, dev):
     return {"metric": "Gabor bank views/s", "value": round(1e3 / ms, 1), "unit": "views/s", "ms_per_view": round(ms, 3),
             "image": [H, W], "kernel": "mh_gabor_mfma2_kernel", "rounds_ms": [round(r, 3) for r in runs],
             "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": round(tf / 157.3, 4), "traffic": prof.get("bank_traffic_bytes")}}
+                         "frac": round(tf / 157.3, 4), "traffic": prof.get("bank_traffic_bytes"),
+                         "traffic_source": PROFILE_SOURCE if prof else None}}
+
+
+def secondary_gabor_sharded(a, dev, dist, backend):
+    """The Gabor stage as the north star shards it (GaborFilter.py:231-237 is a loop over the views): the
+    --views gray uint8 images are resident on every rank, view i is filtered by rank i % N (monohair_amd.gabor.
+    orientation_maps_device: DoG -> bank -> 8-bit codes, two HIP streams per rank), ONE all_gather of the 2 B/px code planes
+    leaves all views' codes on every rank (what PMVO.from_u8 takes).  Barrier + synchronize on both sides, max over ranks,
+    best of three rounds; the all_gather alone is timed the same way on zero planes.  Runs at every N including 1."""
+    import numpy as np
+    import torch
+
+    from monohair_amd import dist as mdist
+    from monohair_amd.gabor import calOrientationGabor, orientation_maps_device
+
+    V, H, W = a.views, a.height, a.width
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    g = torch.Generator(device="cpu").manual_seed(0)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    img = (127 + 70 * torch.cos(2 * np.pi * (0.6 * xx + 0.8 * yy) / 4.0) + 6 * torch.randn((H, W), generator=g))
+    img = img.clamp(0, 255).to(torch.uint8).to(dev)
+    views = [img.roll(7 * k, 1) for k in range(V)]
+    gab = calOrientationGabor(device=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    def over_ranks(dt):
+        if dist is None:
+            return dt
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    orientation_maps_device(views, dev, gab, return_codes=True)        # warm: streams, scratch, the collective
+    rounds = []
+    for _ in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        k8, c8 = orientation_maps_device(views, dev, gab, return_codes=True)
+        barrier()
+        rounds.append(over_ranks(time.perf_counter() - t0))
+    mine = [i for i in range(V) if mdist.owner(i) == rank]
+    local = [torch.zeros((2, H, W), dtype=torch.uint8, device=dev) for _ in mine]
+    gathers = []
+    for _ in range(3):
+        barrier()
+        t0 = time.perf_counter()
+        mdist.all_gather_views(local, V, (2, H, W), torch.uint8, dev)
+        barrier()
+        gathers.append(over_ranks(time.perf_counter() - t0))
+    dt, tg = min(rounds), min(gathers)
+    check = [int(k8.sum().item()), int(c8.sum().item())]
+    agree = True
+    if dist is not None:
+        every = [None] * world
+        dist.all_gather_object(every, check)
+        agree = all(e == every[0] for e in every)
+    return {"metric": "Gabor stage views/s, views sharded over the ranks + one all_gather of the code planes",
+            "value": round(V / dt, 1), "unit": "views/s", "n_gpus": world, "views": V, "image": [H, W],
+            "wall_ms": round(dt * 1e3, 3), "rounds_ms": [round(r * 1e3, 3) for r in rounds],
+            "all_gather_ms": round(tg * 1e3, 3), "all_gather_bytes": int(V * 2 * H * W),
+            "views_per_rank": [len([i for i in range(V) if mdist.owner(i, world) == k]) for k in range(world)],
+            "codes_checksum": check, "codes_agree_on_all_ranks": bool(agree),
+            "scaling": "strong (the view count is fixed; each rank filters ceil(V/N) views)"}
 
 
 def secondary_gabor_stage(a, dev):
@@ -823,12 +908,22 @@ def secondary_gabor_stage(a, dev):
             "codes_checksum": [int(out[3].sum().item()), int(out[4].sum().item())],
             "roofline": {"kernel": "mh_gabor_mfma2_kernel (whole stage timed)", "bound": "mfma", "achieved": round(tf, 1),
                          "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
-                         "traffic": prof.get("traffic_bytes"), "mfma_busy": prof.get("mfma_busy")}}
+                         "traffic": prof.get("traffic_bytes"), "mfma_busy": prof.get("mfma_busy"),
+                         "traffic_source": PROFILE_SOURCE if prof else None,
+                         "mfma_busy_source": PROFILE_SOURCE if prof else None}}
 
 
-def cpu_baseline(a, scene, recs, chunk, gpu_ms):
+class ParityError(AssertionError):
+    pass
+
+
+def cpu_baseline(a, scene, recs, chunk, gpu_ms, gpu_result):
     """The CPU oracle (oracle/pmvo_oracle.c, OpenMP over points) timed on this host on a bounded sample of the
-    same iteration: the first n points of the chunk against all views."""
+    same iteration: the first n points of the chunk against all views.  `chunk` is the chunk the LAST step of the timed
+    region processed and `gpu_result` what that step returned: the oracle's (orientation, loss, high-confidence flag) for the
+    sample is compared with it bit for bit -> (cpu_baseline, parity_check); a mismatch raises ParityError."""
+    import numpy as np
+
     import oracle
     from monohair_amd.pmvo import depth_offsets
 
@@ -841,9 +936,20 @@ def cpu_baseline(a, scene, recs, chunk, gpu_ms):
     t, reps = 0.0, 0
     while reps < 40 and (t < 12.0 or reps == 0):
         t0 = time.perf_counter()
-        oracle.forward(views, chunk[:n], a.patch, a.conf_threshold, offs)
+        o_res = oracle.forward(views, chunk[:n], a.patch, a.conf_threshold, offs)
         t += time.perf_counter() - t0
         reps += 1
+    _, g_ori, g_loss, g_hc = gpu_result
+    g_ori, g_loss, g_hc = g_ori[:n].cpu().numpy(), g_loss[:n].cpu().numpy(), g_hc[:n].cpu().numpy()
+    _, o_ori, o_loss, o_hc = o_res
+    exact = (np.array_equal(g_ori, o_ori, equal_nan=True) and np.array_equal(g_loss, o_loss, equal_nan=True)
+             and np.array_equal(g_hc, o_hc))
+    parity = {"points": int(n), "bit_exact": bool(exact), "finite_losses": int(np.isfinite(o_loss).sum()),
+              "what": "(orientation, loss, high-confidence flag) returned by the LAST step of the timed region == "
+                      "oracle.forward on the same chunk, compared in this run"}
+    if not exact:
+        bad = int((~((g_loss == o_loss) | (np.isnan(g_loss) & np.isnan(o_loss)))).sum())
+        raise ParityError("bench.py: the timed step's outputs differ from the CPU oracle on %d of %d points" % (bad, n))
     n_total = n * reps
     its = (n_total / float(CHUNK)) / t
     return {
@@ -855,7 +961,7 @@ def cpu_baseline(a, scene, recs, chunk, gpu_ms):
                   "OpenMP on %d threads, %.1f s of wall time; the unmodified reference (torch-CPU, 8 vCPU Xeon, "
                   "BASELINE.md §2) needs 250-500 s per iteration = 0.002-0.004 iterations/s" % (reps, n, CHUNK, a.views,
                                                                                               cores, t),
-    }
+    }, parity
 
 
 if __name__ == "__main__":

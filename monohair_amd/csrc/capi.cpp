@@ -39,6 +39,7 @@ struct mh_ctx {
     // views uploaded as 8-bit file codes keep the codes resident as well (2 B per pixel: orientation | confidence << 8) for
     // the per-iteration tap gathers of mh_forward_prepare; used when EVERY view was uploaded that way with one table
     uint16_t *oc = nullptr;           // [V][H][W]
+    bool oc_failed = false;           // the optional allocation of `oc` failed once: stay on the records
     void *code_tabs = nullptr;        // MhCodeTabs (csrc/pmvo_project.hip), derived from lut
     std::vector<unsigned char> code_view;   // per view: uploaded as codes
     float lut_host[1024];             // the table the resident records and code tables were made with
@@ -52,13 +53,13 @@ struct mh_ctx {
     }
     int S = 0;
     int search_variant = 0;
-    int topk_order = 0;       // 0: torch.topk's CPU tie order (mh_topk_wave.h); 1: value desc, view asc; 2: mh_topk_order.h
-    int taps_tile = 1;        // fp32 front end: 1 = mh_project_taps2_kernel (a wave owns 16 points; default since round 3);
-                              // 64 / 32 / 16 = points per workgroup of the first form, mh_project_taps_kernel (A/B)
+    int topk_order = 0;       // 0: torch.topk's CPU tie order (mh_topk_wave.h); 1: value desc, view asc (round 1's rule)
+    int taps_tile = 1;        // (accepted and ignored: round 3's A/B switch between forms of the fp32 front end;
+                              // mh_project_taps2_kernel is the only one left)
     int line_rule = 0;        // strand renderer: 0 GL's diamond-exit, 1 every touched diamond (SwiftShader)
     int raster_subpixel_bits = 8;   // both rasterisers: window positions snapped to 2^-bits pixel (SwiftShader: 4)
-    int gabor_variant = 3;    // 0: v_pk_fma, one pixel/lane; 1: FP32-MFMA im2col, first form; 2: v_pk_fma, split bank;
-                              // 3: FP32-MFMA im2col with re-laid-out bank and immediate-offset LDS reads (default)
+    int gabor_variant = 3;    // 3: FP32-MFMA im2col contraction (default); 0: direct v_pk_fma form (cross-check).
+                              // (1 and 2 named two forms removed in round 4.)
     MhViews views() const { return MhViews{V, H, W, rec, mask, cams}; }
 };
 
@@ -271,8 +272,12 @@ extern "C" int mh_ctx_set_view_u8(mh_ctx *ctx, int view, const float *cam_host, 
     MH_HIP(hipSetDevice(ctx->device));
     if (!ctx->lut) MH_HIP(hipMalloc(&ctx->lut, 256 * sizeof(float4)));
     if (!ctx->code_tabs) MH_HIP(hipMalloc(&ctx->code_tabs, mh_code_tabs_bytes()));
-    if (!ctx->oc) {      // (2 B per pixel next to the 20 B of records; without it the tap gathers simply use the records)
-        if (hipMalloc(&ctx->oc, (size_t)ctx->V * npix * sizeof(uint16_t)) != hipSuccess) ctx->oc = nullptr;
+    if (!ctx->oc && !ctx->oc_failed) {   // (2 B per pixel next to the 20 B of records; without it the tap gathers use the records)
+        if (hipMalloc(&ctx->oc, (size_t)ctx->V * npix * sizeof(uint16_t)) != hipSuccess) {
+            ctx->oc = nullptr;
+            ctx->oc_failed = true;       // not retried per view
+            (void)hipGetLastError();     // the fallback is intended: do not leave the error for the next launch check
+        }
     }
     // one table per context: views decoded through DIFFERENT tables cannot share the code tables of the tap gather
     if (ctx->lut_set && memcmp(ctx->lut_host, lut_host, sizeof ctx->lut_host) != 0) ctx->lut_mixed = true;
@@ -387,6 +392,7 @@ extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
         return MH_OK;
     }
     if (!strcmp(key, "topk_order")) {
+        if ((value & 255) > 1) return fail(MH_ERR_ARG, "mh_ctx_set_option: topk_order must be 0 (torch.topk's order) or 1");
         ctx->topk_order = value;
         return MH_OK;
     }
@@ -399,6 +405,7 @@ extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
         return MH_OK;
     }
     if (!strcmp(key, "gabor_variant")) {
+        if (value != 0 && value != 3) return fail(MH_ERR_ARG, "mh_ctx_set_option: gabor_variant must be 0 (valu) or 3 (mfma2)");
         ctx->gabor_variant = value;
         return MH_OK;
     }

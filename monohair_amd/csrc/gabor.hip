@@ -114,186 +114,22 @@ __global__ __launch_bounds__(256) void mh_gabor_bank_kernel(const float *__restr
 }
 
 // ---------------------------------------------------------------------------------------------
-// Split-bank variant (gabor_variant 2): the same v_pk_fma arithmetic with TWO pixels per lane and HALF of the
-// bank per wave.  Why: the coefficients reach the FMAs through SGPRs (scalar loads, out-of-order return, only
-// lgkmcnt(0) to wait on), ~96 SGPRs are all there is, and with one pixel per lane a loaded SGPR pair feeds one
-// v_pk_fma -- the ~200-cycle scalar latency is exposed twice per tap (PMC: VALU 57 % busy, profiles/
-// r01i_gabor_valu_pmc.txt).  With two pixels per lane every SGPR pair feeds two FMAs, so the same SGPR budget covers
-// twice the cycles.  A pair of waves shares 16x8 pixels: wave A owns orientations 0..95, wave B 96..179.  The
-// exact epilogue survives the split because ATen's cascade sum adds 16-row block sums in order: A carries the
-// chain over blocks 0..5, B hands over its six block sums S6..S11 (each starts from 0, as in the chain), A
-// finishes ((chain + S6) + ... + S10) and adds the trailing partial block S11 last -- the same operations in
-// the same order as mh_gabor_bank_kernel.
-// ---------------------------------------------------------------------------------------------
-template <int F0, int NF>
-__device__ __forceinline__ void mh_gabor_half(const float *__restrict__ bankT, const float *__restrict__ tile, int ty,
-                                              int tx, float (&ra)[NF], float (&rb)[NF]) {
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    v2f aa[NF / 2], ab[NF / 2];
-#pragma unroll
-    for (int k = 0; k < NF / 2; ++k) aa[k] = ab[k] = v2f{0.0f, 0.0f};
-    for (int i = 0; i < MH_GB_KS; ++i) {
-        for (int j = 0; j < MH_GB_KS; ++j) {
-            const float xa = tile[(ty + i) * MH_GB_LDW + tx + j];
-            const float xb = tile[(ty + 4 + i) * MH_GB_LDW + tx + j];
-            const v2f xa2 = v2f{xa, xa}, xb2 = v2f{xb, xb};
-            const v2f *__restrict__ wt =
-                reinterpret_cast<const v2f *>(bankT + (i * MH_GB_KS + j) * MH_GB_KPAD + F0);
-#pragma unroll
-            for (int k = 0; k < NF / 2; ++k) {
-                aa[k] = __builtin_elementwise_fma(xa2, wt[k], aa[k]);
-                ab[k] = __builtin_elementwise_fma(xb2, wt[k], ab[k]);
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NF / 2; ++k) {
-        ra[2 * k] = __builtin_fabsf(aa[k].x);
-        ra[2 * k + 1] = __builtin_fabsf(aa[k].y);
-        rb[2 * k] = __builtin_fabsf(ab[k].x);
-        rb[2 * k + 1] = __builtin_fabsf(ab[k].y);
-    }
-}
-
-template <int F0, int NF>
-__device__ __forceinline__ void mh_gabor_argmax(const float (&r)[NF], float &M, int &b) {
-    M = r[0];
-    b = F0;
-#pragma unroll
-    for (int k = 1; k < NF; ++k)
-        if (r[k] > M) {
-            M = r[k];
-            b = F0 + k;
-        }
-}
-
-__device__ __forceinline__ float mh_gabor_term(float bh, int k, float r, float M) {
-    const float PI_F = 3.14159265358979323846f;
-    const float t1 = bh - mh_theta((float)k);
-    const float d = fminf(__builtin_fabsf(t1), fminf(__builtin_fabsf(t1 - PI_F), __builtin_fabsf(t1 + PI_F)));
-    const float rd = r - M;
-    return (d * rd) * rd;
-}
-
-#define MH_GS_SPLIT 96   // a multiple of the 16-row cascade block
-
-__global__ __launch_bounds__(256) void mh_gabor_split_kernel(const float *__restrict__ bankT,
-                                                             const float *__restrict__ img, int H, int W,
-                                                             int32_t *__restrict__ orient,
-                                                             float *__restrict__ var_out,
-                                                             unsigned int *__restrict__ maxbits) {
-    __shared__ float tile[MH_GB_LDW * MH_GB_LDW];
-    __shared__ float s_M[2][2][2][64];     // [pixel group][role][pixel a/b][lane]
-    __shared__ int s_b[2][2][2][64];
-    __shared__ float s_S[2][2][6][64];     // [pixel group][pixel a/b][block 6..11][lane]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int grp = wave >> 1, role = wave & 1;
-    const int ty = grp * 8 + (lane >> 4), tx = lane & 15;
-    const int y0 = blockIdx.y * MH_GB_TILE, x0 = blockIdx.x * MH_GB_TILE;
-    for (int q = tid; q < MH_GB_LDW * MH_GB_LDW; q += 256) {
-        const int ly = q / MH_GB_LDW, lx = q - ly * MH_GB_LDW;
-        const int gy = y0 + ly - 8, gx = x0 + lx - 8;
-        tile[q] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : 0.0f;
-    }
-    __syncthreads();
-    constexpr int NA = MH_GS_SPLIT, NB = MH_GB_NK - MH_GS_SPLIT;
-    float vmax = 0.0f;
-    if (role == 0) {
-        float ra[NA], rb[NA];
-        mh_gabor_half<0, NA>(bankT, tile, ty, tx, ra, rb);
-        float Ma, Mb;
-        int ba, bb;
-        mh_gabor_argmax<0, NA>(ra, Ma, ba);
-        mh_gabor_argmax<0, NA>(rb, Mb, bb);
-        s_M[grp][0][0][lane] = Ma, s_b[grp][0][0][lane] = ba;
-        s_M[grp][0][1][lane] = Mb, s_b[grp][0][1][lane] = bb;
-        __syncthreads();
-        // first maximum over all 180: the upper half only wins with a strictly larger response
-        const float Ua = s_M[grp][1][0][lane], Ub = s_M[grp][1][1][lane];
-        if (Ua > Ma) Ma = Ua, ba = s_b[grp][1][0][lane];
-        if (Ub > Mb) Mb = Ub, bb = s_b[grp][1][1][lane];
-        const float bha = mh_theta((float)ba), bhb = mh_theta((float)bb);
-        MhCasc ca = {0.f, 0.f}, cb = {0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < NA; ++k) {
-            if (k > 0 && (k & 15) == 0) {
-                mh_casc_flush(ca);
-                mh_casc_flush(cb);
-            }
-            ca.a0 = ca.a0 + mh_gabor_term(bha, k, ra[k], Ma);
-            cb.a0 = cb.a0 + mh_gabor_term(bhb, k, rb[k], Mb);
-        }
-        mh_casc_flush(ca);   // k == 96 is a block boundary
-        mh_casc_flush(cb);
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {   // S6..S10: flushed blocks, in order
-            ca.a1 = ca.a1 + s_S[grp][0][q][lane];
-            cb.a1 = cb.a1 + s_S[grp][1][q][lane];
-        }
-        const float va = __builtin_sqrtf(s_S[grp][0][5][lane] + ca.a1);   // a0 (= S11) + a1
-        const float vb = __builtin_sqrtf(s_S[grp][1][5][lane] + cb.a1);
-        const int x = x0 + tx, ya = y0 + ty, yb = y0 + ty + 4;
-        if (x < W && ya < H) {
-            var_out[(size_t)ya * W + x] = va;
-            orient[(size_t)ya * W + x] = (va > 0.0f) ? ba : 0;
-            vmax = va;
-        }
-        if (x < W && yb < H) {
-            var_out[(size_t)yb * W + x] = vb;
-            orient[(size_t)yb * W + x] = (vb > 0.0f) ? bb : 0;
-            vmax = fmaxf(vmax, vb);
-        }
-    } else {
-        float ra[NB], rb[NB];
-        mh_gabor_half<NA, NB>(bankT, tile, ty, tx, ra, rb);
-        float Ma, Mb;
-        int ba, bb;
-        mh_gabor_argmax<NA, NB>(ra, Ma, ba);
-        mh_gabor_argmax<NA, NB>(rb, Mb, bb);
-        s_M[grp][1][0][lane] = Ma, s_b[grp][1][0][lane] = ba;
-        s_M[grp][1][1][lane] = Mb, s_b[grp][1][1][lane] = bb;
-        __syncthreads();
-        const float La = s_M[grp][0][0][lane], Lb = s_M[grp][0][1][lane];
-        if (!(Ma > La)) Ma = La, ba = s_b[grp][0][0][lane];
-        if (!(Mb > Lb)) Mb = Lb, bb = s_b[grp][0][1][lane];
-        const float bha = mh_theta((float)ba), bhb = mh_theta((float)bb);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            float sa = 0.0f, sb = 0.0f;
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int k = NA + q * 16 + u;
-                if (k < MH_GB_NK) {
-                    sa = sa + mh_gabor_term(bha, k, ra[k - NA], Ma);
-                    sb = sb + mh_gabor_term(bhb, k, rb[k - NA], Mb);
-                }
-            }
-            s_S[grp][0][q][lane] = sa;
-            s_S[grp][1][q][lane] = sb;
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if (lane == 0 && role == 0) atomicMax(maxbits, __float_as_uint(vmax));
-}
-
-// ---------------------------------------------------------------------------------------------
-// FP32-MFMA variant (the default): the bank as an im2col contraction  C[pixel, k] = sum_t A[pixel, t] * B[t, k]
-// (pixels x 289 taps x 180 orientations) on v_mfma_f32_32x32x2_f32.  The MFMA result is bit for bit a
-// k-ordered fp32 fma chain, i.e. exactly the tap-ordered chain of the VALU kernels above, so all variants (and
-// the CPU oracle) produce identical maps.  The coefficient matrix lives in VGPRs distributed over the lanes -- no
-// broadcast through SGPRs, which is what holds the v_pk_fma kernels at ~58 %.
-//   workgroup = 4 waves = 8 image rows x 32 columns; wave w owns rows 2w, 2w+1 (two 32-pixel M-tiles) and all
-//   six 32-wide orientation N-tiles: 12 accumulators x 16 registers, 2 waves per SIMD.  Per K-step (2 taps): the
-//   A fragments are one ds_read each from the LDS image tile (lane l: pixel l&31, tap 2s + (l>>5)), the B
-//   fragments are six coalesced 256-B global reads of the tap-major bank, both requested one step ahead; 12 MFMAs
-//   (768 cycles).  Epilogue: one N-tile at a time goes through an 8 KB LDS staging area so that lane L owns pixel
-//   L&31 of M-tile L>>5 and walks the 180 values in index order (first-max argmax, then the cascade-ordered
-//   variance) exactly like the VALU kernels.  Measured 2.11 ms per 1080p view = 65 % of the fp32 matrix peak
-//   (MFMA pipe busy 69 % of the kernel, the epilogue is ~15 %); the first version of this kernel (one workgroup per
-//   CU because of a 100 KB response exchange, half-idle epilogue) took 3.04 ms.
+// mh_gabor_mfma2_kernel (the shipped form): the bank as an im2col contraction  C[pixel, k] = sum_t A[pixel, t] * B[t, k]
+// (pixels x 289 taps x 180 orientations) on v_mfma_f32_32x32x2_f32.  The MFMA result is bit for bit a k-ordered fp32 fma
+// chain, i.e. exactly the tap-ordered chain of the VALU kernel above (kept as the cross-check), so both kernels and the CPU
+// oracle produce identical maps.  The coefficient matrix lives in VGPRs distributed over the lanes -- no broadcast through
+// SGPRs, which is what holds the v_pk_fma kernel at ~58 %.
+//   workgroup = 4 waves = 8 image rows x 32 columns; wave w owns rows 2w, 2w+1 (two 32-pixel M-tiles) and all six 32-wide
+//   orientation N-tiles: 12 accumulators x 16 registers, 2 waves per SIMD.  Per K-step (2 taps): the A fragments are one
+//   ds_read each from the LDS image tile (lane l: pixel l&31, tap 2s + (l>>5)), the B fragments two dwordx4 loads of the
+//   re-laid-out bank, both requested one step ahead; 12 MFMAs (768 cycles).
+//   * the bank is re-laid out once per installation as bankQ[step][lane][8]: the six coefficients a lane needs for one K-step
+//     are 32 contiguous bytes (coalesced 2 KB per wave);
+//   * the K loop runs in blocks of 17 steps (34 taps = two rows of the 17 x 17 window), fully unrolled, so that every LDS
+//     read is `base register + immediate`: lanes 32-63 (tap 2s+1) keep a second base for the one step per block whose
+//     odd tap wraps to the next window row.  No address arithmetic is left in the loop.
+// (The first MFMA form -- six dword bank loads and computed LDS addresses per step, 2.11 ms per 1080p view -- and the
+// two-pixels-per-lane "split" VALU form were removed in round 4; docs/HISTORY.md has their measurements.)
 // ---------------------------------------------------------------------------------------------
 #define MH_GM_ROWS 8
 #define MH_GM_COLS 32
@@ -303,146 +139,6 @@ __global__ __launch_bounds__(256) void mh_gabor_split_kernel(const float *__rest
 
 typedef float mh_f32x16 __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(256, 2) void mh_gabor_mfma_kernel(const float *__restrict__ bankT,
-                                                               const float *__restrict__ img, int H, int W,
-                                                               int32_t *__restrict__ orient,
-                                                               float *__restrict__ var_out,
-                                                               unsigned int *__restrict__ maxbits) {
-    __shared__ float tile[MH_GM_LDH * MH_GM_LDW];              // [25][48]
-    __shared__ float stage[4][2 * 32 * MH_GM_RS];              // per wave: [M-tile][orientation of the N-tile][33]
-    __shared__ float s_theta[MH_GB_KPAD];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int y0 = blockIdx.y * MH_GM_ROWS, x0 = blockIdx.x * MH_GM_COLS;
-    for (int q = tid; q < MH_GM_LDH * MH_GM_LDW; q += 256) {
-        const int ly = q / MH_GM_LDW, lx = q - ly * MH_GM_LDW;
-        const int gy = y0 + ly - 8, gx = x0 + lx - 8;
-        tile[q] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(size_t)gy * W + gx] : 0.0f;
-    }
-    if (tid < MH_GB_KPAD) s_theta[tid] = mh_theta((float)tid);
-    __syncthreads();
-
-    mh_f32x16 acc[2][6];
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int n = 0; n < 6; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[p][n][r] = 0.0f;
-
-    const int pix = lane & 31, kk = lane >> 5;
-    int ti = 0, tj = kk;                                       // tap of this lane in step 0: t = kk
-    const float *__restrict__ brow = bankT + (size_t)kk * MH_GB_KPAD + pix;
-    float bcur[6], bnxt[6];
-#pragma unroll
-    for (int n = 0; n < 6; ++n) bcur[n] = brow[n * 32];
-    float a0 = tile[(2 * wave + ti) * MH_GM_LDW + pix + tj];
-    float a1 = tile[(2 * wave + 1 + ti) * MH_GM_LDW + pix + tj];
-    constexpr int NSTEP = (MH_GB_NT + 1) / 2;                  // 145; tap 289 is a zero row of the bank
-    for (int s = 0; s < NSTEP; ++s) {
-        // operands of the next K-step (bank fragments from global memory, pixel fragments from LDS) are requested
-        // before this step's 12 MFMAs are issued
-        const float *__restrict__ bn = brow + (size_t)(2 * (s + 1 < NSTEP ? s + 1 : s)) * MH_GB_KPAD;
-#pragma unroll
-        for (int n = 0; n < 6; ++n) bnxt[n] = bn[n * 32];
-        tj += 2;
-        if (tj >= MH_GB_KS) {
-            tj -= MH_GB_KS;
-            ++ti;
-        }
-        const float a0n = tile[(2 * wave + ti) * MH_GM_LDW + pix + tj];     // (the spare tile row keeps this in bounds)
-        const float a1n = tile[(2 * wave + 1 + ti) * MH_GM_LDW + pix + tj];
-        __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the MFMAs (the scheduler sinks them otherwise)
-#pragma unroll
-        for (int n = 0; n < 6; ++n) {
-            acc[0][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bcur[n], acc[0][n], 0, 0, 0);
-            acc[1][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bcur[n], acc[1][n], 0, 0, 0);
-        }
-#pragma unroll
-        for (int n = 0; n < 6; ++n) bcur[n] = bnxt[n];
-        a0 = a0n;
-        a1 = a1n;
-    }
-
-    // Epilogue.  C layout of the 32x32 MFMA: column (orientation) = lane & 31, row (pixel) = (r&3) + 8*(r>>2) +
-    // 4*(lane>>5).  One N-tile (32 orientations x 2 x 32 pixels) at a time is transposed through LDS so that lane L
-    // owns pixel L&31 of M-tile L>>5 and walks the orientations in index order: pass 1 first-maximum argmax, pass 2
-    // the cascade-ordered variance -- the same operations in the same order as the VALU kernels.
-    // the epilogue is a chain of dependent LDS round trips and VALU: it gets issue priority over the co-resident wave,
-    // whose MFMAs keep the matrix pipe full whichever wave the arbiter picks
-    __builtin_amdgcn_s_setprio(1);
-    float *__restrict__ st = stage[wave];
-    const int mt = lane >> 5;
-    const float PI_F = 3.14159265358979323846f;
-    float M = 0.0f, bh = 0.0f;
-    int b = 0;
-    MhCasc sc = {0.f, 0.f};
-#pragma unroll 1
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1) bh = s_theta[b];
-#pragma unroll
-        for (int n = 0; n < 6; ++n) {
-            __builtin_amdgcn_sched_barrier(0);   // one N-tile at a time: do not hoist the 192 |acc| of all tiles
-#pragma unroll
-            for (int p = 0; p < 2; ++p)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
-                    st[(p * 32 + pix) * MH_GM_RS + row] = __builtin_fabsf(acc[p][n][r]);
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const int kmax = (n == 5) ? MH_GB_NK - 160 : 32;
-            if (pass == 0) {
-#pragma unroll
-                for (int kl = 0; kl < kmax; ++kl) {
-                    const float r = st[(mt * 32 + kl) * MH_GM_RS + pix];
-                    if ((n | kl) == 0) {
-                        M = r;
-                    } else if (r > M) {
-                        M = r;
-                        b = n * 32 + kl;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int kl = 0; kl < kmax; ++kl) {
-                    if (kl == 16 || (kl == 0 && n > 0)) mh_casc_flush(sc);
-                    const float t1 = bh - s_theta[n * 32 + kl];
-                    const float d =
-                        fminf(__builtin_fabsf(t1), fminf(__builtin_fabsf(t1 - PI_F), __builtin_fabsf(t1 + PI_F)));
-                    const float rd = st[(mt * 32 + kl) * MH_GM_RS + pix] - M;
-                    sc.a0 = sc.a0 + (d * rd) * rd;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    const float var = __builtin_sqrtf(sc.a0 + sc.a1);
-    const int y = y0 + 2 * wave + mt, x = x0 + pix;
-    float vmax = 0.0f;
-    if (y < H && x < W) {
-        var_out[(size_t)y * W + x] = var;
-        orient[(size_t)y * W + x] = (var > 0.0f) ? b : 0;
-        vmax = var;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if (lane == 0) atomicMax(maxbits, __float_as_uint(vmax));
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// mh_gabor_mfma2_kernel (the default since round 3): the same contraction, same K order, same epilogue -- bit-identical
-// maps -- with the operand traffic of the main loop cut down.  Experiments on the first form (tools/ubench: loads removed
-// one kind at a time) showed the 12 MFMAs of a K-step waiting on its own operand plumbing: the six 4-byte bank loads cost
-// 7 %, the two LDS reads with their ~20 VALU of address arithmetic 5 %.  Here
-//   * the bank is re-laid out once per installation as bankQ[step][lane][8]: the six coefficients a lane needs for one K-step
-//     are 32 contiguous bytes -> two dwordx4 loads instead of six dword loads (coalesced 2 KB per wave);
-//   * the K loop runs in blocks of 17 steps (34 taps = two rows of the 17 x 17 window), fully unrolled, so that every LDS
-//     read is `base register + immediate`: lanes 32-63 (tap 2s+1) keep a second base for the one step per block whose
-//     odd tap wraps to the next window row.  No address arithmetic is left in the loop.
-// ---------------------------------------------------------------------------------------------
 #define MH_GM_NSTEP ((MH_GB_NT + 1) / 2)     // 145 K-steps; tap 289 is the zero row
 
 // bankT [290][192] -> bankQ [145][64][8]: lane (c = lane & 31, kk = lane >> 5) of step s holds bankT[2s+kk][n*32 + c], n = 0..5
@@ -666,18 +362,12 @@ extern "C" int mh_launch_gabor_bank(const float *bankT, const float *bankQ, cons
                                     float *conf, float *var, unsigned int *maxbits, int variant, uint8_t *k8, uint8_t *c8,
                                     hipStream_t st) {
     (void)hipMemsetAsync(maxbits, 0, sizeof(unsigned int), st);
-    if (variant == 2) {
-        const dim3 grid((W + MH_GB_TILE - 1) / MH_GB_TILE, (H + MH_GB_TILE - 1) / MH_GB_TILE);
-        hipLaunchKernelGGL(mh_gabor_split_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);
-    } else if (variant == 3) {
-        const dim3 grid((W + MH_GM_COLS - 1) / MH_GM_COLS, (H + MH_GM_ROWS - 1) / MH_GM_ROWS);
-        hipLaunchKernelGGL(mh_gabor_mfma2_kernel, grid, dim3(256), 0, st, bankQ, img, H, W, orient, var, maxbits);
-    } else if (variant == 1) {
-        const dim3 grid((W + MH_GM_COLS - 1) / MH_GM_COLS, (H + MH_GM_ROWS - 1) / MH_GM_ROWS);
-        hipLaunchKernelGGL(mh_gabor_mfma_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);
-    } else {
+    if (variant == 0) {            // the direct v_pk_fma form (cross-check)
         const dim3 grid((W + MH_GB_TILE - 1) / MH_GB_TILE, (H + MH_GB_TILE - 1) / MH_GB_TILE);
         hipLaunchKernelGGL(mh_gabor_bank_kernel, grid, dim3(256), 0, st, bankT, img, H, W, orient, var, maxbits);
+    } else {                       // 3: the FP32-MFMA contraction (shipped default)
+        const dim3 grid((W + MH_GM_COLS - 1) / MH_GM_COLS, (H + MH_GM_ROWS - 1) / MH_GM_ROWS);
+        hipLaunchKernelGGL(mh_gabor_mfma2_kernel, grid, dim3(256), 0, st, bankQ, img, H, W, orient, var, maxbits);
     }
     const size_t npix = (size_t)H * W;
     const int blocks = (int)((npix + 255) / 256 < 2048 ? (npix + 255) / 256 : 2048);

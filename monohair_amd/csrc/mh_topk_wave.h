@@ -1,5 +1,17 @@
-// mh_topk_wave.h -- mh_topk_order.h once more, for ONE WAVE per column: the same libstdc++ selection / sort steps in the
-// same order (so equal values end up in torch.topk's CPU order), but the array lives in the registers of a wave
+// mh_topk_wave.h -- the order in which torch.topk (CPU) returns tied values, for ONE WAVE per column.
+//
+// PMVO.Find_max_conf_from_visible_view (PMVO.py:339-343) calls torch.topk(k=20, dim=0) on a [V,N] tensor.  ATen's CPU
+// kernel (aten/src/ATen/native/cpu/SortingKernel.cpp -> TopKImpl.h: topk_impl_loop) fills a vector of (value, index)
+// pairs per column and, for k*64 > V, runs   std::nth_element(begin, begin+k-1, end, gt)   followed by
+// std::sort(begin, begin+k-1, gt),   with gt(x, y) = (isnan(x) && !isnan(y)) || x > y  on the values only.  Neither
+// algorithm is stable, so which of several equal values comes first is decided by libstdc++'s introselect / introsort
+// (median-of-three pivot, Hoare partition, insertion sort below 4 resp. 16 elements, heap fall-back when the depth
+// limit 2*floor(log2(n)) is used up).  Real captures reach PMVO through 8-bit confidence maps that saturate at 1.0, so
+// such ties are the rule, and the choice of base views decides which candidates the search tries.  oracle/topk_oracle.cpp
+// calls the real std:: functions, and the tests demand identical index arrays (tie-heavy random columns, adversarial
+// columns that exhaust the depth limit, the reference's own rankings in tests/golden/).
+//
+// This header runs the same libstdc++ selection / sort steps in the same order, but the array lives in the registers of a wave
 // (element e = 64 r + lane in register r of lane e & 63) and every step that the library spells as a scan or a shift is
 // one or two wave operations:
 //   * "while (gt(a[lo], pivot)) ++lo" / "while (gt(pivot, a[hi])) --hi"  -> a ballot of the predicate over the whole
@@ -12,8 +24,18 @@
 // All control flow is wave-uniform (the scalar unit branches), nothing diverges, and a column of 60 values costs
 // ~1.5 k wave-instructions instead of ~60 k when 64 columns share a wave, each on its own branch.
 // R = registers per lane = ceil(V / 64).
+// (A literal one-lane-per-column restatement of the library code, mh_topk_order.h, was the first form and the cross-check
+// until round 4; the oracle is the cross-check now.)
 #pragma once
-#include "mh_topk_order.h"
+
+__device__ static inline int mh_tk_lg(int n) {   // floor(log2(n)), n >= 1
+    int k = 0;
+    while (n > 1) {
+        n >>= 1;
+        ++k;
+    }
+    return k;
+}
 
 __device__ __forceinline__ int mh_tk_key(float x) {
     if (x != x) return 0x7fffffff;

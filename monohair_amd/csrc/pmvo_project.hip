@@ -200,30 +200,7 @@ __global__ __launch_bounds__(256) void mh_topk_kernel(const float *__restrict__ 
     }
 }
 
-// The same ranking in torch.topk's CPU tie order, literal form (mh_topk_order.h): one lane per point runs the library's
-// selection and sort on its own V (value, view) pairs in LDS.  Sequential and divergent (~130 us for 5000 x 60); kept as
-// the cross-check of the wave form below (order = 2).
 #include "mh_topk_wave.h"
-__global__ __launch_bounds__(64) void mh_topk_torch_kernel(const float *__restrict__ vis, const float *__restrict__ conf,
-                                                           int V, int N, int T, int32_t *__restrict__ out_idx,
-                                                           float *__restrict__ out_val) {
-    extern __shared__ __attribute__((aligned(8))) unsigned char s_raw[];
-    const int t = threadIdx.x;
-    const int n = blockIdx.x * T + t;
-    if (t >= T || n >= N) return;
-    MhTkE *a = reinterpret_cast<MhTkE *>(s_raw) + (size_t)t * V;
-    for (int v = 0; v < V; ++v) {
-        const float vb = vis[(size_t)v * N + n], c = conf[(size_t)v * N + n];
-        a[v].v = (vb < 1.0f) ? c * fmaxf(vb, 0.0f) : c;
-        a[v].i = v;
-    }
-    mh_tk_topk(a, V, MH_TOPK);
-    for (int r = 0; r < MH_TOPK; ++r) {
-        out_idx[(size_t)r * N + n] = a[r].i;
-        out_val[(size_t)r * N + n] = a[r].v;
-    }
-}
-
 // torch.topk's CPU order, one WAVE per point (mh_topk_wave.h): the same steps, each scan / shift of the library one wave
 // operation.  The W waves of a workgroup take W consecutive points (their strided column reads share 64-byte sectors);
 // small workgroups spread the 5000 waves evenly over the SIMDs, which matters more: 33 us at W = 4, 41 us at W = 16
@@ -369,160 +346,16 @@ __global__ __launch_bounds__(256) void mh_prep_taps_kernel(const float *__restri
 // straight from the packed maps -- the [V,N,P,..] patch tensors are never written or re-read, and for the
 // (view, point) pairs whose depth test fails (weight 0 in the loss, ~2/3 of them on a closed surface) the
 // patch is not even gathered.  Same arithmetic, same eligibility / duplicate rules and same record layout as
-// mh_project_gather_kernel + mh_prep_taps_kernel.
+// mh_project_gather_kernel + mh_prep_taps_kernel (the unfused pair, kept as the cross-check).  Two kernels:
+// mh_project_taps_codes_kernel for maps uploaded as 8-bit file codes, mh_project_taps2_kernel for fp32 records.
+// One workgroup = one view x 64 consecutive points (the tiling and XCD mapping of mh_project_gather_kernel).
+// (The first fused form -- lane = point for the whole tile, three dependent round trips per wave -- was removed in
+// round 4; docs/HISTORY.md has its measurements.)
 // ---------------------------------------------------------------------------------------------
-template <int PATCH, int TILE>
-__global__ __launch_bounds__(256) void mh_project_taps_kernel(MhViews vw, const float *__restrict__ pts, int N,
-                                                              int tiles, float thr, float *__restrict__ vis,
-                                                              float *__restrict__ ori, float *__restrict__ conf,
-                                                              float *__restrict__ mask, float4 *__restrict__ taps,
-                                                              uint8_t *__restrict__ cnt) {
-    // One workgroup = one view x 64 consecutive points (the tiling and XCD mapping of mh_project_gather_kernel).
-    //   phase 1: 64 lanes project their point, fetch the centre record, decide visibility, write the per-(v,n)
-    //            outputs coalesced and the header of points that fail the depth test;
-    //   phase 2: the 4 waves share the VISIBLE points of the tile; per point, lane = tap: gather, normalise,
-    //            eligibility, duplicate removal (hash table in LDS), order-preserving compaction, list + header.
-    //            The gather of the wave's next point is issued before the current one is processed.
-    constexpr int P = PATCH * PATCH, HP = PATCH / 2;
-    __shared__ int s_r[TILE], s_cc[TILE];
-    __shared__ float s_vis[TILE], s_rowf[TILE], s_colf[TILE];
-    __shared__ float2 s_o[4][MH_PREP_PMAX];
-    __shared__ float s_c[4][MH_PREP_PMAX];
-    __shared__ unsigned char s_el[4][MH_PREP_PMAX];
-    __shared__ unsigned int s_first[4][256];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous view ranges
-    const int V = vw.V, H = vw.H, W = vw.W;
-    if (bid >= V * tiles) return;
-    const int v = bid / tiles, tile = bid - v * tiles;
-    const int n0 = tile * TILE;
-    const int npts = min(TILE, N - n0);
-    const float4 *__restrict__ rec = vw.rec + (size_t)v * H * W;
-
-    if (tid < TILE) {
-        float visv = -1.0f;
-        if (tid < npts) {
-            const int n = n0 + tid;
-            const float *cam = vw.cams + v * MH_CAM_STRIDE;
-            float u, w, z, rowf, colf;
-            mh_cam_project(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, w, z);
-            mh_ndc_to_pixel(u, w, (float)H, (float)W, rowf, colf);
-            float cr = __builtin_rintf(colf), rr = __builtin_rintf(rowf);
-            const bool oob = !(cr <= (float)(W - 1)) || (cr < 0.0f) || !(rr <= (float)(H - 1)) || (rr < 0.0f);
-            cr = fminf(fmaxf(cr, 0.0f), (float)(W - 1));
-            rr = fminf(fmaxf(rr, 0.0f), (float)(H - 1));
-            const int r = (int)rr, c = (int)cr;
-            const float4 q0 = rec[(size_t)r * W + c];
-            visv = mh_soft_visible(q0.w, (-z / 2.0f) * 255.0f);
-            visv = oob ? -1.0f : visv;
-            const size_t vn = (size_t)v * N + n;
-            vis[vn] = visv;
-            reinterpret_cast<float2 *>(ori)[vn] = make_float2(q0.x, q0.y);
-            conf[vn] = mh_clampf(q0.z, 1e-6f, 1.0f);
-            if (mask) mask[vn] = vw.mask[(size_t)v * H * W + (size_t)r * W + c];
-            if (visv == -1.0f) {
-                taps[vn * (P + 1)] = make_float4(__int_as_float(0), visv, 0.0f, 0.0f);
-                cnt[vn] = 0;
-            }
-            s_r[tid] = r;
-            s_cc[tid] = c;
-            s_rowf[tid] = rowf;
-            s_colf[tid] = colf;
-        }
-        s_vis[tid] = visv;
-    }
-    __syncthreads();
-
-    auto next_visible = [&](int nl) -> int {   // uniform per wave
-        while (nl < npts && s_vis[nl] == -1.0f) nl += 4;
-        return nl;
-    };
-    auto gather = [&](int nl, int p) -> float4 {
-        const int i = p / PATCH - HP, j = p - (p / PATCH) * PATCH - HP;
-        return rec[(size_t)min(max(s_r[nl] + i, 0), H - 1) * W + min(max(s_cc[nl] + j, 0), W - 1)];
-    };
-    // The kernel is bound by memory-level parallelism (8192 resident waves x one 784-byte patch gather in flight each at
-    // ~3 us of loaded HBM latency = the 2.3 TB/s it reached with a one-point look-ahead): the gathers of the wave's next
-    // THREE visible points are in flight while the current one is processed.
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    int cur = next_visible(wave);
-    int n1 = next_visible(cur + 4), n2 = next_visible(n1 + 4);
-    float4 qcur = zero4, q1 = zero4, q2 = zero4;
-    if (cur < npts && lane < P) qcur = gather(cur, lane);
-    if (n1 < npts && lane < P) q1 = gather(n1, lane);
-    if (n2 < npts && lane < P) q2 = gather(n2, lane);
-    while (cur < npts) {
-        const int n3 = next_visible(n2 + 4);
-        float4 q3 = zero4;
-        if (n3 < npts && lane < P) q3 = gather(n3, lane);
-        const size_t vn = (size_t)v * N + n0 + cur;
-        float4 *__restrict__ out = taps + vn * (P + 1);
-        for (int b = lane; b < 256; b += MH_WAVE) s_first[wave][b] = 0xffffffffu;
-        float cmax = -1.0f;
-        for (int p = lane; p < P; p += MH_WAVE) {
-            const float4 q = (p < MH_WAVE) ? qcur : gather(cur, p);
-            const float cc = mh_clampf(q.z, 1e-6f, 1.0f);
-            float o0, o1;
-            mh_unit2(q.x, q.y, o0, o1);
-            s_o[wave][p] = make_float2(o0, o1);
-            s_c[wave][p] = cc;
-            cmax = fmaxf(cmax, cc);
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o));
-        const bool hc = cmax > thr;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int p = lane; p < P; p += MH_WAVE) {
-            const bool el = (p == 0) || (hc ? (s_c[wave][p] > thr) : true);
-            s_el[wave][p] = el;
-            if (el) {
-                const float2 o = s_o[wave][p];
-                const unsigned h = ((__float_as_uint(o.x) * 0x9E3779B1u) ^ (__float_as_uint(o.y) * 0x85EBCA77u)) >> 24;
-                atomicMin(&s_first[wave][h], (unsigned)p);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        int base = 0;
-        for (int p0 = 0; p0 < P; p0 += MH_WAVE) {
-            const int p = p0 + lane;
-            bool el = false;
-            float2 o = make_float2(0.f, 0.f);
-            float cc = 0.f;
-            if (p < P) {
-                el = s_el[wave][p] != 0;
-                o = s_o[wave][p];
-                cc = s_c[wave][p];
-                if (el) {
-                    const unsigned ox = __float_as_uint(o.x), oy = __float_as_uint(o.y);
-                    const unsigned q = s_first[wave][((ox * 0x9E3779B1u) ^ (oy * 0x85EBCA77u)) >> 24];
-                    if (q < (unsigned)p) {
-                        const float2 e = s_o[wave][q];
-                        if (__float_as_uint(e.x) == ox && __float_as_uint(e.y) == oy) el = false;
-                    }
-                }
-            }
-            const unsigned long long m = __ballot(el);
-            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (el) out[1 + pos] = make_float4(o.x, o.y, cc, 0.0f);
-            base += __popcll(m);
-        }
-        if (lane == 0) {
-            out[0] = make_float4(__int_as_float(base), s_vis[cur], s_rowf[cur], s_colf[cur]);
-            cnt[vn] = (uint8_t)base;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        cur = n1, n1 = n2, n2 = n3;
-        qcur = q1, q1 = q2, q2 = q3;
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------
 // The fused front end for maps uploaded as 8-bit FILE CODES (mh_ctx_set_view_u8 -- what every real capture is, SURVEY.md
-// App. A.18): same outputs as mh_project_taps_kernel, organised around what bounds it in this regime.  The fp32 form is a
+// App. A.18): same outputs as the fp32 form (mh_project_taps2_kernel below), organised around what bounds it in this regime.  The fp32 form is a
 // chain of three dependent memory round trips per wave (points -> centre record -> patch gather of the points that passed
 // the depth test) at ~50 % occupancy, 64 % of its wave time parked on them (profiles/r03_8bit_*); its LDS work is 87 %
 // bank-conflict cycles (49 lanes bidding for "first tap with this orientation" on one address).  Here
@@ -704,7 +537,7 @@ __global__ __launch_bounds__(256) void mh_project_taps_codes_kernel(MhViews vw, 
 // wave owns 16 points of the 64-point tile (lane = point for the projection, lane = tap for the patches), no workgroup
 // barrier between projection and patches, and the 16-byte patch gathers of up to INF visible points are in flight at once
 // instead of three.  Arithmetic, eligibility, duplicate rule (hash table + bit compare) and record layout are those of
-// mh_project_taps_kernel: the tap lists are identical.
+// the unfused pair mh_project_gather_kernel + mh_prep_taps_kernel: the tap lists are identical.
 // ---------------------------------------------------------------------------------------------
 template <int PATCH>
 __global__ __launch_bounds__(256) void mh_project_taps2_kernel(MhViews vw, const float *__restrict__ pts, int N, int tiles,
@@ -918,13 +751,6 @@ extern "C" int mh_launch_topk_work(const float *vis, const float *conf, int V, i
     const MhWorkArgs wk{cnt, cls, P1, nrank, rank_step < 1 ? 1 : rank_step, S, 256};
     if ((order & 255) == 1) {   // value descending, view index ascending among equal values (round 1's rule; A/B)
         hipLaunchKernelGGL(mh_topk_kernel, dim3((N + 3) / 4), dim3(256), 0, st, vis, conf, V, N, out_idx, out_val);
-    } else if ((order & 255) == 2) {   // torch.topk's CPU order, literal per-lane form (cross-check of the wave form)
-        int T = (order >> 8) > 0 ? (order >> 8) : 64;
-        const int cap = 65536 / (8 * V);
-        T = T > 64 ? 64 : T;
-        T = T > cap ? (cap < 1 ? 1 : cap) : T;
-        hipLaunchKernelGGL(mh_topk_torch_kernel, dim3((N + T - 1) / T), dim3(64), (size_t)T * V * 8, st, vis, conf, V, N,
-                           T, out_idx, out_val);
     } else {            // torch.topk's CPU order, one wave per point
         const int W = (order >> 8) == 16 ? 16 : ((order >> 8) == 8 ? 8 : 4);   // waves (= points) per workgroup; 4 measured best
         const dim3 grid((N + W - 1) / W), block(64 * W);
@@ -964,25 +790,17 @@ extern "C" int mh_launch_project_taps(MhViews vw, const float *pts, int N, int p
     const MhCodeTabs *tabs = (const MhCodeTabs *)tabs_v;
     const bool codes = oc && tabs;
     if (patch * patch > MH_PREP_PMAX) return -1;
-    const int form = tile;                                    // 1: mh_project_taps2_kernel (64-point tiles, a wave owns 16)
-    if (codes || (tile != 16 && tile != 32)) tile = 64;       // (the code form always works on 64-point tiles)
-    if (!codes && form == 1) tile = 1;
-    const int tiles = (N + (tile == 1 ? 64 : tile) - 1) / (tile == 1 ? 64 : tile);
+    (void)tile;      // (round 3's A/B switch between tile sizes of the first fused form; one form per map kind is left)
+    const int tiles = (N + 63) / 64;
     const dim3 grid((vw.V * tiles + 7) & ~7), block(256);
-#define MH_PT_LAUNCH(PS, TL)                                                                                        \
-    hipLaunchKernelGGL((mh_project_taps_kernel<PS, TL>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, conf, mask, \
-                       taps, cnt)
 #define MH_PT_CASE(PS)                                                                                             \
     case PS:                                                                                                       \
         if (codes)                                                                                                 \
             hipLaunchKernelGGL((mh_project_taps_codes_kernel<PS>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, \
                                conf, mask, taps, cnt, oc, tabs);                                                   \
-        else if (tile == 1)                                                                                       \
+        else                                                                                                       \
             hipLaunchKernelGGL((mh_project_taps2_kernel<PS>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, conf, \
                                mask, taps, cnt);                                                                  \
-        else if (tile == 64) MH_PT_LAUNCH(PS, 64);                                                                 \
-        else if (tile == 32) MH_PT_LAUNCH(PS, 32);                                                                 \
-        else MH_PT_LAUNCH(PS, 16);                                                                                 \
         break;
     switch (patch) {
         MH_PT_CASE(1)
@@ -994,7 +812,6 @@ extern "C" int mh_launch_project_taps(MhViews vw, const float *pts, int N, int p
         default:
             return -1;
     }
-#undef MH_PT_LAUNCH
 #undef MH_PT_CASE
     return (int)hipGetLastError();
 }

@@ -131,13 +131,9 @@ def all_gather_rows_inplace(buf, lo, s):
     inp = buf[lo + r * s:lo + (r + 1) * s]
     assert out.shape[0] == R * s and out.is_contiguous(), "all_gather_rows_inplace: the buffer needs world*s rows of slack"
     if d.get_backend() == "nccl":
-        global _INPLACE_GATHER_OK
-        if _INPLACE_GATHER_OK:
-            try:
-                d.all_gather_into_tensor(out, inp)
-                return
-            except (RuntimeError, ValueError):      # an argument check of this torch build (raised before any traffic, on
-                _INPLACE_GATHER_OK = False          # every rank alike): use a separate receive buffer from now on
+        if inplace_gather_supported(buf.device):
+            d.all_gather_into_tensor(out, inp)
+            return
         tmp = torch.empty_like(out)
         d.all_gather_into_tensor(tmp, inp.clone())
         out.copy_(tmp)
@@ -148,7 +144,39 @@ def all_gather_rows_inplace(buf, lo, s):
         out.copy_(torch.cat(parts, 0).to(buf.device))
 
 
-_INPLACE_GATHER_OK = True
+_INPLACE_GATHER_OK = {}     # device index -> bool, decided ONCE per process group by inplace_gather_supported
+
+
+def inplace_gather_supported(device):
+    """Can this torch build's all_gather_into_tensor take an input that aliases its slice of the output (NCCL's in-place
+    form, sendbuff == recvbuff + rank*count)?  Decided once, on a 256-byte probe, and AGREED by all ranks with one
+    all_reduce(MIN): a rank that falls back on its own would issue a collective its peers never enter (deadlock).  An
+    argument check that rejects the aliasing raises before any traffic; the exception is logged, not swallowed."""
+    import warnings
+
+    d = _dist()
+    key = torch.device(device).index or 0
+    if key not in _INPLACE_GATHER_OK:
+        R, r = world(), rank()
+        ok = 1
+        try:
+            probe = torch.full((R * 64,), float(r), dtype=torch.float32, device=device)
+            d.all_gather_into_tensor(probe, probe[r * 64:(r + 1) * 64])
+            want = torch.arange(R, dtype=torch.float32, device=device).repeat_interleave(64)
+            if not torch.equal(probe, want):
+                ok = 0
+                warnings.warn("all_gather_into_tensor in place returned wrong rows on rank %d: using a separate receive "
+                              "buffer" % r)
+        except (RuntimeError, ValueError) as e:
+            ok = 0
+            warnings.warn("all_gather_into_tensor does not accept the in-place form here (%r): using a separate receive "
+                          "buffer" % (e,))
+        t = torch.tensor([ok], dtype=torch.int32, device=device)
+        d.all_reduce(t, op=d.ReduceOp.MIN)
+        _INPLACE_GATHER_OK[key] = bool(int(t.item()))
+    return _INPLACE_GATHER_OK[key]
+
+
 _COMMS = {}
 _CAPI_BROKEN = []          # non-empty once the hand-bound RCCL path failed to come up on some rank: stay on torch
 

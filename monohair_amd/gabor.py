@@ -73,11 +73,11 @@ class calOrientationGabor:
         self._cos = torch.cos(th).to(self.device)
 
     def set_variant(self, variant):
-        """'valu' / 'split': direct forms on v_pk_fma_f32; 'mfma': im2col contraction on v_mfma_f32_32x32x2_f32, first form;
-        'mfma2' (default): the same with the bank in operand order and immediate-offset LDS reads.  Same bits."""
+        """'mfma2' (default): the bank as an im2col contraction on v_mfma_f32_32x32x2_f32; 'valu': the direct form on
+        v_pk_fma_f32, kept as the cross-check.  Same bits."""
         self.variant = variant
         _lib.check(_lib.lib().mh_ctx_set_option(self._ctx, b"gabor_variant",
-                                                {"valu": 0, "mfma": 1, "split": 2, "mfma2": 3}[variant]),
+                                                {"valu": 0, "mfma2": 3}[variant]),
                    "mh_ctx_set_option")
 
     def cuda(self):

@@ -129,12 +129,23 @@ def process_options(opt):
                 suffix, shared_seed = box
             else:
                 # called before init_process_group (tools, tests, infer_inner.get_config): every rank derives the SAME
-                # values from what the launcher gave all of them -- the rendezvous id / port -- instead of failing;
-                # distinct per launch, identical across the ranks of one launch
+                # values from what the launcher gave all of them instead of failing.  The rendezvous id / address / port are
+                # the same for every launch with torchrun's static defaults ("none", 127.0.0.1, 29500), so under torchrun
+                # (TORCHELASTIC_RUN_ID set: all ranks of a node are children of ONE agent process) the agent's pid and the
+                # restart count are mixed in -- distinct per launch, identical across the ranks.  Under any other launcher
+                # nothing per-launch is known to be shared: the values are then a pure function of the environment, and the
+                # run says so (the reference draws a fresh suffix per run; give --name / --seed to choose).
                 import hashlib
+                import warnings
 
                 key = "%s|%s|%s" % (os.environ.get("TORCHELASTIC_RUN_ID", ""), os.environ.get("MASTER_ADDR", ""),
                                     os.environ.get("MASTER_PORT", ""))
+                if "TORCHELASTIC_RUN_ID" in os.environ:
+                    key += "|%d|%s" % (os.getppid(), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+                else:
+                    warnings.warn("options: unseeded multi-rank run without an initialised process group and without "
+                                  "torchrun: the output-name suffix and the candidate jitter are derived from "
+                                  "MASTER_ADDR/MASTER_PORT only and repeat from launch to launch")
                 h = hashlib.sha256(key.encode()).digest()
                 suffix = "".join(string.ascii_uppercase[b % 26] for b in h[:4])
                 shared_seed = int.from_bytes(h[4:8], "little") % (2 ** 31)

@@ -164,6 +164,15 @@ class PMVO:
         torch.cuda.current_stream().synchronize()
 
     def __del__(self):
+        # an object dropped with uploads in flight must not release its pinned slabs under them (see _upload_points)
+        try:
+            for ring in getattr(self, "_stage", {}).values():
+                self._drain_ring(ring)
+            stg = getattr(self, "_stage_all", None)
+            if stg is not None and stg[1] is not None:
+                stg[1].synchronize()
+        except Exception:
+            pass
         try:
             if getattr(self, "_ctx", None):
                 self._L.mh_ctx_destroy(self._ctx)
@@ -230,6 +239,9 @@ class PMVO:
             # ONE pinned slab of 32 slots per launch stream (3 MB), allocated on the stream's first call (a ring that grew
             # slot by slot paid a pinned allocation -- milliseconds, and it drains the device -- up to 32 times per stream
             # during the first few hundred iterations of a loop)
+            # The copies go through mh_upload_async, which torch's host caching allocator does not track: before the old slab
+            # is dropped (its pinned block could be handed out again at once), every copy still queued out of it must be over.
+            self._drain_ring(ring)
             cap = max(n, 8192)
             slab = torch.empty((self._STAGE_SLOTS, cap, 3), dtype=torch.float32, pin_memory=True)
             ring = self._stage[cs.cuda_stream] = {"cap": cap, "slab": slab, "np": slab.numpy(), "i": 0,
@@ -253,6 +265,13 @@ class PMVO:
         return dev
 
     _STAGE_SLOTS = 32
+
+    @staticmethod
+    def _drain_ring(ring):
+        """wait for every asynchronous copy that still reads from a staging ring's pinned slab"""
+        for ev in (ring or {}).get("ev", ()):
+            if ev is not None:
+                ev.synchronize()
 
     # ------------------------------------------------------------------ reference methods
     def Compute_Visible_and_Ori(self, points):
@@ -810,6 +829,9 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         # makes every rank's copy complete again -- the arrays a rank holds at the start of a chunk are the single-rank
         # ones, bit for bit.  Neighbour queries are needed for the owned rows only.
         R, rk = (mdist.world(), mdist.rank()) if mdist.refine_sharded() else (1, 0)
+        # MH_REFINE_CHAIN=0: one rank runs the four-launches-per-chunk form of the sharded path (tests pin BOTH forms to the
+        # reference's multi-chunk run, tests/test_multichunk_gpu.py)
+        chain = R == 1 and os.environ.get("MH_REFINE_CHAIN", "1") != "0"
 
         def own(i):
             lo, hi = i * sub_num, min((i + 1) * sub_num, n_all)
@@ -848,7 +870,7 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         head = torch.empty((sub_num,), dtype=torch.uint8, device=device)
         L, ctx, st = pmvo._L, pmvo._ctx, _lib.stream_ptr()
         off = lambda t, row, width=1: ctypes.c_void_p(t.data_ptr() + row * width * t.element_size())   # noqa: E731
-        if R == 1:
+        if chain:
             # One rank.  Only the ORIENTATIONS chain from chunk to chunk (chunk k+1's medoids read what chunk k replaced,
             # PMVO.py:614,640): medoid -> replacement rule, 2 small launches per chunk on the main stream.  The loss of a
             # chunk's medoid directions (PMVO.py:619-623) and the head-filter votes feed nothing in later chunks, so they
@@ -886,7 +908,7 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
             _lib.check(L.mh_refine_combine(ctx, _lib.ptr(centers), _lib.ptr(loss_all), _lib.ptr(head_all),
                                            _lib.ptr(head_top_all), 0.95, None, _lib.ptr(loss_dev), n_all, st),
                        "mh_refine_combine")
-        for i in range(step if R > 1 else 0):
+        for i in range(0 if chain else step):
             lo, hi, s_, a, b = own(i)
             if hi <= lo:
                 continue

@@ -623,20 +623,29 @@ class SparseMatWriter:
                 _lib.check(self._L.mh_mat_sparse_store_voxels(
                     h, v.ctypes.data_as(ctypes.c_void_p), None if val is None else val.ctypes.data_as(ctypes.c_void_p),
                     int(val is not None and val.dtype == np.float64), len(v), X, Y, Z), "mh_mat_sparse_store_voxels")
-                os.replace(self._names[k] + self._TMP, self._names[k])
             except BaseException as e:
                 err.append(e)
             stored[k].set()
             self._L.mh_mat_sparse_close(h)
 
+        names = list(self._names)
         self._files = []
         self._closers = [threading.Thread(target=store, args=(k,) + jobs[k]) for k in (0, 1)]   # ctypes releases the GIL
         for t in self._closers:
             t.start()
         for e in stored:
             e.wait()
+        # two-phase: the pair is renamed into place only when BOTH files hold their elements (an Occ3D.mat / Ori3D.mat pair
+        # from two different runs is worse than none); a failed store leaves no temporary file behind
         if err:
+            for n in names:
+                try:
+                    os.remove(n + self._TMP)
+                except OSError:
+                    pass
             raise err[0]
+        for n in names:
+            os.replace(n + self._TMP, n)
 
     def wait_closed(self):
         for t in getattr(self, "_closers", []):

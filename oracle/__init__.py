@@ -262,6 +262,60 @@ def medoid_segmented(ori, seg_start):
     return out, idx
 
 
+def replace_dissimilar(center, ori, thr=0.95):
+    """refine's replacement rule (PMVO.py:631-636), in place on `ori` [N,3] float32; returns the number of replaced rows."""
+    center = np.ascontiguousarray(center, np.float32)
+    assert ori.dtype == np.float32 and ori.flags.c_contiguous and ori.shape == center.shape
+    return int(lib().orc_replace_dissimilar(_p(center), _p(ori), ctypes.c_float(thr), ori.shape[0]))
+
+
+def head_top_mask(points, scalp_tree, scalp_max):
+    """The scalp half of filter_head_points (PMVO.py:112-121): within 4 cm of the scalp and below its top by 1 cm."""
+    pts = np.asarray(points)
+    d, _ = scalp_tree.query(pts, k=1)
+    return np.logical_and(d < 0.04, pts[:, 2] < scalp_max[2] - 0.01)
+
+
+def refine_loop(views, points, ori, loss, patch, thr, vis_thr, scalp_tree, scalp_max, sub_num=5000, k=100, sim_thr=0.95,
+                workers=-1, trace=None):
+    """The smoothing loop of refine (PMVO.py:602-643), IN PLACE on `ori` [N,3] / `loss` [N] (float32) like the reference:
+    chunks of `sub_num` points in order; a chunk's neighbour orientations are read from `ori` AS IT IS when the chunk starts
+    (:612 -- earlier chunks have already written back, :640), medoid of the k nearest (self included, scipy's order),
+    loss of that direction (PMVO.refine, :82-93: head-filtered points get -1), replacement where |cos| < 0.95 (:631-636),
+    -1 -> 0.5 (:639), write-back (:640-641).  `step = N // sub_num + 1` (:603): when N is a multiple of sub_num the
+    reference enters one more chunk with zero points; see tests/golden/e2e_multichunk.npz (`exact_raised`) for what it does
+    there -- this restatement skips it.
+    points: [N,3] as the reference holds them (the float32 select_p.npy); the KDTree is built on them as given.
+    trace: optional list that receives (lo, hi, replaced) per chunk."""
+    from scipy.spatial import KDTree
+
+    assert ori.dtype == np.float32 and loss.dtype == np.float32
+    N = points.shape[0]
+    tree = KDTree(data=points)
+    kk = min(k, N)
+    step = N // sub_num + 1
+    for i in range(step):
+        lo, hi = i * sub_num, min((i + 1) * sub_num, N)
+        if hi <= lo:
+            continue
+        sub_points = np.ascontiguousarray(points[lo:hi], np.float32)
+        _, index = tree.query(points[lo:hi], kk, workers=workers)
+        index = np.asarray(index).reshape(hi - lo, kk)
+        center, _ = medoid_dense(ori[index])                              # ori as of NOW
+        update_loss, _ = refine_loss(views, sub_points, center, patch, thr)
+        votes = filter_votes(views, sub_points, patch, thr, vis_thr)[3]
+        filt = votes & ~head_top_mask(sub_points, scalp_tree, scalp_max)  # filter_head_points (:110-137)
+        update_loss[filt] = -1
+        sub_ori = ori[lo:hi].copy()
+        replaced = replace_dissimilar(center, sub_ori, sim_thr)
+        update_loss[update_loss == -1] = 0.5
+        ori[lo:hi] = sub_ori
+        loss[lo:hi] = update_loss
+        if trace is not None:
+            trace.append((lo, hi, replaced))
+    return ori, loss
+
+
 def p2v(points, voxel_min, voxel_size, grid_resolution):
     """p2v (PMVO_utils.py:386-404): flips y,z IN PLACE, float64 round-half-even, clip."""
     points[:, 1:] *= -1

@@ -129,3 +129,25 @@ void orc_medoid_segmented(const float *ori, const int32_t *seg_start, int G, flo
         if (out_index) out_index[g] = b;
     }
 }
+
+/* refine's replacement rule (/root/reference/PMVO.py:631-636):
+ *     similar = maximum(cosine_similarity(center, ori), cosine_similarity(center, -ori));  ori[similar < thr] = center
+ * on [N,3] float32 tensors.  cosine_similarity(center, -ori) is the exact negation of cosine_similarity(center, ori)
+ * (negation commutes with every rounding involved), so the maximum is |cos|.  Returns the number of replaced rows.
+ * Pinned by tests/golden/e2e_multichunk.npz through oracle.refine_loop (tests/test_oracle_more.py). */
+int orc_replace_dissimilar(const float *center, float *ori, float thr, int N) {
+    int replaced = 0;
+    for (int n = 0; n < N; ++n) {
+        float cu[3], ou[3];
+        unit3(center + 3 * n, cu);
+        unit3(ori + 3 * n, ou);
+        const float cs = (cu[0] * ou[0] + cu[1] * ou[1]) + cu[2] * ou[2];
+        if (fabsf(cs) < thr) {
+            ori[3 * n] = center[3 * n];
+            ori[3 * n + 1] = center[3 * n + 1];
+            ori[3 * n + 2] = center[3 * n + 2];
+            ++replaced;
+        }
+    }
+    return replaced;
+}

@@ -32,7 +32,7 @@ DEV = "cuda:0"
 t_end = time.time() + a.minutes * 60
 count = {"knn": 0, "raster": 0, "strands": 0, "gabor": 0, "medoid": 0, "voxel_fit": 0, "trace": 0}
 bad = []
-gabs = {v: calOrientationGabor(device=DEV, variant=v) for v in ("valu", "mfma", "split", "mfma2")}
+gabs = {v: calOrientationGabor(device=DEV, variant=v) for v in ("mfma2", "valu")}
 bank = gabor_bank()
 
 

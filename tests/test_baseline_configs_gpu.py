@@ -20,6 +20,7 @@ def eq(a, b):
 
 
 @pytest.mark.parametrize("V,H,W,res,quant", [(20, 512, 512, 64, True), (30, 1920, 1080, 128, False),
+                                              (60, 1920, 1080, 256, False),        # bench.py's own scene (continuous maps)
                                               (120, 3840, 2160, 512, True)])
 def test_config_subset_parity(V, H, W, res, quant):
     from monohair_amd import synth
@@ -56,26 +57,30 @@ def test_config_subset_parity(V, H, W, res, quant):
     assert np.median(cosv) > 0.95, np.median(cosv)
 
 
-def test_gabor_4k_mfma_variant():
-    """configs[4]: the 180x289 bank as an im2col contraction on the FP32 matrix cores must give the bits of the VALU
-    kernel at 3840x2160, and both those of the oracle on a crop (index and un-normalised variance are local, so pixels
-    further than the 8-pixel filter radius from the crop border do not see the crop)."""
+@pytest.mark.parametrize("H,W", [(1920, 1080), (3840, 2160)])
+def test_gabor_shipped_kernel_at_full_size(H, W):
+    """configs[2]/[4]: the shipped bank kernel (mfma2: the 180x289 bank as an im2col contraction on the FP32 matrix cores,
+    GaborFilter.py:29-113) at 1080p and 3840x2160 gives the bits of the VALU cross-check kernel on every pixel, and both those
+    of the oracle on crops (index and un-normalised variance are local, so pixels further than the 8-pixel filter radius from
+    an interior crop border do not see the crop; crops that touch the image border share its zero padding there)."""
     from monohair_amd.gabor import calOrientationGabor, gabor_bank
 
-    H, W = 3840, 2160
     g = torch.Generator().manual_seed(0)
     yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
     img = (0.25 * torch.cos(2 * np.pi * (0.6 * xx + 0.8 * yy) / 4.0) + 0.02 * torch.randn((H, W), generator=g)).float()
     outs = {}
-    for variant in ("valu", "mfma", "split", "mfma2"):
+    for variant in ("mfma2", "valu"):
         gf = calOrientationGabor(device=DEV, variant=variant)
         idx, conf, var = gf.filter_index(img.to(DEV))
         outs[variant] = (idx.cpu().numpy(), conf.cpu().numpy(), var.cpu().numpy())
-    for other in ("mfma", "split"):
-        for a, b in zip(outs["valu"], outs[other]):
-            assert np.array_equal(a, b), other
-    r0, c0, n = 1800, 1000, 200
-    o_idx, _, o_var = oracle.gabor_bank(gabor_bank(), img[r0:r0 + n, c0:c0 + n].numpy())
-    s = slice(8, n - 8)
-    assert np.array_equal(outs["mfma"][0][r0:r0 + n, c0:c0 + n][s, s], o_idx[s, s])
-    assert np.array_equal(outs["mfma"][2][r0:r0 + n, c0:c0 + n][s, s], o_var[s, s])
+    assert calOrientationGabor(device=DEV).variant == "mfma2"
+    for a, b in zip(outs["mfma2"], outs["valu"]):
+        assert np.array_equal(a, b)
+    n = 160
+    bank = gabor_bank()
+    for r0, c0 in ((H // 2 - 100, W // 2 - 80), (0, 0), (H - n, W - n), (0, W - n), (H // 3, 0)):
+        o_idx, _, o_var = oracle.gabor_bank(bank, img[r0:r0 + n, c0:c0 + n].numpy())
+        rs = slice(0 if r0 == 0 else 8, n if r0 + n == H else n - 8)
+        cs = slice(0 if c0 == 0 else 8, n if c0 + n == W else n - 8)
+        assert np.array_equal(outs["mfma2"][0][r0:r0 + n, c0:c0 + n][rs, cs], o_idx[rs, cs]), (r0, c0)
+        assert np.array_equal(outs["mfma2"][2][r0:r0 + n, c0:c0 + n][rs, cs], o_var[rs, cs]), (r0, c0)

@@ -39,6 +39,20 @@ def test_single_gpu_line_and_rooflines_of_the_timed_kernels():
     for k in d["roofline_kernels"]:
         assert abs(k["algorithmic_bytes_per_launch"] / (k["launch_ms"] * 1e-3) / 1e9 - k["achieved"]) < 1.0
     assert "refine_and_volume_s" in d["secondary_full_pass"]
+    assert d["timed_region_s"] > 0 and abs(d["timed_region_s"] / d["steps"] * 1e3 - d["ms_per_step"]) < 1e-3
+    g = d["secondary_gabor_sharded"]
+    assert g["n_gpus"] == 1 and g["views"] == 24 and g["value"] > 0 and g["codes_agree_on_all_ranks"] is True
+
+
+def test_line_verifies_its_own_outputs_against_the_oracle():
+    """with the CPU leg: the outputs of the LAST timed step are compared with oracle.forward in the same run, and whatever the
+    line copies from profiles/traffic.json says so"""
+    d = run_bench([x for x in SMALL if x != "--no-cpu"] + ["--no-secondary", "--cpu-points", "800"])
+    pc = d["parity_check"]
+    assert pc["bit_exact"] is True and pc["points"] == 800 and pc["finite_losses"] > 0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0
+    rf = d["roofline"]
+    assert rf["traffic"] is None or "profiles/traffic.json" in rf["traffic_source"]
 
 
 def test_gpus_2_spawns_two_ranks_itself():
@@ -46,6 +60,9 @@ def test_gpus_2_spawns_two_ranks_itself():
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo"
     assert d["secondary_full_pass"]["ranks"] == 2 and "total_s" in d["secondary_full_pass"]
     assert len(d["per_rank_iterations_per_s"]) == 2 and min(d["per_rank_iterations_per_s"]) > 0
+    g = d["secondary_gabor_sharded"]
+    assert g["n_gpus"] == 2 and g["views_per_rank"] == [12, 12] and g["codes_agree_on_all_ranks"] is True
+    assert g["all_gather_bytes"] == 24 * 2 * 240 * 136 and g["all_gather_ms"] > 0
 
 
 def test_gpus_2_volume_exchange_legs_run_through_the_rccl_stand_in():

@@ -260,7 +260,7 @@ def test_topk_tie_order_is_torchs_on_adversarial_columns():
         vd, cd = torch.from_numpy(vis).to(DEV), torch.from_numpy(conf).to(DEV)
         oi = torch.empty((20, N), dtype=torch.int32, device=DEV)
         ov = torch.empty((20, N), dtype=torch.float32, device=DEV)
-        for order in (0, 2):       # the wave form (default) and the literal per-lane form
+        for order in (0, 0 | (8 << 8), 0 | (16 << 8)):       # the wave form: 4 (default), 8 and 16 points per workgroup
             _lib.check(L.mh_ctx_set_option(ctx, b"topk_order", order))
             oi.fill_(-1)
             _lib.check(L.mh_topk_views(ctx, _lib.ptr(vd), _lib.ptr(cd), N, _lib.ptr(oi), _lib.ptr(ov), _lib.stream_ptr()))

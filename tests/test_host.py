@@ -163,6 +163,22 @@ V = 7
 local = [torch.full((2, 3, 4), i, dtype=torch.uint8) for i in range(V) if mdist.owner(i) == r]
 allv = mdist.all_gather_views(local, V, (2, 3, 4), torch.uint8, "cpu")
 assert allv.shape == (V, 2, 3, 4) and all(int(allv[i].max()) == i and int(allv[i].min()) == i for i in range(V))
+# --- all_gather_rows_inplace (refine's per-chunk exchange): rows each rank wrote end up on every rank; the in-place
+# capability probe is decided once and agreed by all ranks (gloo: the staged path is used, the probe must still agree)
+buf = torch.zeros((20 + 2 * 4, 3))
+buf[:] = torch.arange(28, dtype=torch.float32)[:, None]
+buf[8 + r * 4: 8 + (r + 1) * 4] = 1000.0 + r                     # chunk rows [8, 16): 4 rows per rank
+mdist.all_gather_rows_inplace(buf, 8, 4)
+assert torch.equal(buf[8:12], torch.full((4, 3), 1000.0)) and torch.equal(buf[12:16], torch.full((4, 3), 1001.0))
+assert torch.equal(buf[:8, 0], torch.arange(8.0)) and torch.equal(buf[16:, 0], torch.arange(16.0, 28.0))
+try:
+    flag = mdist.inplace_gather_supported("cpu")
+except Exception as e:          # a backend without all_reduce on this tensor would be a bug of the probe
+    raise AssertionError("probe raised: %%r" %% (e,))
+flags = [None, None]
+dist.all_gather_object(flags, flag)
+assert flags[0] == flags[1], flags
+assert mdist.inplace_gather_supported("cpu") == flag                # cached
 # --- voxel_fit_reduced: disjoint ownership + ONE reduce == single-process fit, bit for bit
 import oracle
 def fit(p, o, device, vmin, vsize, g, dense=True):

@@ -1,0 +1,118 @@
+"""GPU: the CHUNKED drivers against the reference's own multi-chunk run (tests/golden/e2e_multichunk.npz, made by
+tools/gen_golden_multichunk.py from /root/reference: 16 901 surface points = four 5000-point chunks with a ragged last one,
+and refine on exactly 10 000 points).
+
+SURVEY.md §8 row a14: refine's smoothing loop is Gauss-Seidel over the chunks -- `Neighbor_ori = ori[index]`
+(/root/reference/PMVO.py:612) reads what earlier chunks wrote back (:640).  Every form of the loop the product has is pinned
+here to the REFERENCE's files, not to another form of itself:
+  * one rank, split chain (medoid -> replacement on the main stream, losses in groups of eight chunks on a side stream);
+  * one rank, four launches per chunk (MH_REFINE_CHAIN=0: the form the sharded path runs);
+  * 2 and 3 ranks (gloo ranks sharing the test GPU), every rank owning a slice of every chunk, one in-place all_gather per chunk.
+optimize over four chunks on three rotating streams is pinned the same way (row a10)."""
+import ast
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, check_rows_against_recomposed
+
+pytestmark = pytest.mark.gpu
+HELPER = os.path.join(ROOT, "tests", "golden_drivers.py")
+
+
+def golden():
+    z = np.load(os.path.join(GOLDEN, "e2e_multichunk.npz"), allow_pickle=False)
+    return z, ast.literal_eval(str(z["meta"]))
+
+
+def same_rows(a, b):
+    s = (a == b) | (np.isnan(a) & np.isnan(b))
+    return s if s.ndim == 1 else s.all(axis=1)
+
+
+def loss_strict_mask(n, sub_num=5000):
+    """all rows except the trailing (chunk length mod 64) of each chunk: ATen adds the [V,N,1] sums of those columns in another
+    order (one ulp; tests/test_oracle_more.py::test_refine_method_loss)"""
+    strict = np.ones(n, bool)
+    for lo in range(0, n, sub_num):
+        hi = min(lo + sub_num, n)
+        strict[hi - (hi - lo) % 64:hi] = False
+    return strict
+
+
+def check_refine_files(out, z, prefix, n):
+    import scipy.io
+
+    r = {k: np.load(os.path.join(out, "refine", k + ".npy")) for k in
+         ("select_p", "select_o", "min_loss", "filter_unvisible", "filter_unvisible_ori")}
+    assert len(r["select_o"]) == n
+    om = same_rows(r["select_o"], z[prefix + "select_o"])
+    assert om.all(), ("orientations", float(om.mean()), np.flatnonzero(~om)[:5])
+    lm = same_rows(r["min_loss"], z[prefix + "min_loss"])
+    assert lm[loss_strict_mask(n)].all(), ("losses", float(lm.mean()))
+    assert np.allclose(r["min_loss"], z[prefix + "min_loss"], rtol=0, atol=2e-7, equal_nan=True)
+    assert np.array_equal(r["filter_unvisible"], z[prefix + "filter_unvisible"])
+    fm = same_rows(r["filter_unvisible_ori"], z[prefix + "filter_unvisible_ori"])
+    assert fm.mean() >= 0.999, float(fm.mean())
+    Occ3 = scipy.io.loadmat(os.path.join(out, "refine", "Occ3D.mat"))["Occ"]
+    Ori3 = scipy.io.loadmat(os.path.join(out, "refine", "Ori3D.mat"))["Ori"]
+    nz = np.argwhere(Occ3 != 0).astype(np.int32)
+    ref_nz = z[prefix + "mat_occ_nz"]
+    a, b = set(map(tuple, nz.tolist())), set(map(tuple, ref_nz.tolist()))
+    assert len(a ^ b) <= 0.001 * len(b), (len(a), len(b), len(a ^ b))
+    Z = Occ3.shape[2]
+    got = np.stack([Ori3[ref_nz[:, 0], ref_nz[:, 1], c * Z + ref_nz[:, 2]] for c in range(3)], 1)
+    vm = np.all(got == z[prefix + "mat_ori_at_nz"], axis=1)
+    assert vm.mean() >= 0.999, float(vm.mean())
+
+
+def run_helper(out, what, ranks=1, env_extra=None, port=29600):
+    env = dict(os.environ, PYTHONPATH=ROOT, **(env_extra or {}))
+    if ranks == 1:
+        cmd = [sys.executable, HELPER, "--out", str(out), "--what", what]
+    else:
+        env.update(MH_DIST_BACKEND="gloo", MH_DEVICE_OVERRIDE="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), HELPER, "--out", str(out), "--what", what]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdin=subprocess.DEVNULL, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("form", ["chain", "four_launch"])
+def test_refine_four_chunks_equals_the_reference(tmp_path, form):
+    z, meta = golden()
+    run_helper(tmp_path, "refine,refine_exact", env_extra={"MH_REFINE_CHAIN": "1" if form == "chain" else "0"})
+    check_refine_files(os.path.join(tmp_path, "run"), z, "ref_", 16901)
+    # N = 10 000: `step = N // 5000 + 1` (PMVO.py:603) makes a third, empty chunk; the reference runs through it and so do we
+    assert str(z["exact_raised"]) == ""
+    check_refine_files(os.path.join(tmp_path, "exact"), z, "exact_", meta["exact"])
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_refine_four_chunks_sharded_over_ranks_equals_the_reference(tmp_path, ranks):
+    """every rank owns ceil(n/ranks) rows of every chunk (3 ranks: slices that do not divide 5000 or 1901)"""
+    z, meta = golden()
+    run_helper(tmp_path, "refine,refine_exact", ranks=ranks, env_extra={"MH_REFINE_SHARD": "1"}, port=29600 + ranks)
+    check_refine_files(os.path.join(tmp_path, "run"), z, "ref_", 16901)
+    check_refine_files(os.path.join(tmp_path, "exact"), z, "exact_", meta["exact"])
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_optimize_four_chunks_equals_the_reference(tmp_path, ranks):
+    """optimize (PMVO.py:565-595) over four chunks rotating over three HIP streams (one rank) / dealt to two ranks: every row
+    equals the reference's answer in the doubled-chunk composition, and rows that differ from its four-chunk files are rows on
+    which the reference disagrees with itself (MKL's batch-size-dependent gemm)."""
+    z, meta = golden()
+    run_helper(tmp_path, "optimize", ranks=ranks, port=29610 + ranks)
+    got = {k: np.load(os.path.join(tmp_path, "run", "optimize", k + ".npy")) for k in
+           ("select_p", "select_o", "min_loss", "high_conf_index")}
+    assert got["select_p"].dtype == np.float32 and got["high_conf_index"].dtype == np.bool_
+    assert np.array_equal(got["select_p"], z["opt_select_p"])
+    st = check_rows_against_recomposed(
+        "e2e_multichunk optimize", (got["select_o"], got["min_loss"], got["high_conf_index"]),
+        (z["opt_select_o"], z["opt_min_loss"], z["opt_high_conf_index"]),
+        [(z["optrec_select_o"], z["optrec_min_loss"], z["optrec_high_conf_index"])])
+    assert st["rows"] == 16901

@@ -11,6 +11,17 @@ This script demonstrates it and pins the composition-independent answer:
   dup_*   forward(concat(points, points))[:N]   -- every base view owns >= 2 points at every rank: MKL's gemm kernel
                                                    everywhere, the form the oracle restates
 
+The same doubled batch is recorded STEP BY STEP as well (round 4), for the step-level oracle tests
+(tests/test_oracle_golden.py::test_sample_reproject_loss): for base-view ranks 0 and 2 of the doubled batch,
+
+  dup_samples_r<k>   sample_next_3d_pos (PMVO.py:263-335)          first N rows  [N,90,3]
+  dup_Dhead_r<k>     compute_reproject_ori (PMVO.py:222-241)       first n_d points [V,n_d,90,2]
+  dup_Dsum_r<k>      its float64 checksums per (view, point)       [V,N]
+  dup_loss_r<k>, dup_idx_r<k>, dup_hc_r<k>   compute_prj_loss (PMVO.py:151-220), first N rows
+
+In the doubled batch every base view owns >= 2 points (MKL's gemm kernel, not gemv), and the first N points are not in the
+trailing (2N*90 mod 64) columns that ATen's [V, N*S] sums add in another order -- so the oracle must equal these on EVERY row.
+
     python tools/gen_golden_recompose.py          (build container only: imports /root/reference)
 """
 import os
@@ -56,6 +67,25 @@ def main():
         od, ld, hd = fwd(np.concatenate([pts, pts], 0))
         # the two halves of the doubled batch agree with each other: this answer does not depend on the position
         assert np.array_equal(od[:N], od[N:], equal_nan=True) and np.array_equal(ld[:N], ld[N:], equal_nan=True)
+        # the steps of the doubled batch (ranks 0 and 2, as tools/gen_golden.py records them for the original batch)
+        import torch
+
+        nd = case["n_d"]
+        p2 = torch.from_numpy(np.concatenate([pts, pts], 0)).type(torch.float)
+        pm.Compute_Visible_and_Ori(p2)
+        bidx, bval = pm.Find_max_conf_from_visible_view()
+        assert np.array_equal(bidx[:, :N].numpy(), z["base_idx"]) and np.array_equal(bidx[:, N:].numpy(), z["base_idx"])
+        for rank in (0, 2):
+            samples, surface = pm.sample_next_3d_pos(p2, bidx[rank])
+            D = pm.compute_reproject_ori(surface, samples)
+            loss, idx, hc = pm.compute_prj_loss(D, pm.Ori, None)
+            assert torch.equal(samples[:N], samples[N:])
+            out["%s__dup_samples_r%d" % (name, rank)] = samples[:N].numpy()
+            out["%s__dup_Dhead_r%d" % (name, rank)] = D[:, :nd].numpy()
+            out["%s__dup_Dsum_r%d" % (name, rank)] = D[:, :N].double().sum(dim=(2, 3)).numpy()
+            out["%s__dup_loss_r%d" % (name, rank)] = loss[:N].numpy()
+            out["%s__dup_idx_r%d" % (name, rank)] = idx[:N].numpy().astype(np.int32)
+            out["%s__dup_hc_r%d" % (name, rank)] = hc[:N].numpy()
         for tag, (o, l, h) in (("rev", (orv, lrv, hrv)), ("dup", (od[:N], ld[:N], hd[:N]))):
             out["%s__%s_ori" % (name, tag)] = o
             out["%s__%s_loss" % (name, tag)] = l

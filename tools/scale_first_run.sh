@@ -1,0 +1,106 @@
+#!/usr/bin/env bash
+# First run on a node with >= 2 MI355X.  No multi-GPU hardware was available to the builder
+# in rounds 1-4: every multi-rank path has run only as gloo ranks sharing ONE GPU and through tests/fake_rccl.cpp.  This
+# script is what to run, in order, the first time real RCCL over xGMI is there; it stops at the first failure.
+#
+#   bash tools/scale_first_run.sh [OUT_DIR]            (from the repo root; ~10 minutes on 8 GPUs)
+#
+#   1. the real 2-GPU exchange test            tests/test_volume_reduce_gpu.py (skipped on < 2 GPUs until now)
+#   2. PMVO.py, N ranks, MH_VOLUME_EXCHANGE=torch and =capi, against the 1-rank files -- bit for bit
+#   3. the view-sharded Gabor stage, N ranks (nccl), against the 1-rank codes and files -- byte for byte
+#   4. refine's four-chunk golden under real RCCL (in-place all_gather per chunk) -- the reference's files
+#   5. bench.py --gpus 1/2/4/8 and the curve next to docs' expectations
+set -euo pipefail
+cd "$(dirname "$0")/.."
+ROOT=$PWD
+OUT=${1:-$ROOT/gpurun_out/scale_first_run}
+mkdir -p "$OUT"
+export PYTHONPATH=$ROOT HSA_ENABLE_IPC_MODE_LEGACY=${HSA_ENABLE_IPC_MODE_LEGACY:-0}
+NG=$(python -c 'import torch; print(torch.cuda.device_count())')
+echo "== $NG GPU(s) visible"
+if [ "$NG" -lt 2 ]; then echo "needs >= 2 GPUs"; exit 2; fi
+NR=$(( NG >= 8 ? 8 : (NG >= 4 ? 4 : 2) ))
+TR="python -m torch.distributed.run --nnodes=1 --master-addr 127.0.0.1"
+
+echo "== 1. real 2-GPU slab gather / dense reduce through the C ABI"
+python -m pytest tests/test_volume_reduce_gpu.py -x -q -m gpu 2>&1 | tee "$OUT/1_volume_reduce.log" | tail -3
+
+echo "== 2. PMVO.py: $NR ranks vs 1 rank, both exchanges"
+DATA=$OUT/data
+python - <<PY
+from monohair_amd import synth
+synth.write_case("$DATA", "synthetic_sphere", V=24, H=480, W=270, res=64)
+PY
+COMMON="--yaml=configs/reconstruct/synthetic_sphere --data.root=$DATA --data.image_size=[480,270] --PMVO.patch_size=5"
+python PMVO.py $COMMON --name=one > "$OUT/2_one.log" 2>&1
+PORT=29800
+for EX in torch capi; do
+  PORT=$((PORT+1))
+  MH_VOLUME_EXCHANGE=$EX $TR --nproc-per-node $NR --master-port $PORT PMVO.py $COMMON --name=many_$EX > "$OUT/2_many_$EX.log" 2>&1
+  python - <<PY
+import numpy as np, scipy.io, sys
+base = "$DATA/synthetic_sphere/output/"
+one = [d for d in __import__("os").listdir(base) if d.startswith("one")][0]
+many = [d for d in __import__("os").listdir(base) if d.startswith("many_$EX")][0]
+for f in ("optimize/select_p.npy", "optimize/select_o.npy", "optimize/min_loss.npy", "optimize/high_conf_index.npy",
+          "refine/select_o.npy", "refine/min_loss.npy", "refine/filter_unvisible.npy", "refine/filter_unvisible_ori.npy"):
+    a, b = np.load(base + one + "/" + f), np.load(base + many + "/" + f)
+    assert np.array_equal(a, b, equal_nan=True), ("$EX", f)
+for f, k in (("refine/Ori3D.mat", "Ori"), ("refine/Occ3D.mat", "Occ")):
+    assert np.array_equal(scipy.io.loadmat(base + one + "/" + f)[k], scipy.io.loadmat(base + many + "/" + f)[k]), ("$EX", f)
+print("   $NR ranks, MH_VOLUME_EXCHANGE=$EX: every file equals the 1-rank run bit for bit")
+PY
+done
+
+echo "== 3. view-sharded Gabor stage: $NR ranks (nccl) vs 1 rank"
+python tests/gabor_ranks_helper.py --out "$OUT/gabor_one" --views 13 > "$OUT/3_one.log" 2>&1
+$TR --nproc-per-node $NR --master-port 29811 tests/gabor_ranks_helper.py --out "$OUT/gabor_many" --views 13 > "$OUT/3_many.log" 2>&1
+python - <<PY
+import numpy as np, os
+a = np.load("$OUT/gabor_one/codes_rank0.npz")
+for r in range($NR):
+    b = np.load("$OUT/gabor_many/codes_rank%d.npz" % r)
+    assert np.array_equal(a["k8"], b["k8"]) and np.array_equal(a["c8"], b["c8"]), r
+for sub in ("best_ori", "conf", "Ori"):
+    for n in sorted(os.listdir("$OUT/gabor_one/files/" + sub)):
+        assert open("$OUT/gabor_one/files/%s/%s" % (sub, n), "rb").read() == open("$OUT/gabor_many/files/%s/%s" % (sub, n), "rb").read(), (sub, n)
+print("   codes on every rank and all files equal the 1-rank stage byte for byte")
+PY
+
+echo "== 4. refine over four chunks, sharded over $NR ranks with RCCL's in-place all_gather, vs the REFERENCE's files"
+$TR --nproc-per-node $NR --master-port 29821 tests/golden_drivers.py --out "$OUT/golden" --what refine,refine_exact > "$OUT/4_refine.log" 2>&1
+python - <<PY
+import sys; sys.path.insert(0, "tests")
+import test_multichunk_gpu as T
+z, meta = T.golden()
+T.check_refine_files("$OUT/golden/run", z, "ref_", 16901)
+T.check_refine_files("$OUT/golden/exact", z, "exact_", meta["exact"])
+print("   equal to the reference's refine/*.npy (tests/golden/e2e_multichunk.npz)")
+PY
+
+echo "== 5. bench.py --gpus 1/2/4/8"
+for N in 1 2 4 8; do
+  if [ "$N" -le "$NG" ]; then
+    python bench.py --gpus $N --steps 100 --warmup 5 2> "$OUT/5_bench_$N.err" | grep '^{' > "$OUT/5_bench_$N.json"
+  fi
+done
+python - <<PY
+import json, os
+rows = {}
+for n in (1, 2, 4, 8):
+    p = "$OUT/5_bench_%d.json" % n
+    if os.path.exists(p) and os.path.getsize(p):
+        rows[n] = json.loads(open(p).read())
+base = rows[1]["value"]
+print("   N   it/s     x1     expected   full pass s   Gabor views/s   volume exchange ms")
+for n, d in rows.items():
+    fp = d.get("secondary_full_pass", {})
+    g = d.get("secondary_gabor_sharded", {})
+    vr = d.get("secondary_volume_reduce", {})
+    print("   %d  %8.1f  %5.2f   >= %4.2f    %10s   %12s   %s" % (
+        n, d["value"], d["value"] / base, 0.975 * n, fp.get("steady_total_s", fp.get("total_s", "-")),
+        g.get("value", "-"), vr.get("slab_gather_torch_ms", "-")))
+print("   expectations (DESIGN.md §8): iterations/s >= 7.8x at 8 GPUs (no collective inside an iteration); the full pass "
+      "~3.8x (Amdahl: k-NN build, .npy/.mat writes on rank 0); Gabor stage ~N x minus one 249 MB all_gather")
+PY
+echo "== done; logs and lines under $OUT"
