@@ -96,47 +96,56 @@ def test_topk_column_equals_torch_on_tie_heavy_columns():
         assert np.array_equal(got, want), trial
 
 
+_recomposed = {}
+
+
+def recomposed(name, key):
+    """tests/golden/pmvo_recompose.npz: the reference's steps on the DOUBLED batch (tools/gen_golden_recompose.py)"""
+    if not _recomposed:
+        import os
+
+        from conftest import GOLDEN
+
+        zz = np.load(os.path.join(GOLDEN, "pmvo_recompose.npz"))
+        _recomposed.update({k: zz[k] for k in zz.files})
+    return _recomposed["%s__dup_%s" % (name, key)]
+
+
 @pytest.mark.parametrize("rank", [0, 2])
-def test_sample_reproject_loss(case, rank, depth_offsets):
+def test_sample_reproject_loss(case, rank, depth_offsets, request):
+    """sample_next_3d_pos / compute_reproject_ori / compute_prj_loss (PMVO.py:263-335, 222-241, 151-220) for one base-view rank.
+    Against the reference's DOUBLED batch (every base view owns >= 2 points: MKL's gemm kernel, the form the oracle restates;
+    the first N points are clear of the trailing columns ATen sums in another order): EVERY row, bit for bit.
+    Against the ORIGINAL batch: the rows that differ are rows where the reference's two compositions differ from each other."""
     meta, z, scene, views = case
+    name = request.node.callspec.params["case"]
     pts = z["points"]
-    samples = oracle.sample_next(views, pts, z["base_idx"][rank], z["Ori"], depth_offsets)
-    ref_s = z["samples_r%d" % rank]
-    # Bit-exact except where the reference's matmul lands in another MKL kernel: a base view that owns a
-    # single point of the batch goes through gemv instead of gemm (see oracle/pmvo_oracle.c, cam_unproject).
-    exact = np.all(samples == ref_s, axis=(1, 2))
-    shared = np.bincount(z["base_idx"][rank], minlength=z["visible"].shape[0])[z["base_idx"][rank]] >= 2
-    assert exact[shared].mean() >= 0.97          # (with 300 views and 64 points most base views own one point)
-    assert shared.mean() < 0.6 or exact.mean() >= 0.97
-    assert np.allclose(samples, ref_s, rtol=0, atol=2e-7)
-    D = oracle.reproject_ori(views, pts, samples)
     nd = meta["n_d"]
-    ex_d = exact[:nd]
-    assert eq_nan(D[:, :nd][:, ex_d], z["D_head_r%d" % rank][:, ex_d])
-    assert np.allclose(D.astype(np.float64).sum(axis=(2, 3)), z["D_sum_r%d" % rank], rtol=0, atol=1e-2,
+    samples = oracle.sample_next(views, pts, z["base_idx"][rank], z["Ori"], depth_offsets)
+    dup_s = recomposed(name, "samples_r%d" % rank)
+    assert np.array_equal(samples, dup_s)                                   # every sample of every point
+    D = oracle.reproject_ori(views, pts, samples)
+    assert eq_nan(D[:, :nd], recomposed(name, "Dhead_r%d" % rank))
+    assert np.allclose(D.astype(np.float64).sum(axis=(2, 3)), recomposed(name, "Dsum_r%d" % rank), rtol=0, atol=1e-9,
                        equal_nan=True)
     o = oracle.visible_and_ori(views, pts, meta["patch"])
     loss, idx, hc = oracle.prj_loss(D, o["Ori_patch"], o["Conf_patch"], o["visible"], meta["thr"])
+    assert eq_nan(loss, recomposed(name, "loss_r%d" % rank))
+    assert np.array_equal(idx, recomposed(name, "idx_r%d" % rank))
+    assert np.array_equal(hc, recomposed(name, "hc_r%d" % rank))
+    # the original batch: differences only where the reference differs from itself (a base view that owns ONE point of the
+    # batch goes through MKL's gemv; the last point sits in the trailing N*S mod 64 columns of the [V, N*S] sums)
+    ref_s = z["samples_r%d" % rank]
+    ref_self = np.all(ref_s == dup_s, axis=(1, 2))
+    assert np.all(~ref_self[~np.all(samples == ref_s, axis=(1, 2))])
+    own = np.bincount(z["base_idx"][rank], minlength=z["visible"].shape[0])[z["base_idx"][rank]]
+    assert np.all(own[~ref_self] == 1)                                      # ... and those are exactly single-owner points
+    assert np.allclose(samples, ref_s, rtol=0, atol=2e-7)
     ref_loss, ref_idx, ref_hc = z["loss_r%d" % rank], z["idx_r%d" % rank], z["hc_r%d" % rank]
-    # ATen sums the trailing (N*S mod 64) columns of a [V, N*S] tensor in a different order
-    # (row_sum instead of the cascade), so the last point of the batch may differ by an ulp.
-    body = exact.copy()
+    body = ref_self.copy()
     body[-1] = False
-    assert eq_nan(loss[body], ref_loss[body])
-    assert np.array_equal(idx[body], ref_idx[body])
+    assert eq_nan(loss[body], ref_loss[body]) and np.array_equal(idx[body], ref_idx[body])
     assert np.array_equal(hc[body], ref_hc[body])
-    # the other points (gemv-path samples one ulp off): same loss up to the discretisation of the tiny 40x32 images
-    assert np.allclose(loss, ref_loss, rtol=0, atol=1e-6 if z["visible"].shape[0] < 256 else 1e-3, equal_nan=True)
-
-
-def _comparable(z, depth_offsets, views, pts):
-    """points whose rank-r sample sets are bit-identical to the reference's for every rank tried"""
-    ok = np.ones(len(pts), bool)
-    ok[-1] = False
-    for rank in (0, 2):
-        s = oracle.sample_next(views, pts, z["base_idx"][rank], z["Ori"], depth_offsets)
-        ok &= np.all(s == z["samples_r%d" % rank], axis=(1, 2))
-    return ok
 
 
 def test_forward(case, depth_offsets, request):
