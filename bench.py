@@ -247,7 +247,7 @@ def main():
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": round(ms, 4),
-        "timed_region_s": round(dt, 5),
+        "timed_region_s": round(dt, 7),
         "per_rank_iterations_per_s": [round(v, 2) for v in per_rank],
         "higher_is_better": True,
         "scaling": "weak",

@@ -340,7 +340,7 @@ def orientation_maps_device(images, device=None, gabor=None, return_codes=False)
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     gabor = gabor or calOrientationGabor(device=device)
     V = len(images)
-    H, W = np.asarray(images[0]).shape
+    H, W = (int(v) for v in images[0].shape)          # numpy arrays or device tensors (gabor.view takes both)
     local = []
     # views are independent: they rotate over two HIP streams, so that the DoG / finish launches of one view run in the tail of
     # the previous view's bank kernel (1.82 -> 1.79 ms per 1080p view, tools/bench_gabor.py --stage --streams 2)

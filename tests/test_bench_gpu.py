@@ -39,7 +39,7 @@ def test_single_gpu_line_and_rooflines_of_the_timed_kernels():
     for k in d["roofline_kernels"]:
         assert abs(k["algorithmic_bytes_per_launch"] / (k["launch_ms"] * 1e-3) / 1e9 - k["achieved"]) < 1.0
     assert "refine_and_volume_s" in d["secondary_full_pass"]
-    assert d["timed_region_s"] > 0 and abs(d["timed_region_s"] / d["steps"] * 1e3 - d["ms_per_step"]) < 1e-3
+    assert d["timed_region_s"] > 0 and abs(d["timed_region_s"] / d["steps"] * 1e3 - d["ms_per_step"]) < 1e-3 * d["ms_per_step"] + 1e-4
     g = d["secondary_gabor_sharded"]
     assert g["n_gpus"] == 1 and g["views"] == 24 and g["value"] > 0 and g["codes_agree_on_all_ranks"] is True
 

@@ -46,6 +46,8 @@ def loss_strict_mask(n, sub_num=5000):
 def check_refine_files(out, z, prefix, n):
     import scipy.io
 
+    mat = "" if prefix == "ref_" else prefix           # (the main run's voxel arrays carry no prefix in the fixture)
+
     r = {k: np.load(os.path.join(out, "refine", k + ".npy")) for k in
          ("select_p", "select_o", "min_loss", "filter_unvisible", "filter_unvisible_ori")}
     assert len(r["select_o"]) == n
@@ -60,12 +62,12 @@ def check_refine_files(out, z, prefix, n):
     Occ3 = scipy.io.loadmat(os.path.join(out, "refine", "Occ3D.mat"))["Occ"]
     Ori3 = scipy.io.loadmat(os.path.join(out, "refine", "Ori3D.mat"))["Ori"]
     nz = np.argwhere(Occ3 != 0).astype(np.int32)
-    ref_nz = z[prefix + "mat_occ_nz"]
+    ref_nz = z[mat + "mat_occ_nz"]
     a, b = set(map(tuple, nz.tolist())), set(map(tuple, ref_nz.tolist()))
     assert len(a ^ b) <= 0.001 * len(b), (len(a), len(b), len(a ^ b))
     Z = Occ3.shape[2]
     got = np.stack([Ori3[ref_nz[:, 0], ref_nz[:, 1], c * Z + ref_nz[:, 2]] for c in range(3)], 1)
-    vm = np.all(got == z[prefix + "mat_ori_at_nz"], axis=1)
+    vm = np.all(got == z[mat + "mat_ori_at_nz"], axis=1)
     assert vm.mean() >= 0.999, float(vm.mean())
 
 
