@@ -9,7 +9,7 @@ writes `render_depth/<view>.npy` = float32 [H,W,3], value (-z_cam / 2) * 255, ba
 come from a specified HIP rasteriser (no OpenGL context needed) and can stay on the device: `render_depth_planes`
 returns a [V,H,W] tensor that `PMVO.from_planes` / `PMVO.from_u8` take as is.  The rasterisers follow the GL
 specification and are pinned against a real OpenGL implementation (SwiftShader) up to what GL leaves to the driver
-(sub-pixel snapping, interpolation rounding).
+(sub-pixel snapping, interpolation rounding; docs/HISTORY.md §4.9, §4.10).
 """
 import ctypes
 import os

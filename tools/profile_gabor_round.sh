@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-3 profile of the Gabor STAGE (GPU box): kernel trace of `tools/bench_gabor.py --stage`, then PMC passes (each in its
-# own run, --pmc only).  Summaries -> gpurun_out/r03_gabor_*.txt (copied to profiles/ by hand).
+# Per-round profile of the Gabor STAGE (GPU box): kernel trace of `tools/bench_gabor.py --stage`, then PMC passes (each in its
+# own run, --pmc only).  Summaries -> gpurun_out/<tag>_*.txt (copied to profiles/ by hand).
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
-TAG=${TAG:-r03_gabor}
+TAG=${TAG:-r04_gabor}
 mkdir -p $OUT
 cd /tmp
 CMD="python $R/tools/bench_gabor.py --stage --reps 5"
@@ -22,7 +22,7 @@ for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_AN
 done
 python - <<PY > $OUT/${TAG}_summary.txt
 import csv, glob, collections
-print("# Gabor stage, one 1920x1080 view per mh_gabor_view call (tools/profile_gabor_r03.sh); per-launch averages")
+print("# Gabor stage, one 1920x1080 view per mh_gabor_view call (tools/profile_gabor_round.sh); per-launch averages")
 for f in sorted(glob.glob("$OUT/${TAG}_trace/**/*kernel_stats.csv", recursive=True)):
     print("## kernel trace (rocprofv3 --kernel-trace --stats)")
     for r in csv.DictReader(open(f)):

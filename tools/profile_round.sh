@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round-3 profile of one bench.py regime on the GPU box:   bash tools/profile_r03.sh <tag> "<bench args>" "<kernel regex>"
-#   e.g.  bash tools/profile_r03.sh r03_8bit "--codes" "mh_project_taps|mh_topk|mh_search"
+# Per-round profile of one bench.py regime on the GPU box:   bash tools/profile_round.sh <tag> "<bench args>" "<kernel regex>"
+#   e.g.  bash tools/profile_round.sh r04_8bit "--codes" "mh_project_taps|mh_topk|mh_search"
 # One rocprofv3 kernel trace (ONE HIP stream: kernels do not overlap, durations are per kernel) and PMC passes, each its
 # own run with --pmc only.  Summary -> gpurun_out/<tag>_summary.txt (copy into profiles/).
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
-TAG=${1:-r03}
+TAG=${1:-r04}
 ARGS=${2:-}
 RX=${3:-"mh_project_taps|mh_project_gather|mh_topk|mh_search"}
 mkdir -p $OUT
@@ -28,7 +28,7 @@ for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_AN
 done
 python - <<PY > $OUT/${TAG}_summary.txt
 import csv, glob, collections
-print("# $TAG: rocprofv3 of \`$CMD\` (tools/profile_r03.sh); MI355X, ONE HIP stream; per-launch averages")
+print("# $TAG: rocprofv3 of \`$CMD\` (tools/profile_round.sh); MI355X, ONE HIP stream; per-launch averages")
 for f in sorted(glob.glob("$OUT/${TAG}_trace/**/*kernel_stats.csv", recursive=True)):
     print("## kernel trace (rocprofv3 --kernel-trace --stats)")
     print("kernel,calls,avg_us,min_us,max_us,pct")

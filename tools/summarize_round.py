@@ -1,15 +1,18 @@
 #!/usr/bin/env python
-"""Copy the round-3 rocprofv3 summaries (tools/profile_r03.sh, tools/profile_gabor_r03.sh -> gpurun_out/<tag>_summary.txt) into
+"""Copy a round's rocprofv3 summaries (tools/profile_round.sh, tools/profile_gabor_round.sh -> gpurun_out/<tag>_summary.txt) into
 profiles/ and rebuild profiles/traffic.json (what bench.py reports as roofline*.traffic / mfma_busy / valu_issue) from them.
 FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled for kernels that read 16 bytes per lane (the record gathers), as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950; kernels that read 2-8 bytes per lane are taken as reported
 (uncalibrated widths, stated in the summary).
-    python tools/summarize_r03.py            # after the three profile scripts have run on the GPU box"""
+    python tools/summarize_round.py r04      # after the three profile scripts have run on the GPU box with tags r04_*"""
 import collections
 import json
 import os
 import re
 import shutil
+import sys
+
+RND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC, DST = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
@@ -40,15 +43,15 @@ def find(d, prefix):
     return next((k for k in d if k.replace("void ", "").startswith(prefix)), None)
 
 
-facts = {"_comment": "facts from rocprofv3 passes (tools/profile_r03.sh, tools/profile_gabor_r03.sh -> tools/summarize_r03.py; "
-                     "profiles/r03_*_summary.txt); FETCH_SIZE / WRITE_SIZE in KiB * 1024, FETCH_SIZE doubled for the kernels "
+facts = {"_comment": "facts from rocprofv3 passes (tools/profile_round.sh, tools/profile_gabor_round.sh -> tools/summarize_round.py; "
+                     "profiles/%s_*_summary.txt)" % RND + "; FETCH_SIZE / WRITE_SIZE in KiB * 1024, FETCH_SIZE doubled for the kernels "
                      "that read 16 B per lane (MI355X_MICROARCH.md)",
-         "round": 3, "workload": "60 views @ 1920x1080, 5000 points, patch 7"}
+         "round": int(RND[1:]), "workload": "60 views @ 1920x1080, 5000 points, patch 7"}
 notes = []
-for tag, pre, kernels in (("r03_main", "", (("mh_project_gather_kernel<7>", "mh_project_gather_kernel<7", 2),
+for tag, pre, kernels in ((RND + "_main", "", (("mh_project_gather_kernel<7>", "mh_project_gather_kernel<7", 2),
                                             ("mh_project_taps_kernel<7>", "mh_project_taps2_kernel<7", 2),
                                             ("mh_search3_kernel<256>", "mh_search3_kernel<256", 2))),
-                          ("r03_8bit", "8bit:", (("mh_project_taps_kernel<7>", "mh_project_taps_codes_kernel<7", 1),
+                          (RND + "_8bit", "8bit:", (("mh_project_taps_kernel<7>", "mh_project_taps_codes_kernel<7", 1),
                                                  ("mh_project_gather_kernel<7>", "mh_project_gather_kernel<7", 2),
                                                  ("mh_search3_kernel<256>", "mh_search3_kernel<256", 2)))):
     path, dur, pmc = parse(tag)
@@ -76,9 +79,9 @@ for tag, pre, kernels in (("r03_main", "", (("mh_project_gather_kernel<7>", "mh_
             "launch_us": round(t_us, 1), "ns_per_valu_instruction_per_simd": round(per, 3),
             "note": "the tap body's own rate, all SIMDs busy, is 1.02 ns per instruction (tools/ubench/valu3.hip); the ratio "
                     "is the kernel's VALU issue utilisation", "valu_issue_utilisation": round(1.02 / per, 3)}
-path, dur, pmc = parse("r03_gabor")
+path, dur, pmc = parse(RND + "_gabor")
 if path is not None:
-    shutil.copy(path, os.path.join(DST, "r03_gabor_summary.txt"))
+    shutil.copy(path, os.path.join(DST, RND + "_gabor_summary.txt"))
     tot = 0.0
     per = {}
     for name in ("mh_dog_vert_kernel", "mh_dog_horz_kernel", "mh_gabor_mfma2_kernel", "mh_gabor_finish_kernel"):
