@@ -316,6 +316,22 @@ def refine_loop(views, points, ori, loss, patch, thr, vis_thr, scalp_tree, scalp
     return ori, loss
 
 
+def shell_orientations(views, select_points, select_ori, shell_points, patch, thr, vis_thr, scalp_tree, scalp_max, k=100,
+                       workers=-1):
+    """Orientations for the occluded shell points (PMVO.py:655-691): medoid of the k nearest KEPT surface points (scipy's
+    order), minus the points the head filter removes.  The reference walks the shell points in chunks of 5000; they are
+    independent of each other, so one pass gives the same rows.  -> (kept shell points [M,3] float32, orientations [M,3])."""
+    from scipy.spatial import KDTree
+
+    tree = KDTree(data=select_points)
+    _, index = tree.query(shell_points, min(k, len(select_points)), workers=workers)
+    centre, _ = medoid_dense(np.asarray(select_ori, np.float32)[np.asarray(index).reshape(len(shell_points), -1)])
+    sub = np.ascontiguousarray(shell_points, np.float32)
+    votes = filter_votes(views, sub, patch, thr, vis_thr)[3]
+    filt = votes & ~head_top_mask(sub, scalp_tree, scalp_max)
+    return sub[~filt], centre[~filt]
+
+
 def p2v(points, voxel_min, voxel_size, grid_resolution):
     """p2v (PMVO_utils.py:386-404): flips y,z IN PLACE, float64 round-half-even, clip."""
     points[:, 1:] *= -1

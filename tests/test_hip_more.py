@@ -148,10 +148,10 @@ def test_gabor_vs_oracle_and_golden():
             assert np.array_equal(idx.cpu().numpy(), o_idx), (name, variant)                 # exact vs oracle
             assert np.array_equal(var.cpu().numpy(), o_var), (name, variant)
             assert np.array_equal(c2.cpu().numpy(), o_conf), (name, variant)
-            agree = best[0, 0].cpu().numpy() == ref_best                          # radians, bitwise
-            assert agree.mean() >= 0.999, (name, variant, agree.mean())
-            assert np.allclose(conf[0, 0].cpu().numpy()[agree], ref_conf[agree], rtol=0, atol=1e-6)
-            assert np.array_equal(two[0].cpu().numpy()[:, agree], ref_two[:, agree])
+            assert np.array_equal(best[0, 0].cpu().numpy(), ref_best), (name, variant)    # radians, bitwise, every pixel
+            cf = conf[0, 0].cpu().numpy()
+            assert np.allclose(cf, ref_conf, rtol=0, atol=1.2e-7) and (cf == ref_conf).mean() >= 0.998   # <= 1 ulp, rarely
+            assert np.array_equal(two[0].cpu().numpy(), ref_two)
             assert two.shape == (1, 2) + img.shape and best.shape == (1, 1) + img.shape
     gab.set_variant("mfma2")
     # the iterated form with a confidence threshold (forward(..., iter=2, threshold=0.3)) and the class's own
@@ -244,7 +244,7 @@ def test_drivers_end_to_end_vs_reference(tmp_path):
     assert np.allclose(r["min_loss"], z["ref_min_loss"], rtol=0, atol=2e-7, equal_nan=True)
     assert np.array_equal(r["filter_unvisible"], z["ref_filter_unvisible"])
     fm = np.all(r["filter_unvisible_ori"] == z["ref_filter_unvisible_ori"], axis=1)
-    assert fm.mean() >= 0.999
+    assert fm.all(), fm.mean()
 
     Ori3 = scipy.io.loadmat(os.path.join(args.save_path, "Ori3D.mat"))["Ori"]
     Occ3 = scipy.io.loadmat(os.path.join(args.save_path, "Occ3D.mat"))["Occ"]
@@ -254,11 +254,11 @@ def test_drivers_end_to_end_vs_reference(tmp_path):
     ref_nz = z["mat_occ_nz"]
     a = set(map(tuple, nz.tolist()))
     b = set(map(tuple, ref_nz.tolist()))
-    assert len(a ^ b) <= 0.001 * len(b), (len(a), len(b), len(a ^ b))        # same occupied voxels
+    assert a == b, (len(a), len(b), len(a ^ b))        # same occupied voxels
     Z = Occ3.shape[2]
     got_o = np.stack([Ori3[ref_nz[:, 0], ref_nz[:, 1], c * Z + ref_nz[:, 2]] for c in range(3)], 1)
     vm = np.all(got_o == z["mat_ori_at_nz"], axis=1)
-    assert vm.mean() >= 0.999, vm.mean()
+    assert vm.all(), vm.mean()
     # the consumer's readers (HairGrow.py:41-55) see the documented shapes
     assert get_ground_truth_3D_occ(os.path.join(args.save_path, "Occ3D.mat")).shape == (192, 256, 256, 1)
     assert get_ground_truth_3D_ori(os.path.join(args.save_path, "Ori3D.mat")).shape == (192, 256, 256, 3)

@@ -1,4 +1,4 @@
-"""GPU: a short, fixed-seed run of the randomised sweeps (tests/stress_parity.py, tests/stress_more.py; run them for
+"""GPU: a short, fixed-seed run of the randomised sweeps (tests/stress_parity.py, tests/stress_more.py, tests/stress_refine.py; run them for
 minutes with other seeds when kernels change)."""
 import os
 import subprocess
@@ -11,7 +11,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("script,seed", [("stress_parity.py", 5), ("stress_more.py", 6)])
+@pytest.mark.parametrize("script,seed", [("stress_parity.py", 5), ("stress_more.py", 6), ("stress_refine.py", 7)])
 def test_short_sweep(script, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", script), "--minutes", "0.2", "--seed", str(seed)],
                        cwd=ROOT, capture_output=True, text=True, timeout=600)
