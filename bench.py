@@ -341,6 +341,16 @@ def main():
             raise                        # the timed kernels did not produce the oracle's bits: no line at all
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)[:200]}
+    if world > 1 and not a.no_cpu and scene is not None:
+        # N > 1: no CPU baseline leg, but the line still verifies itself -- rank 0's last timed step against the oracle on a
+        # bounded sample of its chunk (512 points: a fraction of a second of host time)
+        try:
+            out["parity_check"] = parity_check(a, scene, recs, last_chunk, last, min(512, len(last_chunk)))
+            out["parity_check"]["rank"] = 0
+        except ParityError:
+            raise
+        except Exception as e:
+            out["parity_check"] = {"error": repr(e)[:200]}
     em.emit(out)
     if dist is not None:
         dist.destroy_process_group()
@@ -917,6 +927,35 @@ class ParityError(AssertionError):
     pass
 
 
+def compare_with_oracle(gpu_result, o_res, n):
+    """(orientation, loss, high-confidence flag) of a timed step vs oracle.forward on the same points -> the line's
+    `parity_check` object; raises ParityError on any differing bit."""
+    import numpy as np
+
+    _, g_ori, g_loss, g_hc = gpu_result
+    g_ori, g_loss, g_hc = g_ori[:n].cpu().numpy(), g_loss[:n].cpu().numpy(), g_hc[:n].cpu().numpy()
+    _, o_ori, o_loss, o_hc = o_res
+    exact = (np.array_equal(g_ori, o_ori, equal_nan=True) and np.array_equal(g_loss, o_loss, equal_nan=True)
+             and np.array_equal(g_hc, o_hc))
+    parity = {"points": int(n), "bit_exact": bool(exact), "finite_losses": int(np.isfinite(o_loss).sum()),
+              "what": "(orientation, loss, high-confidence flag) returned by the LAST step of the timed region == "
+                      "oracle.forward on the same chunk, compared in this run"}
+    if not exact:
+        bad = int((~((g_loss == o_loss) | (np.isnan(g_loss) & np.isnan(o_loss)))).sum())
+        raise ParityError("bench.py: the timed step's outputs differ from the CPU oracle on %d of %d points" % (bad, n))
+    return parity
+
+
+def parity_check(a, scene, recs, chunk, gpu_result, n):
+    """the self-check of the line without the timed CPU leg (N > 1): oracle.forward on the first n points of the chunk"""
+    import oracle
+    from monohair_amd.pmvo import depth_offsets
+
+    views = oracle.Views(recs, scene["depth"].cpu().numpy(), scene["ori"].cpu().numpy(),
+                         scene["conf"].cpu().numpy(), scene["mask"].cpu().numpy())
+    return compare_with_oracle(gpu_result, oracle.forward(views, chunk[:n], a.patch, a.conf_threshold, depth_offsets(90)), n)
+
+
 def cpu_baseline(a, scene, recs, chunk, gpu_ms, gpu_result):
     """The CPU oracle (oracle/pmvo_oracle.c, OpenMP over points) timed on this host on a bounded sample of the
     same iteration: the first n points of the chunk against all views.  `chunk` is the chunk the LAST step of the timed
@@ -939,17 +978,7 @@ def cpu_baseline(a, scene, recs, chunk, gpu_ms, gpu_result):
         o_res = oracle.forward(views, chunk[:n], a.patch, a.conf_threshold, offs)
         t += time.perf_counter() - t0
         reps += 1
-    _, g_ori, g_loss, g_hc = gpu_result
-    g_ori, g_loss, g_hc = g_ori[:n].cpu().numpy(), g_loss[:n].cpu().numpy(), g_hc[:n].cpu().numpy()
-    _, o_ori, o_loss, o_hc = o_res
-    exact = (np.array_equal(g_ori, o_ori, equal_nan=True) and np.array_equal(g_loss, o_loss, equal_nan=True)
-             and np.array_equal(g_hc, o_hc))
-    parity = {"points": int(n), "bit_exact": bool(exact), "finite_losses": int(np.isfinite(o_loss).sum()),
-              "what": "(orientation, loss, high-confidence flag) returned by the LAST step of the timed region == "
-                      "oracle.forward on the same chunk, compared in this run"}
-    if not exact:
-        bad = int((~((g_loss == o_loss) | (np.isnan(g_loss) & np.isnan(o_loss)))).sum())
-        raise ParityError("bench.py: the timed step's outputs differ from the CPU oracle on %d of %d points" % (bad, n))
+    parity = compare_with_oracle(gpu_result, o_res, n)
     n_total = n * reps
     its = (n_total / float(CHUNK)) / t
     return {

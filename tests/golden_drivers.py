@@ -3,7 +3,7 @@ reference's own chunked run (tests/golden/e2e_multichunk.npz) and leave the outp
 them with the reference's files -- in this process, or as N ranks under torch.distributed.run (gloo ranks sharing the test GPU,
 as tests/test_cli_gpu.py does; MH_REFINE_SHARD=1 shards the smoothing loop).
 
-    python tests/golden_drivers.py --out DIR [--what optimize,refine,refine_exact]
+    python tests/golden_drivers.py --out DIR [--what optimize,optimize_exact,refine,refine_exact]
 """
 import argparse
 import ast
@@ -47,6 +47,9 @@ def run(out_dir, what=("optimize", "refine", "refine_exact"), device="cuda:0"):
     if "optimize" in what:
         # the surface points exactly as the reference's optimize received them (float32 rows of filter_negative_points)
         optimize(z["opt_select_p"].copy(), pm, args_for("run"))
+    if "optimize_exact" in what:
+        # exactly 10 000 points: `step = N // 5000 + 1` (PMVO.py:566) gives a third chunk of zero points
+        optimize(z["opt_select_p"][:meta["exact"]].copy(), pm, args_for("exact"))
     if "refine" in what:
         # from the REFERENCE's optimize outputs, so that both refine stages see identical inputs
         refine(z["opt_select_p"].copy(), z["opt_select_o"].copy(), z["opt_min_loss"].copy(), pm, fu.copy(), args_for("run"),

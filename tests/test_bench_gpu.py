@@ -14,6 +14,7 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 SMALL = ["--steps", "3", "--warmup", "1", "--views", "24", "--height", "240", "--width", "136", "--volume", "48",
          "--patch", "3", "--no-cpu"]
+SMALL_CPU = [x for x in SMALL if x != "--no-cpu"]
 
 
 def run_bench(args, env=None):
@@ -56,8 +57,9 @@ def test_line_verifies_its_own_outputs_against_the_oracle():
 
 
 def test_gpus_2_spawns_two_ranks_itself():
-    d = run_bench(["--gpus", "2"] + SMALL, env={"MH_DIST_BACKEND": "gloo", "MH_DEVICE_OVERRIDE": "0"})
+    d = run_bench(["--gpus", "2"] + SMALL_CPU, env={"MH_DIST_BACKEND": "gloo", "MH_DEVICE_OVERRIDE": "0"})
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo"
+    assert d["parity_check"]["bit_exact"] is True and d["parity_check"]["points"] > 0 and "cpu_baseline" not in d
     assert d["secondary_full_pass"]["ranks"] == 2 and "total_s" in d["secondary_full_pass"]
     assert len(d["per_rank_iterations_per_s"]) == 2 and min(d["per_rank_iterations_per_s"]) > 0
     g = d["secondary_gabor_sharded"]

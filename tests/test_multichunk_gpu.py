@@ -108,7 +108,7 @@ def test_optimize_four_chunks_equals_the_reference(tmp_path, ranks):
     equals the reference's answer in the doubled-chunk composition, and rows that differ from its four-chunk files are rows on
     which the reference disagrees with itself (MKL's batch-size-dependent gemm)."""
     z, meta = golden()
-    run_helper(tmp_path, "optimize", ranks=ranks, port=29610 + ranks)
+    run_helper(tmp_path, "optimize,optimize_exact", ranks=ranks, port=29610 + ranks)
     got = {k: np.load(os.path.join(tmp_path, "run", "optimize", k + ".npy")) for k in
            ("select_p", "select_o", "min_loss", "high_conf_index")}
     assert got["select_p"].dtype == np.float32 and got["high_conf_index"].dtype == np.bool_
@@ -118,3 +118,11 @@ def test_optimize_four_chunks_equals_the_reference(tmp_path, ranks):
         (z["opt_select_o"], z["opt_min_loss"], z["opt_high_conf_index"]),
         [(z["optrec_select_o"], z["optrec_min_loss"], z["optrec_high_conf_index"])])
     assert st["rows"] == 16901
+    # exactly 10 000 points: the reference walks a third, empty chunk and writes the prefix of the four-chunk run
+    # (recorded: exact_opt_raised == '', exact_opt_equal_prefix); so do we
+    assert str(z["exact_opt_raised"]) == "" and bool(z["exact_opt_equal_prefix"])
+    n = meta["exact"]
+    ex = {k: np.load(os.path.join(tmp_path, "exact", "optimize", k + ".npy")) for k in
+          ("select_p", "select_o", "min_loss", "high_conf_index")}
+    for k in ex:
+        assert len(ex[k]) == n and np.array_equal(ex[k], got[k][:n], equal_nan=(k != "high_conf_index")), k
