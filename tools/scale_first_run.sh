@@ -4,6 +4,8 @@
 # script is what to run, in order, the first time real RCCL over xGMI is there; it stops at the first failure.
 #
 #   bash tools/scale_first_run.sh [OUT_DIR]            (from the repo root; ~10 minutes on 8 GPUs)
+#   DRY=1 bash tools/scale_first_run.sh [OUT_DIR]      rehearsal on a ONE-GPU box: 2 gloo ranks share the GPU, step 1 is skipped,
+#                                                      the bench runs at a toy size -- checks this script, measures nothing
 #
 #   1. the real 2-GPU exchange test            tests/test_volume_reduce_gpu.py (skipped on < 2 GPUs until now)
 #   2. PMVO.py, N ranks, MH_VOLUME_EXCHANGE=torch and =capi, against the 1-rank files -- bit for bit
@@ -18,12 +20,26 @@ mkdir -p "$OUT"
 export PYTHONPATH=$ROOT HSA_ENABLE_IPC_MODE_LEGACY=${HSA_ENABLE_IPC_MODE_LEGACY:-0}
 NG=$(python -c 'import torch; print(torch.cuda.device_count())')
 echo "== $NG GPU(s) visible"
-if [ "$NG" -lt 2 ]; then echo "needs >= 2 GPUs"; exit 2; fi
+DRY=${DRY:-0}
+BENCH_ARGS="--steps 100 --warmup 5"
+BENCH_NS="1 2 4 8"
+EXCHANGES="torch capi"
+if [ "$DRY" = "1" ]; then
+  echo "== DRY RUN: 2 gloo ranks sharing GPU 0; nothing printed below is a measurement"
+  export MH_DIST_BACKEND=gloo MH_DEVICE_OVERRIDE=0 MH_REFINE_SHARD=1
+  NG=2
+  BENCH_ARGS="--steps 3 --warmup 1 --views 24 --height 240 --width 136 --volume 48 --patch 3"
+  BENCH_NS="1 2"
+  EXCHANGES="torch"          # (capi needs either real RCCL on two devices or MH_RCCL_LIB=tests/lib/libfake_rccl.so)
+fi
+if [ "$NG" -lt 2 ]; then echo "needs >= 2 GPUs (or DRY=1)"; exit 2; fi
 NR=$(( NG >= 8 ? 8 : (NG >= 4 ? 4 : 2) ))
 TR="python -m torch.distributed.run --nnodes=1 --master-addr 127.0.0.1"
 
+if [ "$DRY" != "1" ]; then
 echo "== 1. real 2-GPU slab gather / dense reduce through the C ABI"
 python -m pytest tests/test_volume_reduce_gpu.py -x -q -m gpu 2>&1 | tee "$OUT/1_volume_reduce.log" | tail -3
+fi
 
 echo "== 2. PMVO.py: $NR ranks vs 1 rank, both exchanges"
 DATA=$OUT/data
@@ -34,7 +50,7 @@ PY
 COMMON="--yaml=configs/reconstruct/synthetic_sphere --data.root=$DATA --data.image_size=[480,270] --PMVO.patch_size=5"
 python PMVO.py $COMMON --name=one > "$OUT/2_one.log" 2>&1
 PORT=29800
-for EX in torch capi; do
+for EX in $EXCHANGES; do
   PORT=$((PORT+1))
   MH_VOLUME_EXCHANGE=$EX $TR --nproc-per-node $NR --master-port $PORT PMVO.py $COMMON --name=many_$EX > "$OUT/2_many_$EX.log" 2>&1
   python - <<PY
@@ -52,7 +68,7 @@ print("   $NR ranks, MH_VOLUME_EXCHANGE=$EX: every file equals the 1-rank run bi
 PY
 done
 
-echo "== 3. view-sharded Gabor stage: $NR ranks (nccl) vs 1 rank"
+echo "== 3. view-sharded Gabor stage: $NR ranks (${MH_DIST_BACKEND:-nccl}) vs 1 rank"
 python tests/gabor_ranks_helper.py --out "$OUT/gabor_one" --views 13 > "$OUT/3_one.log" 2>&1
 $TR --nproc-per-node $NR --master-port 29811 tests/gabor_ranks_helper.py --out "$OUT/gabor_many" --views 13 > "$OUT/3_many.log" 2>&1
 python - <<PY
@@ -79,9 +95,9 @@ print("   equal to the reference's refine/*.npy (tests/golden/e2e_multichunk.npz
 PY
 
 echo "== 5. bench.py --gpus 1/2/4/8"
-for N in 1 2 4 8; do
+for N in $BENCH_NS; do
   if [ "$N" -le "$NG" ]; then
-    python bench.py --gpus $N --steps 100 --warmup 5 2> "$OUT/5_bench_$N.err" | grep '^{' > "$OUT/5_bench_$N.json"
+    python bench.py --gpus $N $BENCH_ARGS 2> "$OUT/5_bench_$N.err" | grep '^{' > "$OUT/5_bench_$N.json"
   fi
 done
 python - <<PY
@@ -100,6 +116,8 @@ for n, d in rows.items():
     print("   %d  %8.1f  %5.2f   >= %4.2f    %10s   %12s   %s" % (
         n, d["value"], d["value"] / base, 0.975 * n, fp.get("steady_total_s", fp.get("total_s", "-")),
         g.get("value", "-"), vr.get("slab_gather_torch_ms", "-")))
+    pc = d.get("parity_check", {})
+    assert pc.get("bit_exact") is True, ("bench line of N=%d did not verify its outputs" % n, pc)
 print("   expectations (DESIGN.md §8): iterations/s >= 7.8x at 8 GPUs (no collective inside an iteration); the full pass "
       "~3.8x (Amdahl: k-NN build, .npy/.mat writes on rank 0); Gabor stage ~N x minus one 249 MB all_gather")
 PY
