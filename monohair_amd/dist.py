@@ -97,12 +97,12 @@ def all_gather_views(local, n_views, shape, dtype, device):
     buf = torch.zeros((cap,) + tuple(shape), dtype=dtype, device=cdev)
     for j, t in enumerate(local):
         buf[j] = t.to(cdev)
-    gathered = [torch.empty_like(buf) for _ in range(w)]
-    d.all_gather(gathered, buf)
-    out = torch.empty((n_views,) + tuple(shape), dtype=dtype, device=device)
-    for i in range(n_views):
-        out[i] = gathered[owner(i, w)][i // w].to(device)
-    return out
+    # one flat receive buffer [w, cap, *shape] (all_gather_into_tensor: no per-rank tensor list, no flatten copy inside the
+    # backend); view i sits at row (i % w) * cap + i // w
+    gathered = torch.empty((w * cap,) + tuple(shape), dtype=dtype, device=cdev)      # (the concatenated form: both backends take it)
+    d.all_gather_into_tensor(gathered, buf)
+    idx = torch.arange(n_views, device=cdev)
+    return gathered[(idx % w) * cap + idx // w].to(device)
 
 
 def refine_sharded():

@@ -3,7 +3,7 @@ reference's own chunked run (tests/golden/e2e_multichunk.npz) and leave the outp
 them with the reference's files -- in this process, or as N ranks under torch.distributed.run (gloo ranks sharing the test GPU,
 as tests/test_cli_gpu.py does; MH_REFINE_SHARD=1 shards the smoothing loop).
 
-    python tests/golden_drivers.py --out DIR [--what optimize,optimize_exact,refine,refine_exact]
+    python tests/golden_drivers.py --out DIR [--what optimize,optimize_exact,refine,refine_exact,refine_headfilter]
 """
 import argparse
 import ast
@@ -59,6 +59,11 @@ def run(out_dir, what=("optimize", "refine", "refine_exact"), device="cuda:0"):
         refine(z["opt_select_p"][:n].copy(), z["opt_select_o"][:n].copy(), z["opt_min_loss"][:n].copy(), pm, fu[:3000].copy(),
                args_for("exact"), infer_inner=False, threshold=meta["threshold"], genrate_ori_only=False,
                return_dense=False)
+    if "refine_headfilter" in what:
+        # tests/golden/e2e_headfilter.npz: a third of the points head-filtered, 40 NaN rows (tools/gen_golden_headfilter.py)
+        h = np.load(os.path.join(GOLDEN, "e2e_headfilter.npz"), allow_pickle=False)
+        refine(h["in_points"].copy(), h["in_ori"].copy(), h["in_loss"].copy(), pm, h["in_shell"].copy(), args_for("headfilter"),
+               infer_inner=False, threshold=meta["threshold"], genrate_ori_only=False, return_dense=False)
     torch.cuda.synchronize()
 
 

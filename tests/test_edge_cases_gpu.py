@@ -297,3 +297,31 @@ def test_upload_ring_wraps_and_changes_size_with_many_calls_in_flight():
     L = _lib.lib()
     assert L.mh_upload_async(pm._ctx, None, None, 16, None) != 0 and b"mh_upload_async" in L.mh_last_error()
     assert L.mh_upload_async(pm._ctx, None, None, 0, None) == 0
+
+
+@pytest.mark.parametrize("N", [0, 29, 59, 3000, 3001])
+def test_filter_negative_points_chunking_quirks(N, tmp_path):
+    """filter_negative_points (PMVO.py:535-557, SURVEY App. A.14) walks `step` = 30 or 31 pieces of N // 30 points: with N < 30
+    every piece is empty (nothing is covered), with N = 59 only the first 31 points are looked at, with N a multiple of 30
+    there are exactly 30 pieces.  The masks returned cover what the reference covers, and equal the oracle's votes there."""
+    import types
+
+    from monohair_amd import synth
+    from monohair_amd.pmvo import filter_negative_points
+
+    scene, pm, views = build(24, 120, 90, 3)
+    cand = synth.candidate_points(res=32, seed=3)
+    scale = np.ones(len(cand))
+    scale[::3], scale[1::3] = 1.05, 0.93                       # surface, outside and inside points
+    pts = (cand * scale[:, None])[:N]
+    args = types.SimpleNamespace(device=DEV)
+    surf, spts, filt = filter_negative_points(pts, pm, args)
+    step = 30 if N % 30 == 0 else 31
+    covered = min(N, step * (N // 30))
+    assert len(surf) == covered and len(filt) == covered and surf.dtype == np.bool_ and filt.dtype == np.bool_
+    assert spts.dtype == np.float32 and spts.shape == (int(surf.sum()), 3)
+    if covered:
+        o_s, o_f, _, _ = oracle.filter_votes(views, pts[:covered], 3, 0.15, 1.0)
+        assert np.array_equal(surf, o_s) and np.array_equal(filt, o_f)
+        assert np.array_equal(spts, pts[:covered][o_s].astype(np.float32))
+        assert 0 < o_s.sum() < covered or covered < 40

@@ -126,3 +126,24 @@ def test_optimize_four_chunks_equals_the_reference(tmp_path, ranks):
           ("select_p", "select_o", "min_loss", "high_conf_index")}
     for k in ex:
         assert len(ex[k]) == n and np.array_equal(ex[k], got[k][:n], equal_nan=(k != "high_conf_index")), k
+
+
+@pytest.mark.parametrize("form,ranks", [("chain", 1), ("four_launch", 1), ("sharded", 2)])
+def test_refine_head_filtered_and_nan_rows_equal_the_reference(tmp_path, form, ranks):
+    """tests/golden/e2e_headfilter.npz: 6000 points (two chunks), a third head-filtered (loss -1 -> 0.5, PMVO.py:91-92,639),
+    40 rows of NaN orientation / loss among the inputs -- the reference's files, in every form of the loop."""
+    z = np.load(os.path.join(GOLDEN, "e2e_headfilter.npz"), allow_pickle=False)
+    env = {"MH_REFINE_CHAIN": "0" if form == "four_launch" else "1"}
+    if ranks > 1:
+        env["MH_REFINE_SHARD"] = "1"
+    run_helper(tmp_path, "refine_headfilter", ranks=ranks, env_extra=env, port=29640)
+    out = os.path.join(tmp_path, "headfilter", "refine")
+    got_o, got_l = np.load(os.path.join(out, "select_o.npy")), np.load(os.path.join(out, "min_loss.npy"))
+    ref_o, ref_l = z["ref_select_o"], z["ref_min_loss"]
+    assert same_rows(got_o, ref_o).all()
+    lm = same_rows(got_l, ref_l)
+    assert lm[loss_strict_mask(len(ref_l))].all() and np.allclose(got_l, ref_l, rtol=0, atol=2e-7, equal_nan=True)
+    assert np.array_equal(got_l == 0.5, ref_l == 0.5) and (ref_l == 0.5).sum() == 2000
+    assert np.array_equal(np.isnan(got_l), np.isnan(ref_l)) and np.isnan(ref_l).sum() > 0
+    assert np.array_equal(np.load(os.path.join(out, "filter_unvisible.npy")), z["ref_filter_unvisible"])
+    assert np.array_equal(np.load(os.path.join(out, "filter_unvisible_ori.npy")), z["ref_filter_unvisible_ori"], equal_nan=True)

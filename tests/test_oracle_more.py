@@ -277,3 +277,29 @@ def test_shell_points_and_volume_multichunk_vs_reference(multichunk):
     Z = occ_l.shape[2]
     got = np.stack([ori_l[nz[:, 0], nz[:, 1], c * Z + nz[:, 2]] for c in range(3)], 1)
     assert np.array_equal(got, z["mat_ori_at_nz"])
+
+
+def test_refine_loop_head_filter_and_nan_rows_vs_reference(multichunk):
+    """tests/golden/e2e_headfilter.npz (tools/gen_golden_headfilter.py): the reference's smoothing loop on 6000 points (two
+    chunks) of which a third are head-filtered (PMVO.py:91-92: loss -1, then 0.5 at :639) and 40 carry NaN orientations / losses
+    that enter their neighbours' medoids as NaN cosines.  Every orientation (NaN == NaN) and every loss outside the per-chunk
+    N-mod-64 tails, bit for bit; the shell stage behind it as well."""
+    meta, _, views = multichunk
+    z = load_npz("e2e_headfilter")
+    zz = load_npz("e2e_multichunk")
+    scalp = zz["toy_scalp"]
+    pts, ori, loss = z["in_points"], z["in_ori"].copy(), z["in_loss"].copy()
+    trace = []
+    oracle.refine_loop(views, pts, ori, loss, meta["patch"], meta["thr"], meta["vis_thr"], KDTree(data=scalp),
+                       np.max(scalp, axis=0), trace=trace)
+    ref_o, ref_l = z["ref_select_o"], z["ref_min_loss"]
+    assert (ref_l[:5000] == 0.5).sum() == 1667 and (ref_l[5000:] == 0.5).sum() == 333 and np.isnan(ref_l).sum() > 0
+    om = np.all((ori == ref_o) | (np.isnan(ori) & np.isnan(ref_o)), axis=1)
+    assert om.all(), (float(om.mean()), np.flatnonzero(~om)[:10])
+    loss_rows_equal(loss, ref_l)
+    assert np.array_equal(loss == 0.5, ref_l == 0.5) and np.array_equal(np.isnan(loss), np.isnan(ref_l))
+    keep = np.where(ref_l < meta["threshold"])[0]
+    kept, sori = oracle.shell_orientations(views, z["ref_select_p"][keep], ref_o[keep], z["in_shell"], meta["patch"],
+                                           meta["thr"], meta["vis_thr"], KDTree(data=scalp), np.max(scalp, axis=0))
+    assert np.array_equal(kept, z["ref_filter_unvisible"])
+    assert np.array_equal(sori, z["ref_filter_unvisible_ori"], equal_nan=True)
