@@ -430,14 +430,17 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=False):
     t_topk = sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(reps, 2 * reps)) / reps
     t_search = sum(ev[k][2].elapsed_time(ev[k][3]) for k in range(reps, 2 * reps)) / reps
     # API form with materialised patches, rotating chunks as well
-    pm.Compute_Visible_and_Ori(dchunks[0])
+    # (eight chunks spread over the pass: every call materialises 365 MB of patch tensors, and walking 57 of them through
+    # fresh allocations measures the allocator's cold pages -- 0.21 ms -- not the kernel)
+    gchunks = [dchunks[(i * reps) // 8] for i in range(min(8, reps))]
+    pm.Compute_Visible_and_Ori(gchunks[0])
     torch.cuda.synchronize()
     e[0].record()
-    for p in dchunks:
+    for p in gchunks:
         pm.Compute_Visible_and_Ori(p)
     e[1].record()
     torch.cuda.synchronize()
-    t_pg = e[0].elapsed_time(e[1]) / reps
+    t_pg = e[0].elapsed_time(e[1]) / len(gchunks)
 
     nominal = 10 * V * N * 90 * P
     tf = pairs * FLOP_PER_PAIR / (t_search * 1e-3) / 1e12
@@ -481,7 +484,7 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=False):
              "traffic": prof.get("traffic", {}).get(pre + "mh_project_gather_kernel<%d>" % a.patch),
              "traffic_source": prof.get("source"),
              "note": "the API form of Compute_Visible_and_Ori (patch tensors materialised, SURVEY.md §8d byte count); "
-                     "forward() uses mh_project_taps_kernel instead; launches rotate over %d chunks" % reps},
+                     "forward() uses mh_project_taps2_kernel instead; launches rotate over %d chunks" % len(gchunks)},
         ],
         "kernels_ms": {"project_taps": round(t_taps, 4), "topk": round(t_topk, 4),
                        "order+search": round(t_search, 4), "project_gather_api_kernel": round(t_pg, 4)},
