@@ -345,7 +345,7 @@ def main():
         # N > 1: no CPU baseline leg, but the line still verifies itself -- rank 0's last timed step against the oracle on a
         # bounded sample of its chunk (512 points: a fraction of a second of host time)
         try:
-            out["parity_check"] = parity_check(a, scene, recs, last_chunk, last, min(512, len(last_chunk)))
+            _, out["parity_check"] = cpu_baseline(a, scene, recs, last_chunk, ms, last, check_only=512)
             out["parity_check"]["rank"] = 0
         except ParityError:
             raise
@@ -950,21 +950,13 @@ def compare_with_oracle(gpu_result, o_res, n):
     return parity
 
 
-def parity_check(a, scene, recs, chunk, gpu_result, n):
-    """the self-check of the line without the timed CPU leg (N > 1): oracle.forward on the first n points of the chunk"""
-    import oracle
-    from monohair_amd.pmvo import depth_offsets
-
-    views = oracle.Views(recs, scene["depth"].cpu().numpy(), scene["ori"].cpu().numpy(),
-                         scene["conf"].cpu().numpy(), scene["mask"].cpu().numpy())
-    return compare_with_oracle(gpu_result, oracle.forward(views, chunk[:n], a.patch, a.conf_threshold, depth_offsets(90)), n)
-
-
-def cpu_baseline(a, scene, recs, chunk, gpu_ms, gpu_result):
+def cpu_baseline(a, scene, recs, chunk, gpu_ms, gpu_result, check_only=0):
     """The CPU oracle (oracle/pmvo_oracle.c, OpenMP over points) timed on this host on a bounded sample of the
     same iteration: the first n points of the chunk against all views.  `chunk` is the chunk the LAST step of the timed
     region processed and `gpu_result` what that step returned: the oracle's (orientation, loss, high-confidence flag) for the
-    sample is compared with it bit for bit -> (cpu_baseline, parity_check); a mismatch raises ParityError."""
+    sample is compared with it bit for bit -> (cpu_baseline, parity_check); a mismatch raises ParityError.
+    check_only = n > 0 (the N > 1 runs, where the CPU baseline is not reported): one untimed oracle pass over the first n
+    points, only the comparison is returned -> (None, parity_check).  This function is the one place bench.py uses the oracle."""
     import numpy as np
 
     import oracle
@@ -974,6 +966,9 @@ def cpu_baseline(a, scene, recs, chunk, gpu_ms, gpu_result):
                          scene["conf"].cpu().numpy(), scene["mask"].cpu().numpy())
     cores = oracle.num_threads()
     offs = depth_offsets(90)
+    if check_only:
+        n = min(int(check_only), len(chunk))
+        return None, compare_with_oracle(gpu_result, oracle.forward(views, chunk[:n], a.patch, a.conf_threshold, offs), n)
     n = a.cpu_points if a.cpu_points > 0 else len(chunk)
     # repeat the sample until >= 12 s of CPU work have been timed (bounded: at most 40 repeats)
     t, reps = 0.0, 0
