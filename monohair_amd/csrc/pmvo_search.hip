@@ -341,6 +341,162 @@ __device__ __forceinline__ void mh_tap_update(float (&ML)[KA], float (&BC)[KA], 
 }
 
 // ---------------------------------------------------------------------------------------------
+// The running minimum as ONE integer key per item (round 4; tools/ubench/valu5.hip: 69 -> 54 cycles per tap per 4 items).
+// compute_prj_loss keeps, per (item, view), the lexicographic minimum of (loss_t, t) over the taps of the list -- tap 0
+// seeds, a later tap replaces it only on a strictly smaller loss (PMVO.py:173-182) -- and wants the loss and the confidence
+// of that tap.  loss_t = fl(1 - x), x = |cs_t|.  With C = 1 + 2^-14 the value t' = fl(C - x) is
+//   * exactly loss_t + 2^-14 for 2^-14 < x: for x >= 0.5 both subtractions are exact (x is a multiple of 2^-24 there,
+//     and |cs| <= 1 + 7 * 2^-24 for two vectors normalised in fp32, so t' > 0 where the loss itself goes negative); for
+//     x < 0.5 both results lie in [0.5, 1), where the grid is 2^-24 and round-to-nearest-even commutes with adding the
+//     even multiple 2^10 of the grid;
+//   * a positive float in [2^-15, 2), whose bits all start 0b00111: (bits << 5) drops only those constant bits and is
+//     monotone in t', which leaves five bits for the tap index inside a 32-tap group.
+// key = (bits(t') << 5) | (t mod 32); the unsigned minimum of the keys of a group (v_min3_u32, two taps at a time) is
+// the group's first-index minimum, groups are merged with "an earlier group wins ties".  mul, mul, add, sub, lshl_or per
+// evaluation + half a min3: 5.5 instructions instead of 7 (and one register per item instead of two).
+// What the key cannot state -- a winner with x <= 2^-14 (t' >= 1 lands on the coarser grid of [1, 2)), a NaN -- shows as
+// key >= MH_KEY_BAD; a wave that sees one on any of its lanes evaluates that view again with the compare-and-select body
+// (mh_tap_update), which is also what runs for one-tap lists and for a NaN seed tap.  Both bodies give the same bits
+// wherever the key is valid, so the outputs are those of the select body everywhere.
+// ---------------------------------------------------------------------------------------------
+#define MH_KEY_C 1.00006103515625f   // 1 + 2^-14
+#define MH_KEY_E 6.103515625e-05f    // 2^-14
+#define MH_KEY_BAD 0xF0000000u       // key of t' = 1.0 (index 0)
+#define MH_KEY_PAD 4                 // lists are padded in LDS to a multiple of this many taps with (0, 0): cs = 0, t' = C
+#ifdef MH_KEY_STATS   // tools/exp_key_stats.py builds the library with this: how often a wave evaluates a view twice
+__device__ unsigned long long mh_key_stats_dev[4];   // (wave, view) visits: all, one-tap / NaN-seed lists, re-evaluated, -
+extern "C" int mh_debug_key_stats(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mh_key_stats_dev), sizeof(unsigned long long) * 4) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mh_key_stats_dev), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#define MH_KEY_COUNT(i) do { if ((tid & 63) == 0) atomicAdd(&mh_key_stats_dev[i], 1ull); } while (0)
+#else
+#define MH_KEY_COUNT(i) do { } while (0)
+#endif
+__device__ __forceinline__ unsigned mh_tap_key(float cs, int idx) {
+    float t;
+    unsigned k;
+    asm("v_sub_f32_e64 %0, %2, |%1|" : "=v"(t) : "v"(cs), "s"(MH_KEY_C));
+    asm("v_lshl_or_b32 %0, %1, 5, %2" : "=v"(k) : "v"(t), "s"(idx));
+    return k;
+}
+__device__ __forceinline__ unsigned mh_min3u(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// Four taps x four items of the key body as ONE hand-ordered block: 64 full-rate (mul, mul, add, sub) + 16 v_lshl_or +
+// 8 v_min3 = 88 instructions, every result used at least three instructions after it is produced.  (Left to the
+// compiler as one asm statement per instruction, its hazard recogniser pads every inline-asm result that is read by the
+// very next instruction with an s_nop -- it cannot see that no dst_sel is involved: ~9 per block.)
+__device__ __forceinline__ void mh_key_block4(unsigned (&k)[4], const float2 (&g)[4], const float (&DX)[4], const float (&DY)[4],
+                                              int ib) {
+    float a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
+    asm volatile(
+        "v_mul_f32_e32 %[a0], %[t0x], %[x0]\n\t"
+        "v_mul_f32_e32 %[a1], %[t0x], %[x1]\n\t"
+        "v_mul_f32_e32 %[a2], %[t0x], %[x2]\n\t"
+        "v_mul_f32_e32 %[a3], %[t0x], %[x3]\n\t"
+        "v_mul_f32_e32 %[b0], %[t0y], %[y0]\n\t"
+        "v_mul_f32_e32 %[b1], %[t0y], %[y1]\n\t"
+        "v_mul_f32_e32 %[b2], %[t0y], %[y2]\n\t"
+        "v_mul_f32_e32 %[b3], %[t0y], %[y3]\n\t"
+        "v_mul_f32_e32 %[c0], %[t1x], %[x0]\n\t"
+        "v_mul_f32_e32 %[c1], %[t1x], %[x1]\n\t"
+        "v_mul_f32_e32 %[c2], %[t1x], %[x2]\n\t"
+        "v_mul_f32_e32 %[c3], %[t1x], %[x3]\n\t"
+        "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
+        "v_add_f32_e32 %[a1], %[a1], %[b1]\n\t"
+        "v_add_f32_e32 %[a2], %[a2], %[b2]\n\t"
+        "v_add_f32_e32 %[a3], %[a3], %[b3]\n\t"
+        "v_mul_f32_e32 %[b0], %[t1y], %[y0]\n\t"
+        "v_mul_f32_e32 %[b1], %[t1y], %[y1]\n\t"
+        "v_mul_f32_e32 %[b2], %[t1y], %[y2]\n\t"
+        "v_mul_f32_e32 %[b3], %[t1y], %[y3]\n\t"
+        "v_sub_f32_e64 %[a0], %[cc], |%[a0]|\n\t"
+        "v_sub_f32_e64 %[a1], %[cc], |%[a1]|\n\t"
+        "v_sub_f32_e64 %[a2], %[cc], |%[a2]|\n\t"
+        "v_sub_f32_e64 %[a3], %[cc], |%[a3]|\n\t"
+        "v_add_f32_e32 %[c0], %[c0], %[b0]\n\t"
+        "v_add_f32_e32 %[c1], %[c1], %[b1]\n\t"
+        "v_add_f32_e32 %[c2], %[c2], %[b2]\n\t"
+        "v_add_f32_e32 %[c3], %[c3], %[b3]\n\t"
+        "v_lshl_or_b32 %[a0], %[a0], 5, %[i0]\n\t"
+        "v_lshl_or_b32 %[a1], %[a1], 5, %[i0]\n\t"
+        "v_lshl_or_b32 %[a2], %[a2], 5, %[i0]\n\t"
+        "v_lshl_or_b32 %[a3], %[a3], 5, %[i0]\n\t"
+        "v_sub_f32_e64 %[c0], %[cc], |%[c0]|\n\t"
+        "v_sub_f32_e64 %[c1], %[cc], |%[c1]|\n\t"
+        "v_sub_f32_e64 %[c2], %[cc], |%[c2]|\n\t"
+        "v_sub_f32_e64 %[c3], %[cc], |%[c3]|\n\t"
+        "v_lshl_or_b32 %[c0], %[c0], 5, %[i1]\n\t"
+        "v_lshl_or_b32 %[c1], %[c1], 5, %[i1]\n\t"
+        "v_lshl_or_b32 %[c2], %[c2], 5, %[i1]\n\t"
+        "v_lshl_or_b32 %[c3], %[c3], 5, %[i1]\n\t"
+        "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
+        "v_min3_u32 %[k1], %[k1], %[a1], %[c1]\n\t"
+        "v_min3_u32 %[k2], %[k2], %[a2], %[c2]\n\t"
+        "v_min3_u32 %[k3], %[k3], %[a3], %[c3]\n\t"
+        "v_mul_f32_e32 %[a0], %[t2x], %[x0]\n\t"
+        "v_mul_f32_e32 %[a1], %[t2x], %[x1]\n\t"
+        "v_mul_f32_e32 %[a2], %[t2x], %[x2]\n\t"
+        "v_mul_f32_e32 %[a3], %[t2x], %[x3]\n\t"
+        "v_mul_f32_e32 %[b0], %[t2y], %[y0]\n\t"
+        "v_mul_f32_e32 %[b1], %[t2y], %[y1]\n\t"
+        "v_mul_f32_e32 %[b2], %[t2y], %[y2]\n\t"
+        "v_mul_f32_e32 %[b3], %[t2y], %[y3]\n\t"
+        "v_mul_f32_e32 %[c0], %[t3x], %[x0]\n\t"
+        "v_mul_f32_e32 %[c1], %[t3x], %[x1]\n\t"
+        "v_mul_f32_e32 %[c2], %[t3x], %[x2]\n\t"
+        "v_mul_f32_e32 %[c3], %[t3x], %[x3]\n\t"
+        "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
+        "v_add_f32_e32 %[a1], %[a1], %[b1]\n\t"
+        "v_add_f32_e32 %[a2], %[a2], %[b2]\n\t"
+        "v_add_f32_e32 %[a3], %[a3], %[b3]\n\t"
+        "v_mul_f32_e32 %[b0], %[t3y], %[y0]\n\t"
+        "v_mul_f32_e32 %[b1], %[t3y], %[y1]\n\t"
+        "v_mul_f32_e32 %[b2], %[t3y], %[y2]\n\t"
+        "v_mul_f32_e32 %[b3], %[t3y], %[y3]\n\t"
+        "v_sub_f32_e64 %[a0], %[cc], |%[a0]|\n\t"
+        "v_sub_f32_e64 %[a1], %[cc], |%[a1]|\n\t"
+        "v_sub_f32_e64 %[a2], %[cc], |%[a2]|\n\t"
+        "v_sub_f32_e64 %[a3], %[cc], |%[a3]|\n\t"
+        "v_add_f32_e32 %[c0], %[c0], %[b0]\n\t"
+        "v_add_f32_e32 %[c1], %[c1], %[b1]\n\t"
+        "v_add_f32_e32 %[c2], %[c2], %[b2]\n\t"
+        "v_add_f32_e32 %[c3], %[c3], %[b3]\n\t"
+        "v_lshl_or_b32 %[a0], %[a0], 5, %[i2]\n\t"
+        "v_lshl_or_b32 %[a1], %[a1], 5, %[i2]\n\t"
+        "v_lshl_or_b32 %[a2], %[a2], 5, %[i2]\n\t"
+        "v_lshl_or_b32 %[a3], %[a3], 5, %[i2]\n\t"
+        "v_sub_f32_e64 %[c0], %[cc], |%[c0]|\n\t"
+        "v_sub_f32_e64 %[c1], %[cc], |%[c1]|\n\t"
+        "v_sub_f32_e64 %[c2], %[cc], |%[c2]|\n\t"
+        "v_sub_f32_e64 %[c3], %[cc], |%[c3]|\n\t"
+        "v_lshl_or_b32 %[c0], %[c0], 5, %[i3]\n\t"
+        "v_lshl_or_b32 %[c1], %[c1], 5, %[i3]\n\t"
+        "v_lshl_or_b32 %[c2], %[c2], 5, %[i3]\n\t"
+        "v_lshl_or_b32 %[c3], %[c3], 5, %[i3]\n\t"
+        "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
+        "v_min3_u32 %[k1], %[k1], %[a1], %[c1]\n\t"
+        "v_min3_u32 %[k2], %[k2], %[a2], %[c2]\n\t"
+        "v_min3_u32 %[k3], %[k3], %[a3], %[c3]"
+        : [k0] "+v"(k[0]), [k1] "+v"(k[1]), [k2] "+v"(k[2]), [k3] "+v"(k[3]), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2),
+          [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [c0] "=&v"(c0), [c1] "=&v"(c1),
+          [c2] "=&v"(c2), [c3] "=&v"(c3)
+        : [t0x] "v"(g[0].x), [t0y] "v"(g[0].y), [t1x] "v"(g[1].x), [t1y] "v"(g[1].y), [t2x] "v"(g[2].x), [t2y] "v"(g[2].y),
+          [t3x] "v"(g[3].x), [t3y] "v"(g[3].y), [x0] "v"(DX[0]), [x1] "v"(DX[1]), [x2] "v"(DX[2]), [x3] "v"(DX[3]),
+          [y0] "v"(DY[0]), [y1] "v"(DY[1]), [y2] "v"(DY[2]), [y3] "v"(DY[3]), [cc] "s"(MH_KEY_C), [i0] "s"(ib),
+          [i1] "s"(ib + 1), [i2] "s"(ib + 2), [i3] "s"(ib + 3)
+        : "memory");   // (keeps the LDS reads of the NEXT group, issued in front of the block, in front of it)
+}
+
+// ---------------------------------------------------------------------------------------------
 // mh_search3_kernel -- the shipped search: the arithmetic of mh_search_kernel in the same order, laid out for the machine.
 // Where the wave-uniform tap records come from:
 //   * round 2's first form read them with broadcast vector loads: every one of the 4 waves of the workgroup loaded every tap
@@ -354,6 +510,9 @@ __device__ __forceinline__ void mh_tap_update(float (&ML)[KA], float (&BC)[KA], 
 //     lane per view, a wave prefix sum, v_readlane -- no per-view header load, no branch on it.
 // ---------------------------------------------------------------------------------------------
 #define MH_S3_GRP 4      // tap records per ping-pong group
+#ifndef MH_S3_WAVES
+#define MH_S3_WAVES 5   // waves per SIMD the register allocation aims at (A/B builds: -DMH_S3_WAVES=4|6)
+#endif
 #define MH_S3_CAP 1280   // float4 records per workgroup (20 KB; 6 workgroups of 25 KB per CU)
 
 // the cascade of mh_device.h (MhCascV) with the third level only where it can be reached
@@ -373,7 +532,7 @@ struct MhCascS {
     __device__ __forceinline__ float done() const { return BIG ? (a0 + a1) + a2 : (a0 + a1); }
 };
 
-template <int KA, int T, bool BIGV>
+template <int KA, int T, bool BIGV, bool KEYS>
 __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const float *__restrict__ offs, int S,
                                                      int n, int N, int P1, float thr,
                                                      const float4 *__restrict__ taps, const uint8_t *__restrict__ vcnt,
@@ -434,39 +593,133 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
             DX[KA - 1] = dx.x;
             DY[KA - 1] = dy.x;
         }
-#pragma unroll
-        for (int j = 0; j < KA; ++j) {
-            ML[j] = mh_one_minus_abs(mh_vadd(mh_vmul(t0.x, DX[j]), mh_vmul(t0.y, DY[j])));
-            BC[j] = t0.z;
-        }
         constexpr int GRP = MH_S3_GRP;
-        auto process = [&](const float4 (&g)[GRP], int t) {
+        // the compare-and-select body: exact everywhere (the one body of rounds 1-3; with KEYS the re-evaluation path)
+        auto select_body = [&]() {
 #pragma unroll
-            for (int u = 0; u < GRP; ++u) {
-                if (t + u < ntap) {   // uniform
-                    const float4 tp = g[u];
-                    float l[KN];
+            for (int j = 0; j < KA; ++j) {
+                ML[j] = mh_one_minus_abs(mh_vadd(mh_vmul(t0.x, DX[j]), mh_vmul(t0.y, DY[j])));
+                BC[j] = t0.z;
+            }
+            auto process = [&](const float4 (&g)[GRP], int t) {
 #pragma unroll
-                    for (int j = 0; j < KA; ++j)
-                        l[j] = mh_one_minus_abs(mh_vadd(mh_vmul(tp.x, DX[j]), mh_vmul(tp.y, DY[j])));
-                    mh_tap_update<KN>(ML, BC, l, tp.z);
+                for (int u = 0; u < GRP; ++u) {
+                    if (t + u < ntap) {   // uniform
+                        const float4 tp = g[u];
+                        float l[KN];
+#pragma unroll
+                        for (int j = 0; j < KA; ++j)
+                            l[j] = mh_one_minus_abs(mh_vadd(mh_vmul(tp.x, DX[j]), mh_vmul(tp.y, DY[j])));
+                        mh_tap_update<KN>(ML, BC, l, tp.z);
+                    }
                 }
+            };
+            float4 ga[GRP], gb[GRP];
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) ga[u] = rec[2 + u];
+            for (int t = 1; t < ntap;) {
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) gb[u] = rec[1 + t + GRP + u];
+                process(ga, t);
+                t += GRP;
+                if (t >= ntap) break;
+#pragma unroll
+                for (int u = 0; u < GRP; ++u) ga[u] = rec[1 + t + GRP + u];
+                process(gb, t);
+                t += GRP;
             }
         };
         __builtin_amdgcn_s_setprio(0);   // the tap loop: see mh_search3_kernel
-        float4 ga[GRP], gb[GRP];
+        if constexpr (!KEYS) {
+            select_body();
+        } else {
+            // the key body (see mh_tap_key): taps in groups of 32, the list padded to a multiple of MH_KEY_PAD taps
+            bool again = (ntap == 1) || !(t0.x == t0.x && t0.y == t0.y);   // uniform: nothing to search / a NaN seed tap
+            MH_KEY_COUNT(0);
+            if (again) MH_KEY_COUNT(1);
+            if (!again) {
+                const int ntp = (ntap + MH_KEY_PAD - 1) & ~(MH_KEY_PAD - 1);
+                unsigned acc[KN], best[KN];
+                // LDS byte address of the first tap record of the winning group (the confidence gather of the decode)
+                const unsigned rec1 = (unsigned)(size_t)(rec + 1);   // (LDS pointers: the low 32 bits are the address)
+                unsigned gofs[KN];
+                auto process = [&](const float2 (&g)[GRP], int t, int t1) {
+                    const int ib = t & 31;
+                    if constexpr (KA == 4 && MH_KEY_PAD >= 4 && GRP == 4) {
+                        mh_key_block4(acc, g, DX, DY, ib);
+                        return;
+                    }
+                    unsigned k[GRP][KN];
 #pragma unroll
-        for (int u = 0; u < GRP; ++u) ga[u] = rec[2 + u];
-        for (int t = 1; t < ntap;) {
+                    for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int u = 0; u < GRP; ++u) gb[u] = rec[1 + t + GRP + u];
-            process(ga, t);
-            t += GRP;
-            if (t >= ntap) break;
+                        for (int j = 0; j < KA; ++j)
+                            k[u][j] = mh_tap_key(mh_vadd(mh_vmul(g[u].x, DX[j]), mh_vmul(g[u].y, DY[j])), ib + u);
 #pragma unroll
-            for (int u = 0; u < GRP; ++u) ga[u] = rec[1 + t + GRP + u];
-            process(gb, t);
-            t += GRP;
+                    for (int j = 0; j < KA; ++j) acc[j] = mh_min3u(acc[j], k[0][j], k[1][j]);
+                    if (MH_KEY_PAD >= 4 || t + 2 < t1) {   // uniform
+#pragma unroll
+                        for (int u = 2; u < 4; ++u)
+#pragma unroll
+                            for (int j = 0; j < KA; ++j)
+                                k[u][j] = mh_tap_key(mh_vadd(mh_vmul(g[u].x, DX[j]), mh_vmul(g[u].y, DY[j])), ib + u);
+#pragma unroll
+                        for (int j = 0; j < KA; ++j) acc[j] = mh_min3u(acc[j], k[2][j], k[3][j]);
+                    }
+                };
+                // taps [ta, tb) of one 32-tap group into acc: (tx, ty) of tap i is the first half of record 1 + i
+                auto group = [&](int ta, int tb) {
+                    const float2 *__restrict__ t2 = reinterpret_cast<const float2 *>(rec + 1);
+#pragma unroll
+                    for (int j = 0; j < KN; ++j) acc[j] = 0xFFFFFFFFu;
+                    float2 ga[GRP], gb[GRP];
+#pragma unroll
+                    for (int u = 0; u < GRP; ++u) ga[u] = t2[2 * (ta + u)];
+                    for (int t = ta; t < tb;) {
+#pragma unroll
+                        for (int u = 0; u < GRP; ++u) gb[u] = t2[2 * (t + GRP + u)];
+                        __builtin_amdgcn_sched_barrier(0);   // (the next group's reads stay in front of this group's block)
+                        process(ga, t, tb);
+                        t += GRP;
+                        if (t >= tb) break;
+#pragma unroll
+                        for (int u = 0; u < GRP; ++u) ga[u] = t2[2 * (t + GRP + u)];
+                        __builtin_amdgcn_sched_barrier(0);
+                        process(gb, t, tb);
+                        t += GRP;
+                    }
+                };
+                group(0, ntp < 32 ? ntp : 32);
+#pragma unroll
+                for (int j = 0; j < KN; ++j) {
+                    best[j] = acc[j];
+                    gofs[j] = rec1;
+                }
+                for (int ta = 32; ta < ntp; ta += 32) {   // later groups: an earlier group wins ties
+                    group(ta, ntp < ta + 32 ? ntp : ta + 32);
+#pragma unroll
+                    for (int j = 0; j < KN; ++j) {
+                        const bool lt = acc[j] < (best[j] & ~31u);
+                        best[j] = lt ? acc[j] : best[j];
+                        gofs[j] = lt ? rec1 + 16u * (unsigned)ta : gofs[j];
+                    }
+                }
+                // decode: one compare for "any key past the valid range", loss = t' - 2^-14 from the key's upper bits
+                // (v_alignbit puts the constant 0b00111 back in front), confidence of the winning tap from its LDS record
+                unsigned worst = best[0];
+#pragma unroll
+                for (int j = 1; j < KA; ++j) worst = max(worst, best[j]);
+                const bool bad = worst >= MH_KEY_BAD;
+#pragma unroll
+                for (int j = 0; j < KA; ++j) {
+                    BC[j] = *reinterpret_cast<const __attribute__((address_space(3))) float *>(
+                        (size_t)(gofs[j] + ((best[j] & 31u) << 4) + 8u));
+                    ML[j] = __uint_as_float(__builtin_amdgcn_alignbit(7u, best[j], 5u)) - MH_KEY_E;
+                }
+                again = __ballot(bad) != 0ull;
+                if (again) MH_KEY_COUNT(2);
+            }
+            if (again) select_body();
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -481,7 +734,8 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
     for (int vb = 0; vb < V; vb += 64) {
         const int vv = vb + lane;
         const int c = (vv < V) ? (int)vcnt[(size_t)vv * N + n] : 0;   // list length of view vv (0: the view does not see the point)
-        const int len = c ? c + 1 : 0;                               // records: header + taps
+        // records: header + taps (KEYS: the taps padded to a multiple of MH_KEY_PAD with neutral (0, 0) records)
+        const int len = c ? (KEYS ? ((c + MH_KEY_PAD - 1) & ~(MH_KEY_PAD - 1)) : c) + 1 : 0;
         int pre = len;                                               // inclusive prefix sum over the lanes
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -503,7 +757,13 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
                         const int L = __builtin_amdgcn_readlane(len, b);
                         const int off = __builtin_amdgcn_readlane(pre, b) - L - base;
                         const float4 *__restrict__ src = taps + ((size_t)(vb + b) * N + n) * P1;
-                        for (int i = lane; i < L; i += 64) s_taps[off + i] = src[i];
+                        if constexpr (KEYS) {
+                            const int lr = __builtin_amdgcn_readlane(c, b) + 1;   // records the list really has
+                            for (int i = lane; i < L; i += 64)
+                                s_taps[off + i] = (i < lr) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        } else {
+                            for (int i = lane; i < L; i += 64) s_taps[off + i] = src[i];
+                        }
                     }
                     ++k;
                 }
@@ -517,7 +777,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
                     flush_upto(vb + b);
                     const int L = __builtin_amdgcn_readlane(len, b);
                     const int off = __builtin_amdgcn_readlane(pre, b) - L - base;
-                    one_view(vb + b, s_taps + off, L - 1);
+                    one_view(vb + b, s_taps + off, KEYS ? __builtin_amdgcn_readlane(c, b) : L - 1);
                 }
             }
             __syncthreads();
@@ -541,10 +801,10 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
     }
 }
 
-template <int T, bool BIGV>
+template <int T, bool BIGV, bool KEYS>
 // amdgpu_waves_per_eu(5): the register allocator stops at 96 VGPRs (it takes 109 unconstrained = 4 waves per SIMD); the
 // few values it spills are reloaded once per view.  Measured: 4 waves 1305 it/s, 5 waves 1345, 6 waves (80 VGPRs) 1328.
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5))) void mh_search3_kernel(MhViews vw, const float *__restrict__ offs, int S, int nrank,
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MH_S3_WAVES))) void mh_search3_kernel(MhViews vw, const float *__restrict__ offs, int S, int nrank,
                                                        int rank_step, const float *__restrict__ pts, int N, int P1,
                                                        float thr, const float *__restrict__ ori_c,
                                                        const int32_t *__restrict__ base_idx,
@@ -589,11 +849,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(5))) void mh_
     int ka = 0;
     for (int j = 0; j < 4; ++j) ka += (j * T + wave0 < nact) ? 1 : 0;
 #define MH_S3_ARGS vw, offs, S, n, N, P1, thr, taps, vcnt, nact, tid, s_loss, s_pos, s_taps, s_rank
-    if (ka == 4) mh_search_slices_lds<4, T, BIGV>(MH_S3_ARGS);
-    else if (ka == 3) mh_search_slices_lds<3, T, BIGV>(MH_S3_ARGS);
-    else if (ka == 2) mh_search_slices_lds<2, T, BIGV>(MH_S3_ARGS);
-    else if (ka == 1) mh_search_slices_lds<1, T, BIGV>(MH_S3_ARGS);
-    else mh_search_slices_lds<0, T, BIGV>(MH_S3_ARGS);
+    if (ka == 4) mh_search_slices_lds<4, T, BIGV, KEYS>(MH_S3_ARGS);
+    else if (ka == 3) mh_search_slices_lds<3, T, BIGV, KEYS>(MH_S3_ARGS);
+    else if (ka == 2) mh_search_slices_lds<2, T, BIGV, KEYS>(MH_S3_ARGS);
+    else if (ka == 1) mh_search_slices_lds<1, T, BIGV, KEYS>(MH_S3_ARGS);
+    else mh_search_slices_lds<0, T, BIGV, KEYS>(MH_S3_ARGS);
 #undef MH_S3_ARGS
     __syncthreads();
 
@@ -927,6 +1187,10 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
     // variant 0 (default): mh_search3_kernel, workgroups in descending order of work; 7: the same in natural order (A/B);
     // 1256: the portable mh_search_kernel (cross-check) -- also what runs when the caller has no list lengths
     // (8: as 0, the work classes are in order[0..N) already -- the fused forward lets the ranking kernel write them)
+    // (+100: the compare-and-select tap body of rounds 1-3 instead of the key body -- 100 / 107 are the A/B and cross-check
+    // forms of 0 / 7)
+    const bool select_body = variant >= 100 && variant < 200;
+    if (select_body) variant -= 100;
     if (variant == 0) variant = cnt ? 6 : 1256;
     if (variant == 6 || variant == 7 || variant == 8) {
         if (!cnt) return -1;
@@ -938,14 +1202,18 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
             hipLaunchKernelGGL(mh_search_order_kernel, dim3(1), dim3(1024), 0, st, N, order);
             ord = order + N;
         }
-        if (vw.V > 256)
-            hipLaunchKernelGGL((mh_search3_kernel<256, true>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts,
-                               N, P1, thr, ori_c, base_idx, base_val, taps, cnt, ord, line_ori, min_loss, high_conf,
-                               best_sample, best_rank, best_s);
-        else
-            hipLaunchKernelGGL((mh_search3_kernel<256, false>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step,
-                               pts, N, P1, thr, ori_c, base_idx, base_val, taps, cnt, ord, line_ori, min_loss, high_conf,
-                               best_sample, best_rank, best_s);
+#define MH_S3_LAUNCH(BIG, KEYS)                                                                                         \
+    hipLaunchKernelGGL((mh_search3_kernel<256, BIG, KEYS>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts, \
+                       N, P1, thr, ori_c, base_idx, base_val, taps, cnt, ord, line_ori, min_loss, high_conf, best_sample, \
+                       best_rank, best_s)
+        if (vw.V > 256) {
+            if (select_body) MH_S3_LAUNCH(true, false);
+            else MH_S3_LAUNCH(true, true);
+        } else {
+            if (select_body) MH_S3_LAUNCH(false, false);
+            else MH_S3_LAUNCH(false, true);
+        }
+#undef MH_S3_LAUNCH
     } else if (variant == 1256) {
         hipLaunchKernelGGL((mh_search_kernel<4, 256>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts, N, P1,
                            thr, ori_c, base_idx, base_val, taps, line_ori, min_loss, high_conf, best_sample, best_rank,

@@ -27,6 +27,10 @@ ap.add_argument("--max-views", type=int, default=70, help="scenes draw 20 .. max
                 "of the search, above 256: third level of the view cascade)")
 ap.add_argument("--codes", action="store_true", help="maps uploaded as random 8-bit CODES (PMVO.from_u8: the code-gather front "
                 "end, mh_project_taps_codes_kernel) against the oracle on the table-decoded maps")
+ap.add_argument("--ori-mode", default="", help="adversarial orientation fields for the tap search (continuous maps only): "
+                "'mix' draws per scene from: const (one direction per view + tiny noise on a few pixels: near-ties, lists of "
+                "1-3 taps), two (two exactly perpendicular directions), axis ((1,0)/(0,1)/(0,0)), fine (a fan of directions "
+                "1e-7..1e-4 rad apart: many taps on the flat top of the cosine, losses 0 and below), nan (NaN pixels)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 DEV = "cuda:0"
@@ -59,6 +63,7 @@ while time.time() < t_end:
         c["ndc_prj"][3] = float(rng.normal(0, 0.02))
     camd = cameras_from_list(scene["cams"])
     rec = camera_records(camd)
+    mode = ""
     if a.codes:
         from monohair_amd.pmvo_utils import map_code_lut
 
@@ -74,6 +79,27 @@ while time.time() < t_end:
         scene = dict(scene, depth=sc["depth"], ori=torch.from_numpy(lut[k8][..., :2].copy()),
                      conf=torch.from_numpy(lut[c8][..., 2].copy()), mask=torch.from_numpy(lut[m8][..., 3].copy()))
     else:
+        if a.ori_mode:
+            mode = a.ori_mode if a.ori_mode != "mix" else str(rng.choice(["const", "two", "axis", "fine", "nan", "plain"]))
+            o = scene["ori"].numpy().copy()
+            ang = rng.uniform(0, np.pi, size=(V, 1, 1))
+            if mode == "const":
+                th = ang + (rng.random(o.shape[:3]) < rng.uniform(0.0, 0.2)) * rng.normal(0, 10.0 ** rng.uniform(-7, -2), o.shape[:3])
+                o = np.stack([np.cos(th), np.sin(th)], -1).astype(np.float32)
+            elif mode == "two":
+                pick = rng.random(o.shape[:3]) < 0.5
+                c, s_ = np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+                o = np.where(pick[..., None], np.stack([c + 0 * pick, s_ + 0 * pick], -1), np.stack([-s_ + 0 * pick, c + 0 * pick], -1)).astype(np.float32)
+            elif mode == "axis":
+                k = rng.integers(0, 5, o.shape[:3])
+                tab = np.array([[1, 0], [0, 1], [0, 0], [-1, 0], [0.6, 0.8]], np.float32)
+                o = tab[k]
+            elif mode == "fine":
+                th = ang + rng.integers(0, 64, o.shape[:3]) * 10.0 ** rng.uniform(-7.5, -4)
+                o = (np.stack([np.cos(th), np.sin(th)], -1) * rng.uniform(0.5, 2.0, o.shape[:3] + (1,))).astype(np.float32)
+            elif mode == "nan":
+                o[rng.random(o.shape[:3]) < 0.02] = np.nan
+            scene["ori"] = torch.from_numpy(np.ascontiguousarray(o, dtype=np.float32))
         pm = PMVO.from_planes(rec, scene["depth"].to(DEV), scene["ori"].to(DEV), scene["conf"].to(DEV),
                               scene["mask"].to(DEV), device=DEV, patch_size=patch, visible_threshold=1, conf_threshold=thr)
     if a.variant:
@@ -86,7 +112,7 @@ while time.time() < t_end:
         _, ori, loss, hc = pm.forward(pts, fused=fused)
         _, o_ori, o_loss, o_hc = oracle.forward(views, pts, patch, thr, offs)
         if not (eq(loss.cpu().numpy(), o_loss) and eq(ori.cpu().numpy(), o_ori) and eq(hc.cpu().numpy(), o_hc)):
-            bad.append(("forward", fused, V, H, W, patch, thr, quant, seed, N))
+            bad.append(("forward", fused, V, H, W, patch, thr, quant, seed, N, mode))
     surf, _, filt = pm.filter_points(pts)
     unv = pm.compute_unvisible_points(pts)
     o_s, o_f, o_u, _ = oracle.filter_votes(views, pts, patch, thr, 1.0)

@@ -95,7 +95,8 @@ def test_topk_vs_oracle(case):
     assert np.array_equal(idx1.cpu().numpy(), o1) and np.array_equal(val1.cpu().numpy(), v1)
 
 
-@pytest.mark.parametrize("variant", [0, 7, 1256])      # shipped (work-ordered), natural order, portable cross-check
+@pytest.mark.parametrize("variant", [0, 7, 100, 107, 1256])   # shipped key body (work-ordered / natural order), the
+# compare-and-select body of rounds 1-3 in both orders, portable cross-check
 def test_forward_vs_oracle_bit_exact(case, depth_offsets, variant):
     meta, z, scene, views, pm = case
     pm.set_option("search_variant", variant)
