@@ -365,8 +365,13 @@ int mh_mat_sparse_close(void *handle);
 /* Tuning knobs for A/B runs and cross-checks; every setting computes the same results (except "topk_order" 1, which
  * returns tied confidences in view order).
  *   "search_variant": 0 = default: mh_search3_kernel (tap lists staged in LDS), points in descending order of work;
- *       7: the same with the points in their natural order (A/B); 1256: the portable mh_search_kernel, the cross-check
- *       of the shipped kernel (also what runs when the caller has no list lengths).  Same results.
+ *       7: the same with the points in their natural order (A/B); 100 / 107: 0 / 7 with the compare-and-select tap body
+ *       whatever "search_body" says; 1256: the portable mh_search_kernel, the cross-check of the shipped kernel (also
+ *       what runs when the caller has no list lengths).  Same results.
+ *   "search_body": which tap body mh_search3_kernel runs.  0 (default) = by the maps: contexts whose views were ALL
+ *       uploaded with mh_ctx_set_view_u8 (tap lists of ~2 entries after the exact duplicate removal) take the
+ *       compare-and-select body, all others (lists of ~45 entries) the key body -- the running minimum as one integer key
+ *       per candidate, v_min3_u32 over two taps at a time; 1 = key body, 2 = select body.  Same results.
  *   "tap_codes": 1 (default) = contexts whose views were ALL uploaded with mh_ctx_set_view_u8 gather a patch tap as the
  *       two resident 8-bit codes of its pixel (mh_project_taps_codes_kernel); 0 = always the decoded records.
  *   "gabor_variant": 3 (default) mh_gabor_mfma2_kernel; 1 the first FP32-MFMA form; 0 / 2 the direct v_pk_fma forms.

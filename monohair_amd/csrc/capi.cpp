@@ -51,8 +51,24 @@ struct mh_ctx {
             if (!c) return false;
         return true;
     }
+    bool views_8bit() const {   // every view came in as 8-bit file codes (whatever "tap_codes" says)
+        if ((int)code_view.size() != V || V == 0) return false;
+        for (unsigned char c : code_view)
+            if (!c) return false;
+        return true;
+    }
     int S = 0;
     int search_variant = 0;
+    int search_body = 0;      // tap body of mh_search3_kernel: 0 = by the maps (see mh_ctx_set_option), 1 = keys, 2 = select
+    // The shipped search has two tap bodies with the same results (csrc/pmvo_search.hip): the key body (5.5 instructions per
+    // evaluation, a fixed cost per view) and the compare-and-select body (7, none).  Lists of continuous maps hold ~45 taps,
+    // lists of 8-bit maps ~2 after the exact duplicate removal: the kernel that carries both bodies runs short lists 5 %
+    // slower than the select-only kernel (register allocation), so contexts whose views are all 8-bit codes get that one.
+    int search_launch_variant(int v) const {
+        if (v != 0 && v != 6 && v != 7 && v != 8) return v;   // (100.. = select body asked for; 1256 = portable kernel)
+        const bool select = search_body == 2 || (search_body == 0 && views_8bit());
+        return select ? (v == 0 ? 100 : v + 100) : v;
+    }
     int topk_order = 0;       // 0: torch.topk's CPU tie order (mh_topk_wave.h); 1: value desc, view asc (round 1's rule)
     int taps_tile = 1;        // (accepted and ignored: round 3's A/B switch between forms of the fp32 front end;
                               // mh_project_taps2_kernel is the only one left)
@@ -391,6 +407,11 @@ extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
         ctx->search_variant = value;
         return MH_OK;
     }
+    if (!strcmp(key, "search_body")) {
+        if (value < 0 || value > 2) return fail(MH_ERR_ARG, "mh_ctx_set_option: search_body must be 0 (by the maps), 1 (keys) or 2 (select)");
+        ctx->search_body = value;
+        return MH_OK;
+    }
     if (!strcmp(key, "topk_order")) {
         if ((value & 255) > 1) return fail(MH_ERR_ARG, "mh_ctx_set_option: topk_order must be 0 (torch.topk's order) or 1");
         ctx->topk_order = value;
@@ -495,7 +516,8 @@ extern "C" int mh_search_forward(mh_ctx *ctx, const float *points, int N, int pa
                                      conf_threshold, ori, base_idx, base_val, (const float4 *)scratch,
                                      (int32_t *)((char *)scratch + search_order_offset(ctx, N, patch)),
                                      (const uint8_t *)scratch + search_count_offset(ctx, N, patch), line_ori,
-                                     min_loss, high_conf, best_sample, best_rank, best_s, ctx->search_variant, st),
+                                     min_loss, high_conf, best_sample, best_rank, best_s,
+                                     ctx->search_launch_variant(ctx->search_variant), st),
                     "mh_search_forward");
 }
 
@@ -531,8 +553,8 @@ static int search_prepared(mh_ctx *ctx, const float *points, int N, int patch, f
                                      (const float4 *)scratch,
                                      (int32_t *)((char *)scratch + search_order_offset(ctx, N, patch)),
                                      (const uint8_t *)scratch + search_count_offset(ctx, N, patch), line_ori,
-                                     min_loss, high_conf, best_sample, best_rank, best_s, variant,
-                                     (hipStream_t)stream),
+                                     min_loss, high_conf, best_sample, best_rank, best_s,
+                                     ctx->search_launch_variant(variant), (hipStream_t)stream),
                     "mh_search_prepared");
 }
 

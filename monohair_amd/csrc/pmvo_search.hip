@@ -362,6 +362,9 @@ __device__ __forceinline__ void mh_tap_update(float (&ML)[KA], float (&BC)[KA], 
 #define MH_KEY_C 1.00006103515625f   // 1 + 2^-14
 #define MH_KEY_E 6.103515625e-05f    // 2^-14
 #define MH_KEY_BAD 0xF0000000u       // key of t' = 1.0 (index 0)
+#ifndef MH_KEY_MIN_TAPS
+#define MH_KEY_MIN_TAPS 10           // lists up to this length go through the select body directly
+#endif
 #define MH_KEY_PAD 4                 // lists are padded in LDS to a multiple of this many taps with (0, 0): cs = 0, t' = C
 #ifdef MH_KEY_STATS   // tools/exp_key_stats.py builds the library with this: how often a wave evaluates a view twice
 __device__ unsigned long long mh_key_stats_dev[4];   // (wave, view) visits: all, one-tap / NaN-seed lists, re-evaluated, -
@@ -634,7 +637,9 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
             select_body();
         } else {
             // the key body (see mh_tap_key): taps in groups of 32, the list padded to a multiple of MH_KEY_PAD taps
-            bool again = (ntap == 1) || !(t0.x == t0.x && t0.y == t0.y);   // uniform: nothing to search / a NaN seed tap
+            // uniform: a short list (the key body's fixed cost per view -- padding, decode -- only pays from about a dozen
+            // taps on: lists of 8-bit maps are mostly shorter, lists of continuous maps hardly ever) / a NaN seed tap
+            bool again = (ntap <= MH_KEY_MIN_TAPS) || !(t0.x == t0.x && t0.y == t0.y);
             MH_KEY_COUNT(0);
             if (again) MH_KEY_COUNT(1);
             if (!again) {
@@ -734,8 +739,9 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
     for (int vb = 0; vb < V; vb += 64) {
         const int vv = vb + lane;
         const int c = (vv < V) ? (int)vcnt[(size_t)vv * N + n] : 0;   // list length of view vv (0: the view does not see the point)
-        // records: header + taps (KEYS: the taps padded to a multiple of MH_KEY_PAD with neutral (0, 0) records)
-        const int len = c ? (KEYS ? ((c + MH_KEY_PAD - 1) & ~(MH_KEY_PAD - 1)) : c) + 1 : 0;
+        // records: header + taps (KEYS: the taps of a list that goes through the key body padded to a multiple of
+        // MH_KEY_PAD with neutral (0, 0) records)
+        const int len = c ? ((KEYS && c > MH_KEY_MIN_TAPS) ? ((c + MH_KEY_PAD - 1) & ~(MH_KEY_PAD - 1)) : c) + 1 : 0;
         int pre = len;                                               // inclusive prefix sum over the lanes
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {

@@ -100,6 +100,14 @@ def test_random_code_maps_all_patch_sizes(patch, depth_offsets):
     _, o_ori, o_loss, o_hc = oracle.forward(views, pts, patch, thr, depth_offsets)
     assert np.array_equal(res[1][1], o_loss, equal_nan=True) and np.array_equal(res[1][0], o_ori, equal_nan=True)
     assert np.array_equal(res[1][2], o_hc)
+    # both tap bodies of the search (a context of 8-bit views takes the select body by default; the key body on these noisy
+    # code maps sees lists of up to patch^2 taps -- one to four 32-tap groups -- whose losses tie all the time)
+    for body in (1, 2):
+        pm.set_option("search_body", body)
+        _, ori, loss, hc = pm.forward(pts)
+        assert np.array_equal(loss.cpu().numpy(), o_loss, equal_nan=True), body
+        assert np.array_equal(ori.cpu().numpy(), o_ori, equal_nan=True) and np.array_equal(hc.cpu().numpy(), o_hc), body
+    pm.set_option("search_body", 0)
 
 
 def test_mixed_upload_forms_fall_back_to_the_records(depth_offsets):
