@@ -393,110 +393,233 @@ __device__ __forceinline__ unsigned mh_min3u(unsigned a, unsigned b, unsigned c)
     return r;
 }
 
-// Four taps x four items of the key body as ONE hand-ordered block: 64 full-rate (mul, mul, add, sub) + 16 v_lshl_or +
-// 8 v_min3 = 88 instructions, every result used at least three instructions after it is produced.  (Left to the
-// compiler as one asm statement per instruction, its hazard recogniser pads every inline-asm result that is read by the
-// very next instruction with an s_nop -- it cannot see that no dst_sel is involved: ~9 per block.)
-__device__ __forceinline__ void mh_key_block4(unsigned (&k)[4], const float2 (&g)[4], const float (&DX)[4], const float (&DY)[4],
-                                              int ib) {
-    float a0, a1, a2, a3, b0, b1, b2, b3, c0, c1, c2, c3;
-    asm volatile(
-        "v_mul_f32_e32 %[a0], %[t0x], %[x0]\n\t"
-        "v_mul_f32_e32 %[a1], %[t0x], %[x1]\n\t"
-        "v_mul_f32_e32 %[a2], %[t0x], %[x2]\n\t"
-        "v_mul_f32_e32 %[a3], %[t0x], %[x3]\n\t"
-        "v_mul_f32_e32 %[b0], %[t0y], %[y0]\n\t"
-        "v_mul_f32_e32 %[b1], %[t0y], %[y1]\n\t"
-        "v_mul_f32_e32 %[b2], %[t0y], %[y2]\n\t"
-        "v_mul_f32_e32 %[b3], %[t0y], %[y3]\n\t"
-        "v_mul_f32_e32 %[c0], %[t1x], %[x0]\n\t"
-        "v_mul_f32_e32 %[c1], %[t1x], %[x1]\n\t"
-        "v_mul_f32_e32 %[c2], %[t1x], %[x2]\n\t"
-        "v_mul_f32_e32 %[c3], %[t1x], %[x3]\n\t"
-        "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
-        "v_add_f32_e32 %[a1], %[a1], %[b1]\n\t"
-        "v_add_f32_e32 %[a2], %[a2], %[b2]\n\t"
-        "v_add_f32_e32 %[a3], %[a3], %[b3]\n\t"
-        "v_mul_f32_e32 %[b0], %[t1y], %[y0]\n\t"
-        "v_mul_f32_e32 %[b1], %[t1y], %[y1]\n\t"
-        "v_mul_f32_e32 %[b2], %[t1y], %[y2]\n\t"
-        "v_mul_f32_e32 %[b3], %[t1y], %[y3]\n\t"
-        "v_sub_f32_e64 %[a0], %[cc], |%[a0]|\n\t"
-        "v_sub_f32_e64 %[a1], %[cc], |%[a1]|\n\t"
-        "v_sub_f32_e64 %[a2], %[cc], |%[a2]|\n\t"
-        "v_sub_f32_e64 %[a3], %[cc], |%[a3]|\n\t"
-        "v_add_f32_e32 %[c0], %[c0], %[b0]\n\t"
-        "v_add_f32_e32 %[c1], %[c1], %[b1]\n\t"
-        "v_add_f32_e32 %[c2], %[c2], %[b2]\n\t"
-        "v_add_f32_e32 %[c3], %[c3], %[b3]\n\t"
-        "v_lshl_or_b32 %[a0], %[a0], 5, %[i0]\n\t"
-        "v_lshl_or_b32 %[a1], %[a1], 5, %[i0]\n\t"
-        "v_lshl_or_b32 %[a2], %[a2], 5, %[i0]\n\t"
-        "v_lshl_or_b32 %[a3], %[a3], 5, %[i0]\n\t"
-        "v_sub_f32_e64 %[c0], %[cc], |%[c0]|\n\t"
-        "v_sub_f32_e64 %[c1], %[cc], |%[c1]|\n\t"
-        "v_sub_f32_e64 %[c2], %[cc], |%[c2]|\n\t"
-        "v_sub_f32_e64 %[c3], %[cc], |%[c3]|\n\t"
-        "v_lshl_or_b32 %[c0], %[c0], 5, %[i1]\n\t"
-        "v_lshl_or_b32 %[c1], %[c1], 5, %[i1]\n\t"
-        "v_lshl_or_b32 %[c2], %[c2], 5, %[i1]\n\t"
-        "v_lshl_or_b32 %[c3], %[c3], 5, %[i1]\n\t"
-        "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
-        "v_min3_u32 %[k1], %[k1], %[a1], %[c1]\n\t"
-        "v_min3_u32 %[k2], %[k2], %[a2], %[c2]\n\t"
-        "v_min3_u32 %[k3], %[k3], %[a3], %[c3]\n\t"
-        "v_mul_f32_e32 %[a0], %[t2x], %[x0]\n\t"
-        "v_mul_f32_e32 %[a1], %[t2x], %[x1]\n\t"
-        "v_mul_f32_e32 %[a2], %[t2x], %[x2]\n\t"
-        "v_mul_f32_e32 %[a3], %[t2x], %[x3]\n\t"
-        "v_mul_f32_e32 %[b0], %[t2y], %[y0]\n\t"
-        "v_mul_f32_e32 %[b1], %[t2y], %[y1]\n\t"
-        "v_mul_f32_e32 %[b2], %[t2y], %[y2]\n\t"
-        "v_mul_f32_e32 %[b3], %[t2y], %[y3]\n\t"
-        "v_mul_f32_e32 %[c0], %[t3x], %[x0]\n\t"
-        "v_mul_f32_e32 %[c1], %[t3x], %[x1]\n\t"
-        "v_mul_f32_e32 %[c2], %[t3x], %[x2]\n\t"
-        "v_mul_f32_e32 %[c3], %[t3x], %[x3]\n\t"
-        "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
-        "v_add_f32_e32 %[a1], %[a1], %[b1]\n\t"
-        "v_add_f32_e32 %[a2], %[a2], %[b2]\n\t"
-        "v_add_f32_e32 %[a3], %[a3], %[b3]\n\t"
-        "v_mul_f32_e32 %[b0], %[t3y], %[y0]\n\t"
-        "v_mul_f32_e32 %[b1], %[t3y], %[y1]\n\t"
-        "v_mul_f32_e32 %[b2], %[t3y], %[y2]\n\t"
-        "v_mul_f32_e32 %[b3], %[t3y], %[y3]\n\t"
-        "v_sub_f32_e64 %[a0], %[cc], |%[a0]|\n\t"
-        "v_sub_f32_e64 %[a1], %[cc], |%[a1]|\n\t"
-        "v_sub_f32_e64 %[a2], %[cc], |%[a2]|\n\t"
-        "v_sub_f32_e64 %[a3], %[cc], |%[a3]|\n\t"
-        "v_add_f32_e32 %[c0], %[c0], %[b0]\n\t"
-        "v_add_f32_e32 %[c1], %[c1], %[b1]\n\t"
-        "v_add_f32_e32 %[c2], %[c2], %[b2]\n\t"
-        "v_add_f32_e32 %[c3], %[c3], %[b3]\n\t"
-        "v_lshl_or_b32 %[a0], %[a0], 5, %[i2]\n\t"
-        "v_lshl_or_b32 %[a1], %[a1], 5, %[i2]\n\t"
-        "v_lshl_or_b32 %[a2], %[a2], 5, %[i2]\n\t"
-        "v_lshl_or_b32 %[a3], %[a3], 5, %[i2]\n\t"
-        "v_sub_f32_e64 %[c0], %[cc], |%[c0]|\n\t"
-        "v_sub_f32_e64 %[c1], %[cc], |%[c1]|\n\t"
-        "v_sub_f32_e64 %[c2], %[cc], |%[c2]|\n\t"
-        "v_sub_f32_e64 %[c3], %[cc], |%[c3]|\n\t"
-        "v_lshl_or_b32 %[c0], %[c0], 5, %[i3]\n\t"
-        "v_lshl_or_b32 %[c1], %[c1], 5, %[i3]\n\t"
-        "v_lshl_or_b32 %[c2], %[c2], 5, %[i3]\n\t"
-        "v_lshl_or_b32 %[c3], %[c3], 5, %[i3]\n\t"
-        "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
-        "v_min3_u32 %[k1], %[k1], %[a1], %[c1]\n\t"
-        "v_min3_u32 %[k2], %[k2], %[a2], %[c2]\n\t"
-        "v_min3_u32 %[k3], %[k3], %[a3], %[c3]"
-        : [k0] "+v"(k[0]), [k1] "+v"(k[1]), [k2] "+v"(k[2]), [k3] "+v"(k[3]), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2),
-          [a3] "=&v"(a3), [b0] "=&v"(b0), [b1] "=&v"(b1), [b2] "=&v"(b2), [b3] "=&v"(b3), [c0] "=&v"(c0), [c1] "=&v"(c1),
-          [c2] "=&v"(c2), [c3] "=&v"(c3)
-        : [t0x] "v"(g[0].x), [t0y] "v"(g[0].y), [t1x] "v"(g[1].x), [t1y] "v"(g[1].y), [t2x] "v"(g[2].x), [t2y] "v"(g[2].y),
-          [t3x] "v"(g[3].x), [t3y] "v"(g[3].y), [x0] "v"(DX[0]), [x1] "v"(DX[1]), [x2] "v"(DX[2]), [x3] "v"(DX[3]),
-          [y0] "v"(DY[0]), [y1] "v"(DY[1]), [y2] "v"(DY[2]), [y3] "v"(DY[3]), [cc] "s"(MH_KEY_C), [i0] "s"(ib),
-          [i1] "s"(ib + 1), [i2] "s"(ib + 2), [i3] "s"(ib + 3)
-        : "memory");   // (keeps the LDS reads of the NEXT group, issued in front of the block, in front of it)
+// Four taps x NI items of the key body as ONE hand-ordered block: per item 16 full-rate (mul, mul, add, sub) + 4 v_lshl_or +
+// 2 v_min3 (88 instructions for four items), every result used at least NI - 1 instructions after it is produced.  (Left to
+// the compiler as one asm statement per instruction, its hazard recogniser pads every inline-asm result that is read by
+// the very next instruction with an s_nop -- it cannot see that no dst_sel is involved: ~9 per block.)  The "memory"
+// clobber keeps the LDS reads of the NEXT tap group, issued in front of the block, in front of it.
+// k[0..NI), DX, DY: the first NI entries of the caller's arrays are used.
+template <int NI, int KN>
+__device__ __forceinline__ void mh_key_block(unsigned (&k)[KN], const float2 (&g)[4], const float (&DX)[KN],
+                                             const float (&DY)[KN], int ib) {
+    static_assert(NI >= 2 && NI <= 4 && NI <= KN, "mh_key_block: 2..4 items");
+    float a[NI], b[NI], c[NI];
+    if constexpr (NI == 4) {
+        asm volatile(
+            "v_mul_f32_e32 %[a0], %[t0x], %[x0]\n\t"
+            "v_mul_f32_e32 %[a1], %[t0x], %[x1]\n\t"
+            "v_mul_f32_e32 %[a2], %[t0x], %[x2]\n\t"
+            "v_mul_f32_e32 %[a3], %[t0x], %[x3]\n\t"
+            "v_mul_f32_e32 %[b0], %[t0y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t0y], %[y1]\n\t"
+            "v_mul_f32_e32 %[b2], %[t0y], %[y2]\n\t"
+            "v_mul_f32_e32 %[b3], %[t0y], %[y3]\n\t"
+            "v_mul_f32_e32 %[c0], %[t1x], %[x0]\n\t"
+            "v_mul_f32_e32 %[c1], %[t1x], %[x1]\n\t"
+            "v_mul_f32_e32 %[c2], %[t1x], %[x2]\n\t"
+            "v_mul_f32_e32 %[c3], %[t1x], %[x3]\n\t"
+            "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
+            "v_add_f32_e32 %[a1], %[a1], %[b1]\n\t"
+            "v_add_f32_e32 %[a2], %[a2], %[b2]\n\t"
+            "v_add_f32_e32 %[a3], %[a3], %[b3]\n\t"
+            "v_mul_f32_e32 %[b0], %[t1y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t1y], %[y1]\n\t"
+            "v_mul_f32_e32 %[b2], %[t1y], %[y2]\n\t"
+            "v_mul_f32_e32 %[b3], %[t1y], %[y3]\n\t"
+            "v_sub_f32_e64 %[a0], %[cc], |%[a0]|\n\t"
+            "v_sub_f32_e64 %[a1], %[cc], |%[a1]|\n\t"
+            "v_sub_f32_e64 %[a2], %[cc], |%[a2]|\n\t"
+            "v_sub_f32_e64 %[a3], %[cc], |%[a3]|\n\t"
+            "v_add_f32_e32 %[c0], %[c0], %[b0]\n\t"
+            "v_add_f32_e32 %[c1], %[c1], %[b1]\n\t"
+            "v_add_f32_e32 %[c2], %[c2], %[b2]\n\t"
+            "v_add_f32_e32 %[c3], %[c3], %[b3]\n\t"
+            "v_lshl_or_b32 %[a0], %[a0], 5, %[i0]\n\t"
+            "v_lshl_or_b32 %[a1], %[a1], 5, %[i0]\n\t"
+            "v_lshl_or_b32 %[a2], %[a2], 5, %[i0]\n\t"
+            "v_lshl_or_b32 %[a3], %[a3], 5, %[i0]\n\t"
+            "v_sub_f32_e64 %[c0], %[cc], |%[c0]|\n\t"
+            "v_sub_f32_e64 %[c1], %[cc], |%[c1]|\n\t"
+            "v_sub_f32_e64 %[c2], %[cc], |%[c2]|\n\t"
+            "v_sub_f32_e64 %[c3], %[cc], |%[c3]|\n\t"
+            "v_lshl_or_b32 %[c0], %[c0], 5, %[i1]\n\t"
+            "v_lshl_or_b32 %[c1], %[c1], 5, %[i1]\n\t"
+            "v_lshl_or_b32 %[c2], %[c2], 5, %[i1]\n\t"
+            "v_lshl_or_b32 %[c3], %[c3], 5, %[i1]\n\t"
+            "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
+            "v_min3_u32 %[k1], %[k1], %[a1], %[c1]\n\t"
+            "v_min3_u32 %[k2], %[k2], %[a2], %[c2]\n\t"
+            "v_min3_u32 %[k3], %[k3], %[a3], %[c3]\n\t"
+            "v_mul_f32_e32 %[a0], %[t2x], %[x0]\n\t"
+            "v_mul_f32_e32 %[a1], %[t2x], %[x1]\n\t"
+            "v_mul_f32_e32 %[a2], %[t2x], %[x2]\n\t"
+            "v_mul_f32_e32 %[a3], %[t2x], %[x3]\n\t"
+            "v_mul_f32_e32 %[b0], %[t2y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t2y], %[y1]\n\t"
+            "v_mul_f32_e32 %[b2], %[t2y], %[y2]\n\t"
+            "v_mul_f32_e32 %[b3], %[t2y], %[y3]\n\t"
+            "v_mul_f32_e32 %[c0], %[t3x], %[x0]\n\t"
+            "v_mul_f32_e32 %[c1], %[t3x], %[x1]\n\t"
+            "v_mul_f32_e32 %[c2], %[t3x], %[x2]\n\t"
+            "v_mul_f32_e32 %[c3], %[t3x], %[x3]\n\t"
+            "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
+            "v_add_f32_e32 %[a1], %[a1], %[b1]\n\t"
+            "v_add_f32_e32 %[a2], %[a2], %[b2]\n\t"
+            "v_add_f32_e32 %[a3], %[a3], %[b3]\n\t"
+            "v_mul_f32_e32 %[b0], %[t3y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t3y], %[y1]\n\t"
+            "v_mul_f32_e32 %[b2], %[t3y], %[y2]\n\t"
+            "v_mul_f32_e32 %[b3], %[t3y], %[y3]\n\t"
+            "v_sub_f32_e64 %[a0], %[cc], |%[a0]|\n\t"
+            "v_sub_f32_e64 %[a1], %[cc], |%[a1]|\n\t"
+            "v_sub_f32_e64 %[a2], %[cc], |%[a2]|\n\t"
+            "v_sub_f32_e64 %[a3], %[cc], |%[a3]|\n\t"
+            "v_add_f32_e32 %[c0], %[c0], %[b0]\n\t"
+            "v_add_f32_e32 %[c1], %[c1], %[b1]\n\t"
+            "v_add_f32_e32 %[c2], %[c2], %[b2]\n\t"
+            "v_add_f32_e32 %[c3], %[c3], %[b3]\n\t"
+            "v_lshl_or_b32 %[a0], %[a0], 5, %[i2]\n\t"
+            "v_lshl_or_b32 %[a1], %[a1], 5, %[i2]\n\t"
+            "v_lshl_or_b32 %[a2], %[a2], 5, %[i2]\n\t"
+            "v_lshl_or_b32 %[a3], %[a3], 5, %[i2]\n\t"
+            "v_sub_f32_e64 %[c0], %[cc], |%[c0]|\n\t"
+            "v_sub_f32_e64 %[c1], %[cc], |%[c1]|\n\t"
+            "v_sub_f32_e64 %[c2], %[cc], |%[c2]|\n\t"
+            "v_sub_f32_e64 %[c3], %[cc], |%[c3]|\n\t"
+            "v_lshl_or_b32 %[c0], %[c0], 5, %[i3]\n\t"
+            "v_lshl_or_b32 %[c1], %[c1], 5, %[i3]\n\t"
+            "v_lshl_or_b32 %[c2], %[c2], 5, %[i3]\n\t"
+            "v_lshl_or_b32 %[c3], %[c3], 5, %[i3]\n\t"
+            "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
+            "v_min3_u32 %[k1], %[k1], %[a1], %[c1]\n\t"
+            "v_min3_u32 %[k2], %[k2], %[a2], %[c2]\n\t"
+            "v_min3_u32 %[k3], %[k3], %[a3], %[c3]"
+            : [k0] "+v"(k[0]), [k1] "+v"(k[1]), [k2] "+v"(k[2]), [k3] "+v"(k[3]), [a0] "=&v"(a[0]), [a1] "=&v"(a[1]), [a2] "=&v"(a[2]), [a3] "=&v"(a[3]), [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [b2] "=&v"(b[2]), [b3] "=&v"(b[3]), [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2]), [c3] "=&v"(c[3])
+            : [t0x] "v"(g[0].x), [t0y] "v"(g[0].y), [t1x] "v"(g[1].x), [t1y] "v"(g[1].y), [t2x] "v"(g[2].x), [t2y] "v"(g[2].y), [t3x] "v"(g[3].x), [t3y] "v"(g[3].y), [x0] "v"(DX[0]), [y0] "v"(DY[0]), [x1] "v"(DX[1]), [y1] "v"(DY[1]), [x2] "v"(DX[2]), [y2] "v"(DY[2]), [x3] "v"(DX[3]), [y3] "v"(DY[3]), [cc] "s"(MH_KEY_C), [i0] "s"(ib), [i1] "s"(ib + 1), [i2] "s"(ib + 2), [i3] "s"(ib + 3)
+            : "memory");
+    }
+    else if constexpr (NI == 3) {
+        asm volatile(
+            "v_mul_f32_e32 %[a0], %[t0x], %[x0]\n\t"
+            "v_mul_f32_e32 %[a1], %[t0x], %[x1]\n\t"
+            "v_mul_f32_e32 %[a2], %[t0x], %[x2]\n\t"
+            "v_mul_f32_e32 %[b0], %[t0y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t0y], %[y1]\n\t"
+            "v_mul_f32_e32 %[b2], %[t0y], %[y2]\n\t"
+            "v_mul_f32_e32 %[c0], %[t1x], %[x0]\n\t"
+            "v_mul_f32_e32 %[c1], %[t1x], %[x1]\n\t"
+            "v_mul_f32_e32 %[c2], %[t1x], %[x2]\n\t"
+            "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
+            "v_add_f32_e32 %[a1], %[a1], %[b1]\n\t"
+            "v_add_f32_e32 %[a2], %[a2], %[b2]\n\t"
+            "v_mul_f32_e32 %[b0], %[t1y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t1y], %[y1]\n\t"
+            "v_mul_f32_e32 %[b2], %[t1y], %[y2]\n\t"
+            "v_sub_f32_e64 %[a0], %[cc], |%[a0]|\n\t"
+            "v_sub_f32_e64 %[a1], %[cc], |%[a1]|\n\t"
+            "v_sub_f32_e64 %[a2], %[cc], |%[a2]|\n\t"
+            "v_add_f32_e32 %[c0], %[c0], %[b0]\n\t"
+            "v_add_f32_e32 %[c1], %[c1], %[b1]\n\t"
+            "v_add_f32_e32 %[c2], %[c2], %[b2]\n\t"
+            "v_lshl_or_b32 %[a0], %[a0], 5, %[i0]\n\t"
+            "v_lshl_or_b32 %[a1], %[a1], 5, %[i0]\n\t"
+            "v_lshl_or_b32 %[a2], %[a2], 5, %[i0]\n\t"
+            "v_sub_f32_e64 %[c0], %[cc], |%[c0]|\n\t"
+            "v_sub_f32_e64 %[c1], %[cc], |%[c1]|\n\t"
+            "v_sub_f32_e64 %[c2], %[cc], |%[c2]|\n\t"
+            "v_lshl_or_b32 %[c0], %[c0], 5, %[i1]\n\t"
+            "v_lshl_or_b32 %[c1], %[c1], 5, %[i1]\n\t"
+            "v_lshl_or_b32 %[c2], %[c2], 5, %[i1]\n\t"
+            "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
+            "v_min3_u32 %[k1], %[k1], %[a1], %[c1]\n\t"
+            "v_min3_u32 %[k2], %[k2], %[a2], %[c2]\n\t"
+            "v_mul_f32_e32 %[a0], %[t2x], %[x0]\n\t"
+            "v_mul_f32_e32 %[a1], %[t2x], %[x1]\n\t"
+            "v_mul_f32_e32 %[a2], %[t2x], %[x2]\n\t"
+            "v_mul_f32_e32 %[b0], %[t2y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t2y], %[y1]\n\t"
+            "v_mul_f32_e32 %[b2], %[t2y], %[y2]\n\t"
+            "v_mul_f32_e32 %[c0], %[t3x], %[x0]\n\t"
+            "v_mul_f32_e32 %[c1], %[t3x], %[x1]\n\t"
+            "v_mul_f32_e32 %[c2], %[t3x], %[x2]\n\t"
+            "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
+            "v_add_f32_e32 %[a1], %[a1], %[b1]\n\t"
+            "v_add_f32_e32 %[a2], %[a2], %[b2]\n\t"
+            "v_mul_f32_e32 %[b0], %[t3y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t3y], %[y1]\n\t"
+            "v_mul_f32_e32 %[b2], %[t3y], %[y2]\n\t"
+            "v_sub_f32_e64 %[a0], %[cc], |%[a0]|\n\t"
+            "v_sub_f32_e64 %[a1], %[cc], |%[a1]|\n\t"
+            "v_sub_f32_e64 %[a2], %[cc], |%[a2]|\n\t"
+            "v_add_f32_e32 %[c0], %[c0], %[b0]\n\t"
+            "v_add_f32_e32 %[c1], %[c1], %[b1]\n\t"
+            "v_add_f32_e32 %[c2], %[c2], %[b2]\n\t"
+            "v_lshl_or_b32 %[a0], %[a0], 5, %[i2]\n\t"
+            "v_lshl_or_b32 %[a1], %[a1], 5, %[i2]\n\t"
+            "v_lshl_or_b32 %[a2], %[a2], 5, %[i2]\n\t"
+            "v_sub_f32_e64 %[c0], %[cc], |%[c0]|\n\t"
+            "v_sub_f32_e64 %[c1], %[cc], |%[c1]|\n\t"
+            "v_sub_f32_e64 %[c2], %[cc], |%[c2]|\n\t"
+            "v_lshl_or_b32 %[c0], %[c0], 5, %[i3]\n\t"
+            "v_lshl_or_b32 %[c1], %[c1], 5, %[i3]\n\t"
+            "v_lshl_or_b32 %[c2], %[c2], 5, %[i3]\n\t"
+            "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
+            "v_min3_u32 %[k1], %[k1], %[a1], %[c1]\n\t"
+            "v_min3_u32 %[k2], %[k2], %[a2], %[c2]"
+            : [k0] "+v"(k[0]), [k1] "+v"(k[1]), [k2] "+v"(k[2]), [a0] "=&v"(a[0]), [a1] "=&v"(a[1]), [a2] "=&v"(a[2]), [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [b2] "=&v"(b[2]), [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2])
+            : [t0x] "v"(g[0].x), [t0y] "v"(g[0].y), [t1x] "v"(g[1].x), [t1y] "v"(g[1].y), [t2x] "v"(g[2].x), [t2y] "v"(g[2].y), [t3x] "v"(g[3].x), [t3y] "v"(g[3].y), [x0] "v"(DX[0]), [y0] "v"(DY[0]), [x1] "v"(DX[1]), [y1] "v"(DY[1]), [x2] "v"(DX[2]), [y2] "v"(DY[2]), [cc] "s"(MH_KEY_C), [i0] "s"(ib), [i1] "s"(ib + 1), [i2] "s"(ib + 2), [i3] "s"(ib + 3)
+            : "memory");
+    }
+    else if constexpr (NI == 2) {
+        asm volatile(
+            "v_mul_f32_e32 %[a0], %[t0x], %[x0]\n\t"
+            "v_mul_f32_e32 %[a1], %[t0x], %[x1]\n\t"
+            "v_mul_f32_e32 %[b0], %[t0y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t0y], %[y1]\n\t"
+            "v_mul_f32_e32 %[c0], %[t1x], %[x0]\n\t"
+            "v_mul_f32_e32 %[c1], %[t1x], %[x1]\n\t"
+            "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
+            "v_add_f32_e32 %[a1], %[a1], %[b1]\n\t"
+            "v_mul_f32_e32 %[b0], %[t1y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t1y], %[y1]\n\t"
+            "v_sub_f32_e64 %[a0], %[cc], |%[a0]|\n\t"
+            "v_sub_f32_e64 %[a1], %[cc], |%[a1]|\n\t"
+            "v_add_f32_e32 %[c0], %[c0], %[b0]\n\t"
+            "v_add_f32_e32 %[c1], %[c1], %[b1]\n\t"
+            "v_lshl_or_b32 %[a0], %[a0], 5, %[i0]\n\t"
+            "v_lshl_or_b32 %[a1], %[a1], 5, %[i0]\n\t"
+            "v_sub_f32_e64 %[c0], %[cc], |%[c0]|\n\t"
+            "v_sub_f32_e64 %[c1], %[cc], |%[c1]|\n\t"
+            "v_lshl_or_b32 %[c0], %[c0], 5, %[i1]\n\t"
+            "v_lshl_or_b32 %[c1], %[c1], 5, %[i1]\n\t"
+            "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
+            "v_min3_u32 %[k1], %[k1], %[a1], %[c1]\n\t"
+            "v_mul_f32_e32 %[a0], %[t2x], %[x0]\n\t"
+            "v_mul_f32_e32 %[a1], %[t2x], %[x1]\n\t"
+            "v_mul_f32_e32 %[b0], %[t2y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t2y], %[y1]\n\t"
+            "v_mul_f32_e32 %[c0], %[t3x], %[x0]\n\t"
+            "v_mul_f32_e32 %[c1], %[t3x], %[x1]\n\t"
+            "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
+            "v_add_f32_e32 %[a1], %[a1], %[b1]\n\t"
+            "v_mul_f32_e32 %[b0], %[t3y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t3y], %[y1]\n\t"
+            "v_sub_f32_e64 %[a0], %[cc], |%[a0]|\n\t"
+            "v_sub_f32_e64 %[a1], %[cc], |%[a1]|\n\t"
+            "v_add_f32_e32 %[c0], %[c0], %[b0]\n\t"
+            "v_add_f32_e32 %[c1], %[c1], %[b1]\n\t"
+            "v_lshl_or_b32 %[a0], %[a0], 5, %[i2]\n\t"
+            "v_lshl_or_b32 %[a1], %[a1], 5, %[i2]\n\t"
+            "v_sub_f32_e64 %[c0], %[cc], |%[c0]|\n\t"
+            "v_sub_f32_e64 %[c1], %[cc], |%[c1]|\n\t"
+            "v_lshl_or_b32 %[c0], %[c0], 5, %[i3]\n\t"
+            "v_lshl_or_b32 %[c1], %[c1], 5, %[i3]\n\t"
+            "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
+            "v_min3_u32 %[k1], %[k1], %[a1], %[c1]"
+            : [k0] "+v"(k[0]), [k1] "+v"(k[1]), [a0] "=&v"(a[0]), [a1] "=&v"(a[1]), [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [c0] "=&v"(c[0]), [c1] "=&v"(c[1])
+            : [t0x] "v"(g[0].x), [t0y] "v"(g[0].y), [t1x] "v"(g[1].x), [t1y] "v"(g[1].y), [t2x] "v"(g[2].x), [t2y] "v"(g[2].y), [t3x] "v"(g[3].x), [t3y] "v"(g[3].y), [x0] "v"(DX[0]), [y0] "v"(DY[0]), [x1] "v"(DX[1]), [y1] "v"(DY[1]), [cc] "s"(MH_KEY_C), [i0] "s"(ib), [i1] "s"(ib + 1), [i2] "s"(ib + 2), [i3] "s"(ib + 3)
+            : "memory");
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -542,6 +665,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
                                                      int nact, int tid, float *s_loss, uint8_t *s_pos, float4 *s_taps,
                                                      const float4 *s_rank) {
     constexpr int KN = KA > 0 ? KA : 1;   // a wave without items (KA == 0) only helps to stage the lists
+    constexpr int KM = KA;
     const int V = vw.V;
     const float Hf = (float)vw.H, Wf = (float)vw.W;
     float X0[KN], X1[KN], X2[KN];
@@ -578,6 +702,16 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
         const float4 hdr = rec[0];
         const float4 t0 = rec[1];
         float DX[KN], DY[KN], ML[KN], BC[KN];
+#ifdef MH_EXP_NOTAPS   // timing experiments only (wrong results): tools/exp_search_parts.sh
+        ntap = 1;
+#endif
+#ifdef MH_EXP_NOPROJ
+#pragma unroll
+        for (int j = 0; j < KN; ++j) {
+            DX[j] = X0[j] + hdr.z;
+            DY[j] = X1[j] + hdr.w;
+        }
+#else
 #pragma unroll
         for (int jp = 0; jp < KA / 2; ++jp) {
             mh_v2f row, col, dx, dy;
@@ -596,6 +730,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
             DX[KA - 1] = dx.x;
             DY[KA - 1] = dy.x;
         }
+#endif
         constexpr int GRP = MH_S3_GRP;
         // the compare-and-select body: exact everywhere (the one body of rounds 1-3; with KEYS the re-evaluation path)
         auto select_body = [&]() {
@@ -650,26 +785,26 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
                 unsigned gofs[KN];
                 auto process = [&](const float2 (&g)[GRP], int t, int t1) {
                     const int ib = t & 31;
-                    if constexpr (KA == 4 && MH_KEY_PAD >= 4 && GRP == 4) {
-                        mh_key_block4(acc, g, DX, DY, ib);
+                    if constexpr (KM >= 2 && KM <= 4 && MH_KEY_PAD >= 4 && GRP == 4) {
+                        mh_key_block<KM, KN>(acc, g, DX, DY, ib);
                         return;
                     }
                     unsigned k[GRP][KN];
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int j = 0; j < KA; ++j)
+                        for (int j = 0; j < KM; ++j)
                             k[u][j] = mh_tap_key(mh_vadd(mh_vmul(g[u].x, DX[j]), mh_vmul(g[u].y, DY[j])), ib + u);
 #pragma unroll
-                    for (int j = 0; j < KA; ++j) acc[j] = mh_min3u(acc[j], k[0][j], k[1][j]);
+                    for (int j = 0; j < KM; ++j) acc[j] = mh_min3u(acc[j], k[0][j], k[1][j]);
                     if (MH_KEY_PAD >= 4 || t + 2 < t1) {   // uniform
 #pragma unroll
                         for (int u = 2; u < 4; ++u)
 #pragma unroll
-                            for (int j = 0; j < KA; ++j)
+                            for (int j = 0; j < KM; ++j)
                                 k[u][j] = mh_tap_key(mh_vadd(mh_vmul(g[u].x, DX[j]), mh_vmul(g[u].y, DY[j])), ib + u);
 #pragma unroll
-                        for (int j = 0; j < KA; ++j) acc[j] = mh_min3u(acc[j], k[2][j], k[3][j]);
+                        for (int j = 0; j < KM; ++j) acc[j] = mh_min3u(acc[j], k[2][j], k[3][j]);
                     }
                 };
                 // taps [ta, tb) of one 32-tap group into acc: (tx, ty) of tap i is the first half of record 1 + i
@@ -694,32 +829,35 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
                         t += GRP;
                     }
                 };
-                group(0, ntp < 32 ? ntp : 32);
+                bool bad = false;
+                if constexpr (KM > 0) {
+                    group(0, ntp < 32 ? ntp : 32);
 #pragma unroll
-                for (int j = 0; j < KN; ++j) {
-                    best[j] = acc[j];
-                    gofs[j] = rec1;
-                }
-                for (int ta = 32; ta < ntp; ta += 32) {   // later groups: an earlier group wins ties
-                    group(ta, ntp < ta + 32 ? ntp : ta + 32);
-#pragma unroll
-                    for (int j = 0; j < KN; ++j) {
-                        const bool lt = acc[j] < (best[j] & ~31u);
-                        best[j] = lt ? acc[j] : best[j];
-                        gofs[j] = lt ? rec1 + 16u * (unsigned)ta : gofs[j];
+                    for (int j = 0; j < KM; ++j) {
+                        best[j] = acc[j];
+                        gofs[j] = rec1;
                     }
-                }
-                // decode: one compare for "any key past the valid range", loss = t' - 2^-14 from the key's upper bits
-                // (v_alignbit puts the constant 0b00111 back in front), confidence of the winning tap from its LDS record
-                unsigned worst = best[0];
+                    for (int ta = 32; ta < ntp; ta += 32) {   // later groups: an earlier group wins ties
+                        group(ta, ntp < ta + 32 ? ntp : ta + 32);
 #pragma unroll
-                for (int j = 1; j < KA; ++j) worst = max(worst, best[j]);
-                const bool bad = worst >= MH_KEY_BAD;
+                        for (int j = 0; j < KM; ++j) {
+                            const bool lt = acc[j] < (best[j] & ~31u);
+                            best[j] = lt ? acc[j] : best[j];
+                            gofs[j] = lt ? rec1 + 16u * (unsigned)ta : gofs[j];
+                        }
+                    }
+                    // decode: one compare for "any key past the valid range", loss = t' - 2^-14 from the key's upper bits
+                    // (v_alignbit puts the constant 0b00111 back in front), confidence of the winning tap from its record
+                    unsigned worst = best[0];
 #pragma unroll
-                for (int j = 0; j < KA; ++j) {
-                    BC[j] = *reinterpret_cast<const __attribute__((address_space(3))) float *>(
-                        (size_t)(gofs[j] + ((best[j] & 31u) << 4) + 8u));
-                    ML[j] = __uint_as_float(__builtin_amdgcn_alignbit(7u, best[j], 5u)) - MH_KEY_E;
+                    for (int j = 1; j < KM; ++j) worst = max(worst, best[j]);
+                    bad = worst >= MH_KEY_BAD;
+#pragma unroll
+                    for (int j = 0; j < KM; ++j) {
+                        BC[j] = *reinterpret_cast<const __attribute__((address_space(3))) float *>(
+                            (size_t)(gofs[j] + ((best[j] & 31u) << 4) + 8u));
+                        ML[j] = __uint_as_float(__builtin_amdgcn_alignbit(7u, best[j], 5u)) - MH_KEY_E;
+                    }
                 }
                 again = __ballot(bad) != 0ull;
                 if (again) MH_KEY_COUNT(2);

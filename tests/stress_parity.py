@@ -30,7 +30,10 @@ ap.add_argument("--codes", action="store_true", help="maps uploaded as random 8-
 ap.add_argument("--ori-mode", default="", help="adversarial orientation fields for the tap search (continuous maps only): "
                 "'mix' draws per scene from: const (one direction per view + tiny noise on a few pixels: near-ties, lists of "
                 "1-3 taps), two (two exactly perpendicular directions), axis ((1,0)/(0,1)/(0,0)), fine (a fan of directions "
-                "1e-7..1e-4 rad apart: many taps on the flat top of the cosine, losses 0 and below), nan (NaN pixels)")
+                "1e-7..1e-4 rad apart: many taps on the flat top of the cosine, losses 0 and below); 'nan' (NaN pixels) is not part of "
+                "'mix': NaN map pixels are outside the pinned domain (the front-end kernels and the oracle treat them differently, "
+                "with either tap body of the search)")
+ap.add_argument("--body", type=int, default=0, help="tap body of the shipped search: 0 by the maps, 1 keys, 2 select (option search_body)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 DEV = "cuda:0"
@@ -80,7 +83,7 @@ while time.time() < t_end:
                      conf=torch.from_numpy(lut[c8][..., 2].copy()), mask=torch.from_numpy(lut[m8][..., 3].copy()))
     else:
         if a.ori_mode:
-            mode = a.ori_mode if a.ori_mode != "mix" else str(rng.choice(["const", "two", "axis", "fine", "nan", "plain"]))
+            mode = a.ori_mode if a.ori_mode != "mix" else str(rng.choice(["const", "two", "axis", "fine", "plain"]))
             o = scene["ori"].numpy().copy()
             ang = rng.uniform(0, np.pi, size=(V, 1, 1))
             if mode == "const":
@@ -104,6 +107,8 @@ while time.time() < t_end:
                               scene["mask"].to(DEV), device=DEV, patch_size=patch, visible_threshold=1, conf_threshold=thr)
     if a.variant:
         pm.set_option("search_variant", a.variant)
+    if a.body:
+        pm.set_option("search_body", a.body)
     views = oracle.Views(rec, scene["depth"].numpy(), scene["ori"].numpy(), scene["conf"].numpy(), scene["mask"].numpy())
     N = int(rng.integers(1, 400))
     cand = synth.candidate_points(res=int(rng.choice([32, 64])), seed=seed % 1000)

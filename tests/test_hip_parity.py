@@ -214,3 +214,43 @@ def test_intermediate_methods_vs_oracle_and_golden(case, depth_offsets):
         assert np.array_equal(hc.cpu().numpy(), o_hc)
         w = pm.compute_weight(pm.visible, pm.Conf, pm.mask)
         assert torch.equal(w, (pm.visible != -1).float() * pm.Conf)
+
+
+@pytest.mark.parametrize("V,patch", [(20, 7), (23, 7), (27, 9), (33, 5), (41, 11), (58, 7)])
+def test_item_slices_both_bodies(V, patch, depth_offsets):
+    """How many of the 10 base-view ranks of a point are usable decides how its 90-sample runs fall on the 64-lane item
+    slices of the four waves (10 ranks: 4 + 4 + 4 + 3 slices, the last one of 4 items; 5 ranks: 2 + 2 + 2 + 2 with a last
+    slice of 2; ...): every count of slices per wave is its own instantiation of the tap loop (hand-ordered key blocks for
+    4, 3 and 2 items, the generic form for 1).  Camera counts from 20 up give points with every count; patch 9 and 11 give tap
+    lists of three and four 32-tap groups.  Key body, select body and the portable kernel against the oracle, every point."""
+    from monohair_amd import synth
+    from monohair_amd.camera import camera_records, cameras_from_list
+    from monohair_amd.pmvo import PMVO
+
+    DEV = "cuda:0"
+    H, W, thr = 200, 150, 0.15
+    scene = synth.make_scene(V, H, W, device=DEV, seed=100 + V, quantize=False)
+    cams = cameras_from_list(scene["cams"])
+    rec = camera_records(cams)
+    pm = PMVO.from_planes(rec, scene["depth"], scene["ori"], scene["conf"], scene["mask"], device=DEV, patch_size=patch,
+                          visible_threshold=1, conf_threshold=thr, camera=cams)
+    views = oracle.Views(rec, scene["depth"].cpu().numpy(), scene["ori"].cpu().numpy(), scene["conf"].cpu().numpy(),
+                         scene["mask"].cpu().numpy())
+    pts = synth.candidate_points(res=64, seed=V, limit=700)
+    _, o_ori, o_loss, o_hc, o_ex = oracle.forward(views, pts, patch, thr, depth_offsets, extra=True)
+    usable = set()
+    for body, variant in ((1, 0), (2, 0), (0, 1256)):
+        pm.set_option("search_body", body)
+        pm.set_option("search_variant", variant)
+        _, ori, loss, hc, ex = pm.forward(pts, extras=True)
+        assert eq_nan(loss.cpu().numpy(), o_loss), (body, variant)
+        assert eq_nan(ori.cpu().numpy(), o_ori) and np.array_equal(hc.cpu().numpy(), o_hc), (body, variant)
+        assert np.array_equal(ex["best_s"].cpu().numpy(), o_ex["best_s"]), (body, variant)
+        assert np.array_equal(ex["best_rank"].cpu().numpy(), o_ex["best_rank"]), (body, variant)
+    pm.set_option("search_body", 0)
+    pm.set_option("search_variant", 0)
+    # the scene really has points with different numbers of usable ranks (rank r > 0 is usable if base_view_conf[2r] > 0)
+    _, val = pm.Find_max_conf_from_visible_view()
+    nvalid = 1 + (val.cpu().numpy()[2:20:2] > 0).sum(0)
+    usable.update(np.unique(nvalid).tolist())
+    assert len(usable) >= 3, usable
