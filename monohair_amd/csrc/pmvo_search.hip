@@ -663,7 +663,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
                                                      int n, int N, int P1, float thr,
                                                      const float4 *__restrict__ taps, const uint8_t *__restrict__ vcnt,
                                                      int nact, int tid, float *s_loss, uint8_t *s_pos, float4 *s_taps,
-                                                     const float4 *s_rank) {
+                                                     const float4 *s_rank, int c_first) {
     constexpr int KN = KA > 0 ? KA : 1;   // a wave without items (KA == 0) only helps to stage the lists
     constexpr int KM = KA;
     const int V = vw.V;
@@ -876,7 +876,9 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
     const int lane = tid & 63, wave = tid >> 6;
     for (int vb = 0; vb < V; vb += 64) {
         const int vv = vb + lane;
-        const int c = (vv < V) ? (int)vcnt[(size_t)vv * N + n] : 0;   // list length of view vv (0: the view does not see the point)
+        // list length of view vv (0: the view does not see the point); the first block's was requested in the kernel's
+        // prologue, in front of the first barrier
+        const int c = vb == 0 ? c_first : ((vv < V) ? (int)vcnt[(size_t)vv * N + n] : 0);
         // records: header + taps (KEYS: the taps of a list that goes through the key body padded to a multiple of
         // MH_KEY_PAD with neutral (0, 0) records)
         const int len = c ? ((KEYS && c > MH_KEY_MIN_TAPS) ? ((c + MH_KEY_PAD - 1) & ~(MH_KEY_PAD - 1)) : c) + 1 : 0;
@@ -965,7 +967,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MH_S3_WAVES))
     __shared__ float s_rl[MH_MAX_RANKS];
     __shared__ int s_ri[MH_MAX_RANKS];
     __shared__ int s_rh[MH_MAX_RANKS];
-    __shared__ float4 s_rank[MH_MAX_RANKS * 4];   // mh_sample_rank's record of every usable base-view rank
+    __shared__ float4 s_rank[MH_MAX_RANKS * 4];   // mh_sample_rank's record of every base-view rank
+    __shared__ float s_bval[MH_MAX_RANKS];        // base_view_conf of the ranks
 
     // Wave priority: everything that is not the tap loop -- prologue, staging, the per-view projection, the epilogue -- runs
     // at priority 1, the tap loop at 0.  The tap loops saturate the VALU whatever the arbiter picks; the other phases are
@@ -975,24 +978,30 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MH_S3_WAVES))
     const int tid = threadIdx.x;
     const int n = order ? order[blockIdx.x] : (int)blockIdx.x;
     const float P0 = pts[3 * n], P1x = pts[3 * n + 1], P2 = pts[3 * n + 2];
-    // usable base-view ranks: rank 0 always, rank r > 0 only if base_view_conf[r] > 0 (PMVO.py:57-64); keep every rank up
-    // to the last usable one
-    int nvalid = 1;
-    for (int r = 1; r < nrank; ++r)
-        if (base_val[(size_t)(r * rank_step) * N + n] > 0.0f) nvalid = r + 1;
-    const int nact = nvalid * S;
-    // what the S samples of a rank share (mh_sample_rank), once per (point, rank): lane r of the first wave
-    if (tid < nvalid) {
-        const int b = base_idx[(size_t)(tid * rank_step) * N + n];
+    // what the S samples of a rank share (mh_sample_rank), once per (point, rank): lane r of the first wave -- for every
+    // rank, usable or not, so that the rank's confidence, its base view, that view's centre orientation and camera are one
+    // chain of loads per lane, all ranks in parallel (a scalar loop over base_view_conf first cost five more round trips
+    // before the workgroup's first barrier)
+    const int c_first = ((tid & 63) < vw.V) ? (int)vcnt[(size_t)(tid & 63) * N + n] : 0;   // (see mh_search_slices_lds)
+    if (tid < nrank) {
+        const size_t ro = (size_t)(tid * rank_step) * N + n;
+        s_bval[tid] = base_val[ro];
+        const int b = base_idx[ro];
         const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
         mh_sample_rank(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, (float)vw.H, (float)vw.W,
                        reinterpret_cast<float *>(s_rank + 4 * tid));
     }
     __syncthreads();
+    // usable base-view ranks: rank 0 always, rank r > 0 only if base_view_conf[r] > 0 (PMVO.py:57-64); keep every rank up
+    // to the last usable one
+    int nvalid = 1;
+    for (int r = 1; r < nrank; ++r)
+        if (s_bval[r] > 0.0f) nvalid = r + 1;
+    const int nact = nvalid * S;
     const int wave0 = tid & ~63;   // first item of this wave in slice 0
     int ka = 0;
     for (int j = 0; j < 4; ++j) ka += (j * T + wave0 < nact) ? 1 : 0;
-#define MH_S3_ARGS vw, offs, S, n, N, P1, thr, taps, vcnt, nact, tid, s_loss, s_pos, s_taps, s_rank
+#define MH_S3_ARGS vw, offs, S, n, N, P1, thr, taps, vcnt, nact, tid, s_loss, s_pos, s_taps, s_rank, c_first
     if (ka == 4) mh_search_slices_lds<4, T, BIGV, KEYS>(MH_S3_ARGS);
     else if (ka == 3) mh_search_slices_lds<3, T, BIGV, KEYS>(MH_S3_ARGS);
     else if (ka == 2) mh_search_slices_lds<2, T, BIGV, KEYS>(MH_S3_ARGS);
@@ -1043,7 +1052,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MH_S3_WAVES))
         int br = 0, bs = s_ri[0], hc = s_rh[0];
         for (int r = 1; r < nvalid; ++r) {
             const float l = s_rl[r];
-            if ((l < ml) && (base_val[(size_t)(r * rank_step) * N + n] > 0.0f)) {
+            if ((l < ml) && (s_bval[r] > 0.0f)) {
                 ml = l;
                 br = r;
                 bs = s_ri[r];
