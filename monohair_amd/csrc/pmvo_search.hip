@@ -10,7 +10,9 @@
 // No [V,N,S] tensor ever exists.  The patch of (view, point) is the same for every lane of the
 // workgroup, so the tap list (pmvo_project.hip: mh_prep_taps_kernel) is read with wave-uniform loads (header
 // and first tap: scalar loads; the rest: broadcast vector loads, what the backend selects for the ping-pong
-// groups) and the inner loop is pure VALU: per (item, tap) 2 mul + add + (1-|x|) + cmp + 2 cndmask.
+// groups) and the inner loop is pure VALU: per (item, tap) 2 mul + add + (1-|x|) + cmp + 2 cndmask in the portable kernel and
+// the select body of the shipped one; its key body keeps the running (loss, tap) minimum as one integer key per item and
+// needs 2 mul + add + sub + lshl_or + half a min3 (see mh_tap_key).
 // Views in which the point is not visible (vis == -1 => weight 0, PMVO.py:212) are skipped: adding
 // their exact zeros would not change any sum.
 #include "mh_device.h"
