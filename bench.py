@@ -454,6 +454,11 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=False):
     return {
         "roofline": {
             "kernel": "mh_search3_kernel<256>", "bound": "valu",
+            # which of the kernel's two tap bodies this context runs (same results; monohair_amd/csrc/capi.cpp: contexts of
+            # 8-bit views take the select-only kernel, all others the key kernel; search_variant 100.. forces the select body)
+            "tap_body": ("select (v_cmp + 2 v_cndmask, 7 instructions per evaluation)" if (codes or 100 <= a.variant < 200)
+                         else "key ((loss, tap) as one integer, v_min3_u32: 5.5 instructions per evaluation)")
+                        if a.variant != 1256 else "portable kernel",
             "achieved": round(tf, 2), "peak": VALU_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TF, 4),
             "traffic": prof.get("traffic", {}).get(pre + "mh_search3_kernel<256>"),
             "traffic_source": prof.get("source"), "valu_issue_source": prof.get("source"),
