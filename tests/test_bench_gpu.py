@@ -33,6 +33,7 @@ def test_single_gpu_line_and_rooflines_of_the_timed_kernels():
     rf = d["roofline"]
     assert rf["kernel"].startswith("mh_search3_kernel") and rf["bound"] == "valu" and rf["peak"] == 157.3
     assert 0 < rf["pair_evals_executed"] <= rf["pair_evals_nominal"]
+    assert rf["tap_body"].startswith("key") and d["secondary_8bit_maps"]["roofline"]["tap_body"].startswith("select")
     # frac must be recomputable from the line itself
     assert abs(rf["pair_evals_executed"] * rf["flop_per_pair_eval"] / (rf["launch_ms"] * 1e-3) / 1e12 - rf["achieved"]) < 0.05
     names = [k["kernel"] for k in d["roofline_kernels"]]
