@@ -28,8 +28,7 @@ if __name__ == "__main__":
     if "--build-only" in sys.argv:
         build()
         sys.exit(0)
-    if not os.path.exists(LIB):
-        build()
+    build()   # (always: a stale copy would count another kernel)
     sys.path.insert(0, ROOT)
     from monohair_amd import _lib
 
