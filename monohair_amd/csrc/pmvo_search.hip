@@ -783,7 +783,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
                 const int ntp = (ntap + MH_KEY_PAD - 1) & ~(MH_KEY_PAD - 1);
                 unsigned acc[KN], best[KN];
                 // LDS byte address of the first tap record of the winning group (the confidence gather of the decode)
-                const unsigned rec1 = (unsigned)(size_t)(rec + 1);   // (LDS pointers: the low 32 bits are the address)
+                const unsigned rec1 = (unsigned)(size_t)(const __attribute__((address_space(3))) float4 *)(rec + 1);
                 unsigned gofs[KN];
                 auto process = [&](const float2 (&g)[GRP], int t, int t1) {
                     const int ib = t & 31;
