@@ -352,10 +352,14 @@ __device__ __forceinline__ void mh_tap_update(float (&ML)[KA], float (&BC)[KA], 
 //     x < 0.5 both results lie in [0.5, 1), where the grid is 2^-24 and round-to-nearest-even commutes with adding the
 //     even multiple 2^10 of the grid;
 //   * a positive float in [2^-15, 2), whose bits all start 0b00111: (bits << 5) drops only those constant bits and is
-//     monotone in t', which leaves five bits for the tap index inside a 32-tap group.
-// key = (bits(t') << 5) | (t mod 32); the unsigned minimum of the keys of a group (v_min3_u32, two taps at a time) is
-// the group's first-index minimum, groups are merged with "an earlier group wins ties".  mul, mul, add, sub, lshl_or per
-// evaluation + half a min3: 5.5 instructions instead of 7 (and one register per item instead of two).
+//     monotone in t', which leaves five bits for a tap index.
+// A list is walked in groups of 64 taps (one group for every patch up to 8 x 8); the even taps of a group fold into one
+// accumulator, the odd taps into a second one, key = (bits(t') << 5) | (place of the tap among them, 0..31), two taps per
+// v_min3_u32.  The group's first-index minimum is the odd accumulator's key if it is STRICTLY smaller than the even one's
+// (equal loss and place: tap 2i is earlier than 2i + 1; equal loss, smaller place i' < i: 2i' + 1 < 2i), else the even
+// one's; its tap = 2 * place + parity.  A later group replaces an earlier one only on a strictly smaller loss.  mul, mul,
+// add, sub, lshl_or per evaluation + half a min3: 5.5 instructions instead of 7, two accumulators per item, one compare
+// and two selects per (item, view) to merge them.
 // What the key cannot state -- a winner with x <= 2^-14 (t' >= 1 lands on the coarser grid of [1, 2)), a NaN -- shows as
 // key >= MH_KEY_BAD; a wave that sees one on any of its lanes evaluates that view again with the compare-and-select body
 // (mh_tap_update), which is also what runs for one-tap lists and for a NaN seed tap.  Both bodies give the same bits
@@ -400,11 +404,14 @@ __device__ __forceinline__ unsigned mh_min3u(unsigned a, unsigned b, unsigned c)
 // the compiler as one asm statement per instruction, its hazard recogniser pads every inline-asm result that is read by
 // the very next instruction with an s_nop -- it cannot see that no dst_sel is involved: ~9 per block.)  The "memory"
 // clobber keeps the LDS reads of the NEXT tap group, issued in front of the block, in front of it.
-// k[0..NI), DX, DY: the first NI entries of the caller's arrays are used.
+// Taps g[0], g[2] (places ib, ib + 1 among the even taps) go into ke, taps g[1], g[3] (the same places among the odd taps)
+// into ko; the first NI entries of the caller's arrays are used.  (Padding lists to two taps instead of four, with a
+// two-tap block for the tail, was measured: the choice between two asm blocks that update the same registers costs eight
+// register copies and a wait for every LDS read per call -- 0.634 instead of 0.582 ms.)
 template <int NI, int KN>
-__device__ __forceinline__ void mh_key_block(unsigned (&k)[KN], const float2 (&g)[4], const float (&DX)[KN],
-                                             const float (&DY)[KN], int ib) {
-    static_assert(NI >= 2 && NI <= 4 && NI <= KN, "mh_key_block: 2..4 items");
+__device__ __forceinline__ void mh_key_block4(unsigned (&ke)[KN], unsigned (&ko)[KN], const float2 (&g)[4],
+                                              const float (&DX)[KN], const float (&DY)[KN], int ib) {
+    static_assert(NI >= 1 && NI <= 4 && NI <= KN, "mh_key_block4: 1..4 items");
     float a[NI], b[NI], c[NI];
     if constexpr (NI == 4) {
         asm volatile(
@@ -416,18 +423,18 @@ __device__ __forceinline__ void mh_key_block(unsigned (&k)[KN], const float2 (&g
             "v_mul_f32_e32 %[b1], %[t0y], %[y1]\n\t"
             "v_mul_f32_e32 %[b2], %[t0y], %[y2]\n\t"
             "v_mul_f32_e32 %[b3], %[t0y], %[y3]\n\t"
-            "v_mul_f32_e32 %[c0], %[t1x], %[x0]\n\t"
-            "v_mul_f32_e32 %[c1], %[t1x], %[x1]\n\t"
-            "v_mul_f32_e32 %[c2], %[t1x], %[x2]\n\t"
-            "v_mul_f32_e32 %[c3], %[t1x], %[x3]\n\t"
+            "v_mul_f32_e32 %[c0], %[t2x], %[x0]\n\t"
+            "v_mul_f32_e32 %[c1], %[t2x], %[x1]\n\t"
+            "v_mul_f32_e32 %[c2], %[t2x], %[x2]\n\t"
+            "v_mul_f32_e32 %[c3], %[t2x], %[x3]\n\t"
             "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
             "v_add_f32_e32 %[a1], %[a1], %[b1]\n\t"
             "v_add_f32_e32 %[a2], %[a2], %[b2]\n\t"
             "v_add_f32_e32 %[a3], %[a3], %[b3]\n\t"
-            "v_mul_f32_e32 %[b0], %[t1y], %[y0]\n\t"
-            "v_mul_f32_e32 %[b1], %[t1y], %[y1]\n\t"
-            "v_mul_f32_e32 %[b2], %[t1y], %[y2]\n\t"
-            "v_mul_f32_e32 %[b3], %[t1y], %[y3]\n\t"
+            "v_mul_f32_e32 %[b0], %[t2y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t2y], %[y1]\n\t"
+            "v_mul_f32_e32 %[b2], %[t2y], %[y2]\n\t"
+            "v_mul_f32_e32 %[b3], %[t2y], %[y3]\n\t"
             "v_sub_f32_e64 %[a0], %[cc], |%[a0]|\n\t"
             "v_sub_f32_e64 %[a1], %[cc], |%[a1]|\n\t"
             "v_sub_f32_e64 %[a2], %[cc], |%[a2]|\n\t"
@@ -448,18 +455,18 @@ __device__ __forceinline__ void mh_key_block(unsigned (&k)[KN], const float2 (&g
             "v_lshl_or_b32 %[c1], %[c1], 5, %[i1]\n\t"
             "v_lshl_or_b32 %[c2], %[c2], 5, %[i1]\n\t"
             "v_lshl_or_b32 %[c3], %[c3], 5, %[i1]\n\t"
-            "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
-            "v_min3_u32 %[k1], %[k1], %[a1], %[c1]\n\t"
-            "v_min3_u32 %[k2], %[k2], %[a2], %[c2]\n\t"
-            "v_min3_u32 %[k3], %[k3], %[a3], %[c3]\n\t"
-            "v_mul_f32_e32 %[a0], %[t2x], %[x0]\n\t"
-            "v_mul_f32_e32 %[a1], %[t2x], %[x1]\n\t"
-            "v_mul_f32_e32 %[a2], %[t2x], %[x2]\n\t"
-            "v_mul_f32_e32 %[a3], %[t2x], %[x3]\n\t"
-            "v_mul_f32_e32 %[b0], %[t2y], %[y0]\n\t"
-            "v_mul_f32_e32 %[b1], %[t2y], %[y1]\n\t"
-            "v_mul_f32_e32 %[b2], %[t2y], %[y2]\n\t"
-            "v_mul_f32_e32 %[b3], %[t2y], %[y3]\n\t"
+            "v_min3_u32 %[e0], %[e0], %[a0], %[c0]\n\t"
+            "v_min3_u32 %[e1], %[e1], %[a1], %[c1]\n\t"
+            "v_min3_u32 %[e2], %[e2], %[a2], %[c2]\n\t"
+            "v_min3_u32 %[e3], %[e3], %[a3], %[c3]\n\t"
+            "v_mul_f32_e32 %[a0], %[t1x], %[x0]\n\t"
+            "v_mul_f32_e32 %[a1], %[t1x], %[x1]\n\t"
+            "v_mul_f32_e32 %[a2], %[t1x], %[x2]\n\t"
+            "v_mul_f32_e32 %[a3], %[t1x], %[x3]\n\t"
+            "v_mul_f32_e32 %[b0], %[t1y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t1y], %[y1]\n\t"
+            "v_mul_f32_e32 %[b2], %[t1y], %[y2]\n\t"
+            "v_mul_f32_e32 %[b3], %[t1y], %[y3]\n\t"
             "v_mul_f32_e32 %[c0], %[t3x], %[x0]\n\t"
             "v_mul_f32_e32 %[c1], %[t3x], %[x1]\n\t"
             "v_mul_f32_e32 %[c2], %[t3x], %[x2]\n\t"
@@ -480,24 +487,24 @@ __device__ __forceinline__ void mh_key_block(unsigned (&k)[KN], const float2 (&g
             "v_add_f32_e32 %[c1], %[c1], %[b1]\n\t"
             "v_add_f32_e32 %[c2], %[c2], %[b2]\n\t"
             "v_add_f32_e32 %[c3], %[c3], %[b3]\n\t"
-            "v_lshl_or_b32 %[a0], %[a0], 5, %[i2]\n\t"
-            "v_lshl_or_b32 %[a1], %[a1], 5, %[i2]\n\t"
-            "v_lshl_or_b32 %[a2], %[a2], 5, %[i2]\n\t"
-            "v_lshl_or_b32 %[a3], %[a3], 5, %[i2]\n\t"
+            "v_lshl_or_b32 %[a0], %[a0], 5, %[i0]\n\t"
+            "v_lshl_or_b32 %[a1], %[a1], 5, %[i0]\n\t"
+            "v_lshl_or_b32 %[a2], %[a2], 5, %[i0]\n\t"
+            "v_lshl_or_b32 %[a3], %[a3], 5, %[i0]\n\t"
             "v_sub_f32_e64 %[c0], %[cc], |%[c0]|\n\t"
             "v_sub_f32_e64 %[c1], %[cc], |%[c1]|\n\t"
             "v_sub_f32_e64 %[c2], %[cc], |%[c2]|\n\t"
             "v_sub_f32_e64 %[c3], %[cc], |%[c3]|\n\t"
-            "v_lshl_or_b32 %[c0], %[c0], 5, %[i3]\n\t"
-            "v_lshl_or_b32 %[c1], %[c1], 5, %[i3]\n\t"
-            "v_lshl_or_b32 %[c2], %[c2], 5, %[i3]\n\t"
-            "v_lshl_or_b32 %[c3], %[c3], 5, %[i3]\n\t"
-            "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
-            "v_min3_u32 %[k1], %[k1], %[a1], %[c1]\n\t"
-            "v_min3_u32 %[k2], %[k2], %[a2], %[c2]\n\t"
-            "v_min3_u32 %[k3], %[k3], %[a3], %[c3]"
-            : [k0] "+v"(k[0]), [k1] "+v"(k[1]), [k2] "+v"(k[2]), [k3] "+v"(k[3]), [a0] "=&v"(a[0]), [a1] "=&v"(a[1]), [a2] "=&v"(a[2]), [a3] "=&v"(a[3]), [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [b2] "=&v"(b[2]), [b3] "=&v"(b[3]), [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2]), [c3] "=&v"(c[3])
-            : [t0x] "v"(g[0].x), [t0y] "v"(g[0].y), [t1x] "v"(g[1].x), [t1y] "v"(g[1].y), [t2x] "v"(g[2].x), [t2y] "v"(g[2].y), [t3x] "v"(g[3].x), [t3y] "v"(g[3].y), [x0] "v"(DX[0]), [y0] "v"(DY[0]), [x1] "v"(DX[1]), [y1] "v"(DY[1]), [x2] "v"(DX[2]), [y2] "v"(DY[2]), [x3] "v"(DX[3]), [y3] "v"(DY[3]), [cc] "s"(MH_KEY_C), [i0] "s"(ib), [i1] "s"(ib + 1), [i2] "s"(ib + 2), [i3] "s"(ib + 3)
+            "v_lshl_or_b32 %[c0], %[c0], 5, %[i1]\n\t"
+            "v_lshl_or_b32 %[c1], %[c1], 5, %[i1]\n\t"
+            "v_lshl_or_b32 %[c2], %[c2], 5, %[i1]\n\t"
+            "v_lshl_or_b32 %[c3], %[c3], 5, %[i1]\n\t"
+            "v_min3_u32 %[o0], %[o0], %[a0], %[c0]\n\t"
+            "v_min3_u32 %[o1], %[o1], %[a1], %[c1]\n\t"
+            "v_min3_u32 %[o2], %[o2], %[a2], %[c2]\n\t"
+            "v_min3_u32 %[o3], %[o3], %[a3], %[c3]"
+            : [e0] "+v"(ke[0]), [e1] "+v"(ke[1]), [e2] "+v"(ke[2]), [e3] "+v"(ke[3]), [o0] "+v"(ko[0]), [o1] "+v"(ko[1]), [o2] "+v"(ko[2]), [o3] "+v"(ko[3]), [a0] "=&v"(a[0]), [a1] "=&v"(a[1]), [a2] "=&v"(a[2]), [a3] "=&v"(a[3]), [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [b2] "=&v"(b[2]), [b3] "=&v"(b[3]), [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2]), [c3] "=&v"(c[3])
+            : [t0x] "v"(g[0].x), [t0y] "v"(g[0].y), [t1x] "v"(g[1].x), [t1y] "v"(g[1].y), [t2x] "v"(g[2].x), [t2y] "v"(g[2].y), [t3x] "v"(g[3].x), [t3y] "v"(g[3].y), [x0] "v"(DX[0]), [y0] "v"(DY[0]), [x1] "v"(DX[1]), [y1] "v"(DY[1]), [x2] "v"(DX[2]), [y2] "v"(DY[2]), [x3] "v"(DX[3]), [y3] "v"(DY[3]), [cc] "s"(MH_KEY_C), [i0] "s"(ib), [i1] "s"(ib + 1)
             : "memory");
     }
     else if constexpr (NI == 3) {
@@ -508,15 +515,15 @@ __device__ __forceinline__ void mh_key_block(unsigned (&k)[KN], const float2 (&g
             "v_mul_f32_e32 %[b0], %[t0y], %[y0]\n\t"
             "v_mul_f32_e32 %[b1], %[t0y], %[y1]\n\t"
             "v_mul_f32_e32 %[b2], %[t0y], %[y2]\n\t"
-            "v_mul_f32_e32 %[c0], %[t1x], %[x0]\n\t"
-            "v_mul_f32_e32 %[c1], %[t1x], %[x1]\n\t"
-            "v_mul_f32_e32 %[c2], %[t1x], %[x2]\n\t"
+            "v_mul_f32_e32 %[c0], %[t2x], %[x0]\n\t"
+            "v_mul_f32_e32 %[c1], %[t2x], %[x1]\n\t"
+            "v_mul_f32_e32 %[c2], %[t2x], %[x2]\n\t"
             "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
             "v_add_f32_e32 %[a1], %[a1], %[b1]\n\t"
             "v_add_f32_e32 %[a2], %[a2], %[b2]\n\t"
-            "v_mul_f32_e32 %[b0], %[t1y], %[y0]\n\t"
-            "v_mul_f32_e32 %[b1], %[t1y], %[y1]\n\t"
-            "v_mul_f32_e32 %[b2], %[t1y], %[y2]\n\t"
+            "v_mul_f32_e32 %[b0], %[t2y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t2y], %[y1]\n\t"
+            "v_mul_f32_e32 %[b2], %[t2y], %[y2]\n\t"
             "v_sub_f32_e64 %[a0], %[cc], |%[a0]|\n\t"
             "v_sub_f32_e64 %[a1], %[cc], |%[a1]|\n\t"
             "v_sub_f32_e64 %[a2], %[cc], |%[a2]|\n\t"
@@ -532,15 +539,15 @@ __device__ __forceinline__ void mh_key_block(unsigned (&k)[KN], const float2 (&g
             "v_lshl_or_b32 %[c0], %[c0], 5, %[i1]\n\t"
             "v_lshl_or_b32 %[c1], %[c1], 5, %[i1]\n\t"
             "v_lshl_or_b32 %[c2], %[c2], 5, %[i1]\n\t"
-            "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
-            "v_min3_u32 %[k1], %[k1], %[a1], %[c1]\n\t"
-            "v_min3_u32 %[k2], %[k2], %[a2], %[c2]\n\t"
-            "v_mul_f32_e32 %[a0], %[t2x], %[x0]\n\t"
-            "v_mul_f32_e32 %[a1], %[t2x], %[x1]\n\t"
-            "v_mul_f32_e32 %[a2], %[t2x], %[x2]\n\t"
-            "v_mul_f32_e32 %[b0], %[t2y], %[y0]\n\t"
-            "v_mul_f32_e32 %[b1], %[t2y], %[y1]\n\t"
-            "v_mul_f32_e32 %[b2], %[t2y], %[y2]\n\t"
+            "v_min3_u32 %[e0], %[e0], %[a0], %[c0]\n\t"
+            "v_min3_u32 %[e1], %[e1], %[a1], %[c1]\n\t"
+            "v_min3_u32 %[e2], %[e2], %[a2], %[c2]\n\t"
+            "v_mul_f32_e32 %[a0], %[t1x], %[x0]\n\t"
+            "v_mul_f32_e32 %[a1], %[t1x], %[x1]\n\t"
+            "v_mul_f32_e32 %[a2], %[t1x], %[x2]\n\t"
+            "v_mul_f32_e32 %[b0], %[t1y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t1y], %[y1]\n\t"
+            "v_mul_f32_e32 %[b2], %[t1y], %[y2]\n\t"
             "v_mul_f32_e32 %[c0], %[t3x], %[x0]\n\t"
             "v_mul_f32_e32 %[c1], %[t3x], %[x1]\n\t"
             "v_mul_f32_e32 %[c2], %[t3x], %[x2]\n\t"
@@ -556,20 +563,20 @@ __device__ __forceinline__ void mh_key_block(unsigned (&k)[KN], const float2 (&g
             "v_add_f32_e32 %[c0], %[c0], %[b0]\n\t"
             "v_add_f32_e32 %[c1], %[c1], %[b1]\n\t"
             "v_add_f32_e32 %[c2], %[c2], %[b2]\n\t"
-            "v_lshl_or_b32 %[a0], %[a0], 5, %[i2]\n\t"
-            "v_lshl_or_b32 %[a1], %[a1], 5, %[i2]\n\t"
-            "v_lshl_or_b32 %[a2], %[a2], 5, %[i2]\n\t"
+            "v_lshl_or_b32 %[a0], %[a0], 5, %[i0]\n\t"
+            "v_lshl_or_b32 %[a1], %[a1], 5, %[i0]\n\t"
+            "v_lshl_or_b32 %[a2], %[a2], 5, %[i0]\n\t"
             "v_sub_f32_e64 %[c0], %[cc], |%[c0]|\n\t"
             "v_sub_f32_e64 %[c1], %[cc], |%[c1]|\n\t"
             "v_sub_f32_e64 %[c2], %[cc], |%[c2]|\n\t"
-            "v_lshl_or_b32 %[c0], %[c0], 5, %[i3]\n\t"
-            "v_lshl_or_b32 %[c1], %[c1], 5, %[i3]\n\t"
-            "v_lshl_or_b32 %[c2], %[c2], 5, %[i3]\n\t"
-            "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
-            "v_min3_u32 %[k1], %[k1], %[a1], %[c1]\n\t"
-            "v_min3_u32 %[k2], %[k2], %[a2], %[c2]"
-            : [k0] "+v"(k[0]), [k1] "+v"(k[1]), [k2] "+v"(k[2]), [a0] "=&v"(a[0]), [a1] "=&v"(a[1]), [a2] "=&v"(a[2]), [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [b2] "=&v"(b[2]), [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2])
-            : [t0x] "v"(g[0].x), [t0y] "v"(g[0].y), [t1x] "v"(g[1].x), [t1y] "v"(g[1].y), [t2x] "v"(g[2].x), [t2y] "v"(g[2].y), [t3x] "v"(g[3].x), [t3y] "v"(g[3].y), [x0] "v"(DX[0]), [y0] "v"(DY[0]), [x1] "v"(DX[1]), [y1] "v"(DY[1]), [x2] "v"(DX[2]), [y2] "v"(DY[2]), [cc] "s"(MH_KEY_C), [i0] "s"(ib), [i1] "s"(ib + 1), [i2] "s"(ib + 2), [i3] "s"(ib + 3)
+            "v_lshl_or_b32 %[c0], %[c0], 5, %[i1]\n\t"
+            "v_lshl_or_b32 %[c1], %[c1], 5, %[i1]\n\t"
+            "v_lshl_or_b32 %[c2], %[c2], 5, %[i1]\n\t"
+            "v_min3_u32 %[o0], %[o0], %[a0], %[c0]\n\t"
+            "v_min3_u32 %[o1], %[o1], %[a1], %[c1]\n\t"
+            "v_min3_u32 %[o2], %[o2], %[a2], %[c2]"
+            : [e0] "+v"(ke[0]), [e1] "+v"(ke[1]), [e2] "+v"(ke[2]), [o0] "+v"(ko[0]), [o1] "+v"(ko[1]), [o2] "+v"(ko[2]), [a0] "=&v"(a[0]), [a1] "=&v"(a[1]), [a2] "=&v"(a[2]), [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [b2] "=&v"(b[2]), [c0] "=&v"(c[0]), [c1] "=&v"(c[1]), [c2] "=&v"(c[2])
+            : [t0x] "v"(g[0].x), [t0y] "v"(g[0].y), [t1x] "v"(g[1].x), [t1y] "v"(g[1].y), [t2x] "v"(g[2].x), [t2y] "v"(g[2].y), [t3x] "v"(g[3].x), [t3y] "v"(g[3].y), [x0] "v"(DX[0]), [y0] "v"(DY[0]), [x1] "v"(DX[1]), [y1] "v"(DY[1]), [x2] "v"(DX[2]), [y2] "v"(DY[2]), [cc] "s"(MH_KEY_C), [i0] "s"(ib), [i1] "s"(ib + 1)
             : "memory");
     }
     else if constexpr (NI == 2) {
@@ -578,12 +585,12 @@ __device__ __forceinline__ void mh_key_block(unsigned (&k)[KN], const float2 (&g
             "v_mul_f32_e32 %[a1], %[t0x], %[x1]\n\t"
             "v_mul_f32_e32 %[b0], %[t0y], %[y0]\n\t"
             "v_mul_f32_e32 %[b1], %[t0y], %[y1]\n\t"
-            "v_mul_f32_e32 %[c0], %[t1x], %[x0]\n\t"
-            "v_mul_f32_e32 %[c1], %[t1x], %[x1]\n\t"
+            "v_mul_f32_e32 %[c0], %[t2x], %[x0]\n\t"
+            "v_mul_f32_e32 %[c1], %[t2x], %[x1]\n\t"
             "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
             "v_add_f32_e32 %[a1], %[a1], %[b1]\n\t"
-            "v_mul_f32_e32 %[b0], %[t1y], %[y0]\n\t"
-            "v_mul_f32_e32 %[b1], %[t1y], %[y1]\n\t"
+            "v_mul_f32_e32 %[b0], %[t2y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t2y], %[y1]\n\t"
             "v_sub_f32_e64 %[a0], %[cc], |%[a0]|\n\t"
             "v_sub_f32_e64 %[a1], %[cc], |%[a1]|\n\t"
             "v_add_f32_e32 %[c0], %[c0], %[b0]\n\t"
@@ -594,12 +601,12 @@ __device__ __forceinline__ void mh_key_block(unsigned (&k)[KN], const float2 (&g
             "v_sub_f32_e64 %[c1], %[cc], |%[c1]|\n\t"
             "v_lshl_or_b32 %[c0], %[c0], 5, %[i1]\n\t"
             "v_lshl_or_b32 %[c1], %[c1], 5, %[i1]\n\t"
-            "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
-            "v_min3_u32 %[k1], %[k1], %[a1], %[c1]\n\t"
-            "v_mul_f32_e32 %[a0], %[t2x], %[x0]\n\t"
-            "v_mul_f32_e32 %[a1], %[t2x], %[x1]\n\t"
-            "v_mul_f32_e32 %[b0], %[t2y], %[y0]\n\t"
-            "v_mul_f32_e32 %[b1], %[t2y], %[y1]\n\t"
+            "v_min3_u32 %[e0], %[e0], %[a0], %[c0]\n\t"
+            "v_min3_u32 %[e1], %[e1], %[a1], %[c1]\n\t"
+            "v_mul_f32_e32 %[a0], %[t1x], %[x0]\n\t"
+            "v_mul_f32_e32 %[a1], %[t1x], %[x1]\n\t"
+            "v_mul_f32_e32 %[b0], %[t1y], %[y0]\n\t"
+            "v_mul_f32_e32 %[b1], %[t1y], %[y1]\n\t"
             "v_mul_f32_e32 %[c0], %[t3x], %[x0]\n\t"
             "v_mul_f32_e32 %[c1], %[t3x], %[x1]\n\t"
             "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
@@ -610,16 +617,44 @@ __device__ __forceinline__ void mh_key_block(unsigned (&k)[KN], const float2 (&g
             "v_sub_f32_e64 %[a1], %[cc], |%[a1]|\n\t"
             "v_add_f32_e32 %[c0], %[c0], %[b0]\n\t"
             "v_add_f32_e32 %[c1], %[c1], %[b1]\n\t"
-            "v_lshl_or_b32 %[a0], %[a0], 5, %[i2]\n\t"
-            "v_lshl_or_b32 %[a1], %[a1], 5, %[i2]\n\t"
+            "v_lshl_or_b32 %[a0], %[a0], 5, %[i0]\n\t"
+            "v_lshl_or_b32 %[a1], %[a1], 5, %[i0]\n\t"
             "v_sub_f32_e64 %[c0], %[cc], |%[c0]|\n\t"
             "v_sub_f32_e64 %[c1], %[cc], |%[c1]|\n\t"
-            "v_lshl_or_b32 %[c0], %[c0], 5, %[i3]\n\t"
-            "v_lshl_or_b32 %[c1], %[c1], 5, %[i3]\n\t"
-            "v_min3_u32 %[k0], %[k0], %[a0], %[c0]\n\t"
-            "v_min3_u32 %[k1], %[k1], %[a1], %[c1]"
-            : [k0] "+v"(k[0]), [k1] "+v"(k[1]), [a0] "=&v"(a[0]), [a1] "=&v"(a[1]), [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [c0] "=&v"(c[0]), [c1] "=&v"(c[1])
-            : [t0x] "v"(g[0].x), [t0y] "v"(g[0].y), [t1x] "v"(g[1].x), [t1y] "v"(g[1].y), [t2x] "v"(g[2].x), [t2y] "v"(g[2].y), [t3x] "v"(g[3].x), [t3y] "v"(g[3].y), [x0] "v"(DX[0]), [y0] "v"(DY[0]), [x1] "v"(DX[1]), [y1] "v"(DY[1]), [cc] "s"(MH_KEY_C), [i0] "s"(ib), [i1] "s"(ib + 1), [i2] "s"(ib + 2), [i3] "s"(ib + 3)
+            "v_lshl_or_b32 %[c0], %[c0], 5, %[i1]\n\t"
+            "v_lshl_or_b32 %[c1], %[c1], 5, %[i1]\n\t"
+            "v_min3_u32 %[o0], %[o0], %[a0], %[c0]\n\t"
+            "v_min3_u32 %[o1], %[o1], %[a1], %[c1]"
+            : [e0] "+v"(ke[0]), [e1] "+v"(ke[1]), [o0] "+v"(ko[0]), [o1] "+v"(ko[1]), [a0] "=&v"(a[0]), [a1] "=&v"(a[1]), [b0] "=&v"(b[0]), [b1] "=&v"(b[1]), [c0] "=&v"(c[0]), [c1] "=&v"(c[1])
+            : [t0x] "v"(g[0].x), [t0y] "v"(g[0].y), [t1x] "v"(g[1].x), [t1y] "v"(g[1].y), [t2x] "v"(g[2].x), [t2y] "v"(g[2].y), [t3x] "v"(g[3].x), [t3y] "v"(g[3].y), [x0] "v"(DX[0]), [y0] "v"(DY[0]), [x1] "v"(DX[1]), [y1] "v"(DY[1]), [cc] "s"(MH_KEY_C), [i0] "s"(ib), [i1] "s"(ib + 1)
+            : "memory");
+    }
+    else if constexpr (NI == 1) {
+        asm volatile(
+            "v_mul_f32_e32 %[a0], %[t0x], %[x0]\n\t"
+            "v_mul_f32_e32 %[b0], %[t0y], %[y0]\n\t"
+            "v_mul_f32_e32 %[c0], %[t2x], %[x0]\n\t"
+            "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
+            "v_mul_f32_e32 %[b0], %[t2y], %[y0]\n\t"
+            "v_sub_f32_e64 %[a0], %[cc], |%[a0]|\n\t"
+            "v_add_f32_e32 %[c0], %[c0], %[b0]\n\t"
+            "v_lshl_or_b32 %[a0], %[a0], 5, %[i0]\n\t"
+            "v_sub_f32_e64 %[c0], %[cc], |%[c0]|\n\t"
+            "v_lshl_or_b32 %[c0], %[c0], 5, %[i1]\n\t"
+            "v_min3_u32 %[e0], %[e0], %[a0], %[c0]\n\t"
+            "v_mul_f32_e32 %[a0], %[t1x], %[x0]\n\t"
+            "v_mul_f32_e32 %[b0], %[t1y], %[y0]\n\t"
+            "v_mul_f32_e32 %[c0], %[t3x], %[x0]\n\t"
+            "v_add_f32_e32 %[a0], %[a0], %[b0]\n\t"
+            "v_mul_f32_e32 %[b0], %[t3y], %[y0]\n\t"
+            "v_sub_f32_e64 %[a0], %[cc], |%[a0]|\n\t"
+            "v_add_f32_e32 %[c0], %[c0], %[b0]\n\t"
+            "v_lshl_or_b32 %[a0], %[a0], 5, %[i0]\n\t"
+            "v_sub_f32_e64 %[c0], %[cc], |%[c0]|\n\t"
+            "v_lshl_or_b32 %[c0], %[c0], 5, %[i1]\n\t"
+            "v_min3_u32 %[o0], %[o0], %[a0], %[c0]"
+            : [e0] "+v"(ke[0]), [o0] "+v"(ko[0]), [a0] "=&v"(a[0]), [b0] "=&v"(b[0]), [c0] "=&v"(c[0])
+            : [t0x] "v"(g[0].x), [t0y] "v"(g[0].y), [t1x] "v"(g[1].x), [t1y] "v"(g[1].y), [t2x] "v"(g[2].x), [t2y] "v"(g[2].y), [t3x] "v"(g[3].x), [t3y] "v"(g[3].y), [x0] "v"(DX[0]), [y0] "v"(DY[0]), [cc] "s"(MH_KEY_C), [i0] "s"(ib), [i1] "s"(ib + 1)
             : "memory");
     }
 }
@@ -660,7 +695,7 @@ struct MhCascS {
     __device__ __forceinline__ float done() const { return BIG ? (a0 + a1) + a2 : (a0 + a1); }
 };
 
-template <int KA, int T, bool BIGV, bool KEYS>
+template <int KA, int T, bool BIGV, bool KEYS, bool BIGP>
 __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const float *__restrict__ offs, int S,
                                                      int n, int N, int P1, float thr,
                                                      const float4 *__restrict__ taps, const uint8_t *__restrict__ vcnt,
@@ -773,7 +808,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
         if constexpr (!KEYS) {
             select_body();
         } else {
-            // the key body (see mh_tap_key): taps in groups of 32, the list padded to a multiple of MH_KEY_PAD taps
+            // the key body (see mh_tap_key): taps in groups of 64, the list padded to a multiple of MH_KEY_PAD taps
             // uniform: a short list (the key body's fixed cost per view -- padding, decode -- only pays from about a dozen
             // taps on: lists of 8-bit maps are mostly shorter, lists of continuous maps hardly ever) / a NaN seed tap
             bool again = (ntap <= MH_KEY_MIN_TAPS) || !(t0.x == t0.x && t0.y == t0.y);
@@ -781,85 +816,69 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
             if (again) MH_KEY_COUNT(1);
             if (!again) {
                 const int ntp = (ntap + MH_KEY_PAD - 1) & ~(MH_KEY_PAD - 1);
-                unsigned acc[KN], best[KN];
-                // LDS byte address of the first tap record of the winning group (the confidence gather of the decode)
+                // even taps of a 64-tap group into ke, odd taps into ko, the key's index = the tap's place among them
+                unsigned ke[KN], ko[KN];
                 const unsigned rec1 = (unsigned)(size_t)(const __attribute__((address_space(3))) float4 *)(rec + 1);
-                unsigned gofs[KN];
-                auto process = [&](const float2 (&g)[GRP], int t, int t1) {
-                    const int ib = t & 31;
-                    if constexpr (KM >= 2 && KM <= 4 && MH_KEY_PAD >= 4 && GRP == 4) {
-                        mh_key_block<KM, KN>(acc, g, DX, DY, ib);
-                        return;
-                    }
-                    unsigned k[GRP][KN];
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-#pragma unroll
-                        for (int j = 0; j < KM; ++j)
-                            k[u][j] = mh_tap_key(mh_vadd(mh_vmul(g[u].x, DX[j]), mh_vmul(g[u].y, DY[j])), ib + u);
-#pragma unroll
-                    for (int j = 0; j < KM; ++j) acc[j] = mh_min3u(acc[j], k[0][j], k[1][j]);
-                    if (MH_KEY_PAD >= 4 || t + 2 < t1) {   // uniform
-#pragma unroll
-                        for (int u = 2; u < 4; ++u)
-#pragma unroll
-                            for (int j = 0; j < KM; ++j)
-                                k[u][j] = mh_tap_key(mh_vadd(mh_vmul(g[u].x, DX[j]), mh_vmul(g[u].y, DY[j])), ib + u);
-#pragma unroll
-                        for (int j = 0; j < KM; ++j) acc[j] = mh_min3u(acc[j], k[2][j], k[3][j]);
-                    }
+                auto process = [&](const float2 (&g)[GRP], int t) {
+                    const int ib = (t & 63) >> 1;
+                    static_assert(MH_KEY_PAD == 4 && GRP == 4, "the key block takes four taps");
+                    if constexpr (KM > 0) mh_key_block4<KM, KN>(ke, ko, g, DX, DY, ib);
                 };
-                // taps [ta, tb) of one 32-tap group into acc: (tx, ty) of tap i is the first half of record 1 + i
+                // taps [ta, tb) of one 64-tap group: (tx, ty) of tap i is the first half of record 1 + i
                 auto group = [&](int ta, int tb) {
                     const float2 *__restrict__ t2 = reinterpret_cast<const float2 *>(rec + 1);
 #pragma unroll
-                    for (int j = 0; j < KN; ++j) acc[j] = 0xFFFFFFFFu;
+                    for (int j = 0; j < KN; ++j) ke[j] = ko[j] = 0xFFFFFFFFu;
                     float2 ga[GRP], gb[GRP];
 #pragma unroll
                     for (int u = 0; u < GRP; ++u) ga[u] = t2[2 * (ta + u)];
                     for (int t = ta; t < tb;) {
 #pragma unroll
                         for (int u = 0; u < GRP; ++u) gb[u] = t2[2 * (t + GRP + u)];
-                        __builtin_amdgcn_sched_barrier(0);   // (the next group's reads stay in front of this group's block)
-                        process(ga, t, tb);
+                        process(ga, t);
                         t += GRP;
                         if (t >= tb) break;
 #pragma unroll
                         for (int u = 0; u < GRP; ++u) ga[u] = t2[2 * (t + GRP + u)];
-                        __builtin_amdgcn_sched_barrier(0);
-                        process(gb, t, tb);
+                        process(gb, t);
                         t += GRP;
                     }
                 };
-                bool bad = false;
-                if constexpr (KM > 0) {
-                    group(0, ntp < 32 ? ntp : 32);
+                // the group's winner: the odd key only when it is strictly smaller (equal loss and place: the even tap is the
+                // earlier one; equal loss, smaller place: 2i + 1 < 2i'); its tap = 2 * place + parity
+                unsigned best[KN], badr[KN];   // winning key, LDS byte address of the winner's record
+                auto winner = [&](int ta, bool first) {
 #pragma unroll
                     for (int j = 0; j < KM; ++j) {
-                        best[j] = acc[j];
-                        gofs[j] = rec1;
+                        const bool odd = ko[j] < ke[j];
+                        const unsigned kb = odd ? ko[j] : ke[j];
+                        const unsigned ad = rec1 + 16u * (unsigned)ta + ((kb & 31u) << 5) + (odd ? 16u : 0u);
+                        const bool take = first || kb < (best[j] & ~31u);   // a later group only on a strictly smaller loss
+                        best[j] = take ? kb : best[j];
+                        badr[j] = take ? ad : badr[j];
                     }
-                    for (int ta = 32; ta < ntp; ta += 32) {   // later groups: an earlier group wins ties
-                        group(ta, ntp < ta + 32 ? ntp : ta + 32);
-#pragma unroll
-                        for (int j = 0; j < KM; ++j) {
-                            const bool lt = acc[j] < (best[j] & ~31u);
-                            best[j] = lt ? acc[j] : best[j];
-                            gofs[j] = lt ? rec1 + 16u * (unsigned)ta : gofs[j];
-                        }
+                };
+                if constexpr (!BIGP) {   // patch <= 8x8: every list is one 64-tap group
+                    group(0, ntp);
+                    winner(0, true);
+                } else {                 // patch 9 and 11: up to two groups (a later group wins only on a strictly smaller loss)
+                    group(0, ntp < 64 ? ntp : 64);
+                    winner(0, true);
+                    for (int ta = 64; ta < ntp; ta += 64) {
+                        group(ta, ntp < ta + 64 ? ntp : ta + 64);
+                        winner(ta, false);
                     }
-                    // decode: one compare for "any key past the valid range", loss = t' - 2^-14 from the key's upper bits
-                    // (v_alignbit puts the constant 0b00111 back in front), confidence of the winning tap from its record
-                    unsigned worst = best[0];
+                }
+                // decode: one compare for "any key past the valid range", loss = t' - 2^-14 from the key's upper bits
+                // (v_alignbit puts the constant 0b00111 back in front), confidence of the winning tap from its record
+                unsigned worst = best[0];
 #pragma unroll
-                    for (int j = 1; j < KM; ++j) worst = max(worst, best[j]);
-                    bad = worst >= MH_KEY_BAD;
+                for (int j = 1; j < KM; ++j) worst = max(worst, best[j]);
+                const bool bad = worst >= MH_KEY_BAD;
 #pragma unroll
-                    for (int j = 0; j < KM; ++j) {
-                        BC[j] = *reinterpret_cast<const __attribute__((address_space(3))) float *>(
-                            (size_t)(gofs[j] + ((best[j] & 31u) << 4) + 8u));
-                        ML[j] = __uint_as_float(__builtin_amdgcn_alignbit(7u, best[j], 5u)) - MH_KEY_E;
-                    }
+                for (int j = 0; j < KM; ++j) {
+                    BC[j] = *reinterpret_cast<const __attribute__((address_space(3))) float *>((size_t)(badr[j] + 8u));
+                    ML[j] = __uint_as_float(__builtin_amdgcn_alignbit(7u, best[j], 5u)) - MH_KEY_E;
                 }
                 again = __ballot(bad) != 0ull;
                 if (again) MH_KEY_COUNT(2);
@@ -949,7 +968,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
     }
 }
 
-template <int T, bool BIGV, bool KEYS>
+template <int T, bool BIGV, bool KEYS, bool BIGP>
 // amdgpu_waves_per_eu(5): the register allocator stops at 96 VGPRs (it takes 109 unconstrained = 4 waves per SIMD); the
 // few values it spills are reloaded once per view.  Measured: 4 waves 1305 it/s, 5 waves 1345, 6 waves (80 VGPRs) 1328.
 __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MH_S3_WAVES))) void mh_search3_kernel(MhViews vw, const float *__restrict__ offs, int S, int nrank,
@@ -1004,11 +1023,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MH_S3_WAVES))
     int ka = 0;
     for (int j = 0; j < 4; ++j) ka += (j * T + wave0 < nact) ? 1 : 0;
 #define MH_S3_ARGS vw, offs, S, n, N, P1, thr, taps, vcnt, nact, tid, s_loss, s_pos, s_taps, s_rank, c_first
-    if (ka == 4) mh_search_slices_lds<4, T, BIGV, KEYS>(MH_S3_ARGS);
-    else if (ka == 3) mh_search_slices_lds<3, T, BIGV, KEYS>(MH_S3_ARGS);
-    else if (ka == 2) mh_search_slices_lds<2, T, BIGV, KEYS>(MH_S3_ARGS);
-    else if (ka == 1) mh_search_slices_lds<1, T, BIGV, KEYS>(MH_S3_ARGS);
-    else mh_search_slices_lds<0, T, BIGV, KEYS>(MH_S3_ARGS);
+    if (ka == 4) mh_search_slices_lds<4, T, BIGV, KEYS, BIGP>(MH_S3_ARGS);
+    else if (ka == 3) mh_search_slices_lds<3, T, BIGV, KEYS, BIGP>(MH_S3_ARGS);
+    else if (ka == 2) mh_search_slices_lds<2, T, BIGV, KEYS, BIGP>(MH_S3_ARGS);
+    else if (ka == 1) mh_search_slices_lds<1, T, BIGV, KEYS, BIGP>(MH_S3_ARGS);
+    else mh_search_slices_lds<0, T, BIGV, KEYS, BIGP>(MH_S3_ARGS);
 #undef MH_S3_ARGS
     __syncthreads();
 
@@ -1357,16 +1376,21 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
             hipLaunchKernelGGL(mh_search_order_kernel, dim3(1), dim3(1024), 0, st, N, order);
             ord = order + N;
         }
-#define MH_S3_LAUNCH(BIG, KEYS)                                                                                         \
-    hipLaunchKernelGGL((mh_search3_kernel<256, BIG, KEYS>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts, \
-                       N, P1, thr, ori_c, base_idx, base_val, taps, cnt, ord, line_ori, min_loss, high_conf, best_sample, \
-                       best_rank, best_s)
+#define MH_S3_LAUNCH(BIG, KEYS, BIGP)                                                                                   \
+    hipLaunchKernelGGL((mh_search3_kernel<256, BIG, KEYS, BIGP>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, \
+                       pts, N, P1, thr, ori_c, base_idx, base_val, taps, cnt, ord, line_ori, min_loss, high_conf,       \
+                       best_sample, best_rank, best_s)
+        // (the key kernel for lists of up to 64 taps -- every patch up to 8 x 8 -- keeps two key registers per item; the one
+        // for longer lists two more)
+        const bool bigp = P1 - 1 > 64;
         if (vw.V > 256) {
-            if (select_body) MH_S3_LAUNCH(true, false);
-            else MH_S3_LAUNCH(true, true);
+            if (select_body) MH_S3_LAUNCH(true, false, false);
+            else if (bigp) MH_S3_LAUNCH(true, true, true);
+            else MH_S3_LAUNCH(true, true, false);
         } else {
-            if (select_body) MH_S3_LAUNCH(false, false);
-            else MH_S3_LAUNCH(false, true);
+            if (select_body) MH_S3_LAUNCH(false, false, false);
+            else if (bigp) MH_S3_LAUNCH(false, true, true);
+            else MH_S3_LAUNCH(false, true, false);
         }
 #undef MH_S3_LAUNCH
     } else if (variant == 1256) {
