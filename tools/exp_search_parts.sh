@@ -6,6 +6,7 @@
 # and both.  roofline.launch_ms of the four lines gives the split quoted in DESIGN.md section 7.
 #   bash tools/exp_search_parts.sh
 set -e
+EXTRA="$@"   # e.g. --codes: the split of the select-only kernel on 8-bit maps
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 C=$R/monohair_amd/csrc
 L=$R/monohair_amd/lib
@@ -20,7 +21,7 @@ for v in "" NOTAPS NOPROJ "NOTAPS NOPROJ"; do
     lib=$L/libmhpmvo_exp_$tag.so
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $lib /tmp/ps_$tag.o $OBJS -ldl
   fi
-  python $R/tools/ubench/run_lib.py $lib --no-cpu --no-secondary --streams 1 2>/dev/null | python -c "
+  python $R/tools/ubench/run_lib.py $lib --no-cpu --no-secondary --streams 1 $EXTRA 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('%-16s search launch %.4f ms   (step %.4f ms)' % ('${tag:-full}', d['roofline']['launch_ms'], d['ms_per_step']))"
