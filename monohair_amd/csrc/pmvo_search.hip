@@ -404,6 +404,7 @@ __device__ __forceinline__ unsigned mh_min3u(unsigned a, unsigned b, unsigned c)
 // the compiler as one asm statement per instruction, its hazard recogniser pads every inline-asm result that is read by
 // the very next instruction with an s_nop -- it cannot see that no dst_sel is involved: ~9 per block.)  The "memory"
 // clobber keeps the LDS reads of the NEXT tap group, issued in front of the block, in front of it.
+// (The four bodies below are printed by tools/gen_key_blocks.py.)
 // Taps g[0], g[2] (places ib, ib + 1 among the even taps) go into ke, taps g[1], g[3] (the same places among the odd taps)
 // into ko; the first NI entries of the caller's arrays are used.  (Padding lists to two taps instead of four, with a
 // two-tap block for the tail, was measured: the choice between two asm blocks that update the same registers costs eight
