@@ -861,9 +861,6 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
                 };
                 if constexpr (!BIGP) {   // patch <= 8x8: every list is one 64-tap group
                     group(0, ntp);
-#ifdef MH_EXP_PRIO_DECODE
-                    __builtin_amdgcn_s_setprio(1);
-#endif
                     winner(0, true);
                 } else {                 // patch 9 and 11: up to two groups (a later group wins only on a strictly smaller loss)
                     group(0, ntp < 64 ? ntp : 64);
