@@ -222,7 +222,7 @@ def test_item_slices_both_bodies(V, patch, depth_offsets):
     slices of the four waves (10 ranks: 4 + 4 + 4 + 3 slices, the last one of 4 items; 5 ranks: 2 + 2 + 2 + 2 with a last
     slice of 2; ...): every count of slices per wave is its own instantiation of the tap loop (hand-ordered key blocks for
     4, 3 and 2 items, the generic form for 1).  Camera counts from 20 up give points with every count; patch 9 and 11 give tap
-    lists of three and four 32-tap groups.  Key body, select body and the portable kernel against the oracle, every point."""
+    lists of two 64-tap groups (their own kernel instantiation).  Key body, select body and the portable kernel against the oracle, every point."""
     from monohair_amd import synth
     from monohair_amd.camera import camera_records, cameras_from_list
     from monohair_amd.pmvo import PMVO

@@ -101,7 +101,7 @@ def test_random_code_maps_all_patch_sizes(patch, depth_offsets):
     assert np.array_equal(res[1][1], o_loss, equal_nan=True) and np.array_equal(res[1][0], o_ori, equal_nan=True)
     assert np.array_equal(res[1][2], o_hc)
     # both tap bodies of the search (a context of 8-bit views takes the select body by default; the key body on these noisy
-    # code maps sees lists of up to patch^2 taps -- one to four 32-tap groups -- whose losses tie all the time)
+    # code maps sees lists of up to patch^2 taps -- one or two 64-tap groups -- whose losses tie all the time)
     for body in (1, 2):
         pm.set_option("search_body", body)
         _, ori, loss, hc = pm.forward(pts)
