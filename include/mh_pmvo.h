@@ -138,9 +138,16 @@ int mh_refine_loss(mh_ctx *ctx, const float *points, const float *dir /*[N,3]*/,
 
 /* The same loss evaluated straight from the resident maps (no patch tensors): what refine's smoothing loop needs per
  * chunk (PMVO.py:619-623 calls PMVO.refine, i.e. Compute_Visible_and_Ori + this loss).  Bit-identical to
- * mh_project_gather + mh_refine_loss. */
+ * mh_project_gather + mh_refine_loss.
+ *
+ * batch / row0 / total: where these N points sit in the reference's batches.  The loss is a sum over views of a [V, n]
+ * tensor per batch of n points (PMVO.py:198-204) and ATen adds the trailing n mod 32 columns of such a sum in another
+ * order than the rest (csrc/mh_device.h: mh_row_sum_views), so the last bits of a point's loss depend on where it sits
+ * in its batch.  The points are rows row0 .. row0+N-1 of `total` points that the reference processes `batch` at a time
+ * (PMVO.py:602-606: 5000); batch = 0: these N points are one batch.  mh_ctx_set_option("sum_block", 0) turns the rule off. */
 int mh_refine_loss_maps(mh_ctx *ctx, const float *points, const float *dir, float step_mul, float step_div, int N,
-                        int patch, float conf_threshold, float *loss, uint8_t *high_conf, void *stream);
+                        int patch, float conf_threshold, float *loss, uint8_t *high_conf, int batch, long long row0,
+                        long long total, void *stream);
 
 /* The tail of one chunk of refine's smoothing loop (PMVO.py:91-92, 631-642), in place on slices of the global arrays:
  * update = head_filter && !head_top ? -1 : loss_u;  ori <- center where |cos(center, ori)| < replace_threshold;
@@ -176,10 +183,13 @@ int mh_prj_loss(mh_ctx *ctx, const float *D, const float *ori_patch, const float
 
 /* ---- K13: per-view visibility / mask / confidence votes of PMVO.filter_points (PMVO.py:402-459),
  * PMVO.compute_unvisible_points (:461-480) and PMVO.filter_head_points (:110-137).
- * surface_index/filter_index/unvisible_index/head_filter: uint8 [N]; any may be NULL. */
+ * surface_index/filter_index/unvisible_index/head_filter: uint8 [N]; any may be NULL.
+ * batch / row0 / total: as for mh_refine_loss_maps (the votes are sums over views of [V, n] tensors; mask values in
+ * (0, 0.2] stay fractional, PMVO.py:427, so the order of the sum can matter). */
 int mh_filter_points(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold,
                      float visible_threshold, uint8_t *surface_index, uint8_t *filter_index,
-                     uint8_t *unvisible_index, uint8_t *head_filter, void *stream);
+                     uint8_t *unvisible_index, uint8_t *head_filter, int batch, long long row0, long long total,
+                     void *stream);
 
 /* ---- K11: compute_points_similarity (Utils/PMVO_utils.py:366-382): medoid orientation of each group.
  * Dense form: ori[G,K,3] -> out[G,3], out_index[G].  Segmented form (voxel fit, PMVO.py:717-726):
@@ -375,6 +385,16 @@ int mh_mat_sparse_close(void *handle);
  *   "tap_codes": 1 (default) = contexts whose views were ALL uploaded with mh_ctx_set_view_u8 gather a patch tap as the
  *       two resident 8-bit codes of its pixel (mh_project_taps_codes_kernel); 0 = always the decoded records.
  *   "gabor_variant": 3 (default) mh_gabor_mfma2_kernel; 1 the first FP32-MFMA form; 0 / 2 the direct v_pk_fma forms.
+ *   "reproject_rule": how the sgemms of PMVO.sample_next_3d_pos (Camera.projection / Camera.reprojection of the points that
+ *       share a base view, PMVO.py:289,318 -> Utils/Camera_utils.py:50-53,103) round.  0 (default): by the number M of points
+ *       of the batch that share the (rank, base view), as MKL does in the reference -- M == 1: single-column projection;
+ *       S*M >= "reproject_fma_min_cols" (default 28445 = MKL 2024.2 / AVX-512 / 8 threads, where the goldens were generated;
+ *       the switch is MKL's threaded kernel and moves with the thread count: 2 threads 21334, 4 threads 14223, 1 thread never)
+ *       or S*M <= 3: k-ordered fma chain; otherwise separately rounded products.  1: the mid-size forms for every point
+ *       (rounds 1-4; independent of the batch).  2: the chain forms for every point.
+ *   "sum_block": 32 (default) ATen's sum(dim=0) adds the trailing (columns mod 32) of a [V, N*S] / [V, N] sum in its
+ *       row_sum order (forward: the last samples of the last point of a batch; refine / filter votes: the last points of a
+ *       batch); 0: cascade order everywhere (rounds 1-4).
  *   "topk_order": see mh_topk_views.   "taps_tile": 1 (default) mh_project_taps2_kernel; 64 / 32 / 16: the first
  *       form of the fp32 front end with that many points per workgroup (A/B).
  *   "line_rule" (mh_render_strands): 0 = OpenGL's diamond-exit rule (default), 1 = the pixel that holds a segment's end

@@ -11,6 +11,7 @@ _lib = None
 vp = ctypes.c_void_p
 ci = ctypes.c_int
 cf = ctypes.c_float
+cll = ctypes.c_longlong
 csz = ctypes.c_size_t
 
 _SIGS = {
@@ -34,7 +35,7 @@ _SIGS = {
     "mh_search_prepared": (ci, [vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mh_forward": (ci, [vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, vp, vp, csz, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mh_refine_loss": (ci, [vp, vp, vp, cf, cf, ci, ci, cf, vp, vp, vp, vp, vp, vp]),
-    "mh_filter_points": (ci, [vp, vp, ci, ci, cf, cf, vp, vp, vp, vp, vp]),
+    "mh_filter_points": (ci, [vp, vp, ci, ci, cf, cf, vp, vp, vp, vp, ci, cll, cll, vp]),
     "mh_project_points": (ci, [vp, ci, vp, ci, vp, vp, vp, vp, vp]),
     "mh_gather_pixels": (ci, [vp, ci, vp, ci, ci, vp, vp, vp]),
     "mh_compute_visible": (ci, [vp, vp, vp, csz, vp, vp]),
@@ -42,7 +43,7 @@ _SIGS = {
     "mh_reproject_ori": (ci, [vp, vp, vp, ci, ci, vp, vp]),
     "mh_prj_loss": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp, vp, vp]),
     "mh_medoid_indexed": (ci, [vp, vp, vp, ci, ci, vp, vp, vp]),
-    "mh_refine_loss_maps": (ci, [vp, vp, vp, cf, cf, ci, ci, cf, vp, vp, vp]),
+    "mh_refine_loss_maps": (ci, [vp, vp, vp, cf, cf, ci, ci, cf, vp, vp, ci, cll, cll, vp]),
     "mh_refine_combine": (ci, [vp, vp, vp, vp, vp, cf, vp, vp, ci, vp]),
     "mh_medoid_dense": (ci, [vp, vp, ci, ci, vp, vp, vp]),
     "mh_medoid_segmented": (ci, [vp, vp, vp, ci, ci, vp, vp, vp]),

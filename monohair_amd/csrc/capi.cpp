@@ -69,6 +69,11 @@ struct mh_ctx {
         const bool select = search_body == 2 || (search_body == 0 && views_8bit());
         return select ? (v == 0 ? 100 : v + 100) : v;
     }
+    // The reference's batch composition in the arithmetic (csrc/mh_device.h: MhRule, MhBatch; oracle/pmvo_oracle.c):
+    int reproject_rule = 0;   // 0: sample_next_3d_pos's sgemms round by the size of the (rank, base view) group as MKL does in
+                              //    the reference; 1: the mid-size forms for every point; 2: the chain forms
+    int reproject_fma_min_cols = 28445;   // columns (S x group) from which MKL's threaded sgemm (fma chain) takes over
+    int sum_block = 32;       // ATen's outer sum adds the trailing (columns mod 32) of a batch in row_sum order; 0: never
     int topk_order = 0;       // 0: torch.topk's CPU tie order (mh_topk_wave.h); 1: value desc, view asc (round 1's rule)
     int taps_tile = 1;        // (accepted and ignored: round 3's A/B switch between forms of the fp32 front end;
                               // mh_project_taps2_kernel is the only one left)
@@ -117,11 +122,12 @@ int mh_launch_project_points(const float *, const float *, int, int, int, int32_
                              hipStream_t);
 int mh_launch_gather(MhViews, int, const long long *, int, int, float4 *, float *, hipStream_t);
 int mh_launch_compute_visible(const float *, const float *, size_t, float *, hipStream_t);
-int mh_launch_sample_next(MhViews, const float *, const int32_t *, const float *, const float *, int, int, float *,
+int mh_launch_sample_next(MhViews, const float *, const int32_t *, const float *, const float *, int, int, float *, int, int,
+                          int32_t *,
                           hipStream_t);
 int mh_launch_reproject(MhViews, const float *, const float *, int, int, float *, hipStream_t);
 int mh_launch_prj_loss(const float *, const float *, const float *, const float *, int, int, int, int, float, float *,
-                       long long *, uint8_t *, float *, hipStream_t);
+                       long long *, uint8_t *, float *, int, hipStream_t);
 int mh_launch_project_gather(MhViews, const float *, int, int, float *, float *, float *, float *, float *, float *,
                              float *, hipStream_t);
 int mh_launch_topk(const float *, const float *, int, int, int32_t *, float *, int, hipStream_t);
@@ -133,14 +139,14 @@ int mh_launch_project_taps(MhViews, const float *, int, int, float, float *, flo
                            uint8_t *, int, const uint16_t *, const void *, hipStream_t);
 int mh_launch_search(MhViews, const float *, int, int, int, const float *, int, int, float, const float *,
                      const int32_t *, const float *, const float4 *, int32_t *, const uint8_t *, float *, float *,
-                     uint8_t *, float *, int32_t *, int32_t *, int, hipStream_t);
+                     uint8_t *, float *, int32_t *, int32_t *, int, int, int, int, int32_t *, hipStream_t);
 int mh_launch_refine_loss(MhViews, const float *, const float *, float, float, int, int, float, const float *,
-                          const float *, const float *, float *, uint8_t *, hipStream_t);
+                          const float *, const float *, float *, uint8_t *, int, hipStream_t);
 int mh_launch_filter_points(MhViews, const float *, int, int, float, float, uint8_t *, uint8_t *, uint8_t *,
-                            uint8_t *, hipStream_t);
+                            uint8_t *, int, long long, long long, int, hipStream_t);
 int mh_launch_medoid_dense(const float *, const int32_t *, int, int, float *, int32_t *, hipStream_t);
 int mh_launch_refine_loss_maps(MhViews, const float *, const float *, float, float, int, int, float, float *, uint8_t *,
-                               hipStream_t);
+                               int, long long, long long, int, hipStream_t);
 int mh_launch_refine_combine(const float *, const float *, const uint8_t *, const uint8_t *, float, float *, float *,
                              int, hipStream_t);
 int mh_launch_medoid_segmented(const float *, const int32_t *, int, int, float *, int32_t *, hipStream_t);
@@ -417,6 +423,22 @@ extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
         ctx->topk_order = value;
         return MH_OK;
     }
+    if (!strcmp(key, "reproject_rule")) {
+        if (value < 0 || value > 2)
+            return fail(MH_ERR_ARG, "mh_ctx_set_option: reproject_rule must be 0 (by group size), 1 (mid forms) or 2 (chain forms)");
+        ctx->reproject_rule = value;
+        return MH_OK;
+    }
+    if (!strcmp(key, "reproject_fma_min_cols")) {
+        if (value < 1) return fail(MH_ERR_ARG, "mh_ctx_set_option: reproject_fma_min_cols must be >= 1");
+        ctx->reproject_fma_min_cols = value;
+        return MH_OK;
+    }
+    if (!strcmp(key, "sum_block")) {
+        if (value != 0 && value != 32) return fail(MH_ERR_ARG, "mh_ctx_set_option: sum_block must be 32 (ATen's outer sum) or 0");
+        ctx->sum_block = value;
+        return MH_OK;
+    }
     if (!strcmp(key, "tap_codes")) {
         ctx->use_codes = value ? 1 : 0;
         return MH_OK;
@@ -474,6 +496,11 @@ static size_t search_count_offset(const mh_ctx *ctx, int N, int patch) {
     return search_order_offset(ctx, N, patch) + 2 * (size_t)N * sizeof(int32_t);
 }
 
+// behind the list lengths: the points per (rank, base view) of the batch (16 ranks x V ints) -- csrc/mh_device.h: MhRule
+static size_t search_groups_offset(const mh_ctx *ctx, int N, int patch) {
+    return (search_count_offset(ctx, N, patch) + (size_t)ctx->V * (size_t)N + 255) & ~(size_t)255;
+}
+
 extern "C" size_t mh_search_counts_offset(mh_ctx *ctx, int N, int patch) {
     if (!ctx || N < 0 || patch < 1) return 0;
     return search_count_offset(ctx, N, patch);
@@ -484,7 +511,8 @@ extern "C" size_t mh_search_scratch_bytes(mh_ctx *ctx, int N, int patch) {
     // + 16 records of slack: the search kernel prefetches tap records in groups past the end of a list;
     // + 2N ints behind them: the launch order of the search (mh_search_order_kernel) and its staging area
     // + V*N bytes: the list lengths once more, compact, for the work estimate
-    return search_count_offset(ctx, N, patch) + (size_t)ctx->V * (size_t)N;
+    // + the group sizes of the batch (search_groups_offset)
+    return search_groups_offset(ctx, N, patch) + (size_t)16 * ctx->V * sizeof(int32_t);
 }
 
 extern "C" int mh_search_forward(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank,
@@ -517,7 +545,9 @@ extern "C" int mh_search_forward(mh_ctx *ctx, const float *points, int N, int pa
                                      (int32_t *)((char *)scratch + search_order_offset(ctx, N, patch)),
                                      (const uint8_t *)scratch + search_count_offset(ctx, N, patch), line_ori,
                                      min_loss, high_conf, best_sample, best_rank, best_s,
-                                     ctx->search_launch_variant(ctx->search_variant), st),
+                                     ctx->search_launch_variant(ctx->search_variant), ctx->reproject_rule,
+                                     ctx->reproject_fma_min_cols, ctx->sum_block,
+                                     (int32_t *)((char *)scratch + search_groups_offset(ctx, N, patch)), st),
                     "mh_search_forward");
 }
 
@@ -554,7 +584,9 @@ static int search_prepared(mh_ctx *ctx, const float *points, int N, int patch, f
                                      (int32_t *)((char *)scratch + search_order_offset(ctx, N, patch)),
                                      (const uint8_t *)scratch + search_count_offset(ctx, N, patch), line_ori,
                                      min_loss, high_conf, best_sample, best_rank, best_s,
-                                     ctx->search_launch_variant(variant), (hipStream_t)stream),
+                                     ctx->search_launch_variant(variant), ctx->reproject_rule, ctx->reproject_fma_min_cols,
+                                     ctx->sum_block, (int32_t *)((char *)scratch + search_groups_offset(ctx, N, patch)),
+                                     (hipStream_t)stream),
                     "mh_search_prepared");
 }
 
@@ -600,20 +632,23 @@ extern "C" int mh_refine_loss(mh_ctx *ctx, const float *points, const float *dir
         return fail(MH_ERR_ARG, "mh_refine_loss: bad arguments");
     if (N == 0) return MH_OK;
     return launched(mh_launch_refine_loss(ctx->views(), points, dir, step_mul, step_div, N, patch * patch,
-                                          conf_threshold, vis, ori_patch, conf_patch, loss, high_conf,
+                                          conf_threshold, vis, ori_patch, conf_patch, loss, high_conf, ctx->sum_block,
                                           (hipStream_t)stream),
                     "mh_refine_loss");
 }
 
 extern "C" int mh_filter_points(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold,
                                 float visible_threshold, uint8_t *surface_index, uint8_t *filter_index,
-                                uint8_t *unvisible_index, uint8_t *head_filter, void *stream) {
+                                uint8_t *unvisible_index, uint8_t *head_filter, int batch, long long row0,
+                                long long total, void *stream) {
     if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_filter_points: views not set");
     if (N == 0) return MH_OK;
-    if (!points || N < 0 || patch < 1 || !(patch & 1)) return fail(MH_ERR_ARG, "mh_filter_points: bad arguments");
+    if (!points || N < 0 || patch < 1 || !(patch & 1) || batch < 0 || row0 < 0 || (batch > 0 && total < row0 + N))
+        return fail(MH_ERR_ARG, "mh_filter_points: bad arguments");
+    if (batch == 0) row0 = 0, total = N;
     return launched(mh_launch_filter_points(ctx->views(), points, N, patch, conf_threshold, visible_threshold,
-                                            surface_index, filter_index, unvisible_index, head_filter,
-                                            (hipStream_t)stream),
+                                            surface_index, filter_index, unvisible_index, head_filter, batch, row0, total,
+                                            ctx->sum_block, (hipStream_t)stream),
                     "mh_filter_points");
 }
 
@@ -634,18 +669,20 @@ extern "C" int mh_medoid_indexed(mh_ctx *ctx, const float *ori_rows, const int32
 
 extern "C" int mh_refine_loss_maps(mh_ctx *ctx, const float *points, const float *dir, float step_mul, float step_div,
                                    int N, int patch, float conf_threshold, float *loss, uint8_t *high_conf,
-                                   void *stream) {
+                                   int batch, long long row0, long long total, void *stream) {
     if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_refine_loss_maps: views not set");
     if (N == 0) return MH_OK;
-    if (!points || !dir || !loss || N < 0 || patch < 1 || !(patch & 1))
+    if (!points || !dir || !loss || N < 0 || patch < 1 || !(patch & 1) || batch < 0 || row0 < 0 ||
+        (batch > 0 && total < row0 + N))
         return fail(MH_ERR_ARG, "mh_refine_loss_maps: bad arguments");
+    if (batch == 0) row0 = 0, total = N;
     if (patch > 11)
         return fail(MH_ERR_ARG, "mh_refine_loss_maps: patch side %d is not built in (odd sides 1..11 are; the reference's "
                                 "configurations use 5, 7 and 9) -- use mh_project_gather + mh_refine_loss for larger patches",
                     patch);
     if (ctx->V > 512) return fail(MH_ERR_ARG, "mh_refine_loss_maps: %d views exceed the limit of 512", ctx->V);
     return launched(mh_launch_refine_loss_maps(ctx->views(), points, dir, step_mul, step_div, N, patch, conf_threshold,
-                                               loss, high_conf, (hipStream_t)stream),
+                                               loss, high_conf, batch, row0, total, ctx->sum_block, (hipStream_t)stream),
                     "mh_refine_loss_maps");
 }
 
@@ -780,9 +817,16 @@ extern "C" int mh_sample_next(mh_ctx *ctx, const float *points, const int32_t *b
     if (N == 0) return MH_OK;
     if (!points || !base_view || !ori || !offsets || !samples || N < 0 || S < 1)
         return fail(MH_ERR_ARG, "mh_sample_next: bad arguments");
-    return launched(mh_launch_sample_next(ctx->views(), points, base_view, ori, offsets, N, S, samples,
-                                          (hipStream_t)stream),
-                    "mh_sample_next");
+    // (the V group sizes of this batch -- stream-ordered work space, so that calls on several streams do not share it)
+    int32_t *gcnt = nullptr;
+    if (ctx->reproject_rule == 0)
+        MH_HIP(hipMallocAsync((void **)&gcnt, sizeof(int32_t) * (size_t)ctx->V, (hipStream_t)stream));
+    const int rc = launched(mh_launch_sample_next(ctx->views(), points, base_view, ori, offsets, N, S, samples,
+                                                  ctx->reproject_rule, ctx->reproject_fma_min_cols, gcnt,
+                                                  (hipStream_t)stream),
+                            "mh_sample_next");
+    if (gcnt) (void)hipFreeAsync(gcnt, (hipStream_t)stream);
+    return rc;
 }
 
 extern "C" int mh_reproject_ori(mh_ctx *ctx, const float *points, const float *samples, int N, int S, float *D,
@@ -800,7 +844,7 @@ extern "C" int mh_prj_loss(mh_ctx *ctx, const float *D, const float *ori_patch, 
     if (!ctx || !D || !ori_patch || !conf_patch || !vis || !loss || V < 1 || V >= 4096 || N < 0 || S < 1 || P < 1)
         return fail(MH_ERR_ARG, "mh_prj_loss: bad arguments");
     return launched(mh_launch_prj_loss(D, ori_patch, conf_patch, vis, V, N, S, P, conf_threshold, loss, index, high_conf,
-                                       all_loss, (hipStream_t)stream),
+                                       all_loss, ctx->sum_block, (hipStream_t)stream),
                     "mh_prj_loss");
 }
 

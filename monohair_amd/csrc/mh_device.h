@@ -58,18 +58,114 @@ __device__ __forceinline__ void mh_pixel_of(const float *__restrict__ cam, float
     mh_ndc_to_pixel(u, v, Hf, Wf, row, col);
 }
 
-// Camera.reprojection(to_world=True) (Camera_utils.py:81-106); the 3x3 product is
-// (a0*b0 + a2*b2) + a1*b1 with separately rounded products -- the MKL kernel the reference lands in for
-// fewer than ~28k columns (see oracle/pmvo_oracle.c: cam_unproject).
+// ---- the reference's batch composition in the arithmetic (oracle/pmvo_oracle.c, the table above cam_unproject) ----
+// PMVO.sample_next_3d_pos (PMVO.py:263-335) works, per camera, on the M points of the batch whose base view (at this rank)
+// that camera is; its sgemms round by their column count (MKL 2024.2 / AVX-512 / 8 threads, where the goldens come from):
+//   Camera.projection, [4,4] x [4,M]:      M == 1: p2 + ((fma(a1,b1, a0*b0)) + p3);   M >= 2: k-ordered fma chain
+//   Camera.reprojection, [3,3] x [3,S*M]:  S*M <= 3 or S*M >= fma_min_cols (28445): k-ordered fma chain;
+//                                          else (a0*b0 + a2*b2) + a1*b1 with separately rounded products
+// and ATen's sum(dim=0) of a [V, C] tensor adds its trailing C mod 32 columns (32 = 4 AVX2 vectors) in another order
+// (mh_row_sum_views).
+// MhRule carries what a kernel needs to follow the batch; mode 1 / 2 force the mid / chain forms for every point.
+#define MH_FORM_GEMV 1
+#define MH_FORM_CHAIN 2
+struct MhRule {
+    const int32_t *gcnt;    // [nrank][V] points per (rank, base view) of this batch (nullptr: every group counts as mid-size)
+    long long tail_col0;    // first trailing column of the [V, N*S] sums; N*S if none
+    int mode;               // 0 follow the group size, 1 mid forms, 2 chain forms
+    int fma_min_cols;       // chain-form reprojection from this many columns on
+};
+
+__device__ __forceinline__ int mh_group_forms(const MhRule &rule, int rank, int V, int b, int S) {
+    if (rule.mode == 1) return 0;
+    if (rule.mode == 2) return MH_FORM_CHAIN;
+    const int M = rule.gcnt ? rule.gcnt[rank * V + b] : 2;
+    const long long cols = (long long)M * S;
+    return (M == 1 ? MH_FORM_GEMV : 0) | ((cols <= 3 || cols >= rule.fma_min_cols) ? MH_FORM_CHAIN : 0);
+}
+
+// Camera.projection of a point that is alone in its sgemm (M == 1)
+__device__ __forceinline__ void mh_cam_project_single(const float *__restrict__ cam, float X0, float X1, float X2,
+                                                      float &u, float &v, float &z) {
+    float c[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float f = mh_fma(cam[4 * r + 1], X1, cam[4 * r] * X0);
+        const float p2 = cam[4 * r + 2] * X2;
+        const float p3 = cam[4 * r + 3] * 1.0f;
+        c[r] = p2 + (f + p3);
+    }
+    float q[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const float f = mh_fma(cam[16 + 4 * r + 1], c[1], cam[16 + 4 * r] * c[0]);
+        const float p2 = cam[16 + 4 * r + 2] * c[2];
+        const float p3 = cam[16 + 4 * r + 3] * c[3];
+        q[r] = p2 + (f + p3);
+    }
+    z = c[2];
+    u = q[0] / c[2];
+    v = q[1] / c[2];
+}
+
+// Camera.reprojection(to_world=True) (Camera_utils.py:81-106) in the form the column count of its sgemm selects
 __device__ __forceinline__ void mh_cam_unproject(const float *__restrict__ cam, float u, float v, float z,
-                                                 float &X0, float &X1, float &X2) {
+                                                 float &X0, float &X1, float &X2, bool chain = false) {
     float c0 = (u - cam[18]) / cam[16] * z;
     float c1 = (v - cam[22]) / cam[21] * z;
     float d0 = c0 - cam[3], d1 = c1 - cam[7], d2 = z - cam[11];
     const float *Ri = cam + 32;
-    X0 = (Ri[0] * d0 + Ri[2] * d2) + Ri[1] * d1;
-    X1 = (Ri[3] * d0 + Ri[5] * d2) + Ri[4] * d1;
-    X2 = (Ri[6] * d0 + Ri[8] * d2) + Ri[7] * d1;
+    if (chain) {
+        X0 = mh_fma(Ri[2], d2, mh_fma(Ri[1], d1, Ri[0] * d0));
+        X1 = mh_fma(Ri[5], d2, mh_fma(Ri[4], d1, Ri[3] * d0));
+        X2 = mh_fma(Ri[8], d2, mh_fma(Ri[7], d1, Ri[6] * d0));
+    } else {
+        X0 = (Ri[0] * d0 + Ri[2] * d2) + Ri[1] * d1;
+        X1 = (Ri[3] * d0 + Ri[5] * d2) + Ri[4] * d1;
+        X2 = (Ri[6] * d0 + Ri[8] * d2) + Ri[7] * d1;
+    }
+}
+
+// Where the points of a launch sit in the reference's batches, for the [V, N] sums over views (S = 1): they are rows
+// row0 .. row0 + N - 1 of `total` points that the reference processes `batch` at a time (PMVO.py:604-606: 5000); the
+// trailing (length mod 32) rows of every batch are summed in row_sum order.  block 0: cascade order everywhere.
+struct MhBatch {
+    long long row0, total;
+    int batch, block;
+};
+__device__ __forceinline__ bool mh_tail_row(const MhBatch &bt, int n) {
+    if (bt.block <= 0) return false;
+    const long long row = bt.row0 + n;
+    const long long start = bt.batch > 0 ? row / bt.batch * bt.batch : 0;
+    const long long left = bt.total - start;
+    const long long len = (bt.batch > 0 && bt.batch < left) ? bt.batch : left;
+    return row - start >= len - len % bt.block;
+}
+
+// ATen's row_sum (aten/src/ATen/native/cpu/SumKernel.cpp) of one trailing column of a [V, C] outer sum: rows k, k+4, ...
+// into partial k, each partial a multi_row_sum cascade (16 rows per level-0 block) over its V/4 rows; the V mod 4 left-over
+// rows into partial 0; then partial 0 += partial 1, 2, 3.  term(v) = row v of the column.  Exact for V < 4096.
+template <typename F>
+__device__ __forceinline__ float mh_row_sum_views(int V, F term) {
+    const int L = V >> 2;
+    float part[4];
+    for (int k = 0; k < 4; ++k) {
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+        int i = 0;
+        while (i + 16 <= L) {
+            for (int j = 0; j < 16; ++j, ++i) a0 = a0 + term(4 * i + k);
+            a1 = a1 + a0;
+            a0 = 0.0f;
+            if ((i & 0xF0) == 0) {
+                a2 = a2 + a1;
+                a1 = 0.0f;
+            }
+        }
+        for (; i < L; ++i) a0 = a0 + term(4 * i + k);
+        part[k] = (a0 + a1) + a2;
+    }
+    for (int i = L * 4; i < V; ++i) part[0] = part[0] + term(i);
+    return ((part[0] + part[1]) + part[2]) + part[3];
 }
 
 // x / max(|x|, 1e-8) of a 2-vector as torch.cosine_similarity normalises it (norm = sqrt of an fma chain)

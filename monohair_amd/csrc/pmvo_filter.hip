@@ -4,7 +4,8 @@
 //   PMVO.filter_head_points       (PMVO.py:110-137)  -> head_filter (the mask vote only; the two scipy
 //                                                      KDTree queries of :98-107 stay on the host)
 // One wave per point, lane = view.  Each lane writes its per-view terms to LDS and lane 0 adds them in
-// ATen's cascade order (mask values in (0, 0.2] stay fractional, PMVO.py:427, so order can matter).
+// ATen's cascade order (mask values in (0, 0.2] stay fractional, PMVO.py:427, so order can matter) -- in its row_sum
+// order for the trailing points of a batch of the reference (MhBatch).
 #include "mh_device.h"
 
 #define MH_FILTER_VMAX 512
@@ -15,7 +16,7 @@ __global__ __launch_bounds__(256) void mh_filter_kernel(MhViews vw, const float 
                                                         float vis_thr, uint8_t *__restrict__ surface_index,
                                                         uint8_t *__restrict__ filter_index,
                                                         uint8_t *__restrict__ unvisible_index,
-                                                        uint8_t *__restrict__ head_filter) {
+                                                        uint8_t *__restrict__ head_filter, MhBatch bt) {
     constexpr int HP = PATCH / 2;
     extern __shared__ float s_tbuf[];   // [4 waves][MH_NTERM][V]
 #define s_t(w, t, v) s_tbuf[((w) * MH_NTERM + (t)) * V + (v)]
@@ -80,7 +81,10 @@ __global__ __launch_bounds__(256) void mh_filter_kernel(MhViews vw, const float 
             if (v > 0 && (v & 15) == 0) mh_cascv_flush(a, v);
             a.a0 = a.a0 + s_t(wave, lane, v);
         }
-        s_t(wave, lane, 0) = mh_cascv_done(a);
+        float sum = mh_cascv_done(a);
+        // the trailing (length mod 32) points of a batch of the reference: ATen's row_sum order (mh_device.h: MhBatch)
+        if (mh_tail_row(bt, n)) sum = mh_row_sum_views(V, [&](int v) { return s_t(wave, lane, v); });
+        s_t(wave, lane, 0) = sum;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -102,14 +106,16 @@ __global__ __launch_bounds__(256) void mh_filter_kernel(MhViews vw, const float 
 
 extern "C" int mh_launch_filter_points(MhViews vw, const float *pts, int N, int patch, float thr, float vis_thr,
                                        uint8_t *surface_index, uint8_t *filter_index, uint8_t *unvisible_index,
-                                       uint8_t *head_filter, hipStream_t st) {
+                                       uint8_t *head_filter, int batch, long long row0, long long total, int sum_block,
+                                       hipStream_t st) {
     if (vw.V > MH_FILTER_VMAX) return -1;
+    const MhBatch bt = {row0, total, batch, sum_block};
     const dim3 grid((N + 3) / 4), block(256);
     const size_t lds = (size_t)4 * MH_NTERM * vw.V * sizeof(float);
 #define MH_F_CASE(PS)                                                                                              \
     case PS:                                                                                                       \
         hipLaunchKernelGGL(mh_filter_kernel<PS>, grid, block, lds, st, vw, pts, N, thr, vis_thr, surface_index,       \
-                           filter_index, unvisible_index, head_filter);                                            \
+                           filter_index, unvisible_index, head_filter, bt);                                        \
         break;
     switch (patch) {
         MH_F_CASE(1)

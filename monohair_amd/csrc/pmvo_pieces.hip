@@ -55,13 +55,22 @@ __global__ __launch_bounds__(256) void mh_compute_visible_kernel(const float *__
     if (i < n) out[i] = mh_soft_visible(depth[i], z[i]);
 }
 
+// points per base view among base_view[0..N) (the M of mh_group_forms): gcnt[V], zeroed by the launcher
+__global__ __launch_bounds__(256) void mh_piece_group_sizes_kernel(const int32_t *__restrict__ base_view, int N, int V,
+                                                                   int32_t *__restrict__ gcnt) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int b = base_view[n];
+    if (b >= 0 && b < V) atomicAdd(&gcnt[b], 1);
+}
+
 // sample_next_3d_pos: out[n, s, :] for the base view of point n (the reference leaves points whose base view index
 // matches no camera at zero; indices are assumed valid here)
 __global__ __launch_bounds__(256) void mh_sample_next_kernel(MhViews vw, const float *__restrict__ pts,
                                                              const int32_t *__restrict__ base_view,
                                                              const float *__restrict__ ori /*[V,N,2]*/,
                                                              const float *__restrict__ offs, int N, int S,
-                                                             float *__restrict__ out) {
+                                                             float *__restrict__ out, MhRule rule) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)N * S) return;
     const int n = (int)(i / S), s = (int)(i - (long long)n * S);
@@ -71,7 +80,10 @@ __global__ __launch_bounds__(256) void mh_sample_next_kernel(MhViews vw, const f
         const float2 oc = reinterpret_cast<const float2 *>(ori)[(size_t)b * N + n];
         const float *cam = vw.cams + b * MH_CAM_STRIDE;
         float u, v, z, row, col;
-        mh_cam_project(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, v, z);
+        // (the rounding of the reference's sgemms follows the number of points that share this base view: MhRule)
+        const int forms = mh_group_forms(rule, 0, vw.V, b, S);
+        if (forms & MH_FORM_GEMV) mh_cam_project_single(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, v, z);
+        else mh_cam_project(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, v, z);
         mh_ndc_to_pixel(u, v, (float)vw.H, (float)vw.W, row, col);
         float nx = col + oc.y * 2.0f;
         float ny = row + oc.x * 2.0f;
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(256) void mh_sample_next_kernel(MhViews vw, const f
         nx = nx * 2.0f - 1.0f;
         ny = ny * 2.0f - 1.0f;
         nx = -nx;
-        mh_cam_unproject(cam, nx, ny, z + offs[s], S0, S1, S2);
+        mh_cam_unproject(cam, nx, ny, z + offs[s], S0, S1, S2, (forms & MH_FORM_CHAIN) != 0);
     }
     out[3 * i] = S0;
     out[3 * i + 1] = S1;
@@ -120,7 +132,8 @@ __global__ __launch_bounds__(256) void mh_prj_loss_kernel(const float *__restric
                                                           const float *__restrict__ vis /*[V,N]*/, int V, int N, int S,
                                                           int P, float thr, float *__restrict__ loss,
                                                           long long *__restrict__ index, uint8_t *__restrict__ hc,
-                                                          float *__restrict__ all_loss /*[N,S] or null*/) {
+                                                          float *__restrict__ all_loss /*[N,S] or null*/,
+                                                          long long tail_col0 /* first trailing column of the [V,N*S] sums */) {
     extern __shared__ float s_buf[];   // [S] losses, then [S] positive flags (as floats)
     __shared__ int s_npos;
     __shared__ float s_bl[4];
@@ -132,11 +145,8 @@ __global__ __launch_bounds__(256) void mh_prj_loss_kernel(const float *__restric
     for (int s = tid; s < S; s += blockDim.x) {
         MhCascV num = {0.f, 0.f, 0.f}, den = {0.f, 0.f, 0.f};
         int cnt = 0;
-        for (int v = 0; v < V; ++v) {
-            if (v > 0 && (v & 15) == 0) {
-                mh_cascv_flush(num, v);
-                mh_cascv_flush(den, v);
-            }
+        // the terms of view v: (min_loss * weight, weight) (PMVO.py:160-196)
+        auto term = [&](int v, float &tn, float &td) {
             const size_t vn = (size_t)v * N + n;
             const float2 d = reinterpret_cast<const float2 *>(D)[vn * S + s];
             float dx, dy;
@@ -158,11 +168,25 @@ __global__ __launch_bounds__(256) void mh_prj_loss_kernel(const float *__restric
                 bc = upd ? c : bc;
             }
             const float w = (vis[vn] == -1.0f ? 0.0f : 1.0f) * bc;
-            num.a0 = num.a0 + ml * w;
-            den.a0 = den.a0 + w;
-            cnt += (w > 0.0f) ? 1 : 0;
+            tn = ml * w;
+            td = w;
+        };
+        for (int v = 0; v < V; ++v) {
+            if (v > 0 && (v & 15) == 0) {
+                mh_cascv_flush(num, v);
+                mh_cascv_flush(den, v);
+            }
+            float tn, td;
+            term(v, tn, td);
+            num.a0 = num.a0 + tn;
+            den.a0 = den.a0 + td;
+            cnt += (td > 0.0f) ? 1 : 0;
         }
-        const float dn = mh_cascv_done(den), nm = mh_cascv_done(num);
+        float dn = mh_cascv_done(den), nm = mh_cascv_done(num);
+        if ((long long)n * S + s >= tail_col0) {   // a trailing column: ATen's row_sum order (mh_device.h)
+            nm = mh_row_sum_views(V, [&](int v) { float a, b; term(v, a, b); return a; });
+            dn = mh_row_sum_views(V, [&](int v) { float a, b; term(v, a, b); return b; });
+        }
         const bool pos = (dn / (float)cnt) > thr;
         s_pos[s] = pos ? 1.0f : 0.0f;
         s_loss[s] = nm / dn;
@@ -225,10 +249,20 @@ extern "C" int mh_launch_compute_visible(const float *depth, const float *z, siz
     return (int)hipGetLastError();
 }
 extern "C" int mh_launch_sample_next(MhViews vw, const float *pts, const int32_t *base_view, const float *ori,
-                                     const float *offs, int N, int S, float *out, hipStream_t st) {
+                                     const float *offs, int N, int S, float *out, int rule_mode, int fma_min_cols,
+                                     int32_t *gcnt /* V ints of work space (rule_mode 0) */, hipStream_t st) {
     const long long tot = (long long)N * S;
+    MhRule rule = {};
+    rule.mode = rule_mode;
+    rule.fma_min_cols = fma_min_cols;
+    if (rule_mode == 0) {
+        if (!gcnt) return -1;
+        if (hipMemsetAsync(gcnt, 0, sizeof(int32_t) * (size_t)vw.V, st) != hipSuccess) return -1;
+        hipLaunchKernelGGL(mh_piece_group_sizes_kernel, dim3((N + 255) / 256), dim3(256), 0, st, base_view, N, vw.V, gcnt);
+        rule.gcnt = gcnt;
+    }
     hipLaunchKernelGGL(mh_sample_next_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, vw, pts, base_view,
-                       ori, offs, N, S, out);
+                       ori, offs, N, S, out, rule);
     return (int)hipGetLastError();
 }
 extern "C" int mh_launch_reproject(MhViews vw, const float *pts, const float *samples, int N, int S, float *D,
@@ -240,10 +274,12 @@ extern "C" int mh_launch_reproject(MhViews vw, const float *pts, const float *sa
 }
 extern "C" int mh_launch_prj_loss(const float *D, const float *ori_patch, const float *conf_patch, const float *vis, int V,
                                   int N, int S, int P, float thr, float *loss, long long *index, uint8_t *hc,
-                                  float *all_loss, hipStream_t st) {
+                                  float *all_loss, int sum_block, hipStream_t st) {
     if (S < 1 || S > 8192) return -1;
+    const long long cols = (long long)N * S;
     hipLaunchKernelGGL(mh_prj_loss_kernel, dim3(N), dim3(256), (size_t)2 * S * sizeof(float), st, D, ori_patch,
-                       conf_patch, vis, V, N, S, P, thr, loss, index, hc, all_loss);
+                       conf_patch, vis, V, N, S, P, thr, loss, index, hc, all_loss,
+                       sum_block > 0 ? cols - cols % sum_block : cols);
     return (int)hipGetLastError();
 }
 

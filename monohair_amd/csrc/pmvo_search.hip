@@ -23,9 +23,10 @@
 // PMVO.sample_next_3d_pos for one item: pixel(unrounded) + 2*(ori_col, ori_row) -> ndc -> unproject
 __device__ __forceinline__ void mh_sample_next(const float *__restrict__ cam, float X0, float X1, float X2,
                                                float ori_r, float ori_c, float Hf, float Wf, float off, float &S0,
-                                               float &S1, float &S2) {
+                                               float &S1, float &S2, int forms = 0) {
     float u, v, z, row, col;
-    mh_cam_project(cam, X0, X1, X2, u, v, z);
+    if (forms & MH_FORM_GEMV) mh_cam_project_single(cam, X0, X1, X2, u, v, z);
+    else mh_cam_project(cam, X0, X1, X2, u, v, z);
     mh_ndc_to_pixel(u, v, Hf, Wf, row, col);
     float nx = col + ori_c * 2.0f;
     float ny = row + ori_r * 2.0f;
@@ -34,18 +35,21 @@ __device__ __forceinline__ void mh_sample_next(const float *__restrict__ cam, fl
     nx = nx * 2.0f - 1.0f;
     ny = ny * 2.0f - 1.0f;
     nx = -nx;
-    mh_cam_unproject(cam, nx, ny, z + off, S0, S1, S2);
+    mh_cam_unproject(cam, nx, ny, z + off, S0, S1, S2, (forms & MH_FORM_CHAIN) != 0);
 }
 
 // mh_sample_next split at what the S samples of one base-view rank have in common (the point's pixel in the base view, the
 // shifted pixel in NDC, the two quotients of mh_cam_unproject) and what is per sample (depth + offset onwards).  Same
 // operations on the same values in the same order, so rank part + item part == mh_sample_next bit for bit; the shipped
 // search evaluates the rank part once per (point, rank) instead of once per item (90 times) and keeps it in LDS.
-// rec[16] = { A, B, z, t0 | t1, t2, Ri0, Ri1 | Ri2 .. Ri5 | Ri6, Ri7, Ri8, - }
+// rec[16] = { A, B, z, t0 | t1, t2, Ri0, Ri1 | Ri2 .. Ri5 | Ri6, Ri7, Ri8, forms }
+// forms (mh_group_forms): how the sgemms of this (rank, base view) group round in the reference -- MH_FORM_GEMV here,
+// MH_FORM_CHAIN in the item part.
 __device__ __forceinline__ void mh_sample_rank(const float *__restrict__ cam, float X0, float X1, float X2, float ori_r,
-                                               float ori_c, float Hf, float Wf, float *__restrict__ rec) {
+                                               float ori_c, float Hf, float Wf, float *__restrict__ rec, int forms = 0) {
     float u, v, z, row, col;
-    mh_cam_project(cam, X0, X1, X2, u, v, z);
+    if (forms & MH_FORM_GEMV) mh_cam_project_single(cam, X0, X1, X2, u, v, z);
+    else mh_cam_project(cam, X0, X1, X2, u, v, z);
     mh_ndc_to_pixel(u, v, Hf, Wf, row, col);
     float nx = col + ori_c * 2.0f;
     float ny = row + ori_r * 2.0f;
@@ -62,7 +66,7 @@ __device__ __forceinline__ void mh_sample_rank(const float *__restrict__ cam, fl
     rec[5] = cam[11];
 #pragma unroll
     for (int i = 0; i < 9; ++i) rec[6 + i] = cam[32 + i];
-    rec[15] = 0.0f;
+    rec[15] = __int_as_float(forms);
 }
 
 __device__ __forceinline__ void mh_sample_item(const float4 *__restrict__ rec, float off, float &S0, float &S1, float &S2) {
@@ -70,9 +74,100 @@ __device__ __forceinline__ void mh_sample_item(const float4 *__restrict__ rec, f
     const float z = a.z + off;
     const float c0 = a.x * z, c1 = a.y * z;
     const float d0 = c0 - a.w, d1 = c1 - b.x, d2 = z - b.y;
-    S0 = (b.z * d0 + c.x * d2) + b.w * d1;
-    S1 = (c.y * d0 + c.w * d2) + c.z * d1;
-    S2 = (d.x * d0 + d.z * d2) + d.y * d1;
+    if (__float_as_int(d.w) & MH_FORM_CHAIN) {   // (prologue / epilogue only: once per item)
+        S0 = mh_fma(c.x, d2, mh_fma(b.w, d1, b.z * d0));
+        S1 = mh_fma(c.w, d2, mh_fma(c.z, d1, c.y * d0));
+        S2 = mh_fma(d.z, d2, mh_fma(d.y, d1, d.x * d0));
+    } else {
+        S0 = (b.z * d0 + c.x * d2) + b.w * d1;
+        S1 = (c.y * d0 + c.w * d2) + c.z * d1;
+        S2 = (d.x * d0 + d.z * d2) + d.y * d1;
+    }
+}
+
+// where the trailing columns of the batch's [V, N*S] sums fall in point n: its first trailing sample (S if none)
+__device__ __forceinline__ int mh_tail_from(const MhRule &rule, int n, int S) {
+    const long long c0 = (long long)n * S;
+    if (c0 + S <= rule.tail_col0) return S;
+    return c0 >= rule.tail_col0 ? 0 : (int)(rule.tail_col0 - c0);
+}
+
+// The weighted sums over the views of ONE candidate (item position X) of point n in ATen's row_sum order (mh_device.h:
+// mh_row_sum_views) -- for the trailing columns of the batch's [V, N*S] sums.  The per-view terms are evaluated as the
+// portable kernel evaluates them (same operations as the shipped bodies, bit for bit): tap lists from the scratch records,
+// views that do not see the point (list length 0) add +0; cnt = the number of views with a positive weight.  It runs for a few
+// dozen items per launch, after the view loops, from the item's rank record in LDS -- nothing of it is live in those loops
+// (inside mh_search_slices_lds the same code cost the hot kernel 20 spilled registers).
+__device__ __forceinline__ void mh_tail_item_sums(const float *__restrict__ cams, int V, float Hf, float Wf,
+                                                  const float4 *__restrict__ taps_n, size_t vstride,
+                                                  const uint8_t *__restrict__ vcnt_n, int N, float X0, float X1, float X2,
+                                                  float &nm_out, float &dn_out, int &cnt_out) {
+    int cnt = 0;
+    auto term = [&](int v, float &tn, float &td) {
+        tn = td = 0.0f;
+        const int ntap = vcnt_n ? (int)vcnt_n[(size_t)v * N] : -1;
+        if (ntap == 0) return;
+        const float4 *__restrict__ rec = taps_n + (size_t)v * vstride;
+        const float4 hdr = rec[0];
+        if (hdr.y == -1.0f) return;
+        const int nt = ntap > 0 ? ntap : __float_as_int(hdr.x);
+        float row, col, dx, dy;
+        mh_pixel_of(cams + v * MH_CAM_STRIDE, X0, X1, X2, Hf, Wf, row, col);
+        mh_unit2(row - hdr.z, col - hdr.w, dx, dy);
+        const float4 t0 = rec[1];
+        float ml = 1.0f - __builtin_fabsf(t0.x * dx + t0.y * dy), bc = t0.z;
+        for (int t = 1; t < nt; ++t) {
+            const float4 tp = rec[1 + t];
+            const float l = 1.0f - __builtin_fabsf(tp.x * dx + tp.y * dy);
+            const bool upd = l < ml;
+            ml = upd ? l : ml;
+            bc = upd ? tp.z : bc;
+        }
+        tn = ml * bc;
+        td = bc;
+        cnt += (bc > 0.0f) ? 1 : 0;
+    };
+    const int L = V >> 2;
+    float pn[4][3] = {}, pd[4][3] = {};   // partial k (rows k, k+4, ...): cascade levels 0, 1, 2
+    for (int i = 0; i < L; ++i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float tn, td;
+            term(4 * i + k, tn, td);
+            pn[k][0] = pn[k][0] + tn;
+            pd[k][0] = pd[k][0] + td;
+        }
+        if (((i + 1) & 15) == 0) {   // a full block of 16 rows per partial: level 0 -> 1, every 256 rows level 1 -> 2
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                pn[k][1] = pn[k][1] + pn[k][0];
+                pn[k][0] = 0.0f;
+                pd[k][1] = pd[k][1] + pd[k][0];
+                pd[k][0] = 0.0f;
+                if (((i + 1) & 0xF0) == 0) {
+                    pn[k][2] = pn[k][2] + pn[k][1];
+                    pn[k][1] = 0.0f;
+                    pd[k][2] = pd[k][2] + pd[k][1];
+                    pd[k][1] = 0.0f;
+                }
+            }
+        }
+    }
+    float sn[4], sd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sn[k] = (pn[k][0] + pn[k][1]) + pn[k][2];
+        sd[k] = (pd[k][0] + pd[k][1]) + pd[k][2];
+    }
+    for (int v = L * 4; v < V; ++v) {
+        float tn, td;
+        term(v, tn, td);
+        sn[0] = sn[0] + tn;
+        sd[0] = sd[0] + td;
+    }
+    nm_out = ((sn[0] + sn[1]) + sn[2]) + sn[3];
+    dn_out = ((sd[0] + sd[1]) + sd[2]) + sd[3];
+    cnt_out = cnt;
 }
 
 // torch.min over a row with NaN propagation: NaN beats numbers, first index wins among equals
@@ -103,7 +198,7 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
                                                       const float4 *__restrict__ taps, float *__restrict__ line_ori,
                                                       float *__restrict__ min_loss, uint8_t *__restrict__ high_conf,
                                                       float *__restrict__ best_sample, int32_t *__restrict__ best_rank,
-                                                      int32_t *__restrict__ best_s) {
+                                                      int32_t *__restrict__ best_s, MhRule rule) {
     __shared__ float s_loss[MH_MAX_ITEMS];
     __shared__ uint8_t s_pos[MH_MAX_ITEMS];
     __shared__ float s_rl[MH_MAX_RANKS];
@@ -119,6 +214,7 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
     float X0[K], X1[K], X2[K];
     MhCascV num[K], den[K];
     int cnt[K];
+    const int tail_from = mh_tail_from(rule, n, S);   // first trailing sample of the batch's [V, N*S] sums in this point
 #pragma unroll
     for (int j = 0; j < K; ++j) {
         int it = j * T + tid;
@@ -126,7 +222,8 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
         const int r = it / S, s = it - r * S;
         const int b = base_idx[(size_t)(r * rank_step) * N + n];
         const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
-        mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[s], X0[j], X1[j], X2[j]);
+        mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[s], X0[j], X1[j], X2[j],
+                       mh_group_forms(rule, r, V, b, S));
         num[j] = den[j] = MhCascV{0.0f, 0.0f, 0.0f};
         cnt[j] = 0;
     }
@@ -182,9 +279,13 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
     for (int j = 0; j < K; ++j) {
         const int it = j * T + tid;
         if (it < nitems) {
-            const float dn = mh_cascv_done(den[j]);
-            const float nm = mh_cascv_done(num[j]);
-            const float ratio = dn / (float)cnt[j];
+            float dn = mh_cascv_done(den[j]);
+            float nm = mh_cascv_done(num[j]);
+            int cn = cnt[j];
+            if (it - (it / S) * S >= tail_from)   // a trailing column: the same terms in ATen's row_sum order
+                mh_tail_item_sums(vw.cams, V, Hf, Wf, taps + (size_t)n * P1, (size_t)N * P1, nullptr, N, X0[j], X1[j], X2[j],
+                                  nm, dn, cn);
+            const float ratio = dn / (float)cn;
             s_pos[it] = (ratio > thr) ? 1 : 0;
             s_loss[it] = nm / dn;
         }
@@ -244,7 +345,8 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
         const int b = base_idx[(size_t)(br * rank_step) * N + n];
         const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
         float B0, B1, B2;
-        mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[bs], B0, B1, B2);
+        mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[bs], B0, B1, B2,
+                       mh_group_forms(rule, br, V, b, S));
         const float d0 = B0 - P0, d1 = B1 - P1x, d2 = B2 - P2;
         float s2 = d0 * d0;
         s2 = mh_fma(d1, d1, s2);
@@ -982,7 +1084,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MH_S3_WAVES))
                                                        const int32_t *__restrict__ order, float *__restrict__ line_ori,
                                                        float *__restrict__ min_loss, uint8_t *__restrict__ high_conf,
                                                        float *__restrict__ best_sample, int32_t *__restrict__ best_rank,
-                                                       int32_t *__restrict__ best_s) {
+                                                       int32_t *__restrict__ best_s, MhRule rule) {
     __shared__ float4 s_taps[MH_S3_CAP + 8];   // (+8: the last prefetch group of a list reads past its end)
     __shared__ float s_loss[MH_MAX_ITEMS];
     __shared__ uint8_t s_pos[MH_MAX_ITEMS];
@@ -991,6 +1093,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MH_S3_WAVES))
     __shared__ int s_rh[MH_MAX_RANKS];
     __shared__ float4 s_rank[MH_MAX_RANKS * 4];   // mh_sample_rank's record of every base-view rank
     __shared__ float s_bval[MH_MAX_RANKS];        // base_view_conf of the ranks
+    __shared__ int s_tail;                        // first trailing sample of this point (mh_tail_from); S = none
 
     // Wave priority: everything that is not the tap loop -- prologue, staging, the per-view projection, the epilogue -- runs
     // at priority 1, the tap loop at 0.  The tap loops saturate the VALU whatever the arbiter picks; the other phases are
@@ -1005,13 +1108,14 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MH_S3_WAVES))
     // chain of loads per lane, all ranks in parallel (a scalar loop over base_view_conf first cost five more round trips
     // before the workgroup's first barrier)
     const int c_first = ((tid & 63) < vw.V) ? (int)vcnt[(size_t)(tid & 63) * N + n] : 0;   // (see mh_search_slices_lds)
+    if (tid == 64) s_tail = mh_tail_from(rule, n, S);
     if (tid < nrank) {
         const size_t ro = (size_t)(tid * rank_step) * N + n;
         s_bval[tid] = base_val[ro];
-        const int b = base_idx[ro];
+        const int b = min(max(base_idx[ro], 0), vw.V - 1);   // (a caller's unusable ranks may carry any index)
         const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
         mh_sample_rank(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, (float)vw.H, (float)vw.W,
-                       reinterpret_cast<float *>(s_rank + 4 * tid));
+                       reinterpret_cast<float *>(s_rank + 4 * tid), mh_group_forms(rule, tid, vw.V, b, S));
     }
     __syncthreads();
     // usable base-view ranks: rank 0 always, rank r > 0 only if base_view_conf[r] > 0 (PMVO.py:57-64); keep every rank up
@@ -1031,6 +1135,23 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MH_S3_WAVES))
     else mh_search_slices_lds<0, T, BIGV, KEYS, BIGP>(MH_S3_ARGS);
 #undef MH_S3_ARGS
     __syncthreads();
+    // ---- the trailing columns of the batch's [V, N*S] sums (samples >= s_tail of the batch's last point(s); s_tail == S, i.e.
+    // none, in every other workgroup): ATen adds those in its row_sum order -- their losses once more, that way
+    if (s_tail < S) {   // uniform
+        const int tail_from = s_tail;
+        for (int it = tid; it < nact; it += T) {
+            const int r = it / S, s = it - r * S;
+            if (s < tail_from) continue;
+            float X0, X1, X2, nm, dn;
+            int cnt;
+            mh_sample_item(s_rank + 4 * r, offs[s], X0, X1, X2);
+            mh_tail_item_sums(vw.cams, vw.V, (float)vw.H, (float)vw.W, taps + (size_t)n * P1, (size_t)N * P1, vcnt + n, N, X0, X1,
+                              X2, nm, dn, cnt);
+            s_pos[it] = (dn / (float)cnt > thr) ? 1 : 0;
+            s_loss[it] = nm / dn;
+        }
+        __syncthreads();
+    }
 
     // ---- per rank: low-confidence escape hatch, min / argmin over the S samples (PMVO.py:199-206)
     const int wave = tid >> 6, lane = tid & 63, nwaves = T >> 6;
@@ -1125,10 +1246,41 @@ __global__ __launch_bounds__(256) void mh_search_work_kernel(const uint8_t *__re
     if (lane == 0) order[n] = mh_work_class(nt, nvalid, V, P1, S, T);
 }
 
-__global__ __launch_bounds__(1024) void mh_search_order_kernel(int N, int32_t *__restrict__ order) {
+// Points per (rank, base view) of the batch -- the M of mh_group_forms: gcnt[r * V + b] = #{n : base_idx[r * rank_step, n] == b}.
+// One workgroup per launch (LDS histogram, no global atomics, nothing to zero first).
+#define MH_GROUP_LDS (MH_MAX_RANKS * 512)
+__device__ __forceinline__ void mh_group_sizes_block(const int32_t *__restrict__ base_idx, int N, int V, int nrank,
+                                                     int rank_step, int32_t *__restrict__ gcnt, int *s_g, int tid,
+                                                     int nthreads) {
+    const int cells = nrank * V;   // <= MH_GROUP_LDS (checked by the launcher)
+    for (int i = tid; i < cells; i += nthreads) s_g[i] = 0;
+    __syncthreads();
+    for (int r = 0; r < nrank; ++r) {
+        const int32_t *__restrict__ row = base_idx + (size_t)(r * rank_step) * N;
+        for (int n = tid; n < N; n += nthreads) {
+            const int b = row[n];
+            if (b >= 0 && b < V) atomicAdd(&s_g[r * V + b], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < cells; i += nthreads) gcnt[i] = s_g[i];
+}
+
+__global__ __launch_bounds__(1024) void mh_group_sizes_kernel(const int32_t *__restrict__ base_idx, int N, int V, int nrank,
+                                                              int rank_step, int32_t *__restrict__ gcnt) {
+    __shared__ int s_g[MH_GROUP_LDS];
+    mh_group_sizes_block(base_idx, N, V, nrank, rank_step, gcnt, s_g, threadIdx.x, 1024);
+}
+
+// (gcnt != nullptr: the group sizes as well -- this single workgroup walks the points anyway)
+__global__ __launch_bounds__(1024) void mh_search_order_kernel(int N, int32_t *__restrict__ order,
+                                                               const int32_t *__restrict__ base_idx, int V, int nrank,
+                                                               int rank_step, int32_t *__restrict__ gcnt) {
     __shared__ int s_hist[MH_ORDER_BUCKETS];
     __shared__ int s_part[1024 / 64];
+    __shared__ int s_g[MH_GROUP_LDS];
     const int tid = threadIdx.x;
+    if (gcnt) mh_group_sizes_block(base_idx, N, V, nrank, rank_step, gcnt, s_g, tid, 1024);
     s_hist[tid] = 0;
     __syncthreads();
     for (int n = tid; n < N; n += 1024) atomicAdd(&s_hist[order[n]], 1);
@@ -1162,7 +1314,8 @@ __global__ __launch_bounds__(256) void mh_refine_loss_kernel(MhViews vw, const f
                                                              int N, int P, float thr, const float *__restrict__ vis,
                                                              const float *__restrict__ ori_patch,
                                                              const float *__restrict__ conf_patch,
-                                                             float *__restrict__ loss, uint8_t *__restrict__ hcout) {
+                                                             float *__restrict__ loss, uint8_t *__restrict__ hcout,
+                                                             MhBatch bt) {
     __shared__ float s_num[4][MH_REFINE_VMAX], s_den[4][MH_REFINE_VMAX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + wave;
@@ -1215,8 +1368,12 @@ __global__ __launch_bounds__(256) void mh_refine_loss_kernel(MhViews vw, const f
             dn.a0 = dn.a0 + w;
             cnt += (w > 0.0f) ? 1 : 0;
         }
-        const float d = mh_cascv_done(dn);
-        loss[n] = mh_cascv_done(nm) / d;
+        float d = mh_cascv_done(dn), m = mh_cascv_done(nm);
+        if (mh_tail_row(bt, n)) {   // a trailing column of the batch's [V, N] sums (ATen's row_sum order)
+            m = mh_row_sum_views(V, [&](int v) { return s_num[wave][v]; });
+            d = mh_row_sum_views(V, [&](int v) { return s_den[wave][v]; });
+        }
+        loss[n] = m / d;
         if (hcout) hcout[n] = (d / (float)cnt > thr) ? 1 : 0;
     }
 }
@@ -1233,7 +1390,7 @@ template <int PATCH>
 __global__ __launch_bounds__(256) void mh_refine_loss_maps_kernel(MhViews vw, const float *__restrict__ pts,
                                                                   const float *__restrict__ dir, float mul, float dv,
                                                                   int N, float thr, float *__restrict__ loss,
-                                                                  uint8_t *__restrict__ hcout) {
+                                                                  uint8_t *__restrict__ hcout, MhBatch bt) {
     constexpr int P = PATCH * PATCH, HP = PATCH / 2;
     __shared__ float s_num[4][MH_REFINE_VMAX], s_den[4][MH_REFINE_VMAX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1308,8 +1465,12 @@ __global__ __launch_bounds__(256) void mh_refine_loss_maps_kernel(MhViews vw, co
             dn.a0 = dn.a0 + w;
             cnt += (w > 0.0f) ? 1 : 0;
         }
-        const float d = mh_cascv_done(dn);
-        loss[n] = mh_cascv_done(nm) / d;
+        float d = mh_cascv_done(dn), m = mh_cascv_done(nm);
+        if (mh_tail_row(bt, n)) {   // a trailing column of the batch's [V, N] sums (ATen's row_sum order)
+            m = mh_row_sum_views(V, [&](int v) { return s_num[wave][v]; });
+            d = mh_row_sum_views(V, [&](int v) { return s_den[wave][v]; });
+        }
+        loss[n] = m / d;
         if (hcout) hcout[n] = (d / (float)cnt > thr) ? 1 : 0;
     }
 }
@@ -1356,9 +1517,21 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
                                 const float *base_val, const float4 *taps, int32_t *order /* 2N ints of work space */,
                                 const uint8_t *cnt /* [V,N] list lengths */,
                                 float *line_ori, float *min_loss, uint8_t *high_conf, float *best_sample,
-                                int32_t *best_rank, int32_t *best_s, int variant, hipStream_t st) {
+                                int32_t *best_rank, int32_t *best_s, int variant, int rule_mode, int fma_min_cols,
+                                int sum_block, int32_t *gcnt /* nrank*V ints of work space */, hipStream_t st) {
     const int nitems = nrank * S;
     if (nitems > MH_MAX_ITEMS || nrank > MH_MAX_RANKS || nitems < 1) return -1;
+    // the batch in the arithmetic (MhRule, mh_device.h): group sizes per (rank, base view) and the trailing columns of the
+    // [V, N*S] sums.  rule_mode 0 needs gcnt (the C API hands it out of its scratch).
+    if (sum_block < 0) return -1;
+    MhRule rule;
+    rule.mode = rule_mode;
+    rule.fma_min_cols = fma_min_cols;
+    rule.gcnt = (rule_mode == 0) ? gcnt : nullptr;
+    if (rule_mode == 0 && (!gcnt || (size_t)nrank * vw.V > MH_GROUP_LDS)) return -1;
+    const long long cols = (long long)N * S;
+    rule.tail_col0 = sum_block ? cols - cols % sum_block : cols;
+    bool need_groups = rule.gcnt != nullptr;
     // variant 0 (default): mh_search3_kernel, workgroups in descending order of work; 7: the same in natural order (A/B);
     // 1256: the portable mh_search_kernel (cross-check) -- also what runs when the caller has no list lengths
     // (8: as 0, the work classes are in order[0..N) already -- the fused forward lets the ranking kernel write them)
@@ -1374,13 +1547,17 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
             if (variant == 6)
                 hipLaunchKernelGGL(mh_search_work_kernel, dim3((N + 3) / 4), dim3(256), 0, st, cnt, vw.V, N, P1, base_val,
                                    nrank, rank_step, S, 256, order);
-            hipLaunchKernelGGL(mh_search_order_kernel, dim3(1), dim3(1024), 0, st, N, order);
+            hipLaunchKernelGGL(mh_search_order_kernel, dim3(1), dim3(1024), 0, st, N, order, base_idx, vw.V, nrank, rank_step,
+                               need_groups ? gcnt : nullptr);
+            need_groups = false;
             ord = order + N;
         }
+        if (need_groups)
+            hipLaunchKernelGGL(mh_group_sizes_kernel, dim3(1), dim3(1024), 0, st, base_idx, N, vw.V, nrank, rank_step, gcnt);
 #define MH_S3_LAUNCH(BIG, KEYS, BIGP)                                                                                   \
     hipLaunchKernelGGL((mh_search3_kernel<256, BIG, KEYS, BIGP>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, \
                        pts, N, P1, thr, ori_c, base_idx, base_val, taps, cnt, ord, line_ori, min_loss, high_conf,       \
-                       best_sample, best_rank, best_s)
+                       best_sample, best_rank, best_s, rule)
         // (the key kernel for lists of up to 64 taps -- every patch up to 8 x 8 -- keeps two key registers per item; the one
         // for longer lists two more)
         const bool bigp = P1 - 1 > 64;
@@ -1395,9 +1572,11 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
         }
 #undef MH_S3_LAUNCH
     } else if (variant == 1256) {
+        if (need_groups)
+            hipLaunchKernelGGL(mh_group_sizes_kernel, dim3(1), dim3(1024), 0, st, base_idx, N, vw.V, nrank, rank_step, gcnt);
         hipLaunchKernelGGL((mh_search_kernel<4, 256>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts, N, P1,
                            thr, ori_c, base_idx, base_val, taps, line_ori, min_loss, high_conf, best_sample, best_rank,
-                           best_s);
+                           best_s, rule);
     } else {
         return -1;
     }
@@ -1405,12 +1584,14 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
 }
 
 extern "C" int mh_launch_refine_loss_maps(MhViews vw, const float *pts, const float *dir, float mul, float dv, int N,
-                                         int patch, float thr, float *loss, uint8_t *hc, hipStream_t st) {
+                                         int patch, float thr, float *loss, uint8_t *hc, int batch, long long row0,
+                                         long long total, int sum_block, hipStream_t st) {
     if (vw.V > MH_REFINE_VMAX) return -1;
+    const MhBatch bt = {row0, total, batch, sum_block};
     const dim3 grid((N + 3) / 4), block(256);
 #define MH_RM_CASE(PS)                                                                                               \
     case PS:                                                                                                         \
-        hipLaunchKernelGGL(mh_refine_loss_maps_kernel<PS>, grid, block, 0, st, vw, pts, dir, mul, dv, N, thr, loss, hc); \
+        hipLaunchKernelGGL(mh_refine_loss_maps_kernel<PS>, grid, block, 0, st, vw, pts, dir, mul, dv, N, thr, loss, hc, bt); \
         break;
     switch (patch) {
         MH_RM_CASE(1)
@@ -1436,10 +1617,11 @@ extern "C" int mh_launch_refine_combine(const float *center, const float *loss_u
 
 extern "C" int mh_launch_refine_loss(MhViews vw, const float *pts, const float *dir, float mul, float dv, int N,
                                      int P, float thr, const float *vis, const float *ori_patch,
-                                     const float *conf_patch, float *loss, uint8_t *hc, hipStream_t st) {
+                                     const float *conf_patch, float *loss, uint8_t *hc, int sum_block, hipStream_t st) {
     if (vw.V > MH_REFINE_VMAX) return -1;
+    const MhBatch bt = {0, N, 0, sum_block};   // (the stand-alone method: its N points are one batch of the reference)
     hipLaunchKernelGGL(mh_refine_loss_kernel, dim3((N + 3) / 4), dim3(256), 0, st, vw, pts, dir, mul, dv, N, P, thr,
-                       vis, ori_patch, conf_patch, loss, hc);
+                       vis, ori_patch, conf_patch, loss, hc, bt);
     return (int)hipGetLastError();
 }
 

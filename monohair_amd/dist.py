@@ -52,13 +52,15 @@ def owner(i, n_ranks=None):
     return i % (world() if n_ranks is None else n_ranks)
 
 
-def map_chunks(chunks, fn, device, empty, after=None):
+def map_chunks(chunks, fn, device, empty, after=None, with_index=False):
     """Apply fn to every chunk (each rank takes chunks i with i % world == rank) and return the list of all
     results in chunk order on every rank.  fn returns a 2-D tensor on `device`; `empty()` gives a [0,C] one.
-    after(): called once all chunks have been issued and before any result is read (e.g. to join side streams)."""
+    after(): called once all chunks have been issued and before any result is read (e.g. to join side streams).
+    with_index: fn(chunk, i) instead of fn(chunk)."""
     d = _dist()
     w, r = world(), rank()
-    mine = {i: fn(c) if len(c) else empty() for i, c in enumerate(chunks) if owner(i, w) == r}
+    call = (lambda c, i: fn(c, i)) if with_index else (lambda c, i: fn(c))
+    mine = {i: call(c, i) if len(c) else empty() for i, c in enumerate(chunks) if owner(i, w) == r}
     if after is not None:
         after()
     if not d:

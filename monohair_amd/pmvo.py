@@ -614,14 +614,15 @@ class PMVO:
 
     def _votes(self, points, want, visible_threshold=None, raw=False):
         """mask / visibility votes of mh_filter_points for the requested outputs; raw=True returns the kernel's uint8 0/1
-        arrays instead of bool tensors."""
+        arrays instead of bool tensors.  (The points of one call are one batch of the reference: its sums over views add the
+        trailing len mod 32 points of a batch in another order, include/mh_pmvo.h.)"""
         points = self._dev_points(points)
         N = points.shape[0]
         bufs = [torch.empty((N,), dtype=torch.uint8, device=self.device) if w else None for w in want]
         vt = self.visible_threshold if visible_threshold is None else visible_threshold
         _lib.check(self._L.mh_filter_points(self._ctx, _lib.ptr(points), N, self._side,
                                             float(self.conf_threshold), float(vt), _lib.ptr(bufs[0]),
-                                            _lib.ptr(bufs[1]), _lib.ptr(bufs[2]), _lib.ptr(bufs[3]),
+                                            _lib.ptr(bufs[1]), _lib.ptr(bufs[2]), _lib.ptr(bufs[3]), 0, 0, 0,
                                             _lib.stream_ptr()), "mh_filter_points")
         if raw:
             return points, bufs
@@ -885,8 +886,11 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 st2 = _lib.stream_ptr()
+                # (batch arguments: the reference votes and sums per 5000-point chunk, PMVO.py:604-621 -- the kernels place
+                # every point in its chunk, see include/mh_pmvo.h: mh_refine_loss_maps)
                 _lib.check(L.mh_filter_points(ctx, _lib.ptr(pts_dev), n_all, pmvo._side, float(pmvo.conf_threshold),
-                                              float(pmvo.visible_threshold), None, None, None, _lib.ptr(head_all), st2),
+                                              float(pmvo.visible_threshold), None, None, None, _lib.ptr(head_all),
+                                              sub_num, 0, n_all, st2),
                            "mh_filter_points")
             GROUP, g0 = 8, 0
             for i in range(step):
@@ -901,7 +905,8 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
                     ev.record(main)
                     side.wait_event(ev)
                     _lib.check(L.mh_refine_loss_maps(ctx, off(pts_dev, g0, 3), off(centers, g0, 3), 0.005, 4.0, hi - g0,
-                                                     pmvo._side, float(pmvo.conf_threshold), off(loss_all, g0), None, st2),
+                                                     pmvo._side, float(pmvo.conf_threshold), off(loss_all, g0), None,
+                                                     sub_num, g0, n_all, st2),
                                "mh_refine_loss_maps")
                     g0 = hi
             main.wait_stream(side)
@@ -917,10 +922,12 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
                 _lib.check(L.mh_medoid_indexed(ctx, _lib.ptr(ori_dev), off(index_all, row_of[i], K), n, K,
                                                _lib.ptr(center), None, st), "mh_medoid_indexed")
                 _lib.check(L.mh_refine_loss_maps(ctx, off(pts_dev, a, 3), _lib.ptr(center), 0.005, 4.0, n,
-                                                 pmvo._side, float(pmvo.conf_threshold), _lib.ptr(loss_u), None, st),
+                                                 pmvo._side, float(pmvo.conf_threshold), _lib.ptr(loss_u), None,
+                                                 sub_num, a, n_all, st),
                            "mh_refine_loss_maps")
                 _lib.check(L.mh_filter_points(ctx, off(pts_dev, a, 3), n, pmvo._side, float(pmvo.conf_threshold),
-                                              float(pmvo.visible_threshold), None, None, None, _lib.ptr(head), st),
+                                              float(pmvo.visible_threshold), None, None, None, _lib.ptr(head),
+                                              sub_num, a, n_all, st),
                            "mh_filter_points")
                 _lib.check(L.mh_refine_combine(ctx, _lib.ptr(center), _lib.ptr(loss_u), _lib.ptr(head),
                                                off(head_top_all, a), 0.95, off(ori_dev, a, 3), off(loss_dev, a), n, st),
@@ -981,10 +988,11 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
             ori_rows = select_ori
         sel_ori_dev = torch.from_numpy(np.ascontiguousarray(ori_rows, dtype=np.float32)).to(device)
 
-        def shell_block(fb):
-            """rows of `fb` -> device tensors (medoid orientation of the 100 nearest kept points [n,3], head-filter votes [n],
+        def shell_block(fb, row0=0):
+            """rows row0.. of `fu` -> device tensors (medoid orientation of the 100 nearest kept points [n,3], head-filter votes [n],
             head-top mask [n]).  The points are independent: one medoid launch and one vote launch for all of them (the
-            reference's 5000-point chunks only bound its memory)."""
+            reference's 5000-point chunks bound its memory -- and place a point in a batch of its sums over views, which the
+            vote kernel is told: PMVO.py:662-672)."""
             with stage("refine: knn (shell)", device):
                 if use_grid:
                     idx = grid_all[0].query(fb, 100, int32=True, valid=valid).contiguous()
@@ -998,7 +1006,7 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
                                                  _lib.stream_ptr()), "mh_medoid_indexed")
             _lib.check(pmvo._L.mh_filter_points(pmvo._ctx, _lib.ptr(fb_dev), F, pmvo._side, float(pmvo.conf_threshold),
                                                 float(args.PMVO.visible_threshold), None, None, None, _lib.ptr(hd),
-                                                _lib.stream_ptr()), "mh_filter_points")
+                                                5000, row0, len(fu), _lib.stream_ptr()), "mh_filter_points")
             ht = pmvo.head_top_mask_device(fb_dev)
             return cen, hd, ht
 
@@ -1006,15 +1014,16 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
             W_ = mdist.world()
             cuts = [(len(fu) * k) // W_ for k in range(W_ + 1)]
 
-            def packed(fb):
-                cen, hd, ht = shell_block(fb)
+            def packed(fb, k):
+                cen, hd, ht = shell_block(fb, cuts[k])
                 out = torch.empty((cen.shape[0], 4), dtype=torch.float32, device=device)
                 out[:, :3] = cen
                 out[:, 3] = (~(hd.bool() & ~ht.bool())).to(torch.float32)
                 return out
 
             res = torch.cat(mdist.map_chunks([fu[cuts[k]:cuts[k + 1]] for k in range(W_)], packed, device,
-                                             empty=lambda: torch.empty((0, 4), dtype=torch.float32, device=device)), 0)
+                                             empty=lambda: torch.empty((0, 4), dtype=torch.float32, device=device),
+                                             with_index=True), 0)
             res = res.cpu().numpy()
             keep = res[:, 3] > 0.5
             centres = res[:, :3]

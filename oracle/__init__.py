@@ -157,6 +157,41 @@ def topk_column(values, k):
     return idx, val
 
 
+REPROJECT_RULES = {"group": 0, "mid": 1, "chain": 2}
+REF_FMA_MIN_COLS = 28445   # MKL 2024.2 / AVX-512 / 8 threads: the container the goldens were generated in
+
+
+def set_reproject_rule(mode="group", fma_min_cols=REF_FMA_MIN_COLS):
+    """How sample_next_3d_pos's sgemms round (oracle/pmvo_oracle.c, the table above cam_unproject): "group" follows the
+    number of points that share a (rank, base view) in the batch, as the reference's MKL calls do; "mid" / "chain" force
+    one form for every point.  Returns the previous (mode, fma_min_cols)."""
+    prev = get_reproject_rule()
+    lib().orc_set_reproject_rule(REPROJECT_RULES[mode], ctypes.c_longlong(int(fma_min_cols)))
+    return prev
+
+
+def get_reproject_rule():
+    m, c = ctypes.c_int(0), ctypes.c_longlong(0)
+    lib().orc_get_reproject_rule(ctypes.byref(m), ctypes.byref(c))
+    return {v: k for k, v in REPROJECT_RULES.items()}[m.value], c.value
+
+
+def set_sum_block(cols=32):
+    """Columns per vectorised block of ATen's outer sum (oracle/pmvo_oracle.c: row_sum1): the trailing C mod cols columns
+    of a [V, C] sum(dim=0) are added in another order.  32 where the goldens were generated (ATen dispatches this kernel at AVX2 width); 0 = cascade
+    everywhere.  Returns the previous value."""
+    prev = lib().orc_get_sum_block()
+    lib().orc_set_sum_block(int(cols))
+    return prev
+
+
+def group_sizes(base_view, V):
+    base_view = np.ascontiguousarray(base_view, np.int32)
+    cnt = np.empty(V, np.int32)
+    lib().orc_group_sizes(_p(base_view, c_i), base_view.shape[0], V, _p(cnt, c_i))
+    return cnt
+
+
 def sample_next(views, pts, base_view, ori_c, offsets):
     pts = np.ascontiguousarray(pts, np.float32)
     base_view = np.ascontiguousarray(base_view, np.int32)

@@ -216,22 +216,89 @@ void orc_topk_views_by_index(const float *vis, const float *conf, int V, int N, 
 /* the 90 depth offsets of PMVO.sample_next_3d_pos (PMVO.py:274-278) are torch.arange values that are
  * not start+i*step in fp32; they are passed in (fixture tests/golden/depth_offsets.npy). */
 
-/* Camera.reprojection(..., to_world=True) (Camera_utils.py:81-106) */
-static inline void cam_unproject(const float *cam, float u, float v, float z, float *X) {
+/*
+ * ---- how the reference's matmuls round, by batch composition -------------------------------------------------
+ * PMVO.sample_next_3d_pos (PMVO.py:263-335) loops over the cameras and, for camera i, works on the M points of the
+ * batch whose base view (at this rank) is i: Camera.projection(points[index]) is two [4,4] x [4,M] sgemms and
+ * Camera.reprojection(...) one [3,3] x [3,S*M] sgemm (Camera_utils.py:50-53,103).  Which MKL kernel an sgemm lands in
+ * -- and so how its fp32 sums are associated -- depends on the number of columns.  Probed column by column in the
+ * container the goldens were generated in (torch 2.10.0 CPU, MKL 2024.2, AVX-512, torch.get_num_threads() == 8;
+ * tools/probe_mkl_forms.py repeats the probe and prints the table):
+ *   [4,4] x [4,M]:   M == 1   p2 + ((fma(a1,b1, a0*b0)) + p3)      (a gemv-like kernel, separately rounded p2, p3)
+ *                    M >= 2   fma(a3,b3, fma(a2,b2, fma(a1,b1, a0*b0)))               (k-ordered chain, any M to 1e6)
+ *   [3,3] x [3,C]:   C <= 3   fma(a2,b2, fma(a1,b1, a0*b0))
+ *                    4 <= C <= 28444        (a0*b0 + a2*b2) + a1*b1, separately rounded products
+ *                    C >= 28445             fma(a2,b2, fma(a1,b1, a0*b0))
+ * The upper threshold is MKL's switch to its threaded kernel and moves with the thread count (1 thread: never; 2: 21334;
+ * 3: 16001; 4: 14223; 5, 7: 28889; 6, 8: 28445 columns); the other boundaries do not.  With S = 90 samples per point the
+ * chain form starts at M = 317 points per (rank, base view) -- at the headline shape (60 x 1080p views, 5000-point chunks)
+ * a fifth to a half of a chunk's (rank, point) items sit in such groups.
+ * g_rule.mode: 0 = follow the group size as above (default: what the reference computes for THIS batch),
+ *              1 = the mid-size forms for every point (M >= 2 projection, separately rounded reprojection),
+ *              2 = the chain forms for every point.
+ */
+static struct { int mode; long long fma_min_cols; } g_rule = {0, 28445};
+
+void orc_set_reproject_rule(int mode, long long fma_min_cols) {
+    g_rule.mode = mode;
+    if (fma_min_cols > 0) g_rule.fma_min_cols = fma_min_cols;
+}
+
+void orc_get_reproject_rule(int *mode, long long *fma_min_cols) {
+    *mode = g_rule.mode;
+    *fma_min_cols = g_rule.fma_min_cols;
+}
+
+/* forms for a point whose (rank, base view) group holds M points, S samples each: bit 0 = single-column projection,
+ * bit 1 = chain-form reprojection */
+#define ORC_FORM_GEMV 1
+#define ORC_FORM_CHAIN 2
+static inline int group_forms(int M, int S) {
+    if (g_rule.mode == 1) return 0;
+    if (g_rule.mode == 2) return ORC_FORM_CHAIN;
+    const long long cols = (long long)M * S;
+    return (M == 1 ? ORC_FORM_GEMV : 0) | ((cols <= 3 || cols >= g_rule.fma_min_cols) ? ORC_FORM_CHAIN : 0);
+}
+
+/* Camera.projection of ONE point that is alone in its sgemm (M == 1): see the table above */
+static inline void cam_project_single(const float *cam, const float *X, float *u, float *v, float *z) {
+    const float *P = cam, *Q = cam + 16;
+    float c[4];
+    for (int r = 0; r < 4; ++r) {
+        float f = fmaf(P[r * 4 + 1], X[1], P[r * 4 + 0] * X[0]);
+        float p2 = P[r * 4 + 2] * X[2];
+        float p3 = P[r * 4 + 3] * 1.0f;
+        c[r] = p2 + (f + p3);
+    }
+    float q[2];
+    for (int r = 0; r < 2; ++r) {
+        float f = fmaf(Q[r * 4 + 1], c[1], Q[r * 4 + 0] * c[0]);
+        float p2 = Q[r * 4 + 2] * c[2];
+        float p3 = Q[r * 4 + 3] * c[3];
+        q[r] = p2 + (f + p3);
+    }
+    *z = c[2];
+    *u = q[0] / c[2];
+    *v = q[1] / c[2];
+}
+
+/* Camera.reprojection(..., to_world=True) (Camera_utils.py:81-106); torch.matmul(inv(R) [column-major LAPACK output],
+ * (c - t) [transposed view]) in the form the column count selects (table above) */
+static inline void cam_unproject(const float *cam, float u, float v, float z, float *X, int chain) {
     const float *P = cam, *Q = cam + 16, *Ri = cam + 32;
     float c0 = (u - Q[2]) / Q[0] * z;
     float c1 = (v - Q[6]) / Q[5] * z;
     float c2 = z;
     float d0 = c0 - P[3], d1 = c1 - P[7], d2 = c2 - P[11];
-    /* torch.matmul(inv(R) [column-major LAPACK output], (c - t) [transposed view]) lands in an MKL sgemm
-     * kernel that, for fewer than ~28k columns (<= 316 points per base view -- the production regime and
-     * every golden case), evaluates (a0*b0 + a2*b2) + a1*b1 with separately rounded products; above that
-     * size MKL switches to a k-ordered fma chain.  The oracle (and the HIP kernel) pin the small-size form. */
     for (int r = 0; r < 3; ++r) {
         float p0 = Ri[r * 3 + 0] * d0;
-        float p1 = Ri[r * 3 + 1] * d1;
-        float p2 = Ri[r * 3 + 2] * d2;
-        X[r] = (p0 + p2) + p1;
+        if (chain) {
+            X[r] = fmaf(Ri[r * 3 + 2], d2, fmaf(Ri[r * 3 + 1], d1, p0));
+        } else {
+            float p1 = Ri[r * 3 + 1] * d1;
+            float p2 = Ri[r * 3 + 2] * d2;
+            X[r] = (p0 + p2) + p1;
+        }
     }
 }
 
@@ -242,9 +309,10 @@ static inline void cam_unproject(const float *cam, float u, float v, float z, fl
  * (The surface_points assignments at PMVO.py:333-334 write into temporaries: surface_points == points.)
  */
 static inline void sample_next_point(const float *cam, const float *X, const float *ori_c, int H, int W,
-                                     const float *offs, int S, float *out /* S*3 */) {
+                                     const float *offs, int S, float *out /* S*3 */, int forms) {
     float u, v, z, col, row;
-    cam_project(cam, X, &u, &v, &z);
+    if (forms & ORC_FORM_GEMV) cam_project_single(cam, X, &u, &v, &z);
+    else cam_project(cam, X, &u, &v, &z);
     ndc_to_pixel(u, v, H, W, &col, &row);
     float nx = col + ori_c[1] * 2.0f;
     float ny = row + ori_c[0] * 2.0f;
@@ -253,17 +321,29 @@ static inline void sample_next_point(const float *cam, const float *X, const flo
     nx = nx * 2.0f - 1.0f;
     ny = ny * 2.0f - 1.0f;
     nx = -nx;
-    for (int s = 0; s < S; ++s) cam_unproject(cam, nx, ny, z + offs[s], out + 3 * s);
+    for (int s = 0; s < S; ++s) cam_unproject(cam, nx, ny, z + offs[s], out + 3 * s, forms & ORC_FORM_CHAIN);
 }
+
+/* points per base view among base_view[0..N): the M of the table above (indices outside [0,V) own nothing) */
+static void group_sizes(const int32_t *base_view, int N, int V, int32_t *cnt /* V */) {
+    memset(cnt, 0, sizeof(int32_t) * (size_t)V);
+    for (int n = 0; n < N; ++n)
+        if (base_view[n] >= 0 && base_view[n] < V) cnt[base_view[n]]++;
+}
+
+void orc_group_sizes(const int32_t *base_view, int N, int V, int32_t *cnt) { group_sizes(base_view, N, V, cnt); }
 
 void orc_sample_next(const orc_views *vw, const float *pts, int N, const int32_t *base_view /*N*/,
                      const float *ori /*V,N,2*/, const float *offs, int S, float *out /*N,S,3*/) {
+    int32_t *cnt = (int32_t *)malloc(sizeof(int32_t) * (size_t)vw->V);
+    group_sizes(base_view, N, vw->V, cnt);
 #pragma omp parallel for schedule(static)
     for (int n = 0; n < N; ++n) {
         int b = base_view[n];
         sample_next_point(vw->cams + (size_t)b * ORC_CAM_STRIDE, pts + 3 * n, ori + ((size_t)b * N + n) * 2, vw->H,
-                          vw->W, offs, S, out + (size_t)n * S * 3);
+                          vw->W, offs, S, out + (size_t)n * S * 3, group_forms(cnt[b], S));
     }
+    free(cnt);
 }
 
 /* unrounded pixel (row, col) of a world point: Camera.projection + Camera.uv2pixel (Camera_utils.py:60-71) */
@@ -329,6 +409,50 @@ static inline void casc_step(casc *c, int v, float x) {
 static inline float casc_done(const casc *c) { return (c->a0 + c->a1) + c->a2; }   /* V < 4096 */
 
 /*
+ * ATen's sum(dim=0) of a contiguous [V, C] float tensor (aten/src/ATen/native/cpu/SumKernel.cpp, vectorized_outer_sum):
+ * columns are taken 4 vectors (32 floats: this kernel is dispatched at AVX2 width even on AVX-512 hosts) at a time through multi_row_sum -- the cascade above -- and the
+ * trailing C mod 32 columns through row_sum: the V rows dealt round-robin to four partial cascades (rows k, k+4, ...
+ * into partial k), the V mod 4 left-over rows added to partial 0, then partial 0 += partial 1, 2, 3.  Which columns of
+ * compute_prj_loss's [V, N*S] tensors (PMVO.py:198-204) are "trailing" depends on the batch: the last (N*S) mod 32
+ * samples of the LAST point(s).  Probed at 1 and 8 threads, up to 27 M elements: only the global tail takes this form.
+ * multi_row_sum1 / row_sum1: both for one column, x[i * stride], i < R, any R.
+ */
+static float multi_row_sum1(const float *x, size_t stride, long R) {
+    int clog = 0;
+    while ((1L << clog) < R) ++clog;
+    int level_power = clog / 4;
+    if (level_power < 4) level_power = 4;
+    const long level_step = 1L << level_power, level_mask = level_step - 1;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    long i = 0;
+    while (i + level_step <= R) {
+        for (long j = 0; j < level_step; ++j, ++i) acc[0] = acc[0] + x[(size_t)i * stride];
+        for (int j = 1; j < 4; ++j) {
+            acc[j] = acc[j] + acc[j - 1];
+            acc[j - 1] = 0.0f;
+            if ((i & (level_mask << (j * level_power))) != 0) break;
+        }
+    }
+    for (; i < R; ++i) acc[0] = acc[0] + x[(size_t)i * stride];
+    for (int j = 1; j < 4; ++j) acc[0] = acc[0] + acc[j];
+    return acc[0];
+}
+static float row_sum1(const float *x, size_t stride, long R) {
+    const long L = R / 4;
+    float part[4];
+    for (int k = 0; k < 4; ++k) part[k] = multi_row_sum1(x + (size_t)k * stride, stride * 4, L);
+    for (long i = L * 4; i < R; ++i) part[0] = part[0] + x[(size_t)i * stride];
+    for (int k = 1; k < 4; ++k) part[0] = part[0] + part[k];
+    return part[0];
+}
+/* columns per vectorised block of the outer sum (32 = 4 AVX2 vectors: probed, tools/probe_mkl_forms.py); 0 = no tail */
+static int g_sum_block = 32;
+void orc_set_sum_block(int cols) { g_sum_block = cols; }
+int orc_get_sum_block(void) { return g_sum_block; }
+/* first "trailing" column of a C-column outer sum */
+static inline long long sum_tail_start(long long C) { return g_sum_block > 0 ? C - C % g_sum_block : C; }
+
+/*
  * PMVO.compute_prj_loss (PMVO.py:151-209) for ONE point.
  *   D        [V,S,2] view-strided by dstride floats (projected 2D segment directions)
  *   opatch   [V,P,2], cpatch [V,P] view-strided (clamped confidences), vis [V] view-strided
@@ -337,7 +461,12 @@ static inline float casc_done(const casc *c) { return (c->a0 + c->a1) + c->a2; }
  */
 static void prj_loss_point(int V, int S, int P, float thr, const float *D, size_t dstride, const float *opatch,
                            size_t ostride, const float *cpatch, size_t cstride, const float *vis, size_t vstride,
-                           float *out_loss, int *out_idx, int *out_hc, float *loss_s /*S or NULL*/) {
+ float *out_loss, int *out_idx, int *out_hc, float *loss_s /*S or NULL*/,
+                           int tail_from /* samples >= tail_from are trailing columns of the [V,N*S] sums; S = none */) {
+    const int ntail = tail_from < S ? S - (tail_from < 0 ? 0 : tail_from) : 0;
+    if (tail_from < 0) tail_from = 0;
+    float *tnum = ntail ? (float *)malloc(sizeof(float) * (size_t)V * ntail) : NULL;
+    float *tden = ntail ? (float *)malloc(sizeof(float) * (size_t)V * ntail) : NULL;
     casc *num = (casc *)calloc((size_t)S, sizeof(casc));
     casc *den = (casc *)calloc((size_t)S, sizeof(casc));
     int *cnt = (int *)calloc((size_t)S, sizeof(int));
@@ -366,6 +495,10 @@ static void prj_loss_point(int V, int S, int P, float thr, const float *D, size_
             casc_step(&num[s], v, ml * w);
             casc_step(&den[s], v, w);
             cnt[s] += (w > 0.0f);
+            if (s >= tail_from) {
+                tnum[(size_t)v * ntail + (s - tail_from)] = ml * w;
+                tden[(size_t)v * ntail + (s - tail_from)] = w;
+            }
         }
     }
     int npos = 0;
@@ -374,11 +507,15 @@ static void prj_loss_point(int V, int S, int P, float thr, const float *D, size_
     unsigned char *pos = (unsigned char *)malloc((size_t)S);
     float *ls = (float *)malloc(sizeof(float) * (size_t)S);
     for (int s = 0; s < S; ++s) {
-        float dn = casc_done(&den[s]);
+        float dn = casc_done(&den[s]), nm = casc_done(&num[s]);
+        if (s >= tail_from) {
+            dn = row_sum1(tden + (s - tail_from), (size_t)ntail, V);
+            nm = row_sum1(tnum + (s - tail_from), (size_t)ntail, V);
+        }
         float ratio = dn / (float)cnt[s];
         pos[s] = ratio > thr;
         npos += pos[s];
-        ls[s] = casc_done(&num[s]) / dn;
+        ls[s] = nm / dn;
     }
     const int low = npos < 5;
     for (int s = 0; s < S; ++s) {
@@ -409,6 +546,14 @@ static void prj_loss_point(int V, int S, int P, float thr, const float *D, size_
     free(oh);
     free(pos);
     free(ls);
+    free(tnum);
+    free(tden);
+}
+
+/* first sample of point n (of N, S samples each) that lies in the trailing columns of a [V, N*S] sum; S if none */
+static inline int tail_from_of(int n, int N, int S) {
+    const long long t0 = sum_tail_start((long long)N * S) - (long long)n * S;
+    return t0 >= S ? S : (t0 < 0 ? 0 : (int)t0);
 }
 
 /* compute_prj_loss over N points from materialised tensors: D[V,N,S,2], ori_patch[V,N,P,2], conf_patch[V,N,P], vis[V,N] */
@@ -421,7 +566,7 @@ void orc_prj_loss(int V, int N, int S, int P, float thr, const float *D, const f
         int i, h;
         prj_loss_point(V, S, P, thr, D + (size_t)n * S * 2, (size_t)N * S * 2, ori_patch + (size_t)n * P * 2,
                        (size_t)N * P * 2, conf_patch + (size_t)n * P, (size_t)N * P, vis + n, (size_t)N, &l, &i, &h,
-                       loss_ns ? loss_ns + (size_t)n * S : NULL);
+                       loss_ns ? loss_ns + (size_t)n * S : NULL, tail_from_of(n, N, S));
         loss[n] = l;
         idx[n] = i;
         hc[n] = (uint8_t)h;
@@ -452,6 +597,9 @@ void orc_forward(const orc_views *vw, const float *pts, int N, int patch, float 
         base_idx_in = bidx;
         base_val_in = bval;
     }
+    /* points per (rank, base view) of THIS batch: they select the rounding of sample_next_3d_pos's sgemms */
+    int32_t *gcnt = (int32_t *)malloc(sizeof(int32_t) * (size_t)nrank * V);
+    for (int r = 0; r < nrank; ++r) group_sizes(base_idx_in + (size_t)r * rank_step * N, N, V, gcnt + (size_t)r * V);
 #pragma omp parallel for schedule(dynamic, 2)
     for (int n = 0; n < N; ++n) {
         float *samples = (float *)malloc(sizeof(float) * (size_t)S * 3);
@@ -463,7 +611,7 @@ void orc_forward(const orc_views *vw, const float *pts, int N, int patch, float 
             const int i = r * rank_step;
             const int b = base_idx_in[(size_t)i * N + n];
             sample_next_point(vw->cams + (size_t)b * ORC_CAM_STRIDE, X, ori + ((size_t)b * N + n) * 2, vw->H, vw->W,
-                              offs, S, samples);
+                              offs, S, samples, group_forms(gcnt[(size_t)r * V + b], S));
             for (int v = 0; v < V; ++v) {
                 const float *cam = vw->cams + (size_t)v * ORC_CAM_STRIDE;
                 float r0, c0;
@@ -478,7 +626,8 @@ void orc_forward(const orc_views *vw, const float *pts, int N, int patch, float 
             float l;
             int idx, h;
             prj_loss_point(V, S, P, thr, D, (size_t)S * 2, opatch + (size_t)n * P * 2, (size_t)N * P * 2,
-                           cpatch + (size_t)n * P, (size_t)N * P, vis + n, (size_t)N, &l, &idx, &h, NULL);
+                           cpatch + (size_t)n * P, (size_t)N * P, vis + n, (size_t)N, &l, &idx, &h, NULL,
+                           tail_from_of(n, N, S));
             int take = (r == 0) || ((l < ml) && (base_val_in[(size_t)i * N + n] > 0.0f));
             if (take) {
                 ml = l;
@@ -511,6 +660,7 @@ void orc_forward(const orc_views *vw, const float *pts, int N, int patch, float 
     free(cpatch);
     free(bidx);
     free(bval);
+    free(gcnt);
 }
 
 /*
@@ -541,7 +691,7 @@ void orc_refine_loss(const orc_views *vw, const float *pts, const float *dir, fl
         float l;
         int idx, h;
         prj_loss_point(V, 1, P, thr, D, 2, opatch + (size_t)n * P * 2, (size_t)N * P * 2, cpatch + (size_t)n * P,
-                       (size_t)N * P, vis + n, (size_t)N, &l, &idx, &h, NULL);
+                       (size_t)N * P, vis + n, (size_t)N, &l, &idx, &h, NULL, tail_from_of(n, N, 1));
         loss[n] = l;
         if (hc) hc[n] = (uint8_t)h;
         free(D);
@@ -553,16 +703,18 @@ void orc_refine_loss(const orc_views *vw, const float *pts, const float *dir, fl
 
 /*
  * The per-view votes of PMVO.filter_points (PMVO.py:402-459), PMVO.compute_unvisible_points (:461-480) and the
- * mask vote of PMVO.filter_head_points (:110-137).  Sums over views in ATen's cascade order.
+ * mask vote of PMVO.filter_head_points (:110-137).  Sums over views in ATen's order (cascade; row_sum for the trailing points).
  */
 void orc_filter_points(const orc_views *vw, const float *pts, int N, int patch, float thr, float vis_thr,
                        uint8_t *surface_index, uint8_t *filter_index, uint8_t *unvisible_index,
                        uint8_t *head_filter) {
     const int V = vw->V, H = vw->H, W = vw->W, hp = patch / 2;
+    const long long tail0 = sum_tail_start(N);   /* the N points are one batch: its trailing N mod 32 columns (row_sum1) */
 #pragma omp parallel for schedule(static)
     for (int n = 0; n < N; ++n) {
         casc t[8];
         memset(t, 0, sizeof(t));
+        float *terms = (n >= tail0) ? (float *)malloc(sizeof(float) * 8 * (size_t)V) : NULL;
         for (int v = 0; v < V; ++v) {
             const float *cam = vw->cams + (size_t)v * ORC_CAM_STRIDE;
             int r, c, oob;
@@ -587,9 +739,12 @@ void orc_filter_points(const orc_views *vw, const float *pts, int N, int patch, 
             const float term[8] = {(1.0f - unv) * lowc, 1.0f - unv,          (1.0f - unv) * m, 1.0f - unv1,
                                    (1.0f - unv1) * m,   1.0f - unv9,         1.0f - unvh,      (1.0f - unvh) * m};
             for (int k = 0; k < 8; ++k) casc_step(&t[k], v, term[k]);
+            if (terms)
+                for (int k = 0; k < 8; ++k) terms[(size_t)k * V + v] = term[k];
         }
         float s[8];
-        for (int k = 0; k < 8; ++k) s[k] = casc_done(&t[k]);
+        for (int k = 0; k < 8; ++k) s[k] = terms ? row_sum1(terms + (size_t)k * V, 1, V) : casc_done(&t[k]);
+        free(terms);
         const int low_conf = s[0] > 4.0f;
         const int hair = (s[1] - s[2]) < (s[1] * 1.0f / 2.0f);
         const int hair1 = (s[3] - s[4]) < (s[3] * 1.0f / 2.0f);

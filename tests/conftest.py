@@ -137,6 +137,21 @@ def check_rows_against_recomposed(name, got, orig, recomposed):
     return st
 
 
+def rows_equal(got, ref):
+    """per-row equality of (ori [N,3], loss [N], high-confidence flag [N]) triples, NaN == NaN"""
+    same = lambda a, b: (a == b) | (np.isnan(a) & np.isnan(b))           # noqa: E731
+    return same(got[1], ref[1]) & np.all(same(got[0], ref[0]), axis=1) & (np.asarray(got[2]) == np.asarray(ref[2]))
+
+
+def recompose_golden(name, tag):
+    """(ori, loss, hc) of the reference's forward() on fixture `name` in the batch composition `tag` ("dup": the batch
+    doubled, first N rows; "rev": the batch reversed, rows back in the original order) -- tests/golden/pmvo_recompose.npz"""
+    if not _recompose:
+        zz = np.load(os.path.join(GOLDEN, "pmvo_recompose.npz"))
+        _recompose.update({k: zz[k] for k in zz.files})
+    return tuple(_recompose["%s__%s_%s" % (name, tag, k)] for k in ("ori", "loss", "hc"))
+
+
 def check_forward_against_reference(name, z, ori, loss, hc):
     """check_rows_against_recomposed for the forward() goldens: tests/golden/pmvo_recompose.npz holds the reference's own
     forward() on the same points in two other batch compositions (tools/gen_golden_recompose.py): the batch doubled, and

@@ -145,7 +145,7 @@ while time.time() < t_end:
     from monohair_amd import _lib as L_
 
     L_.check(pm._L.mh_refine_loss_maps(pm._ctx, L_.ptr(pm._points), L_.ptr(torch.from_numpy(dirs).to(DEV).contiguous()),
-                                       0.005, 4.0, N, patch, float(thr), L_.ptr(lf), None, L_.stream_ptr()))
+                                       0.005, 4.0, N, patch, float(thr), L_.ptr(lf), None, 0, 0, 0, L_.stream_ptr()))
     if not eq(lf.cpu().numpy(), o_rl):
         bad.append(("refine_loss_maps", V, H, W, patch, thr, quant, seed, N))
     n_scene += 1

@@ -115,14 +115,46 @@ def test_forward_vs_oracle_bit_exact(case, depth_offsets, variant):
 
 
 def test_forward_vs_reference_golden(case, depth_offsets, request):
-    """Against the reference's own outputs: every row equals the reference's answer for that point bit for bit -- the
-    answer it gives when every base view owns >= 2 points of the batch; where the reference's original-batch answer is
-    another one, the reference disagrees with itself under recomposition (conftest.check_forward_against_reference)."""
+    """Against the reference's own outputs, EVERY row, bit for bit, in every batch composition the reference was run in
+    (tools/gen_golden_recompose.py): the original batch, the batch reversed, the batch doubled.  The reference's answer for a
+    point depends on its batch (MKL's sgemm kernel by the number of points that share a base view, ATen's trailing columns);
+    the kernels follow the batch (options reproject_rule 0, sum_block 32: include/mh_pmvo.h)."""
+    from conftest import recompose_golden, rows_equal
+
+    meta, z, scene, views, pm = case
+    name = request.node.callspec.params["case"]
+    pts = z["points"]
+    N = len(pts)
+    for variant in (0, 1256):
+        pm.set_option("search_variant", variant)
+        fwd = lambda p, **kw: tuple(t.cpu().numpy() for t in pm.forward(p, **kw)[1:])      # noqa: E731
+        assert rows_equal(fwd(pts, base_view=(z["base_idx"], z["base_val"])), (z["fwd_ori"], z["fwd_loss"], z["fwd_hc"])).all()
+        assert rows_equal(tuple(a[::-1] for a in fwd(pts[::-1].copy())), recompose_golden(name, "rev")).all()
+        assert rows_equal(tuple(a[:N] for a in fwd(np.concatenate([pts, pts], 0))), recompose_golden(name, "dup")).all()
+    pm.set_option("search_variant", 0)
+
+
+def test_forward_forced_mid_forms_vs_reference_golden(case, depth_offsets, request):
+    """The batch-independent options (reproject_rule 1, sum_block 0: what rounds 1-4 computed): equal to the oracle under the
+    same options, and to the reference's doubled-batch answer on every row; rows that differ from its original-batch answer
+    are rows on which the reference disagrees with itself (conftest.check_forward_against_reference)."""
     from conftest import check_forward_against_reference
 
     meta, z, scene, views, pm = case
     pts = z["points"]
-    p, ori, loss, hc = pm.forward(pts, base_view=(z["base_idx"], z["base_val"]))
+    pm.set_option("reproject_rule", 1)
+    pm.set_option("sum_block", 0)
+    prev = oracle.set_reproject_rule("mid"), oracle.set_sum_block(0)
+    try:
+        p, ori, loss, hc = pm.forward(pts, base_view=(z["base_idx"], z["base_val"]))
+        _, o_ori, o_loss, o_hc = oracle.forward(views, pts, meta["patch"], meta["thr"], depth_offsets,
+                                                base_idx=z["base_idx"], base_val=z["base_val"])
+    finally:
+        pm.set_option("reproject_rule", 0)
+        pm.set_option("sum_block", 32)
+        oracle.set_reproject_rule(*prev[0])
+        oracle.set_sum_block(prev[1])
+    assert eq_nan(loss.cpu().numpy(), o_loss) and eq_nan(ori.cpu().numpy(), o_ori) and np.array_equal(hc.cpu().numpy(), o_hc)
     check_forward_against_reference(request.node.callspec.params["case"], z, ori.cpu().numpy(), loss.cpu().numpy(),
                                     hc.cpu().numpy())
 
@@ -202,6 +234,7 @@ def test_intermediate_methods_vs_oracle_and_golden(case, depth_offsets):
         samples, surface = pm.sample_next_3d_pos(pts, base)
         o_s = oracle.sample_next(views, pts, base, z["Ori"], depth_offsets)
         assert np.array_equal(samples.cpu().numpy(), o_s) and torch.equal(surface.cpu(), torch.from_numpy(pts).float())
+        assert np.array_equal(o_s, z["samples_r%d" % rank])           # == the reference's own batch, every sample
         D = pm.compute_reproject_ori(pts, samples)
         o_D = oracle.reproject_ori(views, pts, o_s)
         assert eq_nan(D.cpu().numpy(), o_D)
@@ -212,6 +245,7 @@ def test_intermediate_methods_vs_oracle_and_golden(case, depth_offsets):
         o_loss, o_idx, o_hc = oracle.prj_loss(o_D, o["Ori_patch"], o["Conf_patch"], o["visible"], meta["thr"])
         assert eq_nan(loss.cpu().numpy(), o_loss) and np.array_equal(idx.cpu().numpy(), o_idx)
         assert np.array_equal(hc.cpu().numpy(), o_hc)
+        assert eq_nan(o_loss, z["loss_r%d" % rank]) and np.array_equal(o_idx, z["idx_r%d" % rank])   # the reference, every row
         w = pm.compute_weight(pm.visible, pm.Conf, pm.mask)
         assert torch.equal(w, (pm.visible != -1).float() * pm.Conf)
 

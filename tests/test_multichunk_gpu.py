@@ -17,7 +17,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, ROOT, check_rows_against_recomposed
+from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 HELPER = os.path.join(ROOT, "tests", "golden_drivers.py")
@@ -33,16 +33,6 @@ def same_rows(a, b):
     return s if s.ndim == 1 else s.all(axis=1)
 
 
-def loss_strict_mask(n, sub_num=5000):
-    """all rows except the trailing (chunk length mod 64) of each chunk: ATen adds the [V,N,1] sums of those columns in another
-    order (one ulp; tests/test_oracle_more.py::test_refine_method_loss)"""
-    strict = np.ones(n, bool)
-    for lo in range(0, n, sub_num):
-        hi = min(lo + sub_num, n)
-        strict[hi - (hi - lo) % 64:hi] = False
-    return strict
-
-
 def check_refine_files(out, z, prefix, n):
     import scipy.io
 
@@ -54,8 +44,7 @@ def check_refine_files(out, z, prefix, n):
     om = same_rows(r["select_o"], z[prefix + "select_o"])
     assert om.all(), ("orientations", float(om.mean()), np.flatnonzero(~om)[:5])
     lm = same_rows(r["min_loss"], z[prefix + "min_loss"])
-    assert lm[loss_strict_mask(n)].all(), ("losses", float(lm.mean()))
-    assert np.allclose(r["min_loss"], z[prefix + "min_loss"], rtol=0, atol=2e-7, equal_nan=True)
+    assert lm.all(), ("losses", float(lm.mean()), np.flatnonzero(~lm)[:5])   # every row: the chunks' trailing points included
     assert np.array_equal(r["filter_unvisible"], z[prefix + "filter_unvisible"])
     fm = same_rows(r["filter_unvisible_ori"], z[prefix + "filter_unvisible_ori"])
     assert fm.all(), float(fm.mean())                       # every shell point's orientation (rows a15)
@@ -104,20 +93,20 @@ def test_refine_four_chunks_sharded_over_ranks_equals_the_reference(tmp_path, ra
 
 @pytest.mark.parametrize("ranks", [1, 2])
 def test_optimize_four_chunks_equals_the_reference(tmp_path, ranks):
-    """optimize (PMVO.py:565-595) over four chunks rotating over three HIP streams (one rank) / dealt to two ranks: every row
-    equals the reference's answer in the doubled-chunk composition, and rows that differ from its four-chunk files are rows on
-    which the reference disagrees with itself (MKL's batch-size-dependent gemm)."""
+    """optimize (PMVO.py:565-595) over four chunks rotating over three HIP streams (one rank) / dealt to two ranks: ALL
+    16 901 rows of the reference's own four-chunk files, bit for bit (the kernels follow the (rank, base view) group sizes of
+    each chunk as MKL's sgemm does in the reference; with the mid forms for every point 135 rows differ)."""
+    from conftest import rows_equal
+
     z, meta = golden()
     run_helper(tmp_path, "optimize,optimize_exact", ranks=ranks, port=29610 + ranks)
     got = {k: np.load(os.path.join(tmp_path, "run", "optimize", k + ".npy")) for k in
            ("select_p", "select_o", "min_loss", "high_conf_index")}
     assert got["select_p"].dtype == np.float32 and got["high_conf_index"].dtype == np.bool_
     assert np.array_equal(got["select_p"], z["opt_select_p"])
-    st = check_rows_against_recomposed(
-        "e2e_multichunk optimize", (got["select_o"], got["min_loss"], got["high_conf_index"]),
-        (z["opt_select_o"], z["opt_min_loss"], z["opt_high_conf_index"]),
-        [(z["optrec_select_o"], z["optrec_min_loss"], z["optrec_high_conf_index"])])
-    assert st["rows"] == 16901
+    eq = rows_equal((got["select_o"], got["min_loss"], got["high_conf_index"]),
+                    (z["opt_select_o"], z["opt_min_loss"], z["opt_high_conf_index"]))
+    assert len(eq) == 16901 and eq.all(), (int((~eq).sum()), np.flatnonzero(~eq)[:10])
     # exactly 10 000 points: the reference walks a third, empty chunk and writes the prefix of the four-chunk run
     # (recorded: exact_opt_raised == '', exact_opt_equal_prefix); so do we
     assert str(z["exact_opt_raised"]) == "" and bool(z["exact_opt_equal_prefix"])
@@ -142,7 +131,7 @@ def test_refine_head_filtered_and_nan_rows_equal_the_reference(tmp_path, form, r
     ref_o, ref_l = z["ref_select_o"], z["ref_min_loss"]
     assert same_rows(got_o, ref_o).all()
     lm = same_rows(got_l, ref_l)
-    assert lm[loss_strict_mask(len(ref_l))].all() and np.allclose(got_l, ref_l, rtol=0, atol=2e-7, equal_nan=True)
+    assert lm.all(), np.flatnonzero(~lm)[:10]
     assert np.array_equal(got_l == 0.5, ref_l == 0.5) and (ref_l == 0.5).sum() == 2000
     assert np.array_equal(np.isnan(got_l), np.isnan(ref_l)) and np.isnan(ref_l).sum() > 0
     assert np.array_equal(np.load(os.path.join(out, "filter_unvisible.npy")), z["ref_filter_unvisible"])

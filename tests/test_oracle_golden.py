@@ -114,48 +114,73 @@ def recomposed(name, key):
 @pytest.mark.parametrize("rank", [0, 2])
 def test_sample_reproject_loss(case, rank, depth_offsets, request):
     """sample_next_3d_pos / compute_reproject_ori / compute_prj_loss (PMVO.py:263-335, 222-241, 151-220) for one base-view rank.
-    Against the reference's DOUBLED batch (every base view owns >= 2 points: MKL's gemm kernel, the form the oracle restates;
-    the first N points are clear of the trailing columns ATen sums in another order): EVERY row, bit for bit.
-    Against the ORIGINAL batch: the rows that differ are rows where the reference's two compositions differ from each other."""
+    The reference's answer for a point depends on the batch it is in (how many points share its base view selects MKL's sgemm
+    kernel; the trailing N*S mod 32 columns of the [V,N,S] sums are added in another order) and the oracle follows the batch:
+    EVERY row, bit for bit, against the reference's ORIGINAL batch and against its DOUBLED batch (first N rows)."""
     meta, z, scene, views = case
     name = request.node.callspec.params["case"]
     pts = z["points"]
     nd = meta["n_d"]
-    samples = oracle.sample_next(views, pts, z["base_idx"][rank], z["Ori"], depth_offsets)
-    dup_s = recomposed(name, "samples_r%d" % rank)
-    assert np.array_equal(samples, dup_s)                                   # every sample of every point
-    D = oracle.reproject_ori(views, pts, samples)
-    assert eq_nan(D[:, :nd], recomposed(name, "Dhead_r%d" % rank))
-    assert np.allclose(D.astype(np.float64).sum(axis=(2, 3)), recomposed(name, "Dsum_r%d" % rank), rtol=0, atol=1e-9,
-                       equal_nan=True)
+    N = len(pts)
     o = oracle.visible_and_ori(views, pts, meta["patch"])
-    loss, idx, hc = oracle.prj_loss(D, o["Ori_patch"], o["Conf_patch"], o["visible"], meta["thr"])
-    assert eq_nan(loss, recomposed(name, "loss_r%d" % rank))
-    assert np.array_equal(idx, recomposed(name, "idx_r%d" % rank))
-    assert np.array_equal(hc, recomposed(name, "hc_r%d" % rank))
-    # the original batch: differences only where the reference differs from itself (a base view that owns ONE point of the
-    # batch goes through MKL's gemv; the last point sits in the trailing N*S mod 64 columns of the [V, N*S] sums)
-    ref_s = z["samples_r%d" % rank]
-    ref_self = np.all(ref_s == dup_s, axis=(1, 2))
-    assert np.all(~ref_self[~np.all(samples == ref_s, axis=(1, 2))])
+    for tag, P, reps in (("original", pts, 1), ("doubled", np.concatenate([pts, pts], 0), 2)):
+        ref = (lambda k: z[k.replace("Dhead", "D_head").replace("Dsum", "D_sum")]) if reps == 1 else \
+            (lambda k: recomposed(name, k))          # noqa: E731
+        bidx = np.tile(z["base_idx"][rank], reps)
+        samples = oracle.sample_next(views, P, bidx, np.tile(z["Ori"], (1, reps, 1)), depth_offsets)
+        assert np.array_equal(samples[:N], ref("samples_r%d" % rank)), tag                  # every sample of every point
+        D = oracle.reproject_ori(views, P, samples)
+        assert eq_nan(D[:, :nd], ref("Dhead_r%d" % rank)), tag
+        assert np.allclose(D[:, :N].astype(np.float64).sum(axis=(2, 3)), ref("Dsum_r%d" % rank), rtol=0, atol=1e-9,
+                           equal_nan=True)
+        loss, idx, hc = oracle.prj_loss(D, np.tile(o["Ori_patch"], (1, reps, 1, 1)), np.tile(o["Conf_patch"], (1, reps, 1)),
+                                        np.tile(o["visible"], (1, reps)), meta["thr"])
+        assert eq_nan(loss[:N], ref("loss_r%d" % rank)), tag
+        assert np.array_equal(idx[:N], ref("idx_r%d" % rank)) and np.array_equal(hc[:N], ref("hc_r%d" % rank)), tag
+    # where the two compositions of the reference differ from each other, a base view owns ONE point of the original batch
+    # (single-column sgemm in Camera.projection) or the point sits in the original batch's trailing columns
+    ref_s, dup_s = z["samples_r%d" % rank], recomposed(name, "samples_r%d" % rank)
     own = np.bincount(z["base_idx"][rank], minlength=z["visible"].shape[0])[z["base_idx"][rank]]
-    assert np.all(own[~ref_self] == 1)                                      # ... and those are exactly single-owner points
-    assert np.allclose(samples, ref_s, rtol=0, atol=2e-7)
-    ref_loss, ref_idx, ref_hc = z["loss_r%d" % rank], z["idx_r%d" % rank], z["hc_r%d" % rank]
-    body = ref_self.copy()
-    body[-1] = False
-    assert eq_nan(loss[body], ref_loss[body]) and np.array_equal(idx[body], ref_idx[body])
-    assert np.array_equal(hc[body], ref_hc[body])
+    assert np.all(own[~np.all(ref_s == dup_s, axis=(1, 2))] == 1)
+
+
+def _rule(mode, block):
+    prev = oracle.set_reproject_rule(mode), oracle.set_sum_block(block)
+    return prev
 
 
 def test_forward(case, depth_offsets, request):
-    """oracle.forward == the reference's forward, stated without a masked tolerance: see conftest.check_forward_against_reference"""
+    """oracle.forward == the reference's forward on EVERY row, bit for bit, in every batch composition the reference was run
+    in (tools/gen_golden_recompose.py): the original batch, the batch reversed, the batch doubled."""
+    from conftest import recompose_golden, rows_equal
+
+    meta, z, scene, views = case
+    name = request.node.callspec.params["case"]
+    pts = z["points"]
+    N = len(pts)
+    fwd = lambda p, **kw: oracle.forward(views, p, meta["patch"], meta["thr"], depth_offsets, **kw)[1:]     # noqa: E731
+    got = fwd(pts, base_idx=z["base_idx"], base_val=z["base_val"])
+    assert rows_equal(got, (z["fwd_ori"], z["fwd_loss"], z["fwd_hc"])).all()
+    got = tuple(a[::-1] for a in fwd(pts[::-1].copy()))
+    assert rows_equal(got, recompose_golden(name, "rev")).all()
+    got = tuple(a[:N] for a in fwd(np.concatenate([pts, pts], 0)))
+    assert rows_equal(got, recompose_golden(name, "dup")).all()
+
+
+def test_forward_forced_mid_forms(case, depth_offsets, request):
+    """The batch-independent option (reproject_rule "mid", sum_block 0: what rounds 1-4 computed) keeps its weaker statement:
+    equal to the reference's doubled-batch answer on every row; rows that differ from the original batch are rows on which the
+    reference disagrees with itself (conftest.check_forward_against_reference)."""
     from conftest import check_forward_against_reference
 
     meta, z, scene, views = case
-    pts = z["points"]
-    _, ori, loss, hc = oracle.forward(views, pts, meta["patch"], meta["thr"], depth_offsets,
-                                      base_idx=z["base_idx"], base_val=z["base_val"])
+    prev = _rule("mid", 0)
+    try:
+        _, ori, loss, hc = oracle.forward(views, z["points"], meta["patch"], meta["thr"], depth_offsets,
+                                          base_idx=z["base_idx"], base_val=z["base_val"])
+    finally:
+        oracle.set_reproject_rule(*prev[0])
+        oracle.set_sum_block(prev[1])
     check_forward_against_reference(request.node.callspec.params["case"], z, ori, loss, hc)
 
 
