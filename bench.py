@@ -420,15 +420,28 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=False):
     # base-view ranking and search: events around each launch inside an uninterrupted stream of iterations (two rounds
     # over the chunks, the second one is kept), so that the durations are those of a running job -- what the one-stream
     # rocprofv3 trace of this command shows (profiles/) -- and not of a launch into an idle GPU
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(2 * reps)]
+    # search_variant 9 / 10 split the launch (csrc/pmvo_search.hip: mh_launch_search): 9 = what precedes the search in the
+    # unfused sequence (group sizes of the batch, work classes, launch order), 10 = mh_search3_kernel alone
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(2 * reps)]
+    base_variant = a.variant
     for k in range(2 * reps):
         p = dchunks[k % reps]
         prepare(p)
         ev[k][0].record(); topk(); ev[k][1].record()         # noqa: E702
-        ev[k][2].record(); search(p); ev[k][3].record()      # noqa: E702  (order kernels + mh_search3_kernel)
+        split = base_variant in (0, 100)                     # (other variants -- A/B forms, the portable kernel -- are timed whole)
+        if split:
+            pm.set_option("search_variant", base_variant + 9)
+        ev[k][2].record()
+        if split:
+            search(p)                                        # (ordering kernels)
+            pm.set_option("search_variant", base_variant + 10)
+        ev[k][3].record()
+        ev[k][4].record(); search(p); ev[k][5].record()      # noqa: E702  (mh_search3_kernel)
+    pm.set_option("search_variant", base_variant)
     torch.cuda.synchronize()
     t_topk = sum(ev[k][0].elapsed_time(ev[k][1]) for k in range(reps, 2 * reps)) / reps
-    t_search = sum(ev[k][2].elapsed_time(ev[k][3]) for k in range(reps, 2 * reps)) / reps
+    t_order = sum(ev[k][2].elapsed_time(ev[k][3]) for k in range(reps, 2 * reps)) / reps
+    t_search = sum(ev[k][4].elapsed_time(ev[k][5]) for k in range(reps, 2 * reps)) / reps
     # API form with materialised patches, rotating chunks as well
     # (eight chunks spread over the pass: every call materialises 365 MB of patch tensors, and walking 57 of them through
     # fresh allocations measures the allocator's cold pages -- 0.21 ms -- not the kernel)
@@ -468,8 +481,8 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=False):
             "pair_evals_nominal": nominal, "executed_fraction_of_nominal": round(pairs / nominal, 4),
             "visible_view_fraction": round(nvis / (V * N), 4),
             "note": "executed = sum over points of (taps of the views that see the point) x (usable base-view ranks) x 90 "
-                    "samples, read back from the launch's own work arrays; launch_ms includes the two small ordering "
-                    "kernels in front of the search",
+                    "samples, read back from the launch's own work arrays; launch_ms is mh_search3_kernel alone (HIP events on "
+                    "its stream; the ordering kernels of the unfused sequence are kernels_ms.order)",
             "valu_issue": prof.get(pre + "search_valu_issue"),
         },
         "roofline_kernels": [
@@ -491,8 +504,8 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=False):
              "note": "the API form of Compute_Visible_and_Ori (patch tensors materialised, SURVEY.md §8d byte count); "
                      "forward() uses mh_project_taps2_kernel instead; launches rotate over %d chunks" % len(gchunks)},
         ],
-        "kernels_ms": {"project_taps": round(t_taps, 4), "topk": round(t_topk, 4),
-                       "order+search": round(t_search, 4), "project_gather_api_kernel": round(t_pg, 4)},
+        "kernels_ms": {"project_taps": round(t_taps, 4), "topk": round(t_topk, 4), "order": round(t_order, 4),
+                       "search": round(t_search, 4), "project_gather_api_kernel": round(t_pg, 4)},
     }
 
 

@@ -65,7 +65,7 @@ struct mh_ctx {
     // lists of 8-bit maps ~2 after the exact duplicate removal: the kernel that carries both bodies runs short lists 5 %
     // slower than the select-only kernel (register allocation), so contexts whose views are all 8-bit codes get that one.
     int search_launch_variant(int v) const {
-        if (v != 0 && v != 6 && v != 7 && v != 8) return v;   // (100.. = select body asked for; 1256 = portable kernel)
+        if (v != 0 && v != 6 && v != 7 && v != 8 && v != 9 && v != 10) return v;   // (100.. = select body asked for; 1256 = portable kernel)
         const bool select = search_body == 2 || (search_body == 0 && views_8bit());
         return select ? (v == 0 ? 100 : v + 100) : v;
     }
@@ -132,14 +132,14 @@ int mh_launch_project_gather(MhViews, const float *, int, int, float *, float *,
                              float *, hipStream_t);
 int mh_launch_topk(const float *, const float *, int, int, int32_t *, float *, int, hipStream_t);
 int mh_launch_topk_work(const float *, const float *, int, int, int32_t *, float *, int, const uint8_t *, int32_t *, int, int,
-                        int, int, hipStream_t);
+                        int, int, int32_t *, hipStream_t);
 int mh_launch_prep_taps(const float *, const float *, const float *, const float *, int, int, float, float4 *,
                         uint8_t *, hipStream_t);
 int mh_launch_project_taps(MhViews, const float *, int, int, float, float *, float *, float *, float *, float4 *,
-                           uint8_t *, int, const uint16_t *, const void *, hipStream_t);
+                           uint8_t *, int, const uint16_t *, const void *, int32_t *, int, hipStream_t);
 int mh_launch_search(MhViews, const float *, int, int, int, const float *, int, int, float, const float *,
                      const int32_t *, const float *, const float4 *, int32_t *, const uint8_t *, float *, float *,
-                     uint8_t *, float *, int32_t *, int32_t *, int, int, int, int, int32_t *, hipStream_t);
+                     uint8_t *, float *, int32_t *, int32_t *, int, int, int, int, int32_t *, int, hipStream_t);
 int mh_launch_refine_loss(MhViews, const float *, const float *, float, float, int, int, float, const float *,
                           const float *, const float *, float *, uint8_t *, int, hipStream_t);
 int mh_launch_filter_points(MhViews, const float *, int, int, float, float, uint8_t *, uint8_t *, uint8_t *,
@@ -547,13 +547,12 @@ extern "C" int mh_search_forward(mh_ctx *ctx, const float *points, int N, int pa
                                      min_loss, high_conf, best_sample, best_rank, best_s,
                                      ctx->search_launch_variant(ctx->search_variant), ctx->reproject_rule,
                                      ctx->reproject_fma_min_cols, ctx->sum_block,
-                                     (int32_t *)((char *)scratch + search_groups_offset(ctx, N, patch)), st),
+                                     (int32_t *)((char *)scratch + search_groups_offset(ctx, N, patch)), 0, st),
                     "mh_search_forward");
 }
 
-extern "C" int mh_forward_prepare(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold,
-                                  float *vis, float *ori, float *conf, float *mask, void *scratch,
-                                  size_t scratch_bytes, void *stream) {
+static int forward_prepare(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, float *vis, float *ori,
+                           float *conf, float *mask, void *scratch, size_t scratch_bytes, int zero_groups, void *stream) {
     if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_forward_prepare: views not set");
     if (N == 0) return MH_OK;
     if (!points || !vis || !ori || !conf || !scratch || N < 0 || patch < 1 || !(patch & 1))
@@ -563,14 +562,23 @@ extern "C" int mh_forward_prepare(mh_ctx *ctx, const float *points, int N, int p
     return launched(mh_launch_project_taps(ctx->views(), points, N, patch, conf_threshold, vis, ori, conf, mask,
                                            (float4 *)scratch,
                                            (uint8_t *)scratch + search_count_offset(ctx, N, patch), ctx->taps_tile,
-                                           ctx->codes_ready() ? ctx->oc : nullptr, ctx->code_tabs, (hipStream_t)stream),
+                                           ctx->codes_ready() ? ctx->oc : nullptr, ctx->code_tabs,
+                                           (int32_t *)((char *)scratch + search_groups_offset(ctx, N, patch)),
+                                           zero_groups ? 16 * ctx->V : 0, (hipStream_t)stream),
                     "mh_forward_prepare");
+}
+
+extern "C" int mh_forward_prepare(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold,
+                                  float *vis, float *ori, float *conf, float *mask, void *scratch,
+                                  size_t scratch_bytes, void *stream) {
+    return forward_prepare(ctx, points, N, patch, conf_threshold, vis, ori, conf, mask, scratch, scratch_bytes, 0, stream);
 }
 
 static int search_prepared(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank,
                            int rank_step, const float *ori, const int32_t *base_idx, const float *base_val,
                            void *scratch, float *line_ori, float *min_loss, uint8_t *high_conf,
-                           float *best_sample, int32_t *best_rank, int32_t *best_s, int variant, void *stream) {
+                           float *best_sample, int32_t *best_rank, int32_t *best_s, int variant, int groups_ready,
+                           void *stream) {
     if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_search_prepared: views not set");
     if (!ctx->offs) return fail(MH_ERR_STATE, "mh_search_prepared: depth offsets not set");
     if (N == 0) return MH_OK;
@@ -586,7 +594,7 @@ static int search_prepared(mh_ctx *ctx, const float *points, int N, int patch, f
                                      min_loss, high_conf, best_sample, best_rank, best_s,
                                      ctx->search_launch_variant(variant), ctx->reproject_rule, ctx->reproject_fma_min_cols,
                                      ctx->sum_block, (int32_t *)((char *)scratch + search_groups_offset(ctx, N, patch)),
-                                     (hipStream_t)stream),
+                                     groups_ready, (hipStream_t)stream),
                     "mh_search_prepared");
 }
 
@@ -595,19 +603,23 @@ extern "C" int mh_search_prepared(mh_ctx *ctx, const float *points, int N, int p
                                   void *scratch, float *line_ori, float *min_loss, uint8_t *high_conf,
                                   float *best_sample, int32_t *best_rank, int32_t *best_s, void *stream) {
     return search_prepared(ctx, points, N, patch, conf_threshold, nrank, rank_step, ori, base_idx, base_val, scratch, line_ori,
-                           min_loss, high_conf, best_sample, best_rank, best_s, ctx ? ctx->search_variant : 0, stream);
+                           min_loss, high_conf, best_sample, best_rank, best_s, ctx ? ctx->search_variant : 0, 0, stream);
 }
 
 extern "C" int mh_forward(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank, int rank_step,
                           float *vis, float *ori, float *conf, float *mask, void *scratch, size_t scratch_bytes,
                           int32_t *base_idx, float *base_val, float *line_ori, float *min_loss, uint8_t *high_conf,
                           float *best_sample, int32_t *best_rank, int32_t *best_s, void *stream) {
-    if (int rc = mh_forward_prepare(ctx, points, N, patch, conf_threshold, vis, ori, conf, mask, scratch, scratch_bytes, stream))
-        return rc;
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_forward: views not set");
     // with the default kernels the ranking kernel also writes the work classes of the search's launch order (it has the
     // point's ranking in its lanes): one launch less per iteration than the three separate calls
     const bool fuse_cls = ctx->search_variant == 0 && (ctx->topk_order & 255) == 0 && N > 1 && base_idx && base_val && vis &&
                           conf && nrank >= 1 && rank_step >= 1 && ctx->V >= MH_TOPK && ctx->offs;
+    // ... and counts the points per (rank, base view) of the batch (csrc/mh_device.h: MhRule) into the array the front end cleared
+    const int fuse_groups = fuse_cls && ctx->reproject_rule == 0 && nrank <= 16;
+    if (int rc = forward_prepare(ctx, points, N, patch, conf_threshold, vis, ori, conf, mask, scratch, scratch_bytes, fuse_groups,
+                                 stream))
+        return rc;
     if (!fuse_cls) {
         if (int rc = mh_topk_views(ctx, vis, conf, N, base_idx, base_val, stream)) return rc;
         return mh_search_prepared(ctx, points, N, patch, conf_threshold, nrank, rank_step, ori, base_idx, base_val, scratch,
@@ -616,11 +628,15 @@ extern "C" int mh_forward(mh_ctx *ctx, const float *points, int N, int patch, fl
     int32_t *order = (int32_t *)((char *)scratch + search_order_offset(ctx, N, patch));
     const uint8_t *cnt = (const uint8_t *)scratch + search_count_offset(ctx, N, patch);
     if (int rc = launched(mh_launch_topk_work(vis, conf, ctx->V, N, base_idx, base_val, ctx->topk_order, cnt, order,
-                                              patch * patch + 1, nrank, rank_step, ctx->S, (hipStream_t)stream),
+                                              patch * patch + 1, nrank, rank_step, ctx->S,
+                                              fuse_groups ? (int32_t *)((char *)scratch + search_groups_offset(ctx, N, patch))
+                                                          : nullptr,
+                                              (hipStream_t)stream),
                           "mh_forward (base-view ranking)"))
         return rc;
     return search_prepared(ctx, points, N, patch, conf_threshold, nrank, rank_step, ori, base_idx, base_val, scratch, line_ori,
-                           min_loss, high_conf, best_sample, best_rank, best_s, 8 /* ordered, classes written */, stream);
+                           min_loss, high_conf, best_sample, best_rank, best_s, 8 /* ordered, classes written */, fuse_groups,
+                           stream);
 }
 
 extern "C" int mh_refine_loss(mh_ctx *ctx, const float *points, const float *dir, float step_mul, float step_div,

@@ -300,6 +300,7 @@ __device__ __forceinline__ void mh_casc_flush(MhCasc &c) {
 struct MhWorkArgs {
     const uint8_t *cnt;   // [V,N] tap-list lengths
     int32_t *cls;         // [N] out: work class (nullptr: not wanted)
+    int32_t *gcnt;        // [nrank][V] out, zeroed by the front end: points per (rank, base view) (MhRule; nullptr: not wanted)
     int P1, nrank, rank_step, S, T;
 };
 __device__ __forceinline__ int mh_work_class(int nt, int nvalid, int V, int P1, int S, int T) {

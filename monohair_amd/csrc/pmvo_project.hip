@@ -247,6 +247,9 @@ __global__ __launch_bounds__(64 * W) void mh_topk_wave_kernel(const float *__res
         const unsigned long long m = __ballot(usable);
         const int nvalid = m ? (63 - (int)__builtin_clzll(m)) / wk.rank_step + 1 : 1;   // last usable rank + 1
         if (lane == 0) wk.cls[n] = mh_work_class(nt, nvalid, V, wk.P1, wk.S, wk.T);
+        // ... and the points per (rank, base view) of the batch (mh_device.h: MhRule): one fire-and-forget atomic per used
+        // rank into the array the front end zeroed
+        if (wk.gcnt && lane < MH_TOPK && r * wk.rank_step == lane && r < wk.nrank) atomicAdd(&wk.gcnt[r * V + a.i[0]], 1);
     }
 }
 
@@ -378,12 +381,15 @@ __global__ __launch_bounds__(256) void mh_project_taps_codes_kernel(MhViews vw, 
                                                                     float *__restrict__ mask, float4 *__restrict__ taps,
                                                                     uint8_t *__restrict__ cnt,
                                                                     const uint16_t *__restrict__ oc_all,
-                                                                    const MhCodeTabs *__restrict__ tabs) {
+                                                                    const MhCodeTabs *__restrict__ tabs,
+                                                                    int32_t *__restrict__ zero, int nzero) {
     constexpr int P = PATCH * PATCH, HP = PATCH / 2, NCH = (P + MH_WAVE - 1) / MH_WAVE, PW = 16;
     __shared__ float2 s_unit[256];
     __shared__ float s_confc[256];
     __shared__ uint8_t s_canon[256];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (blockIdx.x == 0)   // (the group sizes the ranking kernel behind this launch counts: mh_topk_wave_kernel)
+        for (int i = tid; i < nzero; i += 256) zero[i] = 0;
     const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous view ranges
     const int V = vw.V, H = vw.H, W = vw.W;
     if (bid >= V * tiles) return;
@@ -544,7 +550,8 @@ __global__ __launch_bounds__(256) void mh_project_taps2_kernel(MhViews vw, const
                                                                float thr, float *__restrict__ vis,
                                                                float *__restrict__ ori, float *__restrict__ conf,
                                                                float *__restrict__ mask, float4 *__restrict__ taps,
-                                                               uint8_t *__restrict__ cnt) {
+                                                               uint8_t *__restrict__ cnt, int32_t *__restrict__ zero,
+                                                               int nzero) {
     constexpr int P = PATCH * PATCH, HP = PATCH / 2, NCH = (P + MH_WAVE - 1) / MH_WAVE, PW = 16;
     constexpr int INF = NCH == 1 ? 8 : 4;            // points whose patch gathers are in flight together (32 VGPRs)
     __shared__ float2 s_o[4][MH_PREP_PMAX];
@@ -552,6 +559,8 @@ __global__ __launch_bounds__(256) void mh_project_taps2_kernel(MhViews vw, const
     __shared__ unsigned char s_el[4][MH_PREP_PMAX];
     __shared__ unsigned int s_first[4][256];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (blockIdx.x == 0)   // (the group sizes the ranking kernel behind this launch counts: mh_topk_wave_kernel)
+        for (int i = tid; i < nzero; i += 256) zero[i] = 0;
     const int bid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous view ranges
     const int V = vw.V, H = vw.H, W = vw.W;
     if (bid >= V * tiles) return;
@@ -745,10 +754,11 @@ extern "C" int mh_launch_project_gather(MhViews vw, const float *pts, int N, int
 // wk.cls != nullptr (the fused forward; wave form only): the kernel also writes the work classes of the search's launch order
 extern "C" int mh_launch_topk_work(const float *vis, const float *conf, int V, int N, int32_t *out_idx, float *out_val,
                                    int order, const uint8_t *cnt, int32_t *cls, int P1, int nrank, int rank_step, int S,
-                                   hipStream_t st) {
+                                   int32_t *gcnt /* [nrank][V], zeroed: the batch's group sizes (or nullptr) */, hipStream_t st) {
     if (V > MH_TOPK_VMAX || V < MH_TOPK) return -1;
     if (cls && ((order & 255) != 0 || !cnt || rank_step < 1)) return -1;
-    const MhWorkArgs wk{cnt, cls, P1, nrank, rank_step < 1 ? 1 : rank_step, S, 256};
+    if (gcnt && !cls) return -1;
+    const MhWorkArgs wk{cnt, cls, gcnt, P1, nrank, rank_step < 1 ? 1 : rank_step, S, 256};
     if ((order & 255) == 1) {   // value descending, view index ascending among equal values (round 1's rule; A/B)
         hipLaunchKernelGGL(mh_topk_kernel, dim3((N + 3) / 4), dim3(256), 0, st, vis, conf, V, N, out_idx, out_val);
     } else {            // torch.topk's CPU order, one wave per point
@@ -772,7 +782,7 @@ extern "C" int mh_launch_topk_work(const float *vis, const float *conf, int V, i
 
 extern "C" int mh_launch_topk(const float *vis, const float *conf, int V, int N, int32_t *out_idx, float *out_val,
                               int order, hipStream_t st) {
-    return mh_launch_topk_work(vis, conf, V, N, out_idx, out_val, order, nullptr, nullptr, 0, 0, 1, 0, st);
+    return mh_launch_topk_work(vis, conf, V, N, out_idx, out_val, order, nullptr, nullptr, 0, 0, 1, 0, nullptr, st);
 }
 
 extern "C" int mh_launch_prep_taps(const float *ori_patch, const float *conf_patch, const float *vis,
@@ -786,7 +796,9 @@ extern "C" int mh_launch_prep_taps(const float *ori_patch, const float *conf_pat
 
 extern "C" int mh_launch_project_taps(MhViews vw, const float *pts, int N, int patch, float thr, float *vis,
                                       float *ori, float *conf, float *mask, float4 *taps, uint8_t *cnt, int tile,
-                                      const uint16_t *oc, const void *tabs_v, hipStream_t st) {
+                                      const uint16_t *oc, const void *tabs_v,
+                                      int32_t *zero, int nzero /* ints the first workgroup clears (group sizes of the batch) */,
+                                      hipStream_t st) {
     const MhCodeTabs *tabs = (const MhCodeTabs *)tabs_v;
     const bool codes = oc && tabs;
     if (patch * patch > MH_PREP_PMAX) return -1;
@@ -797,10 +809,10 @@ extern "C" int mh_launch_project_taps(MhViews vw, const float *pts, int N, int p
     case PS:                                                                                                       \
         if (codes)                                                                                                 \
             hipLaunchKernelGGL((mh_project_taps_codes_kernel<PS>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, \
-                               conf, mask, taps, cnt, oc, tabs);                                                   \
+                               conf, mask, taps, cnt, oc, tabs, zero, nzero);                                      \
         else                                                                                                       \
             hipLaunchKernelGGL((mh_project_taps2_kernel<PS>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, conf, \
-                               mask, taps, cnt);                                                                  \
+                               mask, taps, cnt, zero, nzero);                                                     \
         break;
     switch (patch) {
         MH_PT_CASE(1)

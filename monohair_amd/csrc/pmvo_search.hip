@@ -1247,40 +1247,29 @@ __global__ __launch_bounds__(256) void mh_search_work_kernel(const uint8_t *__re
 }
 
 // Points per (rank, base view) of the batch -- the M of mh_group_forms: gcnt[r * V + b] = #{n : base_idx[r * rank_step, n] == b}.
-// One workgroup per launch (LDS histogram, no global atomics, nothing to zero first).
-#define MH_GROUP_LDS (MH_MAX_RANKS * 512)
-__device__ __forceinline__ void mh_group_sizes_block(const int32_t *__restrict__ base_idx, int N, int V, int nrank,
-                                                     int rank_step, int32_t *__restrict__ gcnt, int *s_g, int tid,
-                                                     int nthreads) {
-    const int cells = nrank * V;   // <= MH_GROUP_LDS (checked by the launcher)
-    for (int i = tid; i < cells; i += nthreads) s_g[i] = 0;
+// Workgroup (x, r) counts 256 points of rank r in LDS and adds its non-zero cells to the zeroed global array.  (The fused
+// forward does not launch this: its ranking kernel adds the counts itself, mh_topk_wave_kernel.  A first form -- one
+// workgroup, all ranks, inside mh_search_order_kernel -- took 146 us at the headline size: up to 670 LDS atomics on one address.)
+__global__ __launch_bounds__(256) void mh_group_sizes_kernel(const int32_t *__restrict__ base_idx, int N, int V,
+                                                             int rank_step, int32_t *__restrict__ gcnt) {
+    extern __shared__ int s_g[];   // V
+    const int r = blockIdx.y, tid = threadIdx.x;
+    for (int i = tid; i < V; i += 256) s_g[i] = 0;
     __syncthreads();
-    for (int r = 0; r < nrank; ++r) {
-        const int32_t *__restrict__ row = base_idx + (size_t)(r * rank_step) * N;
-        for (int n = tid; n < N; n += nthreads) {
-            const int b = row[n];
-            if (b >= 0 && b < V) atomicAdd(&s_g[r * V + b], 1);
-        }
+    const int n = blockIdx.x * 256 + tid;
+    if (n < N) {
+        const int b = base_idx[(size_t)(r * rank_step) * N + n];
+        if (b >= 0 && b < V) atomicAdd(&s_g[b], 1);
     }
     __syncthreads();
-    for (int i = tid; i < cells; i += nthreads) gcnt[i] = s_g[i];
+    for (int i = tid; i < V; i += 256)
+        if (s_g[i]) atomicAdd(&gcnt[r * V + i], s_g[i]);
 }
 
-__global__ __launch_bounds__(1024) void mh_group_sizes_kernel(const int32_t *__restrict__ base_idx, int N, int V, int nrank,
-                                                              int rank_step, int32_t *__restrict__ gcnt) {
-    __shared__ int s_g[MH_GROUP_LDS];
-    mh_group_sizes_block(base_idx, N, V, nrank, rank_step, gcnt, s_g, threadIdx.x, 1024);
-}
-
-// (gcnt != nullptr: the group sizes as well -- this single workgroup walks the points anyway)
-__global__ __launch_bounds__(1024) void mh_search_order_kernel(int N, int32_t *__restrict__ order,
-                                                               const int32_t *__restrict__ base_idx, int V, int nrank,
-                                                               int rank_step, int32_t *__restrict__ gcnt) {
+__global__ __launch_bounds__(1024) void mh_search_order_kernel(int N, int32_t *__restrict__ order) {
     __shared__ int s_hist[MH_ORDER_BUCKETS];
     __shared__ int s_part[1024 / 64];
-    __shared__ int s_g[MH_GROUP_LDS];
     const int tid = threadIdx.x;
-    if (gcnt) mh_group_sizes_block(base_idx, N, V, nrank, rank_step, gcnt, s_g, tid, 1024);
     s_hist[tid] = 0;
     __syncthreads();
     for (int n = tid; n < N; n += 1024) atomicAdd(&s_hist[order[n]], 1);
@@ -1518,7 +1507,9 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
                                 const uint8_t *cnt /* [V,N] list lengths */,
                                 float *line_ori, float *min_loss, uint8_t *high_conf, float *best_sample,
                                 int32_t *best_rank, int32_t *best_s, int variant, int rule_mode, int fma_min_cols,
-                                int sum_block, int32_t *gcnt /* nrank*V ints of work space */, hipStream_t st) {
+                                int sum_block, int32_t *gcnt /* nrank*V ints of work space */,
+                                int groups_ready /* gcnt holds the batch's group sizes already (the fused forward) */,
+                                hipStream_t st) {
     const int nitems = nrank * S;
     if (nitems > MH_MAX_ITEMS || nrank > MH_MAX_RANKS || nitems < 1) return -1;
     // the batch in the arithmetic (MhRule, mh_device.h): group sizes per (rank, base view) and the trailing columns of the
@@ -1528,32 +1519,36 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
     rule.mode = rule_mode;
     rule.fma_min_cols = fma_min_cols;
     rule.gcnt = (rule_mode == 0) ? gcnt : nullptr;
-    if (rule_mode == 0 && (!gcnt || (size_t)nrank * vw.V > MH_GROUP_LDS)) return -1;
+    if (rule_mode == 0 && !gcnt) return -1;
     const long long cols = (long long)N * S;
     rule.tail_col0 = sum_block ? cols - cols % sum_block : cols;
-    bool need_groups = rule.gcnt != nullptr;
+    // (variant 9 / 10: the launch split for measurements -- 9 runs what precedes the search (group sizes, work classes, launch
+    // order) and stops, 10 runs mh_search3_kernel alone on what 9 left in the scratch; bench.py times the two with HIP events)
+    const bool select_body = variant >= 100 && variant < 200;
+    if (select_body) variant -= 100;
+    if (variant == 10) groups_ready = 1;
+    if (rule.gcnt && !groups_ready) {
+        if (hipMemsetAsync(gcnt, 0, sizeof(int32_t) * (size_t)nrank * vw.V, st) != hipSuccess) return -1;
+        hipLaunchKernelGGL(mh_group_sizes_kernel, dim3((N + 255) / 256, nrank), dim3(256), sizeof(int) * (size_t)vw.V, st,
+                           base_idx, N, vw.V, rank_step, gcnt);
+    }
     // variant 0 (default): mh_search3_kernel, workgroups in descending order of work; 7: the same in natural order (A/B);
     // 1256: the portable mh_search_kernel (cross-check) -- also what runs when the caller has no list lengths
     // (8: as 0, the work classes are in order[0..N) already -- the fused forward lets the ranking kernel write them)
     // (+100: the compare-and-select tap body of rounds 1-3 instead of the key body -- 100 / 107 are the A/B and cross-check
     // forms of 0 / 7)
-    const bool select_body = variant >= 100 && variant < 200;
-    if (select_body) variant -= 100;
     if (variant == 0) variant = cnt ? 6 : 1256;
-    if (variant == 6 || variant == 7 || variant == 8) {
+    if (variant == 6 || variant == 7 || variant == 8 || variant == 9 || variant == 10) {
         if (!cnt) return -1;
         const int32_t *ord = nullptr;
         if (variant != 7 && order && N > 1) {
-            if (variant == 6)
+            if (variant == 6 || variant == 9)
                 hipLaunchKernelGGL(mh_search_work_kernel, dim3((N + 3) / 4), dim3(256), 0, st, cnt, vw.V, N, P1, base_val,
                                    nrank, rank_step, S, 256, order);
-            hipLaunchKernelGGL(mh_search_order_kernel, dim3(1), dim3(1024), 0, st, N, order, base_idx, vw.V, nrank, rank_step,
-                               need_groups ? gcnt : nullptr);
-            need_groups = false;
+            if (variant != 10) hipLaunchKernelGGL(mh_search_order_kernel, dim3(1), dim3(1024), 0, st, N, order);
             ord = order + N;
         }
-        if (need_groups)
-            hipLaunchKernelGGL(mh_group_sizes_kernel, dim3(1), dim3(1024), 0, st, base_idx, N, vw.V, nrank, rank_step, gcnt);
+        if (variant == 9) return (int)hipGetLastError();
 #define MH_S3_LAUNCH(BIG, KEYS, BIGP)                                                                                   \
     hipLaunchKernelGGL((mh_search3_kernel<256, BIG, KEYS, BIGP>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, \
                        pts, N, P1, thr, ori_c, base_idx, base_val, taps, cnt, ord, line_ori, min_loss, high_conf,       \
@@ -1572,8 +1567,6 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
         }
 #undef MH_S3_LAUNCH
     } else if (variant == 1256) {
-        if (need_groups)
-            hipLaunchKernelGGL(mh_group_sizes_kernel, dim3(1), dim3(1024), 0, st, base_idx, N, vw.V, nrank, rank_step, gcnt);
         hipLaunchKernelGGL((mh_search_kernel<4, 256>), dim3(N), dim3(256), 0, st, vw, offs, S, nrank, rank_step, pts, N, P1,
                            thr, ori_c, base_idx, base_val, taps, line_ori, min_loss, high_conf, best_sample, best_rank,
                            best_s, rule);

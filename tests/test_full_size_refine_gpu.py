@@ -72,9 +72,12 @@ def test_optimize_58_chunks_vs_oracle(headline):
         _, o_ori, o_loss, o_hc = oracle.forward(views, opt["select_p"][lo:hi], h["patch"], h["thr"], offs)
         assert eq(opt["min_loss"][lo:hi], o_loss) and eq(opt["select_o"][lo:hi], o_ori), c
         assert eq(opt["high_conf_index"][lo:hi], o_hc), c
-    sel = np.sort(np.random.default_rng(5).choice(N, 2000, replace=False))
-    _, o_ori, o_loss, o_hc = oracle.forward(views, opt["select_p"][sel], h["patch"], h["thr"], offs)
-    assert eq(opt["min_loss"][sel], o_loss) and eq(opt["select_o"][sel], o_ori) and eq(opt["high_conf_index"][sel], o_hc)
+    # (a point's answer depends on its chunk -- group sizes per base view, trailing columns of the sums -- so chunks are
+    # compared with chunks; two more, picked at random)
+    for c in np.random.default_rng(5).choice(nchunk - 1, 2, replace=False):
+        lo, hi = int(c) * 5000, (int(c) + 1) * 5000
+        _, o_ori, o_loss, o_hc = oracle.forward(views, opt["select_p"][lo:hi], h["patch"], h["thr"], offs)
+        assert eq(opt["min_loss"][lo:hi], o_loss) and eq(opt["select_o"][lo:hi], o_ori) and eq(opt["high_conf_index"][lo:hi], o_hc)
     assert np.isfinite(opt["min_loss"]).mean() > 0.9
 
 

@@ -35,7 +35,7 @@ def _codes_from_scene(scene):
 
 @pytest.mark.parametrize("name", ["pmvo_quant", "pmvo_patch9"])
 def test_forward_from_codes_equals_oracle_and_reference(name, depth_offsets):
-    from conftest import check_forward_against_reference
+    from conftest import rows_equal
     from monohair_amd.camera import cameras_from_list
     from monohair_amd.pmvo import PMVO
 
@@ -60,7 +60,7 @@ def test_forward_from_codes_equals_oracle_and_reference(name, depth_offsets):
                                             base_val=z["base_val"])
     assert np.array_equal(outs[0][1], o_loss, equal_nan=True) and np.array_equal(outs[0][0], o_ori, equal_nan=True)
     assert np.array_equal(outs[0][2], o_hc)
-    check_forward_against_reference(name, z, *outs[0])
+    assert rows_equal(outs[0], (z["fwd_ori"], z["fwd_loss"], z["fwd_hc"])).all()     # the reference's own batch, every row
 
 
 @pytest.mark.parametrize("patch", [1, 3, 5, 7, 9, 11])
