@@ -403,6 +403,13 @@ int mh_mat_sparse_close(void *handle);
  *       default 8; OpenGL requires at least 4, which is what SwiftShader uses (changes the image at silhouettes). */
 int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value);
 
+/* Debug counter of the search's key body (csrc/pmvo_search.hip: mh_tap_key): out[2] = how many (wave, view) visits were
+ * evaluated a second time with the compare-and-select body because a key could not state the winner (a best tap with
+ * |cos| <= 2^-14, a NaN).  Process-wide, all contexts; reset != 0 clears it after the read.  out[0], out[1], out[3] are
+ * only counted in the -DMH_KEY_STATS build (tools/exp_key_stats.py).  The reference has no counterpart: it exists so that
+ * a test can prove it entered that branch (tests/test_key_reeval_gpu.py).  Synchronises the device. */
+int mh_debug_key_stats(unsigned long long *out /* 4 */, int reset);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,7 +132,7 @@ int mh_launch_project_gather(MhViews, const float *, int, int, float *, float *,
                              float *, hipStream_t);
 int mh_launch_topk(const float *, const float *, int, int, int32_t *, float *, int, hipStream_t);
 int mh_launch_topk_work(const float *, const float *, int, int, int32_t *, float *, int, const uint8_t *, int32_t *, int, int,
-                        int, int, int32_t *, hipStream_t);
+                        int, int, int32_t *, int, hipStream_t);
 int mh_launch_prep_taps(const float *, const float *, const float *, const float *, int, int, float, float4 *,
                         uint8_t *, hipStream_t);
 int mh_launch_project_taps(MhViews, const float *, int, int, float, float *, float *, float *, float *, float4 *,
@@ -627,11 +627,14 @@ extern "C" int mh_forward(mh_ctx *ctx, const float *points, int N, int patch, fl
     }
     int32_t *order = (int32_t *)((char *)scratch + search_order_offset(ctx, N, patch));
     const uint8_t *cnt = (const uint8_t *)scratch + search_count_offset(ctx, N, patch);
+    // (the points that hold the trailing columns of the batch's [V, N*S] sums go first in the search's launch order)
+    const long long cols = (long long)N * ctx->S;
+    const int tail_n0 = ctx->sum_block > 0 ? (int)((cols - cols % ctx->sum_block) / ctx->S) : N;
     if (int rc = launched(mh_launch_topk_work(vis, conf, ctx->V, N, base_idx, base_val, ctx->topk_order, cnt, order,
                                               patch * patch + 1, nrank, rank_step, ctx->S,
                                               fuse_groups ? (int32_t *)((char *)scratch + search_groups_offset(ctx, N, patch))
                                                           : nullptr,
-                                              (hipStream_t)stream),
+                                              tail_n0, (hipStream_t)stream),
                           "mh_forward (base-view ranking)"))
         return rc;
     return search_prepared(ctx, points, N, patch, conf_threshold, nrank, rank_step, ori, base_idx, base_val, scratch, line_ori,

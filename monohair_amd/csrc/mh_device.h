@@ -302,6 +302,8 @@ struct MhWorkArgs {
     int32_t *cls;         // [N] out: work class (nullptr: not wanted)
     int32_t *gcnt;        // [nrank][V] out, zeroed by the front end: points per (rank, base view) (MhRule; nullptr: not wanted)
     int P1, nrank, rank_step, S, T;
+    int tail_n0;          // points >= tail_n0 hold trailing columns of the batch's sums: class 0 (mh_search3_kernel evaluates
+                          // those once more in its epilogue -- such a workgroup should start first, not last)
 };
 __device__ __forceinline__ int mh_work_class(int nt, int nvalid, int V, int P1, int S, int T) {
     const int maxwork = V * (P1 - 1) * 4;   // taps of all views x 4 slices

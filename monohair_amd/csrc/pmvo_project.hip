@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64 * W) void mh_topk_wave_kernel(const float *__res
         const bool usable = lane > 0 && lane < MH_TOPK && r * wk.rank_step == lane && r < wk.nrank && val > 0.0f;
         const unsigned long long m = __ballot(usable);
         const int nvalid = m ? (63 - (int)__builtin_clzll(m)) / wk.rank_step + 1 : 1;   // last usable rank + 1
-        if (lane == 0) wk.cls[n] = mh_work_class(nt, nvalid, V, wk.P1, wk.S, wk.T);
+        if (lane == 0) wk.cls[n] = n >= wk.tail_n0 ? 0 : mh_work_class(nt, nvalid, V, wk.P1, wk.S, wk.T);
         // ... and the points per (rank, base view) of the batch (mh_device.h: MhRule): one fire-and-forget atomic per used
         // rank into the array the front end zeroed
         if (wk.gcnt && lane < MH_TOPK && r * wk.rank_step == lane && r < wk.nrank) atomicAdd(&wk.gcnt[r * V + a.i[0]], 1);
@@ -754,11 +754,13 @@ extern "C" int mh_launch_project_gather(MhViews vw, const float *pts, int N, int
 // wk.cls != nullptr (the fused forward; wave form only): the kernel also writes the work classes of the search's launch order
 extern "C" int mh_launch_topk_work(const float *vis, const float *conf, int V, int N, int32_t *out_idx, float *out_val,
                                    int order, const uint8_t *cnt, int32_t *cls, int P1, int nrank, int rank_step, int S,
-                                   int32_t *gcnt /* [nrank][V], zeroed: the batch's group sizes (or nullptr) */, hipStream_t st) {
+                                   int32_t *gcnt /* [nrank][V], zeroed: the batch's group sizes (or nullptr) */,
+                                   int tail_n0 /* first point with trailing columns of the batch's sums (N: none) */,
+                                   hipStream_t st) {
     if (V > MH_TOPK_VMAX || V < MH_TOPK) return -1;
     if (cls && ((order & 255) != 0 || !cnt || rank_step < 1)) return -1;
     if (gcnt && !cls) return -1;
-    const MhWorkArgs wk{cnt, cls, gcnt, P1, nrank, rank_step < 1 ? 1 : rank_step, S, 256};
+    const MhWorkArgs wk{cnt, cls, gcnt, P1, nrank, rank_step < 1 ? 1 : rank_step, S, 256, tail_n0};
     if ((order & 255) == 1) {   // value descending, view index ascending among equal values (round 1's rule; A/B)
         hipLaunchKernelGGL(mh_topk_kernel, dim3((N + 3) / 4), dim3(256), 0, st, vis, conf, V, N, out_idx, out_val);
     } else {            // torch.topk's CPU order, one wave per point
@@ -782,7 +784,7 @@ extern "C" int mh_launch_topk_work(const float *vis, const float *conf, int V, i
 
 extern "C" int mh_launch_topk(const float *vis, const float *conf, int V, int N, int32_t *out_idx, float *out_val,
                               int order, hipStream_t st) {
-    return mh_launch_topk_work(vis, conf, V, N, out_idx, out_val, order, nullptr, nullptr, 0, 0, 1, 0, nullptr, st);
+    return mh_launch_topk_work(vis, conf, V, N, out_idx, out_val, order, nullptr, nullptr, 0, 0, 1, 0, nullptr, N, st);
 }
 
 extern "C" int mh_launch_prep_taps(const float *ori_patch, const float *conf_patch, const float *vis,

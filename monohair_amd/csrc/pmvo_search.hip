@@ -116,6 +116,7 @@ __device__ __forceinline__ void mh_tail_item_sums(const float *__restrict__ cams
         mh_unit2(row - hdr.z, col - hdr.w, dx, dy);
         const float4 t0 = rec[1];
         float ml = 1.0f - __builtin_fabsf(t0.x * dx + t0.y * dy), bc = t0.z;
+#pragma unroll 4
         for (int t = 1; t < nt; ++t) {
             const float4 tp = rec[1 + t];
             const float l = 1.0f - __builtin_fabsf(tp.x * dx + tp.y * dy);
@@ -474,8 +475,11 @@ __device__ __forceinline__ void mh_tap_update(float (&ML)[KA], float (&BC)[KA], 
 #define MH_KEY_MIN_TAPS 10           // lists up to this length go through the select body directly
 #endif
 #define MH_KEY_PAD 4                 // lists are padded in LDS to a multiple of this many taps with (0, 0): cs = 0, t' = C
-#ifdef MH_KEY_STATS   // tools/exp_key_stats.py builds the library with this: how often a wave evaluates a view twice
-__device__ unsigned long long mh_key_stats_dev[4];   // (wave, view) visits: all, one-tap / NaN-seed lists, re-evaluated, -
+// (wave, view) visits of the key body: [0] all, [1] one-tap / short / NaN-seed lists (select body directly), [2] evaluated
+// again with the select body after the key body.  [2] is always counted -- one atomic in a branch the bench scene takes 0 times
+// in 95 M -- so that a test can assert that it was inside that branch (tests/test_key_reeval_gpu.py); [0] and [1] sit in the
+// hot path and are counted only in the -DMH_KEY_STATS build of tools/exp_key_stats.py.
+__device__ unsigned long long mh_key_stats_dev[4];
 extern "C" int mh_debug_key_stats(unsigned long long *out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mh_key_stats_dev), sizeof(unsigned long long) * 4) != hipSuccess) return -1;
     if (reset) {
@@ -484,7 +488,9 @@ extern "C" int mh_debug_key_stats(unsigned long long *out, int reset) {
     }
     return 0;
 }
-#define MH_KEY_COUNT(i) do { if ((tid & 63) == 0) atomicAdd(&mh_key_stats_dev[i], 1ull); } while (0)
+#define MH_KEY_COUNT_ALWAYS(i) do { if ((tid & 63) == 0) atomicAdd(&mh_key_stats_dev[i], 1ull); } while (0)
+#ifdef MH_KEY_STATS
+#define MH_KEY_COUNT(i) MH_KEY_COUNT_ALWAYS(i)
 #else
 #define MH_KEY_COUNT(i) do { } while (0)
 #endif
@@ -984,7 +990,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
                     ML[j] = __uint_as_float(__builtin_amdgcn_alignbit(7u, best[j], 5u)) - MH_KEY_E;
                 }
                 again = __ballot(bad) != 0ull;
-                if (again) MH_KEY_COUNT(2);
+                if (again) MH_KEY_COUNT_ALWAYS(2);
             }
             if (again) select_body();
         }
@@ -1231,7 +1237,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MH_S3_WAVES))
 // point is processed, never what is computed for it.
 __global__ __launch_bounds__(256) void mh_search_work_kernel(const uint8_t *__restrict__ cnt, int V, int N, int P1,
                                                              const float *__restrict__ base_val, int nrank,
-                                                             int rank_step, int S, int T, int32_t *__restrict__ order) {
+                                                             int rank_step, int S, int T, int32_t *__restrict__ order,
+                                                             int tail_n0) {
     // one wave per point: lanes over the views (list lengths, 0 for views that do not see the point) and over the ranks
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + wave;
@@ -1243,7 +1250,7 @@ __global__ __launch_bounds__(256) void mh_search_work_kernel(const uint8_t *__re
     const bool usable = lane > 0 && lane < nrank && base_val[(size_t)(lane * rank_step) * N + n] > 0.0f;
     const unsigned long long m = __ballot(usable);
     const int nvalid = m ? (64 - __builtin_clzll(m)) : 1;   // last usable rank + 1
-    if (lane == 0) order[n] = mh_work_class(nt, nvalid, V, P1, S, T);
+    if (lane == 0) order[n] = n >= tail_n0 ? 0 : mh_work_class(nt, nvalid, V, P1, S, T);   // (MhWorkArgs::tail_n0)
 }
 
 // Points per (rank, base view) of the batch -- the M of mh_group_forms: gcnt[r * V + b] = #{n : base_idx[r * rank_step, n] == b}.
@@ -1544,7 +1551,7 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
         if (variant != 7 && order && N > 1) {
             if (variant == 6 || variant == 9)
                 hipLaunchKernelGGL(mh_search_work_kernel, dim3((N + 3) / 4), dim3(256), 0, st, cnt, vw.V, N, P1, base_val,
-                                   nrank, rank_step, S, 256, order);
+                                   nrank, rank_step, S, 256, order, (int)(rule.tail_col0 / S));
             if (variant != 10) hipLaunchKernelGGL(mh_search_order_kernel, dim3(1), dim3(1024), 0, st, N, order);
             ord = order + N;
         }
