@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="mh_ctx_set_option on the headline context (A/B runs, e.g. --option reproject_rule=1 --option "
+                         "sum_block=0 = the batch-independent arithmetic of rounds 1-4); recorded in config.options")
     ap.add_argument("--topk-order", type=int, default=-1, help="0 torch.topk's tie order (default), 1 index order (A/B)")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the independent iterations alternate on (as monohair_amd.pmvo.optimize does)")
@@ -160,6 +163,9 @@ def main():
         pm.set_option("search_variant", a.variant)
     if a.topk_order >= 0:
         pm.set_option("topk_order", a.topk_order)
+    for kv in a.option:
+        k, v = kv.split("=")
+        pm.set_option(k, int(v))
 
     # candidate points of the 256^3 volume; keep the ones the reference would send to optimize()
     # (filter_negative_points, PMVO.py:535-557), then chunk by 5000 and deal the chunks to the ranks
@@ -266,6 +272,7 @@ def main():
             "parallelism": "points sharded over %d GPU(s) (one process each), views replicated; no collective inside "
                            "an iteration" % world,
             "devices": devices_seen,
+            "options": dict(kv.split("=") for kv in a.option),
             "maps": "8-bit file codes (PMVO.from_u8)" if a.codes else ("quantized-8bit" if a.quantize else "continuous"),
             "streams": len(streams),
             "prewarm_steps": PREWARM,
@@ -342,8 +349,8 @@ def main():
         except Exception as e:
             out["cpu_baseline"] = {"error": repr(e)[:200]}
     if world > 1 and not a.no_cpu and scene is not None:
-        # N > 1: no CPU baseline leg, but the line still verifies itself -- rank 0's last timed step against the oracle on a
-        # bounded sample of its chunk (512 points: a fraction of a second of host time)
+        # N > 1: no CPU baseline leg, but the line still verifies itself -- rank 0's last timed step against the oracle on
+        # its chunk (one untimed pass: about a second of host time)
         try:
             _, out["parity_check"] = cpu_baseline(a, scene, recs, last_chunk, ms, last, check_only=512)
             out["parity_check"]["rank"] = 0
@@ -973,8 +980,8 @@ def cpu_baseline(a, scene, recs, chunk, gpu_ms, gpu_result, check_only=0):
     same iteration: the first n points of the chunk against all views.  `chunk` is the chunk the LAST step of the timed
     region processed and `gpu_result` what that step returned: the oracle's (orientation, loss, high-confidence flag) for the
     sample is compared with it bit for bit -> (cpu_baseline, parity_check); a mismatch raises ParityError.
-    check_only = n > 0 (the N > 1 runs, where the CPU baseline is not reported): one untimed oracle pass over the first n
-    points, only the comparison is returned -> (None, parity_check).  This function is the one place bench.py uses the oracle."""
+    check_only > 0 (the N > 1 runs, where the CPU baseline is not reported): one untimed oracle pass over the chunk, only the
+    comparison is returned -> (None, parity_check).  This function is the one place bench.py uses the oracle."""
     import numpy as np
 
     import oracle
@@ -984,9 +991,17 @@ def cpu_baseline(a, scene, recs, chunk, gpu_ms, gpu_result, check_only=0):
                          scene["conf"].cpu().numpy(), scene["mask"].cpu().numpy())
     cores = oracle.num_threads()
     offs = depth_offsets(90)
+    # (A/B runs with --option: the oracle follows the same arithmetic options as the context)
+    opts = dict(kv.split("=") for kv in a.option)
+    oracle.set_reproject_rule({0: "group", 1: "mid", 2: "chain"}[int(opts.get("reproject_rule", 0))],
+                              int(opts.get("reproject_fma_min_cols", oracle.REF_FMA_MIN_COLS)))
+    oracle.set_sum_block(int(opts.get("sum_block", 32)))
+    # A point's answer depends on the batch it is in (the (rank, base view) group sizes select how the reference's sgemms
+    # round, the batch's last samples sit in the trailing columns of its sums): the comparison is always WHOLE chunk against
+    # whole chunk, whatever part of it the timed sample covers.
     if check_only:
-        n = min(int(check_only), len(chunk))
-        return None, compare_with_oracle(gpu_result, oracle.forward(views, chunk[:n], a.patch, a.conf_threshold, offs), n)
+        n = len(chunk)
+        return None, compare_with_oracle(gpu_result, oracle.forward(views, chunk, a.patch, a.conf_threshold, offs), n)
     n = a.cpu_points if a.cpu_points > 0 else len(chunk)
     # repeat the sample until >= 12 s of CPU work have been timed (bounded: at most 40 repeats)
     t, reps = 0.0, 0
@@ -995,7 +1010,9 @@ def cpu_baseline(a, scene, recs, chunk, gpu_ms, gpu_result, check_only=0):
         o_res = oracle.forward(views, chunk[:n], a.patch, a.conf_threshold, offs)
         t += time.perf_counter() - t0
         reps += 1
-    parity = compare_with_oracle(gpu_result, o_res, n)
+    if n < len(chunk):
+        o_res = oracle.forward(views, chunk, a.patch, a.conf_threshold, offs)
+    parity = compare_with_oracle(gpu_result, o_res, len(chunk))
     n_total = n * reps
     its = (n_total / float(CHUNK)) / t
     return {
