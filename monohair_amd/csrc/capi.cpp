@@ -496,7 +496,8 @@ static size_t search_count_offset(const mh_ctx *ctx, int N, int patch) {
     return search_order_offset(ctx, N, patch) + 2 * (size_t)N * sizeof(int32_t);
 }
 
-// behind the list lengths: the points per (rank, base view) of the batch (16 ranks x V ints) -- csrc/mh_device.h: MhRule
+// behind the list lengths: the points per (rank, base view) of the batch (16 partial copies x 16 ranks x V ints) --
+// csrc/mh_device.h: MhRule
 static size_t search_groups_offset(const mh_ctx *ctx, int N, int patch) {
     return (search_count_offset(ctx, N, patch) + (size_t)ctx->V * (size_t)N + 255) & ~(size_t)255;
 }
@@ -512,7 +513,7 @@ extern "C" size_t mh_search_scratch_bytes(mh_ctx *ctx, int N, int patch) {
     // + 2N ints behind them: the launch order of the search (mh_search_order_kernel) and its staging area
     // + V*N bytes: the list lengths once more, compact, for the work estimate
     // + the group sizes of the batch (search_groups_offset)
-    return search_groups_offset(ctx, N, patch) + (size_t)16 * ctx->V * sizeof(int32_t);
+    return search_groups_offset(ctx, N, patch) + (size_t)16 * 16 * ctx->V * sizeof(int32_t);
 }
 
 extern "C" int mh_search_forward(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank,
@@ -564,7 +565,7 @@ static int forward_prepare(mh_ctx *ctx, const float *points, int N, int patch, f
                                            (uint8_t *)scratch + search_count_offset(ctx, N, patch), ctx->taps_tile,
                                            ctx->codes_ready() ? ctx->oc : nullptr, ctx->code_tabs,
                                            (int32_t *)((char *)scratch + search_groups_offset(ctx, N, patch)),
-                                           zero_groups ? 16 * ctx->V : 0, (hipStream_t)stream),
+                                           zero_groups ? 16 * 16 * ctx->V : 0, (hipStream_t)stream),
                     "mh_forward_prepare");
 }
 
@@ -839,7 +840,7 @@ extern "C" int mh_sample_next(mh_ctx *ctx, const float *points, const int32_t *b
     // (the V group sizes of this batch -- stream-ordered work space, so that calls on several streams do not share it)
     int32_t *gcnt = nullptr;
     if (ctx->reproject_rule == 0)
-        MH_HIP(hipMallocAsync((void **)&gcnt, sizeof(int32_t) * (size_t)ctx->V, (hipStream_t)stream));
+        MH_HIP(hipMallocAsync((void **)&gcnt, sizeof(int32_t) * (size_t)16 * 16 * ctx->V, (hipStream_t)stream));
     const int rc = launched(mh_launch_sample_next(ctx->views(), points, base_view, ori, offsets, N, S, samples,
                                                   ctx->reproject_rule, ctx->reproject_fma_min_cols, gcnt,
                                                   (hipStream_t)stream),

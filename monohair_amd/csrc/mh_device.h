@@ -69,8 +69,13 @@ __device__ __forceinline__ void mh_pixel_of(const float *__restrict__ cam, float
 // MhRule carries what a kernel needs to follow the batch; mode 1 / 2 force the mid / chain forms for every point.
 #define MH_FORM_GEMV 1
 #define MH_FORM_CHAIN 2
+// The counts are kept in MH_GROUP_COPIES partial arrays (a workgroup of the counting kernel adds to copy blockIdx % COPIES):
+// up to 670 points of a 5000-point chunk share one (rank, base view), and that many atomics on ONE address drain in ~9 us.
+#define MH_GROUP_COPIES 16
+#define MH_GROUP_RANKS 16   // = MH_MAX_RANKS of the search
 struct MhRule {
-    const int32_t *gcnt;    // [nrank][V] points per (rank, base view) of this batch (nullptr: every group counts as mid-size)
+    const int32_t *gcnt;    // [MH_GROUP_COPIES][MH_GROUP_RANKS][V] partial counts of the points per (rank, base view) of this
+                            // batch (nullptr: every group counts as mid-size)
     long long tail_col0;    // first trailing column of the [V, N*S] sums; N*S if none
     int mode;               // 0 follow the group size, 1 mid forms, 2 chain forms
     int fma_min_cols;       // chain-form reprojection from this many columns on
@@ -79,7 +84,12 @@ struct MhRule {
 __device__ __forceinline__ int mh_group_forms(const MhRule &rule, int rank, int V, int b, int S) {
     if (rule.mode == 1) return 0;
     if (rule.mode == 2) return MH_FORM_CHAIN;
-    const int M = rule.gcnt ? rule.gcnt[rank * V + b] : 2;
+    int M = 2;
+    if (rule.gcnt) {
+        M = 0;
+#pragma unroll
+        for (int k = 0; k < MH_GROUP_COPIES; ++k) M += rule.gcnt[(k * MH_GROUP_RANKS + rank) * V + b];
+    }
     const long long cols = (long long)M * S;
     return (M == 1 ? MH_FORM_GEMV : 0) | ((cols <= 3 || cols >= rule.fma_min_cols) ? MH_FORM_CHAIN : 0);
 }
@@ -300,7 +310,8 @@ __device__ __forceinline__ void mh_casc_flush(MhCasc &c) {
 struct MhWorkArgs {
     const uint8_t *cnt;   // [V,N] tap-list lengths
     int32_t *cls;         // [N] out: work class (nullptr: not wanted)
-    int32_t *gcnt;        // [nrank][V] out, zeroed by the front end: points per (rank, base view) (MhRule; nullptr: not wanted)
+    int32_t *gcnt;        // [MH_GROUP_COPIES][MH_GROUP_RANKS][V] out, zeroed by the front end: partial counts of the points per
+                          // (rank, base view) (MhRule; nullptr: not wanted)
     int P1, nrank, rank_step, S, T;
     int tail_n0;          // points >= tail_n0 hold trailing columns of the batch's sums: class 0 (mh_search3_kernel evaluates
                           // those once more in its epilogue -- such a workgroup should start first, not last)

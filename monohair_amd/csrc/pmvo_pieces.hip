@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void mh_compute_visible_kernel(const float *__
     if (i < n) out[i] = mh_soft_visible(depth[i], z[i]);
 }
 
-// points per base view among base_view[0..N) (the M of mh_group_forms): gcnt[V], zeroed by the launcher
+// points per base view among base_view[0..N) (the M of mh_group_forms) into rank 0 of copy 0 of a zeroed MhRule::gcnt array
 __global__ __launch_bounds__(256) void mh_piece_group_sizes_kernel(const int32_t *__restrict__ base_view, int N, int V,
                                                                    int32_t *__restrict__ gcnt) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -250,14 +250,16 @@ extern "C" int mh_launch_compute_visible(const float *depth, const float *z, siz
 }
 extern "C" int mh_launch_sample_next(MhViews vw, const float *pts, const int32_t *base_view, const float *ori,
                                      const float *offs, int N, int S, float *out, int rule_mode, int fma_min_cols,
-                                     int32_t *gcnt /* V ints of work space (rule_mode 0) */, hipStream_t st) {
+                                     int32_t *gcnt /* MH_GROUP_COPIES * MH_GROUP_RANKS * V ints of work space (rule_mode 0) */,
+                                     hipStream_t st) {
     const long long tot = (long long)N * S;
     MhRule rule = {};
     rule.mode = rule_mode;
     rule.fma_min_cols = fma_min_cols;
     if (rule_mode == 0) {
         if (!gcnt) return -1;
-        if (hipMemsetAsync(gcnt, 0, sizeof(int32_t) * (size_t)vw.V, st) != hipSuccess) return -1;
+        if (hipMemsetAsync(gcnt, 0, sizeof(int32_t) * (size_t)MH_GROUP_COPIES * MH_GROUP_RANKS * vw.V, st) != hipSuccess)
+            return -1;
         hipLaunchKernelGGL(mh_piece_group_sizes_kernel, dim3((N + 255) / 256), dim3(256), 0, st, base_view, N, vw.V, gcnt);
         rule.gcnt = gcnt;
     }

@@ -249,7 +249,8 @@ __global__ __launch_bounds__(64 * W) void mh_topk_wave_kernel(const float *__res
         if (lane == 0) wk.cls[n] = n >= wk.tail_n0 ? 0 : mh_work_class(nt, nvalid, V, wk.P1, wk.S, wk.T);
         // ... and the points per (rank, base view) of the batch (mh_device.h: MhRule): one fire-and-forget atomic per used
         // rank into the array the front end zeroed
-        if (wk.gcnt && lane < MH_TOPK && r * wk.rank_step == lane && r < wk.nrank) atomicAdd(&wk.gcnt[r * V + a.i[0]], 1);
+        if (wk.gcnt && lane < MH_TOPK && r * wk.rank_step == lane && r < wk.nrank)
+            atomicAdd(&wk.gcnt[(((int)blockIdx.x & (MH_GROUP_COPIES - 1)) * MH_GROUP_RANKS + r) * V + a.i[0]], 1);
     }
 }
 

@@ -1270,7 +1270,7 @@ __global__ __launch_bounds__(256) void mh_group_sizes_kernel(const int32_t *__re
     }
     __syncthreads();
     for (int i = tid; i < V; i += 256)
-        if (s_g[i]) atomicAdd(&gcnt[r * V + i], s_g[i]);
+        if (s_g[i]) atomicAdd(&gcnt[(((int)blockIdx.x & (MH_GROUP_COPIES - 1)) * MH_GROUP_RANKS + r) * V + i], s_g[i]);
 }
 
 __global__ __launch_bounds__(1024) void mh_search_order_kernel(int N, int32_t *__restrict__ order) {
@@ -1514,7 +1514,7 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
                                 const uint8_t *cnt /* [V,N] list lengths */,
                                 float *line_ori, float *min_loss, uint8_t *high_conf, float *best_sample,
                                 int32_t *best_rank, int32_t *best_s, int variant, int rule_mode, int fma_min_cols,
-                                int sum_block, int32_t *gcnt /* nrank*V ints of work space */,
+                                int sum_block, int32_t *gcnt /* MH_GROUP_COPIES * MH_GROUP_RANKS * V ints of work space */,
                                 int groups_ready /* gcnt holds the batch's group sizes already (the fused forward) */,
                                 hipStream_t st) {
     const int nitems = nrank * S;
@@ -1535,7 +1535,7 @@ extern "C" int mh_launch_search(MhViews vw, const float *offs, int S, int nrank,
     if (select_body) variant -= 100;
     if (variant == 10) groups_ready = 1;
     if (rule.gcnt && !groups_ready) {
-        if (hipMemsetAsync(gcnt, 0, sizeof(int32_t) * (size_t)nrank * vw.V, st) != hipSuccess) return -1;
+        if (hipMemsetAsync(gcnt, 0, sizeof(int32_t) * (size_t)MH_GROUP_COPIES * MH_GROUP_RANKS * vw.V, st) != hipSuccess) return -1;
         hipLaunchKernelGGL(mh_group_sizes_kernel, dim3((N + 255) / 256, nrank), dim3(256), sizeof(int) * (size_t)vw.V, st,
                            base_idx, N, vw.V, rank_step, gcnt);
     }
