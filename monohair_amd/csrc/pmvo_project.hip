@@ -546,14 +546,18 @@ __global__ __launch_bounds__(256) void mh_project_taps_codes_kernel(MhViews vw, 
 // instead of three.  Arithmetic, eligibility, duplicate rule (hash table + bit compare) and record layout are those of
 // the unfused pair mh_project_gather_kernel + mh_prep_taps_kernel: the tap lists are identical.
 // ---------------------------------------------------------------------------------------------
-template <int PATCH>
+// PW = points per wave (lane = point for the projection): 16 gives the kernel its best time alone (72 us; more waves = more
+// of their dependent chains overlap), 64 the best ITERATION (fewer, longer waves take less slot time from the search that
+// runs beside it on the other streams: +1.4 % iterations/s at 90 us alone) -- the metric is iterations/s, 64 is the default
+// (round 5; option "taps_tile" 16 / 32 selects the others).
+template <int PATCH, int PW>
 __global__ __launch_bounds__(256) void mh_project_taps2_kernel(MhViews vw, const float *__restrict__ pts, int N, int tiles,
                                                                float thr, float *__restrict__ vis,
                                                                float *__restrict__ ori, float *__restrict__ conf,
                                                                float *__restrict__ mask, float4 *__restrict__ taps,
                                                                uint8_t *__restrict__ cnt, int32_t *__restrict__ zero,
                                                                int nzero) {
-    constexpr int P = PATCH * PATCH, HP = PATCH / 2, NCH = (P + MH_WAVE - 1) / MH_WAVE, PW = 16;
+    constexpr int P = PATCH * PATCH, HP = PATCH / 2, NCH = (P + MH_WAVE - 1) / MH_WAVE;
     constexpr int INF = NCH == 1 ? 8 : 4;            // points whose patch gathers are in flight together (32 VGPRs)
     __shared__ float2 s_o[4][MH_PREP_PMAX];
     __shared__ float s_c[4][MH_PREP_PMAX];
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(256) void mh_project_taps2_kernel(MhViews vw, const
     const int V = vw.V, H = vw.H, W = vw.W;
     if (bid >= V * tiles) return;
     const int v = bid / tiles, tile = bid - v * tiles;
-    const int n0 = tile * MH_PG_TILE + wave * PW;
+    const int n0 = tile * (4 * PW) + wave * PW;
     const float4 *__restrict__ rec = vw.rec + (size_t)v * H * W;
     const int n = n0 + lane;
     const bool mine = lane < PW && n < N;
@@ -805,16 +809,24 @@ extern "C" int mh_launch_project_taps(MhViews vw, const float *pts, int N, int p
     const MhCodeTabs *tabs = (const MhCodeTabs *)tabs_v;
     const bool codes = oc && tabs;
     if (patch * patch > MH_PREP_PMAX) return -1;
-    (void)tile;      // (round 3's A/B switch between tile sizes of the first fused form; one form per map kind is left)
-    const int tiles = (N + 63) / 64;
+    // points per wave of the fp32 form: 64 (default; tile 0 / 1 / 64), 32 or 16 (A/B; 16 = the kernel's own best time).  The
+    // codes form keeps 16.
+    const int pw = codes ? 16 : (tile == 16 || tile == 32 ? tile : 64);
+    const int tiles = (N + 4 * pw - 1) / (4 * pw);
     const dim3 grid((vw.V * tiles + 7) & ~7), block(256);
 #define MH_PT_CASE(PS)                                                                                             \
     case PS:                                                                                                       \
         if (codes)                                                                                                 \
             hipLaunchKernelGGL((mh_project_taps_codes_kernel<PS>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, \
                                conf, mask, taps, cnt, oc, tabs, zero, nzero);                                      \
+        else if (pw == 64)                                                                                         \
+            hipLaunchKernelGGL((mh_project_taps2_kernel<PS, 64>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, conf, \
+                               mask, taps, cnt, zero, nzero);                                                     \
+        else if (pw == 32)                                                                                         \
+            hipLaunchKernelGGL((mh_project_taps2_kernel<PS, 32>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, conf, \
+                               mask, taps, cnt, zero, nzero);                                                     \
         else                                                                                                       \
-            hipLaunchKernelGGL((mh_project_taps2_kernel<PS>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, conf, \
+            hipLaunchKernelGGL((mh_project_taps2_kernel<PS, 16>), grid, block, 0, st, vw, pts, N, tiles, thr, vis, ori, conf, \
                                mask, taps, cnt, zero, nzero);                                                     \
         break;
     switch (patch) {

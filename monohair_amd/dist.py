@@ -146,18 +146,21 @@ def all_gather_rows_inplace(buf, lo, s):
         out.copy_(torch.cat(parts, 0).to(buf.device))
 
 
-_INPLACE_GATHER_OK = {}     # device index -> bool, decided ONCE per process group by inplace_gather_supported
+_INPLACE_GATHER_OK = {}     # (device index, backend, process-group identity) -> bool, decided ONCE per process group
 
 
 def inplace_gather_supported(device):
     """Can this torch build's all_gather_into_tensor take an input that aliases its slice of the output (NCCL's in-place
     form, sendbuff == recvbuff + rank*count)?  Decided once, on a 256-byte probe, and AGREED by all ranks with one
     all_reduce(MIN): a rank that falls back on its own would issue a collective its peers never enter (deadlock).  An
-    argument check that rejects the aliasing raises before any traffic; the exception is logged, not swallowed."""
+    argument check that rejects the aliasing raises before any traffic (on every rank alike -- a probe that raised on some
+    ranks only would leave the others inside the collective); the exception is logged, not swallowed.  The verdict is
+    cached per (device, backend, process group): a group that is destroyed and made again is probed again."""
     import warnings
 
     d = _dist()
-    key = torch.device(device).index or 0
+    pg = d.distributed_c10d._get_default_group() if hasattr(d, "distributed_c10d") else None
+    key = (torch.device(device).index or 0, d.get_backend(), id(pg))
     if key not in _INPLACE_GATHER_OK:
         R, r = world(), rank()
         ok = 1

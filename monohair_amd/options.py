@@ -141,7 +141,18 @@ def process_options(opt):
                 key = "%s|%s|%s" % (os.environ.get("TORCHELASTIC_RUN_ID", ""), os.environ.get("MASTER_ADDR", ""),
                                     os.environ.get("MASTER_PORT", ""))
                 if "TORCHELASTIC_RUN_ID" in os.environ:
-                    key += "|%d|%s" % (os.getppid(), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+                    key += "|%s" % os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+                    # the agent's pid makes the values differ from launch to launch -- but only ranks that are direct
+                    # children of ONE agent share it: one node (every rank local), no wrapper process in between
+                    one_agent = os.environ.get("LOCAL_WORLD_SIZE") == os.environ.get("WORLD_SIZE") and \
+                        os.environ.get("GROUP_WORLD_SIZE", "1") == "1"
+                    if one_agent and not os.environ.get("MH_NO_PPID_SEED"):
+                        key += "|%d" % os.getppid()
+                    else:
+                        warnings.warn("options: unseeded multi-node (or wrapped) torchrun launch without an initialised "
+                                      "process group: the output-name suffix and the candidate jitter are derived from the "
+                                      "rendezvous id / address / port only (give --name / --seed, or initialise the process "
+                                      "group first)")
                 else:
                     warnings.warn("options: unseeded multi-rank run without an initialised process group and without "
                                   "torchrun: the output-name suffix and the candidate jitter are derived from "

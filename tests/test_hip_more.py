@@ -122,7 +122,7 @@ def test_voxel_fit_vs_oracle_and_golden():
     assert np.array_equal(nz, z["mat_occ_nz"])
     Z = occ_l.shape[2]
     got = np.stack([ori_l[nz[:, 0], nz[:, 1], c * Z + nz[:, 2]] for c in range(3)], 1)
-    assert np.all(got == z["mat_ori_at_nz"], axis=1).mean() >= 0.995
+    assert np.all(got == z["mat_ori_at_nz"], axis=1).all()            # every voxel's orientation, bit for bit
 
 
 def test_gabor_vs_oracle_and_golden():
@@ -149,6 +149,9 @@ def test_gabor_vs_oracle_and_golden():
             assert np.array_equal(best[0, 0].cpu().numpy(), ref_best), (name, variant)    # radians, bitwise, every pixel
             cf = conf[0, 0].cpu().numpy()
             assert np.allclose(cf, ref_conf, rtol=0, atol=1.2e-7) and (cf == ref_conf).mean() >= 0.998   # <= 1 ulp, rarely
+            # ... and never across a boundary of the 8-bit code the reference writes to conf/<view>.png (what PMVO reads)
+            code = lambda x: np.clip(x.astype(np.float32) * np.float32(255) + np.float32(0.5), 0, 255).astype(np.uint8)   # noqa: E731
+            assert np.array_equal(code(cf), code(ref_conf)), (name, variant)
             assert np.array_equal(two[0].cpu().numpy(), ref_two)
             assert two.shape == (1, 2) + img.shape and best.shape == (1, 1) + img.shape
     gab.set_variant("mfma2")
@@ -157,6 +160,15 @@ def test_gabor_vs_oracle_and_golden():
     t = torch.from_numpy(z["mixed_img"])[None, None].to(DEV)
     two, best, conf = gab(t, None, 2, threshold=0.3)
     agree = best[0, 0].cpu().numpy() == z["mixed_iter2_best"]
+    # The second pass filters the CONFIDENCE of the first (GaborFilter.py:104-106), which equals the reference's to within one
+    # float32 ulp on < 0.2 % of the pixels (above): a pixel of the second pass can differ only if such a pixel lies inside
+    # its 17 x 17 window.  Asserted: every disagreeing pixel has one, and they are few.
+    from scipy.ndimage import binary_dilation
+
+    _, _, conf1 = gab(t, None, 1, threshold=0.0)
+    seed = conf1[0, 0].cpu().numpy() != z["mixed_conf"]
+    reach = binary_dilation(seed, structure=np.ones((17, 17), bool))
+    assert not (~agree & ~reach).any(), int((~agree & ~reach).sum())
     assert agree.mean() >= 0.995, agree.mean()
     assert np.allclose(conf[0, 0].cpu().numpy()[agree], z["mixed_iter2_conf"][agree], rtol=0, atol=1e-6)
     assert np.allclose(two[0].cpu().numpy()[:, agree], z["mixed_iter2_two"][:, agree], rtol=0, atol=1e-7)

@@ -142,9 +142,20 @@ def test_infer_inner_merge_and_mat_files(tmp_path):
     assert len(set(map(tuple, nz[:, [1, 0, 2]].tolist())) & set(zip(x.tolist(), y.tolist(), z.tolist()))) > 0
 
 
+def conf_code(conf):
+    """the 8-bit code the reference writes for a confidence (preprocess_capture_data/GaborFilter.py:210: torchvision's
+    save_image = mul(255).add_(0.5).clamp_(0, 255) in float32, then the truncating cast to uint8)"""
+    c = conf.astype(np.float32) * np.float32(255.0) + np.float32(0.5)
+    return np.clip(c, 0, 255).astype(np.uint8)
+
+
 def test_gabor_bank_vs_reference():
     z = load_npz("gabor")
     bank = z["bank"]
+    # what PMVO reads is the 8-bit FILE of the confidence: the <= 1-ulp differences below must not cross a code boundary
+    for name in ("stripes0", "stripes30", "stripes90", "stripes135", "noise", "mixed"):
+        _, conf, _ = oracle.gabor_bank(bank, z[name + "_img"])
+        assert np.array_equal(conf_code(conf), conf_code(z[name + "_conf"])), name      # every pixel's code
     for name, want in (("stripes0", 0), ("stripes30", 30), ("stripes90", 90), ("stripes135", 135)):
         orient, conf, var = oracle.gabor_bank(bank, z[name + "_img"])
         ref_idx = np.rint(z[name + "_best"] * 180.0 / np.pi).astype(np.int32)
