@@ -785,6 +785,12 @@ __device__ __forceinline__ void mh_key_block4(unsigned (&ke)[KN], unsigned (&ko)
 #ifndef MH_S3_WAVES
 #define MH_S3_WAVES 5   // waves per SIMD the register allocation aims at (A/B builds: -DMH_S3_WAVES=4|6)
 #endif
+#ifndef MH_PAIR_TAPS
+#define MH_PAIR_TAPS 4    // select-only kernel: two views whose lists hold at most this many taps are evaluated together
+#endif
+#ifndef MH_S3_WAVES_SELECT
+#define MH_S3_WAVES_SELECT MH_S3_WAVES   // the same aim for the select-only kernel (A/B builds: -DMH_S3_WAVES_SELECT=4)
+#endif
 #define MH_S3_CAP 1280   // float4 records per workgroup (20 KB; 6 workgroups of 25 KB per CU)
 
 // the cascade of mh_device.h (MhCascV) with the third level only where it can be reached
@@ -1003,6 +1009,74 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
             cnt[j] += (w > 0.0f) ? 1 : 0;
         }
     };
+    // Two views in flight (select-only kernel, short lists -- the regime of 8-bit maps, ~2 taps per list): there the time of a
+    // view is the dependent chain of its projection (camera record, rcp, sqrt, two refined divisions: 98 of the kernel's 211 us,
+    // 24 for the taps), and five waves per SIMD do not hide it (issue utilisation 0.53).  The projections of TWO visible views
+    // are written as one block of straight-line code, so that the scheduler interleaves the two chains; then the two short tap
+    // loops, then the accumulation in view order -- the same operations on the same values as two calls of one_view.
+    // (The caller pairs views only inside one 16-view block of the cascade: no flush between them.)
+    auto two_views = [&](int va, const float4 *reca, int na, int vb2, const float4 *recb, int nb) {
+        const float *__restrict__ cama = vw.cams + va * MH_CAM_STRIDE;
+        const float *__restrict__ camb = vw.cams + vb2 * MH_CAM_STRIDE;
+        const float4 ha = reca[0], hb = recb[0];
+        const float4 ta = reca[1], tb = recb[1];
+        float DXa[KN], DYa[KN], DXb[KN], DYb[KN];
+#pragma unroll
+        for (int jp = 0; jp < KA / 2; ++jp) {
+            mh_v2f ra, ca, rb, cb, dxa, dya, dxb, dyb;
+            const mh_v2f x0 = mh_v2f{X0[2 * jp], X0[2 * jp + 1]}, x1 = mh_v2f{X1[2 * jp], X1[2 * jp + 1]},
+                         x2 = mh_v2f{X2[2 * jp], X2[2 * jp + 1]};
+            mh_pixel_of_fast2(cama, x0, x1, x2, Hf, Wf, ra, ca);
+            mh_pixel_of_fast2(camb, x0, x1, x2, Hf, Wf, rb, cb);
+            mh_unit2_fast2(ra - mh_splat(ha.z), ca - mh_splat(ha.w), dxa, dya);
+            mh_unit2_fast2(rb - mh_splat(hb.z), cb - mh_splat(hb.w), dxb, dyb);
+            DXa[2 * jp] = dxa.x; DXa[2 * jp + 1] = dxa.y; DYa[2 * jp] = dya.x; DYa[2 * jp + 1] = dya.y;
+            DXb[2 * jp] = dxb.x; DXb[2 * jp + 1] = dxb.y; DYb[2 * jp] = dyb.x; DYb[2 * jp + 1] = dyb.y;
+        }
+        if constexpr (KA & 1) {
+            mh_v2f ra, ca, rb, cb, dxa, dya, dxb, dyb;
+            const mh_v2f x0 = mh_splat(X0[KA - 1]), x1 = mh_splat(X1[KA - 1]), x2 = mh_splat(X2[KA - 1]);
+            mh_pixel_of_fast2(cama, x0, x1, x2, Hf, Wf, ra, ca);
+            mh_pixel_of_fast2(camb, x0, x1, x2, Hf, Wf, rb, cb);
+            mh_unit2_fast2(ra - mh_splat(ha.z), ca - mh_splat(ha.w), dxa, dya);
+            mh_unit2_fast2(rb - mh_splat(hb.z), cb - mh_splat(hb.w), dxb, dyb);
+            DXa[KA - 1] = dxa.x; DYa[KA - 1] = dya.x;
+            DXb[KA - 1] = dxb.x; DYb[KA - 1] = dyb.x;
+        }
+        float MLa[KN], BCa[KN], MLb[KN], BCb[KN];
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int j = 0; j < KA; ++j) {
+            MLa[j] = mh_one_minus_abs(mh_vadd(mh_vmul(ta.x, DXa[j]), mh_vmul(ta.y, DYa[j])));
+            BCa[j] = ta.z;
+            MLb[j] = mh_one_minus_abs(mh_vadd(mh_vmul(tb.x, DXb[j]), mh_vmul(tb.y, DYb[j])));
+            BCb[j] = tb.z;
+        }
+        for (int t = 1; t < na; ++t) {   // uniform
+            const float4 tp = reca[1 + t];
+            float l[KN];
+#pragma unroll
+            for (int j = 0; j < KA; ++j) l[j] = mh_one_minus_abs(mh_vadd(mh_vmul(tp.x, DXa[j]), mh_vmul(tp.y, DYa[j])));
+            mh_tap_update<KN>(MLa, BCa, l, tp.z);
+        }
+        for (int t = 1; t < nb; ++t) {
+            const float4 tp = recb[1 + t];
+            float l[KN];
+#pragma unroll
+            for (int j = 0; j < KA; ++j) l[j] = mh_one_minus_abs(mh_vadd(mh_vmul(tp.x, DXb[j]), mh_vmul(tp.y, DYb[j])));
+            mh_tap_update<KN>(MLb, BCb, l, tp.z);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < KA; ++j) {
+            num[j].a0 = num[j].a0 + MLa[j] * BCa[j];
+            den[j].a0 = den[j].a0 + BCa[j];
+            cnt[j] += (BCa[j] > 0.0f) ? 1 : 0;
+            num[j].a0 = num[j].a0 + MLb[j] * BCb[j];
+            den[j].a0 = den[j].a0 + BCb[j];
+            cnt[j] += (BCb[j] > 0.0f) ? 1 : 0;
+        }
+    };
     const int lane = tid & 63, wave = tid >> 6;
     for (int vb = 0; vb < V; vb += 64) {
         const int vv = vb + lane;
@@ -1053,6 +1127,20 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
                     flush_upto(vb + b);
                     const int L = __builtin_amdgcn_readlane(len, b);
                     const int off = __builtin_amdgcn_readlane(pre, b) - L - base;
+#ifndef MH_NO_VIEW_PAIRS
+                    if constexpr (!KEYS) {   // (see two_views)
+                        if (m && L <= MH_PAIR_TAPS + 1) {
+                            const int b2 = (int)__builtin_ctzll(m);
+                            const int L2 = __builtin_amdgcn_readlane(len, b2);
+                            if (L2 <= MH_PAIR_TAPS + 1 && vb + b2 < nf) {
+                                m &= m - 1;
+                                const int off2 = __builtin_amdgcn_readlane(pre, b2) - L2 - base;
+                                two_views(vb + b, s_taps + off, L - 1, vb + b2, s_taps + off2, L2 - 1);
+                                continue;
+                            }
+                        }
+                    }
+#endif
                     one_view(vb + b, s_taps + off, KEYS ? __builtin_amdgcn_readlane(c, b) : L - 1);
                 }
             }
@@ -1080,7 +1168,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
 template <int T, bool BIGV, bool KEYS, bool BIGP>
 // amdgpu_waves_per_eu(5): the register allocator stops at 96 VGPRs (it takes 109 unconstrained = 4 waves per SIMD); the
 // few values it spills are reloaded once per view.  Measured: 4 waves 1305 it/s, 5 waves 1345, 6 waves (80 VGPRs) 1328.
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(MH_S3_WAVES))) void mh_search3_kernel(MhViews vw, const float *__restrict__ offs, int S, int nrank,
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(KEYS ? MH_S3_WAVES : MH_S3_WAVES_SELECT))) void mh_search3_kernel(MhViews vw, const float *__restrict__ offs, int S, int nrank,
                                                        int rank_step, const float *__restrict__ pts, int N, int P1,
                                                        float thr, const float *__restrict__ ori_c,
                                                        const int32_t *__restrict__ base_idx,

@@ -30,9 +30,11 @@ ap.add_argument("--codes", action="store_true", help="maps uploaded as random 8-
 ap.add_argument("--ori-mode", default="", help="adversarial orientation fields for the tap search (continuous maps only): "
                 "'mix' draws per scene from: const (one direction per view + tiny noise on a few pixels: near-ties, lists of "
                 "1-3 taps), two (two exactly perpendicular directions), axis ((1,0)/(0,1)/(0,0)), fine (a fan of directions "
-                "1e-7..1e-4 rad apart: many taps on the flat top of the cosine, losses 0 and below); 'nan' (NaN pixels) is not part of "
-                "'mix': NaN map pixels are outside the pinned domain (the front-end kernels and the oracle treat them differently, "
-                "with either tap body of the search)")
+                "1e-7..1e-4 rad apart: many taps on the flat top of the cosine, losses 0 and below).  There is no NaN mode: NaN pixels "
+                "in the orientation MAPS are outside the pinned domain (map files are 8-bit; docs/PARITY.md) -- the reference and "
+                "the oracle turn a NaN first tap of a view that does NOT see the point into a NaN loss (NaN x weight 0), the "
+                "kernels never gather the patches of such views.  NaN taps of views that do see the point agree: "
+                "tests/test_key_reeval_gpu.py")
 ap.add_argument("--body", type=int, default=0, help="tap body of the shipped search: 0 by the maps, 1 keys, 2 select (option search_body)")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
@@ -100,8 +102,8 @@ while time.time() < t_end:
             elif mode == "fine":
                 th = ang + rng.integers(0, 64, o.shape[:3]) * 10.0 ** rng.uniform(-7.5, -4)
                 o = (np.stack([np.cos(th), np.sin(th)], -1) * rng.uniform(0.5, 2.0, o.shape[:3] + (1,))).astype(np.float32)
-            elif mode == "nan":
-                o[rng.random(o.shape[:3]) < 0.02] = np.nan
+            elif mode != "plain":
+                raise SystemExit("--ori-mode must be one of mix, const, two, axis, fine, plain")
             scene["ori"] = torch.from_numpy(np.ascontiguousarray(o, dtype=np.float32))
         pm = PMVO.from_planes(rec, scene["depth"].to(DEV), scene["ori"].to(DEV), scene["conf"].to(DEV),
                               scene["mask"].to(DEV), device=DEV, patch_size=patch, visible_threshold=1, conf_threshold=thr)
