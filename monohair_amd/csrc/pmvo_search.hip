@@ -1009,6 +1009,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
             cnt[j] += (w > 0.0f) ? 1 : 0;
         }
     };
+#ifdef MH_EXP_VIEW_PAIRS   // (experiment build only: tools/exp_view_pairs.sh -- measured SLOWER in every form, docs/HISTORY.md round 5)
     // Two views in flight (select-only kernel, short lists -- the regime of 8-bit maps, ~2 taps per list): there the time of a
     // view is the dependent chain of its projection (camera record, rcp, sqrt, two refined divisions: 98 of the kernel's 211 us,
     // 24 for the taps), and five waves per SIMD do not hide it (issue utilisation 0.53).  The projections of TWO visible views
@@ -1077,6 +1078,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
             cnt[j] += (BCb[j] > 0.0f) ? 1 : 0;
         }
     };
+#endif
     const int lane = tid & 63, wave = tid >> 6;
     for (int vb = 0; vb < V; vb += 64) {
         const int vv = vb + lane;
@@ -1127,7 +1129,7 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
                     flush_upto(vb + b);
                     const int L = __builtin_amdgcn_readlane(len, b);
                     const int off = __builtin_amdgcn_readlane(pre, b) - L - base;
-#ifndef MH_NO_VIEW_PAIRS
+#ifdef MH_EXP_VIEW_PAIRS
                     if constexpr (!KEYS) {   // (see two_views)
                         if (m && L <= MH_PAIR_TAPS + 1) {
                             const int b2 = (int)__builtin_ctzll(m);

@@ -10,7 +10,8 @@ OBJS=$(ls $C/*.o | grep -v pmvo_search)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"
 mkdir -p $R/gpurun_out/view_pairs
 i=0
-for defs in "-DMH_NO_VIEW_PAIRS" "" "-DMH_S3_WAVES_SELECT=4" "-DMH_PAIR_TAPS=2" "-DMH_PAIR_TAPS=2 -DMH_S3_WAVES_SELECT=4" "-DMH_NO_VIEW_PAIRS -DMH_S3_WAVES_SELECT=4" "-DMH_PAIR_TAPS=8 -DMH_S3_WAVES_SELECT=4"; do
+P=-DMH_EXP_VIEW_PAIRS
+for defs in "" "$P" "$P -DMH_S3_WAVES_SELECT=4" "$P -DMH_PAIR_TAPS=2" "$P -DMH_PAIR_TAPS=2 -DMH_S3_WAVES_SELECT=4" "-DMH_S3_WAVES_SELECT=4" "$P -DMH_PAIR_TAPS=8 -DMH_S3_WAVES_SELECT=4"; do
   i=$((i+1))
   /opt/rocm/bin/hipcc $FLAGS $defs -c $C/pmvo_search.hip -o /tmp/ps_$i.o
   lib=$L/libmhpmvo_exp_$i.so
@@ -19,7 +20,7 @@ for defs in "-DMH_NO_VIEW_PAIRS" "" "-DMH_S3_WAVES_SELECT=4" "-DMH_PAIR_TAPS=2" 
     python $R/tools/ubench/run_lib.py $lib --no-cpu --no-secondary --codes --steps 300 --warmup 20 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('%-50s %8.1f it/s  step %.4f ms  search %.4f ms' % ('${defs:-pairs, 5 waves (shipped)}', d['value'], d['ms_per_step'], d['roofline']['launch_ms']))"
+print('%-50s %8.1f it/s  step %.4f ms  search %.4f ms' % ('${defs:-shipped (one view at a time, 5 waves)}', d['value'], d['ms_per_step'], d['roofline']['launch_ms']))"
   done
   rm -f $lib
 done | tee $R/gpurun_out/view_pairs/table.txt
