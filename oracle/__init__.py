@@ -185,6 +185,30 @@ def set_sum_block(cols=32):
     return prev
 
 
+def mm4(A, B):
+    """[4,4] @ [4,C] as the reference's torch.matmul rounds it under the rule in force (oracle/pmvo_oracle.c: orc_mm4)"""
+    A, B = np.ascontiguousarray(A, np.float32), np.ascontiguousarray(B, np.float32)
+    out = np.empty_like(B)
+    lib().orc_mm4(_p(A), _p(B), ctypes.c_longlong(B.shape[1]), _p(out))
+    return out
+
+
+def mm3(A, B):
+    """[3,3] @ [3,C] likewise (Camera.reprojection's product, Utils/Camera_utils.py:103)"""
+    A, B = np.ascontiguousarray(A, np.float32), np.ascontiguousarray(B, np.float32)
+    out = np.empty_like(B)
+    lib().orc_mm3(_p(A), _p(B), ctypes.c_longlong(B.shape[1]), _p(out))
+    return out
+
+
+def outer_sum(x):
+    """torch.sum(x, dim=0) of a contiguous [V, C] float32 array in ATen's order (cascade; row_sum for the trailing columns)"""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(x.shape[1], np.float32)
+    lib().orc_outer_sum(_p(x), x.shape[0], ctypes.c_longlong(x.shape[1]), _p(out))
+    return out
+
+
 def group_sizes(base_view, V):
     base_view = np.ascontiguousarray(base_view, np.int32)
     cnt = np.empty(V, np.int32)

@@ -59,25 +59,15 @@ void orc_set_num_threads(int n) {
 #endif
 }
 
+static inline float mm4_elem(const float *a, const float *x, int single);   /* (defined with the table of sgemm forms below) */
+
 /* ---- Camera.projection (Utils/Camera_utils.py:38-58): camera_v = pose@[X;1]; uv = proj@camera_v; uv[:2]/=z */
 static inline void cam_project(const float *cam, const float *X, float *u, float *v, float *z) {
     const float *P = cam, *Q = cam + 16;
-    float c[4];
-    for (int r = 0; r < 4; ++r) {
-        float a = P[r * 4 + 0] * X[0];
-        a = fmaf(P[r * 4 + 1], X[1], a);
-        a = fmaf(P[r * 4 + 2], X[2], a);
-        a = fmaf(P[r * 4 + 3], 1.0f, a);
-        c[r] = a;
-    }
-    float q[2];
-    for (int r = 0; r < 2; ++r) {
-        float a = Q[r * 4 + 0] * c[0];
-        a = fmaf(Q[r * 4 + 1], c[1], a);
-        a = fmaf(Q[r * 4 + 2], c[2], a);
-        a = fmaf(Q[r * 4 + 3], c[3], a);
-        q[r] = a;
-    }
+    const float x[4] = {X[0], X[1], X[2], 1.0f};
+    float c[4], q[2];
+    for (int r = 0; r < 4; ++r) c[r] = mm4_elem(P + 4 * r, x, 0);
+    for (int r = 0; r < 2; ++r) q[r] = mm4_elem(Q + 4 * r, c, 0);
     *z = c[2];
     *u = q[0] / c[2];
     *v = q[1] / c[2];
@@ -260,23 +250,52 @@ static inline int group_forms(int M, int S) {
     return (M == 1 ? ORC_FORM_GEMV : 0) | ((cols <= 3 || cols >= g_rule.fma_min_cols) ? ORC_FORM_CHAIN : 0);
 }
 
+/* one element of a [4,4] x [4,M] sgemm (row a of the matrix, column x) in the form the column count selects */
+static inline float mm4_elem(const float *a, const float *x, int single) {
+    if (single) {
+        float f = fmaf(a[1], x[1], a[0] * x[0]);
+        float p2 = a[2] * x[2];
+        float p3 = a[3] * x[3];
+        return p2 + (f + p3);
+    }
+    float s = a[0] * x[0];
+    s = fmaf(a[1], x[1], s);
+    s = fmaf(a[2], x[2], s);
+    return fmaf(a[3], x[3], s);
+}
+/* one element of a [3,3] x [3,C] sgemm */
+static inline float mm3_elem(const float *a, const float *d, int chain) {
+    float p0 = a[0] * d[0];
+    if (chain) return fmaf(a[2], d[2], fmaf(a[1], d[1], p0));
+    float p1 = a[1] * d[1];
+    float p2 = a[2] * d[2];
+    return (p0 + p2) + p1;
+}
+/* The two products as whole matrices, the form chosen from the column count by the rule in force (g_rule): what
+ * tests/test_oracle_forms.py compares with torch.matmul outputs recorded where the goldens were generated
+ * (tests/golden/mkl_forms.npz, tools/probe_mkl_forms.py).  B is [K, C] row-major, out [K, C]. */
+void orc_mm4(const float *A, const float *B, long long C, float *out) {
+    const int single = (g_rule.mode == 0) && C == 1;
+    for (long long c = 0; c < C; ++c) {
+        const float x[4] = {B[c], B[C + c], B[2 * C + c], B[3 * C + c]};
+        for (int r = 0; r < 4; ++r) out[r * C + c] = mm4_elem(A + 4 * r, x, single);
+    }
+}
+void orc_mm3(const float *A, const float *B, long long C, float *out) {
+    const int chain = g_rule.mode == 2 || (g_rule.mode == 0 && (C <= 3 || C >= g_rule.fma_min_cols));
+    for (long long c = 0; c < C; ++c) {
+        const float d[3] = {B[c], B[C + c], B[2 * C + c]};
+        for (int r = 0; r < 3; ++r) out[r * C + c] = mm3_elem(A + 3 * r, d, chain);
+    }
+}
+
 /* Camera.projection of ONE point that is alone in its sgemm (M == 1): see the table above */
 static inline void cam_project_single(const float *cam, const float *X, float *u, float *v, float *z) {
     const float *P = cam, *Q = cam + 16;
-    float c[4];
-    for (int r = 0; r < 4; ++r) {
-        float f = fmaf(P[r * 4 + 1], X[1], P[r * 4 + 0] * X[0]);
-        float p2 = P[r * 4 + 2] * X[2];
-        float p3 = P[r * 4 + 3] * 1.0f;
-        c[r] = p2 + (f + p3);
-    }
-    float q[2];
-    for (int r = 0; r < 2; ++r) {
-        float f = fmaf(Q[r * 4 + 1], c[1], Q[r * 4 + 0] * c[0]);
-        float p2 = Q[r * 4 + 2] * c[2];
-        float p3 = Q[r * 4 + 3] * c[3];
-        q[r] = p2 + (f + p3);
-    }
+    const float x[4] = {X[0], X[1], X[2], 1.0f};
+    float c[4], q[2];
+    for (int r = 0; r < 4; ++r) c[r] = mm4_elem(P + 4 * r, x, 1);
+    for (int r = 0; r < 2; ++r) q[r] = mm4_elem(Q + 4 * r, c, 1);
     *z = c[2];
     *u = q[0] / c[2];
     *v = q[1] / c[2];
@@ -289,17 +308,8 @@ static inline void cam_unproject(const float *cam, float u, float v, float z, fl
     float c0 = (u - Q[2]) / Q[0] * z;
     float c1 = (v - Q[6]) / Q[5] * z;
     float c2 = z;
-    float d0 = c0 - P[3], d1 = c1 - P[7], d2 = c2 - P[11];
-    for (int r = 0; r < 3; ++r) {
-        float p0 = Ri[r * 3 + 0] * d0;
-        if (chain) {
-            X[r] = fmaf(Ri[r * 3 + 2], d2, fmaf(Ri[r * 3 + 1], d1, p0));
-        } else {
-            float p1 = Ri[r * 3 + 1] * d1;
-            float p2 = Ri[r * 3 + 2] * d2;
-            X[r] = (p0 + p2) + p1;
-        }
-    }
+    const float d[3] = {c0 - P[3], c1 - P[7], c2 - P[11]};
+    for (int r = 0; r < 3; ++r) X[r] = mm3_elem(Ri + 3 * r, d, chain);
 }
 
 /*
@@ -451,6 +461,12 @@ void orc_set_sum_block(int cols) { g_sum_block = cols; }
 int orc_get_sum_block(void) { return g_sum_block; }
 /* first "trailing" column of a C-column outer sum */
 static inline long long sum_tail_start(long long C) { return g_sum_block > 0 ? C - C % g_sum_block : C; }
+/* torch.sum(x, dim=0) of a contiguous [V, C] tensor as restated above (tests/test_oracle_forms.py pins it to recorded outputs) */
+void orc_outer_sum(const float *x, int V, long long C, float *out) {
+    const long long t0 = sum_tail_start(C);
+    for (long long c = 0; c < C; ++c)
+        out[c] = c >= t0 ? row_sum1(x + c, (size_t)C, V) : multi_row_sum1(x + c, (size_t)C, V);
+}
 
 /*
  * PMVO.compute_prj_loss (PMVO.py:151-209) for ONE point.
