@@ -99,7 +99,15 @@ size_t mh_search_counts_offset(mh_ctx *ctx, int N, int patch);
 /* ---- K7-K10 fused: the body of PMVO.forward (PMVO.py:50-78): for base-view ranks 0,rank_step,...
  * sample_next_3d_pos (:263-335), compute_reproject_ori (:219-241), compute_prj_loss (:151-209) and the
  * best-so-far update (:57-70); line_ori = normalize(best_sample - point).
- * Inputs are the tensors mh_project_gather produced for the same points.  Optional outputs may be NULL. */
+ * Inputs are the tensors mh_project_gather produced for the same points.  Optional outputs may be NULL.
+ *
+ * THE N POINTS OF A CALL ARE ONE BATCH OF THE REFERENCE (PMVO.py:572-574 hands forward() 5000 points at a time), and a
+ * point's answer depends on its batch as it does there: the points that share a (rank, base view) select how the sgemms
+ * of sample_next_3d_pos round (Utils/Camera_utils.py:50-53,103; option "reproject_rule"), and the last N*S mod 32 samples of
+ * the batch are the trailing columns of ATen's sums over the views (option "sum_block") -- see mh_ctx_set_option.  Base view
+ * indices of ranks whose base_val is <= 0 may be anything (they are clamped; PMVO.py:64 never takes those ranks).
+ * The scratch is opaque and must come from this library's own preparation calls: the search relies on the tap records being
+ * unit vectors (|cos| <= 1 + 2^-14 in its integer-key body). */
 int mh_search_forward(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank,
                       int rank_step, const float *vis, const float *ori, const float *pixf,
                       const float *ori_patch, const float *conf_patch, const int32_t *base_idx,
@@ -122,8 +130,8 @@ int mh_search_prepared(mh_ctx *ctx, const float *points, int N, int patch, float
 /* PMVO.forward (PMVO.py:39-78) in ONE call: mh_forward_prepare + mh_topk_views + mh_search_prepared on the same stream
  * (base_idx [20,N] int32 and base_val [20,N] receive the ranking).  What monohair_amd.pmvo.PMVO.forward calls: on 8-bit
  * maps an iteration is 0.24 ms of GPU work, so every host-side call per iteration counts.  With the default kernels the
- * ranking kernel also writes the work classes of the search's launch order (one launch less than the three calls; same
- * results -- the order only decides WHEN a point is processed). */
+ * ranking kernel also writes the work classes of the search's launch order and counts the batch's points per (rank, base
+ * view) (fewer launches than the three calls; same results -- the order only decides WHEN a point is processed). */
 int mh_forward(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold, int nrank, int rank_step,
                float *vis, float *ori, float *conf, float *mask, void *scratch, size_t scratch_bytes, int32_t *base_idx,
                float *base_val, float *line_ori, float *min_loss, uint8_t *high_conf, float *best_sample,
