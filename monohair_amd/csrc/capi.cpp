@@ -10,11 +10,12 @@
 
 #include "../../include/mh_pmvo.h"
 
-struct MhViews {
+struct MhViews {   // = MhViews of csrc/mh_device.h
     int V, H, W;
     const float4 *rec;
     const float *mask;
     const float *cams;
+    int batch_rule;
 };
 
 #define MH_DG_MAXR 48
@@ -81,7 +82,7 @@ struct mh_ctx {
     int raster_subpixel_bits = 8;   // both rasterisers: window positions snapped to 2^-bits pixel (SwiftShader: 4)
     int gabor_variant = 3;    // 3: FP32-MFMA im2col contraction (default); 0: direct v_pk_fma form (cross-check).
                               // (1 and 2 named two forms removed in round 4.)
-    MhViews views() const { return MhViews{V, H, W, rec, mask, cams}; }
+    MhViews views() const { return MhViews{V, H, W, rec, mask, cams, reproject_rule == 0 ? 1 : 0}; }
 };
 
 // launchers implemented in the .hip files
@@ -118,7 +119,7 @@ int mh_launch_voxel_group(const void *, int, const float *, int, const double *,
 int mh_launch_render_strands(const float *, const float *, int, const int32_t *, int, const float *, const float *, int,
                              int, int, int, int, int, int, int, int, float, void *, void *, unsigned long long *, int32_t *,
                              unsigned int *, float *, hipStream_t);
-int mh_launch_project_points(const float *, const float *, int, int, int, int32_t *, float *, uint8_t *, float *,
+int mh_launch_project_points(const float *, const float *, int, int, int, int32_t *, float *, uint8_t *, float *, int,
                              hipStream_t);
 int mh_launch_gather(MhViews, int, const long long *, int, int, float4 *, float *, hipStream_t);
 int mh_launch_compute_visible(const float *, const float *, size_t, float *, hipStream_t);
@@ -811,7 +812,8 @@ extern "C" int mh_project_points(mh_ctx *ctx, int view, const float *points, int
     if (N == 0) return MH_OK;
     if (!points || N < 0 || view < 0 || view >= ctx->V) return fail(MH_ERR_ARG, "mh_project_points: bad arguments");
     return launched(mh_launch_project_points(ctx->cams + (size_t)view * MH_CAM_STRIDE, points, N, ctx->H, ctx->W, row_col,
-                                             z_half, out_of_image, pixel_unrounded, (hipStream_t)stream),
+                                             z_half, out_of_image, pixel_unrounded, ctx->reproject_rule == 0 ? 1 : 0,
+                                             (hipStream_t)stream),
                     "mh_project_points");
 }
 

@@ -17,6 +17,8 @@ struct MhViews {
     const float4 *rec;   // [V][H][W] {ori_row, ori_col, conf, depth}
     const float *mask;   // [V][H][W]
     const float *cams;   // [V][MH_CAM_STRIDE]
+    int batch_rule;      // 1: option reproject_rule 0 -- the projections follow the batch (a batch of ONE point projects
+                         // through the single-column form, see mh_cam_project_b); 0: one form for everything
 };
 
 __device__ __forceinline__ float mh_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -118,6 +120,21 @@ __device__ __forceinline__ void mh_cam_project_single(const float *__restrict__ 
     v = q[1] / c[2];
 }
 
+// Camera.projection of a point of a batch: single = the point is alone in its sgemm (a base view that owns one point of the
+// batch in sample_next_3d_pos; a batch of ONE point in every projection of it, e.g. the last chunk of optimize / refine when
+// N mod 5000 == 1 -- tests/golden/pmvo_single.npz)
+__device__ __forceinline__ void mh_cam_project_b(const float *__restrict__ cam, float X0, float X1, float X2, float &u,
+                                                 float &v, float &z, bool single) {
+    if (single) mh_cam_project_single(cam, X0, X1, X2, u, v, z);
+    else mh_cam_project(cam, X0, X1, X2, u, v, z);
+}
+__device__ __forceinline__ void mh_pixel_of_b(const float *__restrict__ cam, float X0, float X1, float X2, float Hf, float Wf,
+                                              float &row, float &col, bool single) {
+    float u, v, z;
+    mh_cam_project_b(cam, X0, X1, X2, u, v, z, single);
+    mh_ndc_to_pixel(u, v, Hf, Wf, row, col);
+}
+
 // Camera.reprojection(to_world=True) (Camera_utils.py:81-106) in the form the column count of its sgemm selects
 __device__ __forceinline__ void mh_cam_unproject(const float *__restrict__ cam, float u, float v, float z,
                                                  float &X0, float &X1, float &X2, bool chain = false) {
@@ -142,14 +159,66 @@ __device__ __forceinline__ void mh_cam_unproject(const float *__restrict__ cam, 
 struct MhBatch {
     long long row0, total;
     int batch, block;
+    int single_ok;   // reproject_rule 0: a batch of ONE point projects through the single-column form
 };
-__device__ __forceinline__ bool mh_tail_row(const MhBatch &bt, int n) {
-    if (bt.block <= 0) return false;
+// length of the batch point n of the launch sits in
+__device__ __forceinline__ long long mh_batch_len(const MhBatch &bt, int n, long long &pos) {
     const long long row = bt.row0 + n;
     const long long start = bt.batch > 0 ? row / bt.batch * bt.batch : 0;
     const long long left = bt.total - start;
-    const long long len = (bt.batch > 0 && bt.batch < left) ? bt.batch : left;
-    return row - start >= len - len % bt.block;
+    pos = row - start;
+    return (bt.batch > 0 && bt.batch < left) ? bt.batch : left;
+}
+__device__ __forceinline__ bool mh_tail_row(const MhBatch &bt, int n) {
+    if (bt.block <= 0) return false;
+    long long pos;
+    const long long len = mh_batch_len(bt, n, pos);
+    return pos >= len - len % bt.block;
+}
+__device__ __forceinline__ bool mh_batch_single(const MhBatch &bt, int n) {
+    long long pos;
+    return mh_batch_len(bt, n, pos) == 1;
+}
+
+// ATen's sum over a CONTIGUOUS innermost dimension of V elements (vectorized_inner_sum, 8 floats per vector; restated for the
+// medoid in consensus.hip / oracle/consensus_oracle.c): what sum(dim=0) of a [V, 1] tensor is once the size-1 dimension is
+// squeezed -- the sums over views of a batch of ONE point.  term(v) = element v.  Cold path (a one-point batch), V < 4096.
+template <typename F>
+__device__ __forceinline__ float mh_inner_sum_views(int V, F term) {
+    if (V < 8) {   // scalar_inner_sum: row_sum on single floats
+        const int L = V >> 2;
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < L; ++i)
+            for (int k = 0; k < 4; ++k) p[k] = p[k] + term(4 * i + k);
+        for (int i = L * 4; i < V; ++i) p[0] = p[0] + term(i);
+        return ((p[0] + p[1]) + p[2]) + p[3];
+    }
+    const int vec = V >> 3, R = vec >> 2;   // full vectors; rows of four vectors
+    float a0[32], a1[32], a2[32];
+    for (int a = 0; a < 32; ++a) a0[a] = a1[a] = a2[a] = 0.0f;
+    for (int r = 0; r < R; ++r) {
+        for (int a = 0; a < 32; ++a) a0[a] = a0[a] + term(32 * r + a);
+        if (((r + 1) & 15) == 0) {
+            for (int a = 0; a < 32; ++a) {
+                a1[a] = a1[a] + a0[a];
+                a0[a] = 0.0f;
+            }
+            if (((r + 1) & 0xF0) == 0)
+                for (int a = 0; a < 32; ++a) {
+                    a2[a] = a2[a] + a1[a];
+                    a1[a] = 0.0f;
+                }
+        }
+    }
+    for (int a = 0; a < 32; ++a) a0[a] = (a0[a] + a1[a]) + a2[a];
+    for (int i = R * 4; i < vec; ++i)
+        for (int l = 0; l < 8; ++l) a0[l] = a0[l] + term(8 * i + l);
+    for (int k = 1; k < 4; ++k)
+        for (int l = 0; l < 8; ++l) a0[l] = a0[l] + a0[8 * k + l];
+    float fin = 0.0f;
+    for (int j = vec * 8; j < V; ++j) fin = fin + term(j);
+    for (int l = 0; l < 8; ++l) fin = fin + a0[l];
+    return fin;
 }
 
 // ATen's row_sum (aten/src/ATen/native/cpu/SumKernel.cpp) of one trailing column of a [V, C] outer sum: rows k, k+4, ...

@@ -25,10 +25,11 @@ __global__ __launch_bounds__(256) void mh_filter_kernel(MhViews vw, const float 
     if (n >= N) return;
     const int V = vw.V, H = vw.H, W = vw.W;
     const float X0 = pts[3 * n], X1 = pts[3 * n + 1], X2 = pts[3 * n + 2];
+    const bool single = bt.single_ok && mh_batch_single(bt, n);   // a batch of one point: single-column projections, [V,1] sums
     for (int v = lane; v < V; v += MH_WAVE) {
         const float *cam = vw.cams + v * MH_CAM_STRIDE;
         float u, w, z, rowf, colf;
-        mh_cam_project(cam, X0, X1, X2, u, w, z);
+        mh_cam_project_b(cam, X0, X1, X2, u, w, z, single);
         mh_ndc_to_pixel(u, w, (float)H, (float)W, rowf, colf);
         float cr = __builtin_rintf(colf), rr = __builtin_rintf(rowf);
         const bool oob = !(cr <= (float)(W - 1)) || (cr < 0.0f) || !(rr <= (float)(H - 1)) || (rr < 0.0f);
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(256) void mh_filter_kernel(MhViews vw, const float 
         }
         float sum = mh_cascv_done(a);
         // the trailing (length mod 32) points of a batch of the reference: ATen's row_sum order (mh_device.h: MhBatch)
-        if (mh_tail_row(bt, n)) sum = mh_row_sum_views(V, [&](int v) { return s_t(wave, lane, v); });
+        if (single && bt.block > 0) sum = mh_inner_sum_views(V, [&](int v) { return s_t(wave, lane, v); });
+        else if (mh_tail_row(bt, n)) sum = mh_row_sum_views(V, [&](int v) { return s_t(wave, lane, v); });
         s_t(wave, lane, 0) = sum;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -109,7 +111,7 @@ extern "C" int mh_launch_filter_points(MhViews vw, const float *pts, int N, int 
                                        uint8_t *head_filter, int batch, long long row0, long long total, int sum_block,
                                        hipStream_t st) {
     if (vw.V > MH_FILTER_VMAX) return -1;
-    const MhBatch bt = {row0, total, batch, sum_block};
+    const MhBatch bt = {row0, total, batch, sum_block, vw.batch_rule};
     const dim3 grid((N + 3) / 4), block(256);
     const size_t lds = (size_t)4 * MH_NTERM * vw.V * sizeof(float);
 #define MH_F_CASE(PS)                                                                                              \

@@ -10,11 +10,13 @@
 __global__ __launch_bounds__(256) void mh_project_points_kernel(const float *__restrict__ cam,
                                                                 const float *__restrict__ pts, int N, int H, int W,
                                                                 int32_t *__restrict__ rc, float *__restrict__ zp,
-                                                                uint8_t *__restrict__ oobo, float *__restrict__ pixf) {
+                                                                uint8_t *__restrict__ oobo, float *__restrict__ pixf,
+                                                                int batch_rule) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
+    const bool single = batch_rule && N == 1;   // (a batch of one point: mh_cam_project_b)
     float u, w, z, rowf, colf;
-    mh_cam_project(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, w, z);
+    mh_cam_project_b(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, w, z, single);
     mh_ndc_to_pixel(u, w, (float)H, (float)W, rowf, colf);
     float cr = __builtin_rintf(colf), rr = __builtin_rintf(rowf);
     const bool oob = !(cr <= (float)(W - 1)) || (cr < 0.0f) || !(rr <= (float)(H - 1)) || (rr < 0.0f);
@@ -111,8 +113,10 @@ __global__ __launch_bounds__(256) void mh_reproject_kernel(MhViews vw, const flo
     const int n = (int)(ns / S);
     const float *cam = vw.cams + v * MH_CAM_STRIDE;
     float r0, c0, r1, c1;
-    mh_pixel_of(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], (float)vw.H, (float)vw.W, r0, c0);
-    mh_pixel_of(cam, samples[3 * ns], samples[3 * ns + 1], samples[3 * ns + 2], (float)vw.H, (float)vw.W, r1, c1);
+    // (a batch of one point / one candidate in all: single-column sgemms, mh_cam_project_b)
+    mh_pixel_of_b(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], (float)vw.H, (float)vw.W, r0, c0, vw.batch_rule && N == 1);
+    mh_pixel_of_b(cam, samples[3 * ns], samples[3 * ns + 1], samples[3 * ns + 2], (float)vw.H, (float)vw.W, r1, c1,
+                  vw.batch_rule && per_view == 1);
     D[2 * i] = r1 - r0;
     D[2 * i + 1] = c1 - c0;
 }
@@ -232,9 +236,9 @@ __global__ __launch_bounds__(256) void mh_prj_loss_kernel(const float *__restric
 }
 
 extern "C" int mh_launch_project_points(const float *cam, const float *pts, int N, int H, int W, int32_t *rc, float *zp,
-                                        uint8_t *oob, float *pixf, hipStream_t st) {
+                                        uint8_t *oob, float *pixf, int batch_rule, hipStream_t st) {
     hipLaunchKernelGGL(mh_project_points_kernel, dim3((N + 255) / 256), dim3(256), 0, st, cam, pts, N, H, W, rc, zp, oob,
-                       pixf);
+                       pixf, batch_rule);
     return (int)hipGetLastError();
 }
 extern "C" int mh_launch_gather(MhViews vw, int v, const long long *uv, int N, int size, float4 *rec_out,

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void mh_project_gather_kernel(MhViews vw, cons
         if (n < N) {
             const float *cam = vw.cams + v * MH_CAM_STRIDE;
             float u, w, z, rowf, colf;
-            mh_cam_project(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, w, z);
+            mh_cam_project_b(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, w, z, vw.batch_rule && N == 1);
             mh_ndc_to_pixel(u, w, (float)H, (float)W, rowf, colf);
             // torch.round (half to even) -> long; bounds tests on the integers (PMVO.py:383-390)
             float cr = __builtin_rintf(colf), rr = __builtin_rintf(rowf);
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void mh_project_taps_codes_kernel(MhViews vw, 
     if (mine) {
         const float *cam = vw.cams + v * MH_CAM_STRIDE;
         float u, w;
-        mh_cam_project(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, w, z);
+        mh_cam_project_b(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, w, z, vw.batch_rule && N == 1);
         mh_ndc_to_pixel(u, w, (float)H, (float)W, rowf, colf);
         float cr = __builtin_rintf(colf), rr = __builtin_rintf(rowf);
         oob = !(cr <= (float)(W - 1)) || (cr < 0.0f) || !(rr <= (float)(H - 1)) || (rr < 0.0f);
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256) void mh_project_taps2_kernel(MhViews vw, const
     if (mine) {
         const float *cam = vw.cams + v * MH_CAM_STRIDE;
         float u, w, z;
-        mh_cam_project(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, w, z);
+        mh_cam_project_b(cam, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], u, w, z, vw.batch_rule && N == 1);
         mh_ndc_to_pixel(u, w, (float)H, (float)W, rowf, colf);
         float cr = __builtin_rintf(colf), rr = __builtin_rintf(rowf);
         const bool oob = !(cr <= (float)(W - 1)) || (cr < 0.0f) || !(rr <= (float)(H - 1)) || (rr < 0.0f);

@@ -1411,11 +1411,12 @@ __global__ __launch_bounds__(256) void mh_refine_loss_kernel(MhViews vw, const f
     const float P0 = pts[3 * n], P1 = pts[3 * n + 1], P2 = pts[3 * n + 2];
     const float Q0 = P0 + dir[3 * n] * mul / dv, Q1 = P1 + dir[3 * n + 1] * mul / dv,
                 Q2 = P2 + dir[3 * n + 2] * mul / dv;
+    const bool single = bt.single_ok && mh_batch_single(bt, n);   // a batch of one point: single-column projections, [V,1] sums
     for (int v = lane; v < V; v += MH_WAVE) {
         const float *cam = vw.cams + v * MH_CAM_STRIDE;
         float r0, c0, r1, c1, dx, dy;
-        mh_pixel_of(cam, P0, P1, P2, Hf, Wf, r0, c0);
-        mh_pixel_of(cam, Q0, Q1, Q2, Hf, Wf, r1, c1);
+        mh_pixel_of_b(cam, P0, P1, P2, Hf, Wf, r0, c0, single);
+        mh_pixel_of_b(cam, Q0, Q1, Q2, Hf, Wf, r1, c1, single);
         mh_unit2(r1 - r0, c1 - c0, dx, dy);
         const size_t vn = (size_t)v * N + n;
         const float *__restrict__ cp = conf_patch + vn * P;
@@ -1455,7 +1456,10 @@ __global__ __launch_bounds__(256) void mh_refine_loss_kernel(MhViews vw, const f
             cnt += (w > 0.0f) ? 1 : 0;
         }
         float d = mh_cascv_done(dn), m = mh_cascv_done(nm);
-        if (mh_tail_row(bt, n)) {   // a trailing column of the batch's [V, N] sums (ATen's row_sum order)
+        if (single && bt.block > 0) {   // [V, 1]: ATen's sum over a contiguous innermost dimension
+            m = mh_inner_sum_views(V, [&](int v) { return s_num[wave][v]; });
+            d = mh_inner_sum_views(V, [&](int v) { return s_den[wave][v]; });
+        } else if (mh_tail_row(bt, n)) {   // a trailing column of the batch's [V, N] sums (ATen's row_sum order)
             m = mh_row_sum_views(V, [&](int v) { return s_num[wave][v]; });
             d = mh_row_sum_views(V, [&](int v) { return s_den[wave][v]; });
         }
@@ -1487,10 +1491,11 @@ __global__ __launch_bounds__(256) void mh_refine_loss_maps_kernel(MhViews vw, co
     const float P0 = pts[3 * n], P1 = pts[3 * n + 1], P2 = pts[3 * n + 2];
     const float Q0 = P0 + dir[3 * n] * mul / dv, Q1 = P1 + dir[3 * n + 1] * mul / dv,
                 Q2 = P2 + dir[3 * n + 2] * mul / dv;
+    const bool single = bt.single_ok && mh_batch_single(bt, n);   // a batch of one point: single-column projections, [V,1] sums
     for (int v = lane; v < V; v += MH_WAVE) {
         const float *cam = vw.cams + v * MH_CAM_STRIDE;
         float u, w, z, r0, c0;
-        mh_cam_project(cam, P0, P1, P2, u, w, z);
+        mh_cam_project_b(cam, P0, P1, P2, u, w, z, single);
         mh_ndc_to_pixel(u, w, Hf, Wf, r0, c0);
         float cr = __builtin_rintf(c0), rr = __builtin_rintf(r0);
         const bool oob = !(cr <= (float)(W - 1)) || (cr < 0.0f) || !(rr <= (float)(H - 1)) || (rr < 0.0f);
@@ -1503,7 +1508,7 @@ __global__ __launch_bounds__(256) void mh_refine_loss_maps_kernel(MhViews vw, co
         float numv = 0.0f, denv = 0.0f;
         if (visv != -1.0f) {
             float r1, c1, dx, dy;
-            mh_pixel_of(cam, Q0, Q1, Q2, Hf, Wf, r1, c1);
+            mh_pixel_of_b(cam, Q0, Q1, Q2, Hf, Wf, r1, c1, single);
             mh_unit2(r1 - r0, c1 - c0, dx, dy);
             // pass 1: the patch maximum of the clamped confidences (PMVO.py:162); pass 2: the masked minimum
             float cmax = 0.0f;
@@ -1552,7 +1557,10 @@ __global__ __launch_bounds__(256) void mh_refine_loss_maps_kernel(MhViews vw, co
             cnt += (w > 0.0f) ? 1 : 0;
         }
         float d = mh_cascv_done(dn), m = mh_cascv_done(nm);
-        if (mh_tail_row(bt, n)) {   // a trailing column of the batch's [V, N] sums (ATen's row_sum order)
+        if (single && bt.block > 0) {   // [V, 1]: ATen's sum over a contiguous innermost dimension
+            m = mh_inner_sum_views(V, [&](int v) { return s_num[wave][v]; });
+            d = mh_inner_sum_views(V, [&](int v) { return s_den[wave][v]; });
+        } else if (mh_tail_row(bt, n)) {   // a trailing column of the batch's [V, N] sums (ATen's row_sum order)
             m = mh_row_sum_views(V, [&](int v) { return s_num[wave][v]; });
             d = mh_row_sum_views(V, [&](int v) { return s_den[wave][v]; });
         }
@@ -1677,7 +1685,7 @@ extern "C" int mh_launch_refine_loss_maps(MhViews vw, const float *pts, const fl
                                          int patch, float thr, float *loss, uint8_t *hc, int batch, long long row0,
                                          long long total, int sum_block, hipStream_t st) {
     if (vw.V > MH_REFINE_VMAX) return -1;
-    const MhBatch bt = {row0, total, batch, sum_block};
+    const MhBatch bt = {row0, total, batch, sum_block, vw.batch_rule};
     const dim3 grid((N + 3) / 4), block(256);
 #define MH_RM_CASE(PS)                                                                                               \
     case PS:                                                                                                         \
@@ -1709,7 +1717,7 @@ extern "C" int mh_launch_refine_loss(MhViews vw, const float *pts, const float *
                                      int P, float thr, const float *vis, const float *ori_patch,
                                      const float *conf_patch, float *loss, uint8_t *hc, int sum_block, hipStream_t st) {
     if (vw.V > MH_REFINE_VMAX) return -1;
-    const MhBatch bt = {0, N, 0, sum_block};   // (the stand-alone method: its N points are one batch of the reference)
+    const MhBatch bt = {0, N, 0, sum_block, vw.batch_rule};   // (the stand-alone method: its N points are one batch of the reference)
     hipLaunchKernelGGL(mh_refine_loss_kernel, dim3((N + 3) / 4), dim3(256), 0, st, vw, pts, dir, mul, dv, N, P, thr,
                        vis, ori_patch, conf_patch, loss, hc, bt);
     return (int)hipGetLastError();

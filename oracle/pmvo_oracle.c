@@ -62,12 +62,14 @@ void orc_set_num_threads(int n) {
 static inline float mm4_elem(const float *a, const float *x, int single);   /* (defined with the table of sgemm forms below) */
 
 /* ---- Camera.projection (Utils/Camera_utils.py:38-58): camera_v = pose@[X;1]; uv = proj@camera_v; uv[:2]/=z */
-static inline void cam_project(const float *cam, const float *X, float *u, float *v, float *z) {
+/* single: the point is ALONE in its sgemm (a [4,4] x [4,1] product rounds in its own way, see the table of forms below):
+ * a base view that owns one point of the batch (sample_next_3d_pos), or a batch of one point (every projection of it) */
+static inline void cam_project(const float *cam, const float *X, float *u, float *v, float *z, int single) {
     const float *P = cam, *Q = cam + 16;
     const float x[4] = {X[0], X[1], X[2], 1.0f};
     float c[4], q[2];
-    for (int r = 0; r < 4; ++r) c[r] = mm4_elem(P + 4 * r, x, 0);
-    for (int r = 0; r < 2; ++r) q[r] = mm4_elem(Q + 4 * r, c, 0);
+    for (int r = 0; r < 4; ++r) c[r] = mm4_elem(P + 4 * r, x, single);
+    for (int r = 0; r < 2; ++r) q[r] = mm4_elem(Q + 4 * r, c, single);
     *z = c[2];
     *u = q[0] / c[2];
     *v = q[1] / c[2];
@@ -81,9 +83,9 @@ static inline void ndc_to_pixel(float u, float v, int H, int W, float *col, floa
 
 /* PMVO.project_points (PMVO.py:378-397) for one point: rounded+clamped (row,col), z'=-z/2, oob flag */
 static inline void project_point(const float *cam, const float *X, int H, int W, int *row, int *col, float *zp,
-                                 int *oob, float *rowf, float *colf) {
+                                 int *oob, float *rowf, float *colf, int single) {
     float u, v, z, cf, rf;
-    cam_project(cam, X, &u, &v, &z);
+    cam_project(cam, X, &u, &v, &z, single);
     ndc_to_pixel(u, v, H, W, &cf, &rf);
     float cr = nearbyintf(cf), rr = nearbyintf(rf);
     /* torch: round -> long; compare on the integers. NaN/inf never occur for points in front of a camera. */
@@ -100,12 +102,15 @@ static inline void project_point(const float *cam, const float *X, int H, int W,
     if (colf) *colf = cf;
 }
 
+static int batch_is_single(long long columns);   /* (with the rule, below) */
+
 void orc_project_points(const float *cam, const float *pts, int N, int H, int W, int32_t *rc, float *zp,
                         uint8_t *oob, float *pixf) {
+    const int single = batch_is_single(N);
     for (int n = 0; n < N; ++n) {
         int r, c, o;
         float z, rf, cf;
-        project_point(cam, pts + 3 * n, H, W, &r, &c, &z, &o, &rf, &cf);
+        project_point(cam, pts + 3 * n, H, W, &r, &c, &z, &o, &rf, &cf, single);
         rc[2 * n] = r;
         rc[2 * n + 1] = c;
         zp[n] = z;
@@ -142,7 +147,7 @@ void orc_visible_and_ori(const orc_views *vw, const float *pts, int N, int patch
             const float *cam = vw->cams + (size_t)v * ORC_CAM_STRIDE;
             int r, c, oob;
             float zp, rf, cf;
-            project_point(cam, pts + 3 * n, H, W, &r, &c, &zp, &oob, &rf, &cf);
+            project_point(cam, pts + 3 * n, H, W, &r, &c, &zp, &oob, &rf, &cf, batch_is_single(N));
             size_t vn = (size_t)v * N + n;
             size_t pix = (size_t)r * W + c;
             if (vis) {
@@ -239,6 +244,9 @@ void orc_get_reproject_rule(int *mode, long long *fma_min_cols) {
     *fma_min_cols = g_rule.fma_min_cols;
 }
 
+/* a [4,4] x [4,columns] product of one column: its own form (unless the rule forces one form for everything) */
+static int batch_is_single(long long columns) { return g_rule.mode == 0 && columns == 1; }
+
 /* forms for a point whose (rank, base view) group holds M points, S samples each: bit 0 = single-column projection,
  * bit 1 = chain-form reprojection */
 #define ORC_FORM_GEMV 1
@@ -289,18 +297,6 @@ void orc_mm3(const float *A, const float *B, long long C, float *out) {
     }
 }
 
-/* Camera.projection of ONE point that is alone in its sgemm (M == 1): see the table above */
-static inline void cam_project_single(const float *cam, const float *X, float *u, float *v, float *z) {
-    const float *P = cam, *Q = cam + 16;
-    const float x[4] = {X[0], X[1], X[2], 1.0f};
-    float c[4], q[2];
-    for (int r = 0; r < 4; ++r) c[r] = mm4_elem(P + 4 * r, x, 1);
-    for (int r = 0; r < 2; ++r) q[r] = mm4_elem(Q + 4 * r, c, 1);
-    *z = c[2];
-    *u = q[0] / c[2];
-    *v = q[1] / c[2];
-}
-
 /* Camera.reprojection(..., to_world=True) (Camera_utils.py:81-106); torch.matmul(inv(R) [column-major LAPACK output],
  * (c - t) [transposed view]) in the form the column count selects (table above) */
 static inline void cam_unproject(const float *cam, float u, float v, float z, float *X, int chain) {
@@ -321,8 +317,7 @@ static inline void cam_unproject(const float *cam, float u, float v, float z, fl
 static inline void sample_next_point(const float *cam, const float *X, const float *ori_c, int H, int W,
                                      const float *offs, int S, float *out /* S*3 */, int forms) {
     float u, v, z, col, row;
-    if (forms & ORC_FORM_GEMV) cam_project_single(cam, X, &u, &v, &z);
-    else cam_project(cam, X, &u, &v, &z);
+    cam_project(cam, X, &u, &v, &z, (forms & ORC_FORM_GEMV) != 0);
     ndc_to_pixel(u, v, H, W, &col, &row);
     float nx = col + ori_c[1] * 2.0f;
     float ny = row + ori_c[0] * 2.0f;
@@ -357,9 +352,9 @@ void orc_sample_next(const orc_views *vw, const float *pts, int N, const int32_t
 }
 
 /* unrounded pixel (row, col) of a world point: Camera.projection + Camera.uv2pixel (Camera_utils.py:60-71) */
-static inline void pixel_of(const float *cam, const float *X, int H, int W, float *row, float *col) {
+static inline void pixel_of(const float *cam, const float *X, int H, int W, float *row, float *col, int single) {
     float u, v, z;
-    cam_project(cam, X, &u, &v, &z);
+    cam_project(cam, X, &u, &v, &z, single);
     ndc_to_pixel(u, v, H, W, col, row);
 }
 
@@ -371,10 +366,10 @@ void orc_reproject_ori(const orc_views *vw, const float *pts, const float *sampl
         for (int n = 0; n < N; ++n) {
             const float *cam = vw->cams + (size_t)v * ORC_CAM_STRIDE;
             float r0, c0;
-            pixel_of(cam, pts + 3 * n, vw->H, vw->W, &r0, &c0);
+            pixel_of(cam, pts + 3 * n, vw->H, vw->W, &r0, &c0, batch_is_single(N));
             for (int s = 0; s < S; ++s) {
                 float r1, c1;
-                pixel_of(cam, samples + ((size_t)n * S + s) * 3, vw->H, vw->W, &r1, &c1);
+                pixel_of(cam, samples + ((size_t)n * S + s) * 3, vw->H, vw->W, &r1, &c1, batch_is_single((long long)N * S));
                 float *d = D + (((size_t)v * N + n) * S + s) * 2;
                 d[0] = r1 - r0;
                 d[1] = c1 - c0;
@@ -455,6 +450,7 @@ static float row_sum1(const float *x, size_t stride, long R) {
     for (int k = 1; k < 4; ++k) part[0] = part[0] + part[k];
     return part[0];
 }
+float orc_aten_inner_sum(const float *x, int K);   /* consensus_oracle.c: ATen's sum over a contiguous innermost dimension */
 /* columns per vectorised block of the outer sum (32 = 4 AVX2 vectors: probed, tools/probe_mkl_forms.py); 0 = no tail */
 static int g_sum_block = 32;
 void orc_set_sum_block(int cols) { g_sum_block = cols; }
@@ -479,8 +475,11 @@ static void prj_loss_point(int V, int S, int P, float thr, const float *D, size_
                            size_t ostride, const float *cpatch, size_t cstride, const float *vis, size_t vstride,
  float *out_loss, int *out_idx, int *out_hc, float *loss_s /*S or NULL*/,
                            int tail_from /* samples >= tail_from are trailing columns of the [V,N*S] sums; S = none */) {
-    const int ntail = tail_from < S ? S - (tail_from < 0 ? 0 : tail_from) : 0;
+    /* tail_from == -1: the tensor is [V, 1] (a batch of ONE candidate): squeezed, its sum over dim 0 is ATen's sum over a
+     * contiguous innermost dimension (orc_aten_inner_sum), not an outer sum */
+    const int inner = tail_from < 0;
     if (tail_from < 0) tail_from = 0;
+    const int ntail = tail_from < S ? S - tail_from : 0;
     float *tnum = ntail ? (float *)malloc(sizeof(float) * (size_t)V * ntail) : NULL;
     float *tden = ntail ? (float *)malloc(sizeof(float) * (size_t)V * ntail) : NULL;
     casc *num = (casc *)calloc((size_t)S, sizeof(casc));
@@ -524,7 +523,10 @@ static void prj_loss_point(int V, int S, int P, float thr, const float *D, size_
     float *ls = (float *)malloc(sizeof(float) * (size_t)S);
     for (int s = 0; s < S; ++s) {
         float dn = casc_done(&den[s]), nm = casc_done(&num[s]);
-        if (s >= tail_from) {
+        if (inner) {
+            dn = orc_aten_inner_sum(tden, V);
+            nm = orc_aten_inner_sum(tnum, V);
+        } else if (s >= tail_from) {
             dn = row_sum1(tden + (s - tail_from), (size_t)ntail, V);
             nm = row_sum1(tnum + (s - tail_from), (size_t)ntail, V);
         }
@@ -568,6 +570,7 @@ static void prj_loss_point(int V, int S, int P, float thr, const float *D, size_
 
 /* first sample of point n (of N, S samples each) that lies in the trailing columns of a [V, N*S] sum; S if none */
 static inline int tail_from_of(int n, int N, int S) {
+    if ((long long)N * S == 1 && g_sum_block > 0) return -1;   /* [V,1]: see prj_loss_point */
     const long long t0 = sum_tail_start((long long)N * S) - (long long)n * S;
     return t0 >= S ? S : (t0 < 0 ? 0 : (int)t0);
 }
@@ -631,10 +634,10 @@ void orc_forward(const orc_views *vw, const float *pts, int N, int patch, float 
             for (int v = 0; v < V; ++v) {
                 const float *cam = vw->cams + (size_t)v * ORC_CAM_STRIDE;
                 float r0, c0;
-                pixel_of(cam, X, vw->H, vw->W, &r0, &c0);
+                pixel_of(cam, X, vw->H, vw->W, &r0, &c0, batch_is_single(N));
                 for (int s = 0; s < S; ++s) {
                     float r1, c1;
-                    pixel_of(cam, samples + 3 * s, vw->H, vw->W, &r1, &c1);
+                    pixel_of(cam, samples + 3 * s, vw->H, vw->W, &r1, &c1, batch_is_single((long long)N * S));
                     D[((size_t)v * S + s) * 2] = r1 - r0;
                     D[((size_t)v * S + s) * 2 + 1] = c1 - c0;
                 }
@@ -699,8 +702,8 @@ void orc_refine_loss(const orc_views *vw, const float *pts, const float *dir, fl
         for (int v = 0; v < V; ++v) {
             const float *cam = vw->cams + (size_t)v * ORC_CAM_STRIDE;
             float r0, c0, r1, c1;
-            pixel_of(cam, X, vw->H, vw->W, &r0, &c0);
-            pixel_of(cam, Q, vw->H, vw->W, &r1, &c1);
+            pixel_of(cam, X, vw->H, vw->W, &r0, &c0, batch_is_single(N));
+            pixel_of(cam, Q, vw->H, vw->W, &r1, &c1, batch_is_single(N));
             D[2 * v] = r1 - r0;
             D[2 * v + 1] = c1 - c0;
         }
@@ -735,7 +738,7 @@ void orc_filter_points(const orc_views *vw, const float *pts, int N, int patch, 
             const float *cam = vw->cams + (size_t)v * ORC_CAM_STRIDE;
             int r, c, oob;
             float zp;
-            project_point(cam, pts + 3 * n, H, W, &r, &c, &zp, &oob, NULL, NULL);
+            project_point(cam, pts + 3 * n, H, W, &r, &c, &zp, &oob, NULL, NULL, batch_is_single(N));
             const size_t pix = (size_t)r * W + c;
             float m = vw->mask[v][pix];
             const float gap = zp * 255.0f - vw->depth[v][pix];
@@ -759,7 +762,8 @@ void orc_filter_points(const orc_views *vw, const float *pts, int N, int patch, 
                 for (int k = 0; k < 8; ++k) terms[(size_t)k * V + v] = term[k];
         }
         float s[8];
-        for (int k = 0; k < 8; ++k) s[k] = terms ? row_sum1(terms + (size_t)k * V, 1, V) : casc_done(&t[k]);
+        for (int k = 0; k < 8; ++k)      /* (a batch of one point: [V,1] sums, ATen's inner-dimension order) */
+            s[k] = !terms ? casc_done(&t[k]) : (N == 1 ? orc_aten_inner_sum(terms + (size_t)k * V, V) : row_sum1(terms + (size_t)k * V, 1, V));
         free(terms);
         const int low_conf = s[0] > 4.0f;
         const int hair = (s[1] - s[2]) < (s[1] * 1.0f / 2.0f);

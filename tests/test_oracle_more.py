@@ -326,3 +326,36 @@ def test_refine_loop_head_filter_and_nan_rows_vs_reference(multichunk):
                                            meta["thr"], meta["vis_thr"], KDTree(data=scalp), np.max(scalp, axis=0))
     assert np.array_equal(kept, z["ref_filter_unvisible"])
     assert np.array_equal(sori, z["ref_filter_unvisible_ori"], equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["pmvo_small", "pmvo_quant"])
+def test_batches_of_one_point_vs_reference(name):
+    """tests/golden/pmvo_single.npz (tools/gen_golden_single.py): points handed to the reference ALONE -- every projection of the
+    point is then a single-column sgemm with its own rounding (oracle/pmvo_oracle.c: batch_is_single), which is what the last chunk
+    of optimize / refine is when N mod 5000 == 1.  forward, the method refine and the votes: every row."""
+    from conftest import GOLDEN, golden_records, golden_scene, load_golden, scene_views
+
+    meta, z = load_golden(name)
+    views = scene_views(golden_scene(meta), golden_records(z))
+    s = np.load(__import__("os").path.join(GOLDEN, "pmvo_single.npz"))
+    g = lambda k: s[name + "__" + k]                                                    # noqa: E731
+    offs = np.load(__import__("os").path.join(GOLDEN, "depth_offsets.npy"))
+    differs = 0
+    for i, n in enumerate(g("pick")):
+        p = z["points"][n:n + 1]
+        _, o, l, h = oracle.forward(views, p, meta["patch"], meta["thr"], offs)
+        assert np.array_equal(o[0], g("fwd_ori")[i], equal_nan=True) and np.array_equal(l[0], g("fwd_loss")[i], equal_nan=True)
+        assert h[0] == g("fwd_hc")[i]
+        differs += not np.array_equal(l[0], z["fwd_loss"][n], equal_nan=True)
+        rl, _ = oracle.refine_loss(views, p, z["refine_ori_in"][n:n + 1], meta["patch"], meta["thr"])
+        _, _, _, head = oracle.filter_votes(views, p, meta["patch"], meta["thr"], meta["vis_thr"])
+        want = g("refine_loss")[i]
+        if want == -1:
+            assert head[0] and not head_top_index(p.astype(np.float32), z["toy_scalp"])[0]
+        else:
+            assert np.array_equal(rl[0], want, equal_nan=True), (i, rl[0], want)
+    assert differs > 5          # alone is not the same as inside the N-point batch: the fixture really pins another form
+    for i, n in enumerate(g("fpick")):
+        q = z["filter_points_in"][n:n + 1]
+        surf, filt, unv, _ = oracle.filter_votes(views, q, meta["patch"], meta["thr"], meta["vis_thr"])
+        assert surf[0] == g("surface")[i] and filt[0] == g("filter")[i] and unv[0] == g("unvisible")[i]
