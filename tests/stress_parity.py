@@ -111,6 +111,16 @@ while time.time() < t_end:
         pm.set_option("search_variant", a.variant)
     if a.body:
         pm.set_option("search_body", a.body)
+    # the batch rules: mostly the defaults, with MKL's switch to the chain form drawn low enough that
+    # batches of a few hundred points have groups on both sides of it; sometimes one form forced, sometimes no trailing columns
+    rule = int(rng.choice([0, 0, 0, 0, 1, 2]))
+    fma_cols = int(rng.choice([28445, 90 * int(rng.integers(2, 60))]))
+    block = int(rng.choice([32, 32, 32, 0]))
+    pm.set_option("reproject_rule", rule)
+    pm.set_option("reproject_fma_min_cols", fma_cols)
+    pm.set_option("sum_block", block)
+    oracle.set_reproject_rule({0: "group", 1: "mid", 2: "chain"}[rule], fma_cols)
+    oracle.set_sum_block(block)
     views = oracle.Views(rec, scene["depth"].numpy(), scene["ori"].numpy(), scene["conf"].numpy(), scene["mask"].numpy())
     N = int(rng.integers(1, 400))
     cand = synth.candidate_points(res=int(rng.choice([32, 64])), seed=seed % 1000)
@@ -119,7 +129,7 @@ while time.time() < t_end:
         _, ori, loss, hc = pm.forward(pts, fused=fused)
         _, o_ori, o_loss, o_hc = oracle.forward(views, pts, patch, thr, offs)
         if not (eq(loss.cpu().numpy(), o_loss) and eq(ori.cpu().numpy(), o_ori) and eq(hc.cpu().numpy(), o_hc)):
-            bad.append(("forward", fused, V, H, W, patch, thr, quant, seed, N, mode))
+            bad.append(("forward", fused, V, H, W, patch, thr, quant, seed, N, mode, rule, fma_cols, block))
     surf, _, filt = pm.filter_points(pts)
     unv = pm.compute_unvisible_points(pts)
     o_s, o_f, o_u, _ = oracle.filter_votes(views, pts, patch, thr, 1.0)
