@@ -9,17 +9,18 @@ OBJS=$(ls $C/*.o | grep -v pmvo_search)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off"
 mkdir -p $R/gpurun_out/sorted
 i=0
-for defs in "" "-DMH_EXP_SORTED" "-DMH_EXP_SORTED -DMH_S3_WAVES=4" "$@"; do
+for defs in "" "-DMH_EXP_SORTED" "$@"; do
   i=$((i+1))
   /opt/rocm/bin/hipcc $FLAGS $defs -c $C/pmvo_search.hip -o /tmp/ps_$i.o || continue
   lib=$L/libmhpmvo_exp_$i.so
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $lib /tmp/ps_$i.o $OBJS -ldl
-  python $R/tools/ubench/run_lib.py $lib --no-secondary --steps 200 --warmup 20 2>$R/gpurun_out/sorted/err_$i.txt | python -c "
+  extra=""; case "$defs" in *MAXIT*) extra="--no-cpu";; esac     # (timing-only builds: no parity check)
+  python $R/tools/ubench/run_lib.py $lib --no-secondary --steps 200 --warmup 20 $extra 2>$R/gpurun_out/sorted/err_$i.txt | python -c "
 import sys, json
 t = sys.stdin.read().strip().splitlines()
 try:
     d = json.loads(t[-1])
-    print('%-40s %8.1f it/s  step %.4f ms  search %.4f ms  parity %s' % ('${defs:-shipped}', d['value'], d['ms_per_step'], d['roofline']['launch_ms'], d['parity_check']['bit_exact']))
+    print('%-40s %8.1f it/s  step %.4f ms  search %.4f ms  parity %s' % ('${defs:-shipped}', d['value'], d['ms_per_step'], d['roofline']['launch_ms'], d.get('parity_check', {}).get('bit_exact')))
 except Exception as e:
     print('%-40s FAILED %r' % ('${defs:-shipped}', e))"
   tail -2 $R/gpurun_out/sorted/err_$i.txt | cut -c1-300
