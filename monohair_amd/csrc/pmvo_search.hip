@@ -474,7 +474,6 @@ __device__ __forceinline__ void mh_tap_update(float (&ML)[KA], float (&BC)[KA], 
 #ifndef MH_KEY_MIN_TAPS
 #define MH_KEY_MIN_TAPS 10           // lists up to this length go through the select body directly
 #endif
-#define MH_SORT_DELTA 3.814697265625e-06f   // 2^-18 (MH_EXP_SORTED: see the sorted list in one_view)
 #define MH_KEY_PAD 4                 // lists are padded in LDS to a multiple of this many taps with (0, 0): cs = 0, t' = C
 // (wave, view) visits of the key body: [0] all, [1] one-tap / short / NaN-seed lists (select body directly), [2] evaluated
 // again with the select body after the key body.  [2] is always counted -- one atomic in a branch the bench scene takes 0 times
@@ -928,57 +927,6 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
             // uniform: a short list (the key body's fixed cost per view -- padding, decode -- only pays from about a dozen
             // taps on: lists of 8-bit maps are mostly shorter, lists of continuous maps hardly ever) / a NaN seed tap
             bool again = (ntap <= MH_KEY_MIN_TAPS) || !(t0.x == t0.x && t0.y == t0.y);
-#ifdef MH_EXP_SORTED
-            const int hx = __float_as_int(hdr.x);
-            if (hx & (1 << 16)) {
-                // ---- (experiment) the sorted list: per candidate, binary search for its direction among the taps, then the taps
-                // outward on both sides while their |cos| is within MH_SORT_DELTA of the best seen: any tap not visited has a
-                // strictly larger loss.  The winner is the lexicographic minimum of (loss, original place) over the visited taps.
-                const int nn = ntap;
-                const unsigned rec1 = (unsigned)(size_t)(const __attribute__((address_space(3))) float4 *)(rec + 1);
-                typedef float mh_v4f __attribute__((ext_vector_type(4)));
-                auto lds2 = [&](unsigned ad) { return *reinterpret_cast<const __attribute__((address_space(3))) mh_v2f *>((size_t)ad); };
-                auto lds4 = [&](unsigned ad) { return *reinterpret_cast<const __attribute__((address_space(3))) mh_v4f *>((size_t)ad); };
-                float cx[KN], cy[KN];
-                int pos[KN];
-                bool dnan = false;
-#pragma unroll
-                for (int j = 0; j < KA; ++j) {
-                    const bool flip = DY[j] < 0.0f || (DY[j] == 0.0f && DX[j] < 0.0f);
-                    cx[j] = flip ? -DX[j] : DX[j];
-                    cy[j] = flip ? -DY[j] : DY[j];
-                    dnan |= !(DX[j] == DX[j] && DY[j] == DY[j]);
-                    pos[j] = 0;
-                }
-                for (int bstep = 32; bstep > 0; bstep >>= 1) {
-                    if (bstep > nn) continue;
-#pragma unroll
-                    for (int j = 0; j < KA; ++j) {
-                        const int q = pos[j] + bstep;
-                        const int idx = min(q, nn) - 1;
-                        const mh_v2f t = lds2(rec1 + 16u * (unsigned)idx);
-                        const float cr = mh_vmul(t.x, cy[j]) - mh_vmul(t.y, cx[j]);
-                        pos[j] = (q <= nn && cr > 0.0f) ? q : pos[j];
-                    }
-                }
-                int il[KN], ir[KN], rem[KN], bp[KN], st[KN];
-                float cm[KN];
-#pragma unroll
-                for (int j = 0; j < KA; ++j) {
-                    il[j] = pos[j] == 0 ? nn - 1 : pos[j] - 1;
-                    ir[j] = pos[j] == nn ? 0 : pos[j];
-                    rem[j] = nn;
-                    bp[j] = 0x7fffffff;
-                    ML[j] = 3.0f;
-                    BC[j] = 0.0f;
-                    cm[j] = -1.0f;
-                    st[j] = 3;
-                }
-#ifdef MH_SORT_MAXIT   // (timing only, wrong results: how much of the time is the length of the walks)
-                for (int it_ = 0; it_ < MH_SORT_MAXIT; ++it_) {
-#else
-                for (;;) {
-#endif
                     bool any = false;
 #pragma unroll
                     for (int j = 0; j < KA; ++j) {
@@ -1027,7 +975,6 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
                 again = false;
             } else
 #endif
-            {
             MH_KEY_COUNT(0);
             if (again) MH_KEY_COUNT(1);
             if (!again) {
@@ -1098,7 +1045,6 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
                 }
                 again = __ballot(bad) != 0ull;
                 if (again) MH_KEY_COUNT_ALWAYS(2);
-            }
             }
             if (again) select_body();
         }
@@ -1213,39 +1159,6 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
                         const float4 *__restrict__ src = taps + ((size_t)(vb + b) * N + n) * P1;
                         if constexpr (KEYS) {
                             const int lr = __builtin_amdgcn_readlane(c, b) + 1;   // records the list really has
-#ifdef MH_EXP_SORTED
-                            // (experiment) lists of MH_KEY_MIN_TAPS+1 .. 63 taps without NaN / zero vectors are staged SORTED by
-                            // the angle of their line direction on the half circle, each tap flipped into the upper half plane
-                            // (|cos| does not see the flip), w = its original place; header.x |= 1 << 16, bits 8..13 = the slot of
-                            // original tap 0
-                            if (lr > MH_KEY_MIN_TAPS + 1 && lr <= 64) {
-                                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-                                if (lane < lr) r = src[lane];
-                                const bool tap = lane >= 1 && lane < lr;
-                                const bool flip = r.y < 0.0f || (r.y == 0.0f && r.x < 0.0f);
-                                const float x = flip ? -r.x : r.x, y = flip ? -r.y : r.y;
-                                const bool bad = tap && (!(x == x && y == y) || (x == 0.0f && y == 0.0f));
-                                // pseudo-angle on [0, 2): y / (|x| + y) for x >= 0, 2 - that for x < 0 (monotone in the angle)
-                                const float pa = y * __builtin_amdgcn_rcpf(__builtin_fabsf(x) + y);
-                                const unsigned key = __float_as_uint(x >= 0.0f ? pa : 2.0f - pa);
-                                if (__ballot(bad) == 0ull) {
-                                    int rank = 0;
-                                    for (int q = 1; q < lr; ++q) {
-                                        const unsigned kq = (unsigned)__builtin_amdgcn_readlane((int)key, q);
-                                        rank += (kq < key || (kq == key && q < lane)) ? 1 : 0;
-                                    }
-                                    const int slot0 = __builtin_amdgcn_readlane(rank, 1);
-                                    if (lane == 0)
-                                        s_taps[off] = make_float4(__int_as_float(__float_as_int(r.x) | (slot0 << 8) | (1 << 16)), r.y, r.z, r.w);
-                                    else if (tap)
-                                        s_taps[off + 1 + rank] = make_float4(x, y, r.z, __int_as_float(lane - 1));
-                                    for (int i = lr + lane; i < L; i += 64) s_taps[off + i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                                } else {
-                                    for (int i = lane; i < L; i += 64)
-                                        s_taps[off + i] = (i < lr) ? (i == lane ? r : src[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
-                                }
-                            } else
-#endif
                             for (int i = lane; i < L; i += 64)
                                 s_taps[off + i] = (i < lr) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
                         } else {
