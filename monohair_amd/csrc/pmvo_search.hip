@@ -927,54 +927,6 @@ __device__ __forceinline__ void mh_search_slices_lds(const MhViews &vw, const fl
             // uniform: a short list (the key body's fixed cost per view -- padding, decode -- only pays from about a dozen
             // taps on: lists of 8-bit maps are mostly shorter, lists of continuous maps hardly ever) / a NaN seed tap
             bool again = (ntap <= MH_KEY_MIN_TAPS) || !(t0.x == t0.x && t0.y == t0.y);
-                    bool any = false;
-#pragma unroll
-                    for (int j = 0; j < KA; ++j) {
-                        if (st[j] & 1) {
-                            const mh_v4f t = lds4(rec1 + 16u * (unsigned)il[j]);
-                            const float cs = mh_vadd(mh_vmul(t.x, cx[j]), mh_vmul(t.y, cy[j]));
-                            const float ca = __builtin_fabsf(cs), l = mh_one_minus_abs(cs);
-                            const int pp = __float_as_int(t.w);
-                            const bool better = l < ML[j] || (l == ML[j] && pp < bp[j]);
-                            ML[j] = better ? l : ML[j];
-                            bp[j] = better ? pp : bp[j];
-                            BC[j] = better ? t.z : BC[j];
-                            cm[j] = ca > cm[j] ? ca : cm[j];
-                            il[j] = il[j] == 0 ? nn - 1 : il[j] - 1;
-                            rem[j] -= 1;
-                            if (!(ca >= cm[j] - MH_SORT_DELTA) || rem[j] == 0) st[j] &= ~1;
-                        }
-                        if ((st[j] & 2) && rem[j] > 0) {
-                            const mh_v4f t = lds4(rec1 + 16u * (unsigned)ir[j]);
-                            const float cs = mh_vadd(mh_vmul(t.x, cx[j]), mh_vmul(t.y, cy[j]));
-                            const float ca = __builtin_fabsf(cs), l = mh_one_minus_abs(cs);
-                            const int pp = __float_as_int(t.w);
-                            const bool better = l < ML[j] || (l == ML[j] && pp < bp[j]);
-                            ML[j] = better ? l : ML[j];
-                            bp[j] = better ? pp : bp[j];
-                            BC[j] = better ? t.z : BC[j];
-                            cm[j] = ca > cm[j] ? ca : cm[j];
-                            ir[j] = ir[j] == nn - 1 ? 0 : ir[j] + 1;
-                            rem[j] -= 1;
-                            if (!(ca >= cm[j] - MH_SORT_DELTA)) st[j] &= ~2;
-                        }
-                        if (rem[j] <= 0) st[j] = 0;
-                        any |= st[j] != 0;
-                    }
-                    if (__ballot(any) == 0ull) break;
-                }
-                if (__ballot(dnan) != 0ull) {   // a NaN direction: loss NaN, the confidence of original tap 0 (the seed of PMVO.py:173)
-                    const float c0 = lds4(rec1 + 16u * (unsigned)((hx >> 8) & 63)).z;
-#pragma unroll
-                    for (int j = 0; j < KA; ++j)
-                        if (!(DX[j] == DX[j] && DY[j] == DY[j])) {
-                            ML[j] = DX[j] + DY[j];
-                            BC[j] = c0;
-                        }
-                }
-                again = false;
-            } else
-#endif
             MH_KEY_COUNT(0);
             if (again) MH_KEY_COUNT(1);
             if (!again) {
