@@ -430,14 +430,19 @@ def mat_layout(occ, ori):
     return o, occ.transpose((1, 0, 2))
 
 
-def gabor_bank(bank, img):
-    """calOrientationGabor.filter/forward, iter=1 (GaborFilter.py:29-113): (orient index, conf, variance)."""
+def gabor_bank(bank, img, want_sum=False):
+    """calOrientationGabor.filter/forward, iter=1 (GaborFilter.py:29-113): (orient index, conf, variance[, the sum under the
+    variance's root])."""
     bank = np.ascontiguousarray(bank, np.float32).reshape(180, 17, 17)
     img = np.ascontiguousarray(img, np.float32)
     H, W = img.shape
     orient = np.empty((H, W), np.int32)
     conf = np.empty((H, W), np.float32)
     var = np.empty((H, W), np.float32)
+    if want_sum:
+        vs = np.empty((H, W), np.float32)
+        lib().orc_gabor_bank_sums(_p(bank), _p(img), H, W, _p(orient, c_i), _p(conf), _p(var), _p(vs))
+        return orient, conf, var, vs
     lib().orc_gabor_bank(_p(bank), _p(img), H, W, _p(orient, c_i), _p(conf), _p(var))
     return orient, conf, var
 

@@ -7,10 +7,15 @@
  *   M = max_k R_k, b = first argmax, d_k = min(|bh-th_k|, |bh-th_k-pi|, |bh-th_k+pi|) in fp32,
  *   var = sqrt( cascade-sum_k (d_k*(R_k-M))*(R_k-M) ), orient = var>0 ? b : 0,
  *   conf = clamp( (var / max_image var) / 0.2, 0, 1 ).
- * The 289-term correlation is accumulated tap by tap (row-major) with fma -- the order the HIP kernel uses; the
- * reference's conv2d (oneDNN/MKL im2col GEMM) may associate differently, so a pixel whose two best responses tie
- * to ~1e-7 relative can flip by one degree: parity against the reference's goldens is therefore reported as a
- * match rate (tests/test_gabor.py), while HIP vs this oracle is exact.
+ * The 289-term correlation is accumulated tap by tap (row-major) with fma -- the order the HIP kernel uses, and (probed in
+ * round 5: every response of three orientations on three images, bit for bit) the order of the reference's conv2d on the CPU.
+ * The orientation index and the sum under the root equal the reference's on every pixel of the goldens.  What differs is the
+ * root itself: `variance ** (1 / 2)` (GaborFilter.py:77) is an elementwise op on a contiguous tensor, which ATen hands to
+ * MKL's vector math library (vsSqrt, "high accuracy" mode: below 1 ulp, NOT correctly rounded -- torch.sqrt differs from the
+ * IEEE root on 0.7 % of random floats, on tensors large enough for the vector path).  sqrtf here is the IEEE root, so the
+ * confidence differs from the reference's by one float32 ulp on < 0.8 % of the pixels; it equals the reference's on EVERY pixel
+ * once torch's own root is applied to this oracle's sums (var_sum_out; tests/test_oracle_more.py).  MKL is closed source: the
+ * root is not restated.
  */
 #include <math.h>
 #include <stdint.h>
@@ -20,6 +25,8 @@
 #define KS 17
 
 static inline float theta_of(float k) { return (3.14159265358979323846f * k) / 180.0f; }
+
+static float *g_var_sum_out = NULL;   /* optional: the sums under the root (set through orc_gabor_bank_sums) */
 
 void orc_gabor_bank(const float *bank /*[180][17][17]*/, const float *img, int H, int W, int32_t *orient,
                     float *conf, float *var_out) {
@@ -61,6 +68,7 @@ void orc_gabor_bank(const float *bank /*[180][17][17]*/, const float *img, int H
                 a0 = a0 + (d * rd) * rd;
             }
             const float var = sqrtf(a0 + a1);
+            if (g_var_sum_out) g_var_sum_out[(size_t)y * W + x] = a0 + a1;
             var_out[(size_t)y * W + x] = var;
             orient[(size_t)y * W + x] = (var > 0.0f) ? b : 0;
             if (var > vmax) vmax = var;
@@ -71,4 +79,12 @@ void orc_gabor_bank(const float *bank /*[180][17][17]*/, const float *img, int H
         v = (v - 0.0f) / 0.2f;
         conf[i] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
     }
+}
+
+/* the same, also returning the sum under the root of every pixel (not thread-safe with respect to other callers) */
+void orc_gabor_bank_sums(const float *bank, const float *img, int H, int W, int32_t *orient, float *conf, float *var_out,
+                         float *var_sum_out) {
+    g_var_sum_out = var_sum_out;
+    orc_gabor_bank(bank, img, H, W, orient, conf, var_out);
+    g_var_sum_out = NULL;
 }

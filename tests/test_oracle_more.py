@@ -175,6 +175,29 @@ def test_gabor_bank_vs_reference():
         assert (conf == z[name + "_conf"]).mean() >= 0.998, name
 
 
+def test_gabor_confidence_is_exact_up_to_the_root_of_mkl():
+    """Where the <= 1 ulp of the Gabor confidence comes from: `variance ** (1 / 2)` (GaborFilter.py:77) is handed to MKL's
+    vector math library by ATen (vsSqrt, high-accuracy mode: below 1 ulp, not correctly rounded), everything else -- the 289-tap
+    correlations, the argmax, the cascade sum under the root, the two divisions -- is restated exactly.  Asserted: torch's own
+    root applied to the ORACLE's sums gives the reference's confidence on EVERY pixel of every golden image.  (The root is
+    host code of a closed-source library: the comparison runs where torch.sqrt reproduces the values recorded with the goldens,
+    tests/golden/mkl_forms.npz, and is skipped elsewhere.)"""
+    import torch
+    from conftest import GOLDEN
+
+    rec = np.load(__import__("os").path.join(GOLDEN, "mkl_forms.npz"))
+    if not np.array_equal(torch.sqrt(torch.from_numpy(rec["sqrt_x"])).numpy(), rec["sqrt_out"]):
+        pytest.skip("this host's MKL rounds sqrt differently from the one the goldens were generated with")
+    assert (rec["sqrt_out"] != np.sqrt(rec["sqrt_x"])).sum() > 0          # ... and that root is not the IEEE one
+    z = load_npz("gabor")
+    for name in ("stripes0", "stripes30", "stripes90", "stripes135", "noise", "mixed"):
+        _, conf, var, vsum = oracle.gabor_bank(z["bank"], z[name + "_img"], want_sum=True)
+        assert np.array_equal(np.sqrt(vsum), var)
+        v = torch.from_numpy(vsum)[None, None] ** (1 / 2)
+        ref_like = ((v / torch.max(v) - 0) / (0.2 - 0)).clamp(0, 1)[0, 0].numpy()
+        assert np.array_equal(ref_like, z[name + "_conf"]), name
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # The CHUNKED drivers (tests/golden/e2e_multichunk.npz, tools/gen_golden_multichunk.py): the reference's own optimize +
 # refine over 16 901 surface points = four 5000-point chunks, ragged last, and refine on exactly 10 000 points.
