@@ -12,7 +12,7 @@
  * The orientation index and the sum under the root equal the reference's on every pixel of the goldens.  What differs is the
  * root itself: `variance ** (1 / 2)` (GaborFilter.py:77) is an elementwise op on a contiguous tensor, which ATen hands to
  * MKL's vector math library (vsSqrt, "high accuracy" mode: below 1 ulp, NOT correctly rounded -- torch.sqrt differs from the
- * IEEE root on 0.7 % of random floats, on tensors large enough for the vector path).  sqrtf here is the IEEE root, so the
+ * IEEE root on 0.7 % of random floats and doubles, at any tensor size, contiguous or not).  sqrtf here is the IEEE root, so the
  * confidence differs from the reference's by one float32 ulp on < 0.8 % of the pixels; it equals the reference's on EVERY pixel
  * once torch's own root is applied to this oracle's sums (var_sum_out; tests/test_oracle_more.py).  MKL is closed source: the
  * root is not restated.

@@ -190,8 +190,8 @@ def main():
                               ((a != t) & (b != t)).sum()))
         if (V, C) in ((24, 376), (300, 72), (20, 270)):
             out["sum_V%d_C%d_x" % (V, C)], out["sum_V%d_C%d_out" % (V, C)] = x.numpy(), t
-    # torch.sqrt / x ** 0.5 on a contiguous float tensor large enough for the vector path goes to MKL's vector math library
-    # (vsSqrt, high-accuracy mode: below 1 ulp, not correctly rounded) -- the one operation of the Gabor confidence
+    # torch.sqrt / x ** 0.5 is not the IEEE root in this build (float and double, any size, contiguous or not: 0.7 % of random
+    # values are one ulp off -- ATen's unary ops go through MKL's vector math library, vsSqrt in high-accuracy mode: below 1 ulp) -- the one operation of the Gabor confidence
     # (`variance ** (1 / 2)`, preprocess_capture_data/GaborFilter.py:77) that is not restated (closed source)
     xs = torch.rand(4096, generator=g) * 3
     rs = torch.sqrt(xs)
