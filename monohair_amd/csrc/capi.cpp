@@ -76,8 +76,7 @@ struct mh_ctx {
     int reproject_fma_min_cols = 28445;   // columns (S x group) from which MKL's threaded sgemm (fma chain) takes over
     int sum_block = 32;       // ATen's outer sum adds the trailing (columns mod 32) of a batch in row_sum order; 0: never
     int topk_order = 0;       // 0: torch.topk's CPU tie order (mh_topk_wave.h); 1: value desc, view asc (round 1's rule)
-    int taps_tile = 1;        // (accepted and ignored: round 3's A/B switch between forms of the fp32 front end;
-                              // mh_project_taps2_kernel is the only one left)
+    int taps_tile = 1;        // points per wave of mh_project_taps2_kernel: 16 / 32 (A/B), anything else = 64 (default)
     int line_rule = 0;        // strand renderer: 0 GL's diamond-exit, 1 every touched diamond (SwiftShader)
     int raster_subpixel_bits = 8;   // both rasterisers: window positions snapped to 2^-bits pixel (SwiftShader: 4)
     int gabor_variant = 3;    // 3: FP32-MFMA im2col contraction (default); 0: direct v_pk_fma form (cross-check).
