@@ -403,6 +403,9 @@ int mh_mat_sparse_close(void *handle);
  *   "sum_block": 32 (default) ATen's sum(dim=0) adds the trailing (columns mod 32) of a [V, N*S] / [V, N] sum in its
  *       row_sum order (forward: the last samples of the last point of a batch; refine / filter votes: the last points of a
  *       batch); 0: cascade order everywhere (rounds 1-4).
+ *   "tap_plane": 1 (default) contexts with fp32 views keep every pixel once more as a ready-made patch tap (unit orientation,
+ *       clamped confidence: 16 B per pixel, made at upload) and the fused front end gathers those; 0: it normalises per
+ *       iteration (same results; A/B and cross-check).
  *   "topk_order": see mh_topk_views.   "taps_tile": points per wave of the fp32 front end (mh_project_taps2_kernel): 64
  *       (default; any other value) gives the fastest iteration, 32 / 16 the kernel's own best time (A/B; same results).
  *   "line_rule" (mh_render_strands): 0 = OpenGL's diamond-exit rule (default), 1 = the pixel that holds a segment's end

@@ -15,6 +15,7 @@ struct MhViews {   // = MhViews of csrc/mh_device.h
     const float4 *rec;
     const float *mask;
     const float *cams;
+    const float4 *tap;
     int batch_rule;
 };
 
@@ -30,6 +31,19 @@ struct mh_ctx {
     float4 *rec = nullptr;    // [V][H][W]
     float *mask = nullptr;    // [V][H][W]
     float *cams = nullptr;    // [V][MH_CAM_STRIDE]
+    // every pixel as a ready-made patch tap {unit ori, clamped conf} (MhViews::tap; 16 B per pixel more, 2 GB at 60 x 1080p):
+    // allocated with the first view that comes in as fp32 planes, used by the fused front end once every view has been
+    // written since; contexts of 8-bit code views never allocate it (their front end reads the 2 B codes)
+    float4 *tapp = nullptr;
+    bool tapp_failed = false;
+    int use_tap_plane = 1;             // option "tap_plane": 0 = normalise per iteration (A/B, cross-check)
+    std::vector<unsigned char> tap_view;   // per view: its slice of tapp is current
+    const float4 *tap_ready() const {
+        if (!tapp || !use_tap_plane || (int)tap_view.size() != V) return nullptr;
+        for (unsigned char c : tap_view)
+            if (!c) return nullptr;
+        return tapp;
+    }
     float *offs = nullptr;    // [S]
     float *gabor = nullptr;   // tap-major Gabor bank [289][192]
     float *gabor_q = nullptr; // the same coefficients in the operand order of mh_gabor_mfma2_kernel [145][64][8]
@@ -81,15 +95,15 @@ struct mh_ctx {
     int raster_subpixel_bits = 8;   // both rasterisers: window positions snapped to 2^-bits pixel (SwiftShader: 4)
     int gabor_variant = 3;    // 3: FP32-MFMA im2col contraction (default); 0: direct v_pk_fma form (cross-check).
                               // (1 and 2 named two forms removed in round 4.)
-    MhViews views() const { return MhViews{V, H, W, rec, mask, cams, reproject_rule == 0 ? 1 : 0}; }
+    MhViews views() const { return MhViews{V, H, W, rec, mask, cams, tap_ready(), reproject_rule == 0 ? 1 : 0}; }
 };
 
 // launchers implemented in the .hip files
 extern "C" {
 int mh_launch_pack_view(float4 *, float *, const float *, int, const float *, const float *, const float *, int,
-                        size_t, hipStream_t);
+                        size_t, float4 *, hipStream_t);
 int mh_launch_pack_view_u8(float4 *, float *, const float *, int, const uint8_t *, const uint8_t *, const uint8_t *,
-                           const float4 *, size_t, uint16_t *, hipStream_t);
+                           const float4 *, size_t, uint16_t *, float4 *, hipStream_t);
 size_t mh_code_tabs_bytes();
 int mh_preload_pmvo_project();
 int mh_preload_pmvo_search();
@@ -223,6 +237,10 @@ static void free_views(mh_ctx *c) {
     if (c->cams) (void)hipFree(c->cams);
     if (c->oc) (void)hipFree(c->oc);
     c->oc = nullptr;
+    if (c->tapp) (void)hipFree(c->tapp);
+    c->tapp = nullptr;
+    c->tapp_failed = false;
+    c->tap_view.clear();
     c->code_view.clear();
     c->lut_set = c->lut_mixed = false;
     c->rec = nullptr;
@@ -261,6 +279,7 @@ extern "C" int mh_ctx_alloc_views(mh_ctx *ctx, int V, int H, int W) {
     ctx->H = H;
     ctx->W = W;
     ctx->code_view.assign(V, 0);
+    ctx->tap_view.assign(V, 0);
     return MH_OK;
 }
 
@@ -277,8 +296,19 @@ extern "C" int mh_ctx_set_view(mh_ctx *ctx, int view, const float *cam_host, con
     MH_HIP(hipMemcpyAsync(ctx->cams + (size_t)view * MH_CAM_STRIDE, cam_host, MH_CAM_STRIDE * sizeof(float),
                           hipMemcpyHostToDevice, st));
     if ((int)ctx->code_view.size() == ctx->V) ctx->code_view[view] = 0;      // this view has no resident codes (any more)
+    // the plane of ready-made taps (MhViews::tap): optional, like the code plane of the 8-bit views
+    if (!ctx->tapp && !ctx->tapp_failed) {
+        MH_HIP(hipSetDevice(ctx->device));
+        if (hipMalloc(&ctx->tapp, (size_t)ctx->V * npix * sizeof(float4)) != hipSuccess) {
+            ctx->tapp = nullptr;
+            ctx->tapp_failed = true;     // not retried per view: the front end normalises per iteration instead
+            (void)hipGetLastError();
+        }
+    }
+    if (ctx->tapp && (int)ctx->tap_view.size() == ctx->V) ctx->tap_view[view] = 1;
     return launched(mh_launch_pack_view(ctx->rec + (size_t)view * npix, ctx->mask + (size_t)view * npix, depth,
-                                        depth_stride, ori, conf, mask, mask_stride, npix, st),
+                                        depth_stride, ori, conf, mask, mask_stride, npix,
+                                        ctx->tapp ? ctx->tapp + (size_t)view * npix : nullptr, st),
                     "mh_ctx_set_view");
 }
 
@@ -313,9 +343,11 @@ extern "C" int mh_ctx_set_view_u8(mh_ctx *ctx, int view, const float *cam_host, 
     MH_HIP(hipMemcpyAsync(ctx->cams + (size_t)view * MH_CAM_STRIDE, cam_host, MH_CAM_STRIDE * sizeof(float),
                           hipMemcpyHostToDevice, st));
     if ((int)ctx->code_view.size() == ctx->V) ctx->code_view[view] = ctx->oc ? 1 : 0;
+    if (ctx->tapp && (int)ctx->tap_view.size() == ctx->V) ctx->tap_view[view] = 1;   // (only when an fp32 view allocated it)
     return launched(mh_launch_pack_view_u8(ctx->rec + (size_t)view * npix, ctx->mask + (size_t)view * npix, depth,
                                            depth_stride, ori_u8, conf_u8, mask_u8, ctx->lut, npix,
-                                           ctx->oc ? ctx->oc + (size_t)view * npix : nullptr, st),
+                                           ctx->oc ? ctx->oc + (size_t)view * npix : nullptr,
+                                           ctx->tapp ? ctx->tapp + (size_t)view * npix : nullptr, st),
                     "mh_ctx_set_view_u8");
 }
 
@@ -437,6 +469,10 @@ extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
     if (!strcmp(key, "sum_block")) {
         if (value != 0 && value != 32) return fail(MH_ERR_ARG, "mh_ctx_set_option: sum_block must be 32 (ATen's outer sum) or 0");
         ctx->sum_block = value;
+        return MH_OK;
+    }
+    if (!strcmp(key, "tap_plane")) {
+        ctx->use_tap_plane = value ? 1 : 0;
         return MH_OK;
     }
     if (!strcmp(key, "tap_codes")) {

@@ -17,6 +17,9 @@ struct MhViews {
     const float4 *rec;   // [V][H][W] {ori_row, ori_col, conf, depth}
     const float *mask;   // [V][H][W]
     const float *cams;   // [V][MH_CAM_STRIDE]
+    const float4 *tap;   // [V][H][W] {unit ori_row, unit ori_col, clamped conf, 0}: what a patch tap of the search is, per pixel,
+                         // made once at upload by the same mh_unit2 / mh_clampf the front end would apply per iteration
+                         // (nullptr: not resident -- views uploaded as 8-bit codes use the code tables instead)
     int batch_rule;      // 1: option reproject_rule 0 -- the projections follow the batch (a batch of ONE point projects
                          // through the single-column form, see mh_cam_project_b); 0: one form for everything
 };

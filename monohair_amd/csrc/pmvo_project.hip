@@ -14,13 +14,19 @@ __global__ __launch_bounds__(256) void mh_pack_view_kernel(float4 *__restrict__ 
                                                            const float *__restrict__ ori,
                                                            const float *__restrict__ conf,
                                                            const float *__restrict__ mask, int mstride,
-                                                           size_t npix) {
+                                                           size_t npix, float4 *__restrict__ tapp) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;
     for (; i < npix; i += step) {
         const float2 o = reinterpret_cast<const float2 *>(ori)[i];
-        rec[i] = make_float4(o.x, o.y, conf[i], depth[i * dstride]);
+        const float c = conf[i];
+        rec[i] = make_float4(o.x, o.y, c, depth[i * dstride]);
         maskp[i] = mask[i * mstride];
+        if (tapp) {   // the pixel as a patch tap (MhViews::tap): normalised and clamped here, once, instead of per iteration
+            float o0, o1;
+            mh_unit2(o.x, o.y, o0, o1);
+            tapp[i] = make_float4(o0, o1, mh_clampf(c, 1e-6f, 1.0f), 0.0f);
+        }
     }
 }
 
@@ -31,7 +37,7 @@ __global__ __launch_bounds__(256) void mh_pack_view_u8_kernel(float4 *__restrict
                                                               const uint8_t *__restrict__ conf,
                                                               const uint8_t *__restrict__ mask,
                                                               const float4 *__restrict__ lut, size_t npix,
-                                                              uint16_t *__restrict__ oc) {
+                                                              uint16_t *__restrict__ oc, float4 *__restrict__ tapp) {
     __shared__ float4 s_lut[256];
     s_lut[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
@@ -43,6 +49,11 @@ __global__ __launch_bounds__(256) void mh_pack_view_u8_kernel(float4 *__restrict
         rec[i] = make_float4(o.x, o.y, s_lut[kc].z, depth[i * dstride]);
         maskp[i] = s_lut[mask[i]].w;
         if (oc) oc[i] = (uint16_t)(ko | (kc << 8));      // the two file codes themselves, kept resident for the tap gathers
+        if (tapp) {   // (a context that also holds fp32 views keeps the tap plane complete)
+            float o0, o1;
+            mh_unit2(o.x, o.y, o0, o1);
+            tapp[i] = make_float4(o0, o1, mh_clampf(s_lut[kc].z, 1e-6f, 1.0f), 0.0f);
+        }
     }
 }
 
@@ -572,6 +583,9 @@ __global__ __launch_bounds__(256) void mh_project_taps2_kernel(MhViews vw, const
     const int v = bid / tiles, tile = bid - v * tiles;
     const int n0 = tile * (4 * PW) + wave * PW;
     const float4 *__restrict__ rec = vw.rec + (size_t)v * H * W;
+    // the patch taps: from the plane of ready-made taps when it is resident (uniform), else normalised here per tap
+    const bool pre = vw.tap != nullptr;
+    const float4 *__restrict__ tsrc = pre ? vw.tap + (size_t)v * H * W : rec;
     const int n = n0 + lane;
     const bool mine = lane < PW && n < N;
     int r = 0, c = 0;
@@ -626,7 +640,7 @@ __global__ __launch_bounds__(256) void mh_project_taps2_kernel(MhViews vw, const
                 for (int ch = 0; ch < NCH; ++ch) {
                     q[k][ch] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (ch * MH_WAVE + lane < P)
-                        q[k][ch] = rec[(size_t)min(max(rj + di[ch], 0), H - 1) * W + min(max(cj + dj[ch], 0), W - 1)];
+                        q[k][ch] = tsrc[(size_t)min(max(rj + di[ch], 0), H - 1) * W + min(max(cj + dj[ch], 0), W - 1)];
                 }
             }
         }
@@ -643,9 +657,11 @@ __global__ __launch_bounds__(256) void mh_project_taps2_kernel(MhViews vw, const
             for (int ch = 0; ch < NCH; ++ch) {
                 const int p = ch * MH_WAVE + lane;
                 if (p < P) {
-                    const float cc = mh_clampf(q[k][ch].z, 1e-6f, 1.0f);
-                    float o0, o1;
-                    mh_unit2(q[k][ch].x, q[k][ch].y, o0, o1);
+                    float cc = q[k][ch].z, o0 = q[k][ch].x, o1 = q[k][ch].y;
+                    if (!pre) {
+                        cc = mh_clampf(cc, 1e-6f, 1.0f);
+                        mh_unit2(q[k][ch].x, q[k][ch].y, o0, o1);
+                    }
                     s_o[wave][p] = make_float2(o0, o1);
                     s_c[wave][p] = cc;
                     cmax = fmaxf(cmax, cc);
@@ -709,19 +725,19 @@ __global__ __launch_bounds__(256) void mh_project_taps2_kernel(MhViews vw, const
 // ---------------------------------------------------------------------------------------------
 extern "C" int mh_launch_pack_view(float4 *rec, float *maskp, const float *depth, int dstride, const float *ori,
                                    const float *conf, const float *mask, int mstride, size_t npix,
-                                   hipStream_t st) {
+                                   float4 *tapp, hipStream_t st) {
     const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
     hipLaunchKernelGGL(mh_pack_view_kernel, dim3(blocks), dim3(256), 0, st, rec, maskp, depth, dstride, ori, conf,
-                       mask, mstride, npix);
+                       mask, mstride, npix, tapp);
     return (int)hipGetLastError();
 }
 
 extern "C" int mh_launch_pack_view_u8(float4 *rec, float *maskp, const float *depth, int dstride, const uint8_t *ori,
                                       const uint8_t *conf, const uint8_t *mask, const float4 *lut, size_t npix,
-                                      uint16_t *oc, hipStream_t st) {
+                                      uint16_t *oc, float4 *tapp, hipStream_t st) {
     const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
     hipLaunchKernelGGL(mh_pack_view_u8_kernel, dim3(blocks), dim3(256), 0, st, rec, maskp, depth, dstride, ori, conf,
-                       mask, lut, npix, oc);
+                       mask, lut, npix, oc, tapp);
     return (int)hipGetLastError();
 }
 

@@ -175,6 +175,21 @@ def test_fused_and_unfused_front_ends_agree(case):
     assert torch.equal(mask1, pm.mask) and torch.equal(lazy, pm.Ori_patch)
 
 
+def test_tap_plane_on_and_off_agree(case):
+    """option "tap_plane": the fused front end gathers ready-made taps (normalised and clamped once, at upload) or normalises
+    per iteration -- the same tap lists, the same results, bit for bit"""
+    meta, z, scene, views, pm = case
+    pts = z["points"]
+    res = {}
+    for use in (1, 0):
+        pm.set_option("tap_plane", use)
+        _, o, l, h = pm.forward(pts)
+        res[use] = (o.clone(), l.clone(), h.clone(), pm.search_work(len(pts))[0].clone(), pm.visible.clone(), pm.Conf.clone())
+    pm.set_option("tap_plane", 1)
+    for a, b in zip(res[1], res[0]):
+        assert torch.equal(torch.nan_to_num(a.float(), nan=-7.0), torch.nan_to_num(b.float(), nan=-7.0))
+
+
 def test_forward_own_ranking_runs_and_matches_oracle(case, depth_offsets):
     meta, z, scene, views, pm = case
     pts = z["points"]
