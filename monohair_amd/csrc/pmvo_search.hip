@@ -1503,6 +1503,7 @@ __global__ __launch_bounds__(256) void mh_refine_loss_maps_kernel(MhViews vw, co
         rr = fminf(fmaxf(rr, 0.0f), (float)(H - 1));
         const int r = (int)rr, c = (int)cr;
         const float4 *__restrict__ rec = vw.rec + (size_t)v * H * W;
+        const float4 *__restrict__ tp = vw.tap ? vw.tap + (size_t)v * H * W : nullptr;
         const float4 q = rec[(size_t)r * W + c];
         const float visv = oob ? -1.0f : mh_soft_visible(q.w, (-z / 2.0f) * 255.0f);
         float numv = 0.0f, denv = 0.0f;
@@ -1516,7 +1517,7 @@ __global__ __launch_bounds__(256) void mh_refine_loss_maps_kernel(MhViews vw, co
             for (int p = 0; p < P; ++p) {
                 const int i = p / PATCH - HP, j = p - (p / PATCH) * PATCH - HP;
                 const int r2 = min(max(r + i, 0), H - 1), c2 = min(max(c + j, 0), W - 1);
-                const float cf = mh_clampf(rec[(size_t)r2 * W + c2].z, 1e-6f, 1.0f);
+                const float cf = tp ? tp[(size_t)r2 * W + c2].z : mh_clampf(rec[(size_t)r2 * W + c2].z, 1e-6f, 1.0f);
                 cmax = (p == 0 || cf > cmax) ? cf : cmax;
             }
             const bool hc = cmax > thr;
@@ -1525,12 +1526,19 @@ __global__ __launch_bounds__(256) void mh_refine_loss_maps_kernel(MhViews vw, co
             for (int p = 0; p < P; ++p) {
                 const int i = p / PATCH - HP, j = p - (p / PATCH) * PATCH - HP;
                 const int r2 = min(max(r + i, 0), H - 1), c2 = min(max(c + j, 0), W - 1);
-                const float4 t = rec[(size_t)r2 * W + c2];
-                float o0, o1;
-                mh_unit2(t.x, t.y, o0, o1);
+                float o0, o1, cf;
+                if (tp) {   // (the plane of ready-made taps, MhViews::tap: the same values, made once at upload)
+                    const float4 t = tp[(size_t)r2 * W + c2];
+                    o0 = t.x;
+                    o1 = t.y;
+                    cf = t.z;
+                } else {
+                    const float4 t = rec[(size_t)r2 * W + c2];
+                    mh_unit2(t.x, t.y, o0, o1);
+                    cf = mh_clampf(t.z, 1e-6f, 1.0f);
+                }
                 const float cs = o0 * dx + o1 * dy;
                 const float l = 1.0f - __builtin_fabsf(cs);
-                const float cf = mh_clampf(t.z, 1e-6f, 1.0f);
                 const bool upd = (p == 0) || ((l < ml) && (hc ? (cf > thr) : true));
                 ml = upd ? l : ml;
                 bc = upd ? cf : bc;
