@@ -100,6 +100,44 @@ for name, fp, sp_ in (("equal priorities", 0, 0), ("front low / search high", lo
         ms = timed(lambda n: split_run(front, search, slots, n))
         print("split streams, %-24s %d slots: %.4f ms per iteration = %.1f it/s" % (name, nslots, ms, 1e3 / ms))
 
+
+def paired_run(fronts, searches, slots, iters):
+    """one (front, search) PAIR of streams per slot: the searches of different slots may overlap (tails filled)"""
+    for i in range(iters):
+        k = i % len(slots)
+        s, front, search = slots[k], fronts[k], searches[k]
+        p = chunks[i % NCH]
+        with torch.cuda.stream(front):
+            sp = _lib.stream_ptr()
+            front.wait_event(s["done"])
+            _lib.check(L.mh_forward_prepare(ctx, _lib.ptr(p), N, pm._side, float(pm.conf_threshold), _lib.ptr(s["vis"]),
+                                            _lib.ptr(s["ori"]), _lib.ptr(s["conf"]), _lib.ptr(s["mask"]), _lib.ptr(s["scratch"]),
+                                            s["need"], sp))
+            _lib.check(L.mh_topk_views(ctx, _lib.ptr(s["vis"]), _lib.ptr(s["conf"]), N, _lib.ptr(s["bidx"]), _lib.ptr(s["bval"]), sp))
+            pm.set_option("search_variant", 109 if codes else 9)
+            _lib.check(L.mh_search_prepared(ctx, _lib.ptr(p), N, pm._side, float(pm.conf_threshold), len(ranks), ranks[1] - ranks[0],
+                                            _lib.ptr(s["ori"]), _lib.ptr(s["bidx"]), _lib.ptr(s["bval"]), _lib.ptr(s["scratch"]),
+                                            _lib.ptr(s["lo"]), _lib.ptr(s["ml"]), _lib.ptr(s["hc"]), None, None, None, sp))
+            s["ready"].record(front)
+        with torch.cuda.stream(search):
+            search.wait_event(s["ready"])
+            pm.set_option("search_variant", 110 if codes else 10)
+            _lib.check(L.mh_search_prepared(ctx, _lib.ptr(p), N, pm._side, float(pm.conf_threshold), len(ranks), ranks[1] - ranks[0],
+                                            _lib.ptr(s["ori"]), _lib.ptr(s["bidx"]), _lib.ptr(s["bval"]), _lib.ptr(s["scratch"]),
+                                            _lib.ptr(s["lo"]), _lib.ptr(s["ml"]), _lib.ptr(s["hc"]), None, None, None,
+                                            _lib.stream_ptr()))
+            s["done"].record(search)
+    pm.set_option("search_variant", 0)
+
+
+for name, fp, sp_ in (("equal priorities", 0, 0), ("front low / search high", lo_p, hi_p)):
+    for nslots in (2, 3, 4):
+        fronts = [torch.cuda.Stream(dev, priority=fp) for _ in range(nslots)]
+        searches = [torch.cuda.Stream(dev, priority=sp_) for _ in range(nslots)]
+        slots = make_slots(fronts[0], nslots)
+        ms = timed(lambda n: paired_run(fronts, searches, slots, n))
+        print("paired streams per slot, %-24s %d slots: %.4f ms per iteration = %.1f it/s" % (name, nslots, ms, 1e3 / ms))
+
 streams = pm.side_streams(3)
 
 
