@@ -91,7 +91,10 @@ RECOMPOSE_REPORT = {}     # case -> stats of the last check (printed by the test
 
 
 def check_rows_against_recomposed(name, got, orig, recomposed):
-    """The reference-parity statement for per-point results (ori [N,3], loss [N], high-confidence flag [N]) of forward().
+    """(Round 5: the statement of the BATCH-INDEPENDENT options only -- reproject_rule "mid" / 1 with sum_block 0, what rounds
+    1-4 computed.  With the default options the kernels follow the batch and the tests assert plain equality with the
+    reference's original-batch answer on every row.)
+    The reference-parity statement for per-point results (ori [N,3], loss [N], high-confidence flag [N]) of forward().
     `orig`: the reference's answer in the batch composition it ran; `recomposed`: its answers on the same points in other
     batch compositions, the FIRST being the doubled batch (every base view owns >= 2 points: MKL's gemm kernel in
     Camera.reprojection everywhere).  Asserted:
@@ -126,6 +129,8 @@ def check_rows_against_recomposed(name, got, orig, recomposed):
     # rows where the reference's own two answers are further apart than the tolerance (a flipped near-tie)
     ref_far = fin & (np.abs(np.nan_to_num(o0) - np.nan_to_num(od)).max(axis=1) > 1e-4)
     chk = fin & ~ref_far
+    # (given assertion 1, `got` IS the doubled-batch answer, so this bound restates how far the reference's own two answers are
+    # apart on the rows that are not flipped near-ties; the callers pin the COUNT of flipped rows, which is the real content)
     linf = float(np.abs(ori[chk] - o0[chk]).max()) if chk.any() else 0.0
     assert linf <= 1e-4, "%s: orientation L-inf %.3g vs the reference's original-batch answer" % (name, linf)
     st = dict(rows=int(len(loss)), differ_from_original_batch=int((~vs_orig).sum()), ori_linf_vs_original=linf,
