@@ -132,10 +132,20 @@ def test_multi_rank_branches_on_one_gpu_through_the_rccl_stand_in(tmp_path, nran
     script.write_text(FAKE_WORKER % {"root": ROOT})
     env = dict(os.environ, PYTHONPATH=ROOT, MH_RCCL_LIB=fake_rccl_lib(), MASTER_ADDR="127.0.0.1")
     env.pop("MH_VOLUME_EXCHANGE", None)
+    logs = tmp_path / "logs"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nranks,
-                        "--master-addr", "127.0.0.1", "--master-port", str(29741 + nranks), str(script)], env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "FAKE_RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+                        "--master-addr", "127.0.0.1", "--master-port", str(29741 + nranks), "--redirects", "3",
+                        "--log-dir", str(logs), str(script)], env=env, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:      # every rank's own stderr (the launcher's summary names the failing rank, not its traceback)
+        import glob
+
+        tails = []
+        for f in sorted(glob.glob(str(logs / "**" / "stderr.log"), recursive=True)):
+            t = [ln for ln in open(f).read().splitlines() if "amdgpu.ids" not in ln and "socket.cpp" not in ln]
+            tails.append("== %s\n%s" % (f[len(str(logs)):], "\n".join(t[-12:])))
+        raise AssertionError("\n".join(tails)[-6000:] + r.stderr[-1500:])
+    out = r.stdout + "".join(open(f).read() for f in sorted(__import__("glob").glob(str(logs / "**" / "stdout.log"), recursive=True)))
+    assert "FAKE_RCCL_OK" in out, out[-2000:]
 
 
 def test_unloadable_rccl_override_is_an_error_not_a_fall_through(tmp_path):
