@@ -259,6 +259,27 @@ int mh_voxel_group(mh_ctx *ctx, const void *points, int points_f64, const float 
                    double voxel_size, const int32_t *dims, void *scratch, size_t scratch_bytes,
                    unsigned long long *keys_sorted, int32_t *order, float *ori_sorted, void *stream);
 
+/* ---- Selection on the device between the stages of refine: the `points[index]` / `ori[index]` of the loss threshold
+ * (PMVO.py:651-653), the `centres[keep]` of the shell points (:680-686), their np.concatenate (:690-693) and the run
+ * boundaries of the sorted voxel keys (:705-715) -- stable stream compaction, no host round trip.
+ * mh_select_rows: element i is selected when (flags[i] && !(veto && veto[i])) != invert.  Selected rows of a / b ([n,3]
+ * float32, optional) are written to a_out / b_out starting at row *base (device int32, optional: 0), in their original
+ * order; index_out (optional) receives the selected i; *count (device int32) = *base + number selected -- hand it as
+ * `base` to a second call to append.  scratch: mh_select_scratch_bytes(n).
+ * mh_segment_heads: keys_sorted[n] ascending -> seg_start[G+1] (first position of every run of equal keys, seg_start[G]
+ * = n; capacity n+1), head_keys[G] (optional, capacity n), meta (device int32[2]) = {G, largest run}.
+ * mh_flag_less: out[i] = x[i] < threshold (float32 comparison; NaN -> 0). */
+size_t mh_select_scratch_bytes(int n);
+int mh_select_rows(mh_ctx *ctx, const unsigned char *flags, const unsigned char *veto, int invert, int n, const float *a,
+                   const float *b, float *a_out, float *b_out, int32_t *index_out, const int32_t *base, int32_t *count,
+                   void *scratch, size_t scratch_bytes, void *stream);
+int mh_segment_heads(mh_ctx *ctx, const unsigned long long *keys_sorted, int n, int32_t *seg_start,
+                     unsigned long long *head_keys, int32_t *meta, void *scratch, size_t scratch_bytes, void *stream);
+int mh_flag_less(mh_ctx *ctx, const float *x, float threshold, int n, unsigned char *out, void *stream);
+/* flag[0] (device int32) = 1 when two device buffers of `bytes` (a multiple of 4) differ in any bit, else 0: how refine
+ * recognises the points a neighbour table was prepared for while optimize ran (monohair_amd/pmvo.py: RefinePrefetch). */
+int mh_buffers_differ(mh_ctx *ctx, const void *a, const void *b, size_t bytes, int32_t *flag, void *stream);
+
 /* ---- depth-map producer (the step before the path): Utils/Render_utils.py:310-347 render_bust_hair_depth with
  * the BustObj shader (:146-188) and Renderer.draw/ReadBuffer (:239-262) -- triangles drawn with a LESS depth test,
  * value (-z_camera / 2) * 255, background 255, top-left image origin.  verts[Nv,3] (world, bust offset applied),

@@ -62,6 +62,11 @@ _SIGS = {
     "mh_sort_keys": (ci, [vp, vp, ci, ci, vp, csz, vp, vp, vp]),
     "mh_voxel_group_scratch_bytes": (csz, [ci]),
     "mh_voxel_group": (ci, [vp, vp, ci, vp, ci, vp, ctypes.c_double, vp, vp, csz, vp, vp, vp, vp]),
+    "mh_select_scratch_bytes": (csz, [ci]),
+    "mh_select_rows": (ci, [vp, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, csz, vp]),
+    "mh_segment_heads": (ci, [vp, vp, ci, vp, vp, vp, vp, csz, vp]),
+    "mh_flag_less": (ci, [vp, vp, cf, ci, vp, vp]),
+    "mh_buffers_differ": (ci, [vp, vp, vp, csz, vp, vp]),
     "mh_render_scratch_bytes": (csz, [ci, ci, ci, ci]),
     "mh_render_depth": (ci, [vp, vp, vp, ci, vp, ci, ci, ci, cf, vp, csz, vp, ci, vp]),
     "mh_comm_unique_id": (ci, [vp]),

@@ -127,6 +127,13 @@ int mh_launch_grid_build(const float *, int, float, float, float, float, int, in
 int mh_launch_sort_keys(const unsigned long long *, int, int, void *, size_t, unsigned long long *, int32_t *,
                         hipStream_t);
 size_t mh_voxel_group_scratch_bytes_impl(int);
+size_t mh_select_scratch_bytes_impl(int);
+int mh_launch_select_rows(const uint8_t *, const uint8_t *, int, int, const float *, const float *, float *, float *,
+                          int32_t *, const int32_t *, int32_t *, void *, hipStream_t);
+int mh_launch_segment_heads(const unsigned long long *, int, int32_t *, unsigned long long *, int32_t *, void *,
+                            hipStream_t);
+int mh_launch_flag_less(const float *, float, int, uint8_t *, hipStream_t);
+int mh_launch_words_differ(const void *, const void *, size_t, int32_t *, hipStream_t);
 int mh_launch_voxel_group(const void *, int, const float *, int, const double *, double, const int32_t *, void *, size_t,
                           unsigned long long *, int32_t *, float *, hipStream_t);
 int mh_launch_render_strands(const float *, const float *, int, const int32_t *, int, const float *, const float *, int,
@@ -838,6 +845,46 @@ extern "C" int mh_voxel_group(mh_ctx *ctx, const void *points, int points_f64, c
     return launched(mh_launch_voxel_group(points, points_f64, ori, n, voxel_min, voxel_size, dims, scratch, scratch_bytes,
                                           keys_sorted, order, ori_sorted, (hipStream_t)stream),
                     "mh_voxel_group");
+}
+
+// ---- device-side selection between the stages of refine (csrc/sortgroup.hip): no host round trip ------------------
+extern "C" size_t mh_select_scratch_bytes(int n) { return n < 0 ? 0 : mh_select_scratch_bytes_impl(n); }
+
+extern "C" int mh_select_rows(mh_ctx *ctx, const uint8_t *flags, const uint8_t *veto, int invert, int n, const float *a,
+                              const float *b, float *a_out, float *b_out, int32_t *index_out, const int32_t *base,
+                              int32_t *count, void *scratch, size_t scratch_bytes, void *stream) {
+    if (!ctx || !count || !scratch || n < 0 ||
+        (n > 0 && (!flags || (a == nullptr) != (a_out == nullptr) || (b == nullptr) != (b_out == nullptr))))
+        return fail(MH_ERR_ARG, "mh_select_rows: bad arguments");
+    if (scratch_bytes < mh_select_scratch_bytes_impl(n)) return fail(MH_ERR_ARG, "mh_select_rows: scratch too small");
+    MH_HIP(hipSetDevice(ctx->device));
+    return launched(mh_launch_select_rows(flags, veto, invert, n, a, b, a_out, b_out, index_out, base, count, scratch,
+                                          (hipStream_t)stream),
+                    "mh_select_rows");
+}
+
+extern "C" int mh_segment_heads(mh_ctx *ctx, const unsigned long long *keys_sorted, int n, int32_t *seg_start,
+                                unsigned long long *head_keys, int32_t *meta, void *scratch, size_t scratch_bytes,
+                                void *stream) {
+    if (!ctx || !seg_start || !meta || !scratch || n < 0 || (n > 0 && !keys_sorted))
+        return fail(MH_ERR_ARG, "mh_segment_heads: bad arguments");
+    if (scratch_bytes < mh_select_scratch_bytes_impl(n)) return fail(MH_ERR_ARG, "mh_segment_heads: scratch too small");
+    MH_HIP(hipSetDevice(ctx->device));
+    return launched(mh_launch_segment_heads(keys_sorted, n, seg_start, head_keys, meta, scratch, (hipStream_t)stream),
+                    "mh_segment_heads");
+}
+
+extern "C" int mh_flag_less(mh_ctx *ctx, const float *x, float threshold, int n, uint8_t *out, void *stream) {
+    if (n == 0) return MH_OK;
+    if (!ctx || !x || !out || n < 0) return fail(MH_ERR_ARG, "mh_flag_less: bad arguments");
+    MH_HIP(hipSetDevice(ctx->device));
+    return launched(mh_launch_flag_less(x, threshold, n, out, (hipStream_t)stream), "mh_flag_less");
+}
+
+extern "C" int mh_buffers_differ(mh_ctx *ctx, const void *a, const void *b, size_t bytes, int32_t *flag, void *stream) {
+    if (!ctx || !flag || (bytes && (!a || !b)) || (bytes & 3)) return fail(MH_ERR_ARG, "mh_buffers_differ: bad arguments");
+    MH_HIP(hipSetDevice(ctx->device));
+    return launched(mh_launch_words_differ(a, b, bytes / 4, flag, (hipStream_t)stream), "mh_buffers_differ");
 }
 
 // ---- the intermediate methods of the reference's class, as stand-alone calls (csrc/pmvo_pieces.hip) ---------------

@@ -15,7 +15,9 @@
 // for all points (refine queries the points kept by the loss threshold right after querying all of them).
 #include "mh_device.h"
 
-#define MH_KNN_CAP 2048
+#define MH_KNN_CAP 2048        // candidate buffer of the second pass (and the largest k)
+#define MH_KNN_CAP_FIRST 512   // ... of the first pass: 12 KB of LDS per two-wave block instead of 48 -> 26 waves per CU
+                               // instead of 6 (round 6: a block of 27 cells holds ~11 k points, ~1.7 k of them within reach)
 #define MH_KNN_MAXRING 6
 
 struct MhGrid {
@@ -33,14 +35,17 @@ __global__ __launch_bounds__(128) void mh_knn_kernel(MhGrid g, const float *__re
                                                      const void *__restrict__ queries, int q64, int Q, int k,
                                                      int ring0, const int32_t *__restrict__ qperm,
                                                      const uint8_t *__restrict__ valid,
-                                                     int32_t *__restrict__ out_idx, int32_t *__restrict__ status) {
+                                                     int32_t *__restrict__ out_idx, int32_t *__restrict__ status,
+                                                     int cap, int only_status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double *s_d = reinterpret_cast<double *>(smem) + (size_t)wave * MH_KNN_CAP;
-    int *s_i = reinterpret_cast<int *>(smem + 2 * MH_KNN_CAP * sizeof(double)) + (size_t)wave * MH_KNN_CAP;
+    double *s_d = reinterpret_cast<double *>(smem) + (size_t)wave * cap;
+    int *s_i = reinterpret_cast<int *>(smem + 2 * (size_t)cap * sizeof(double)) + (size_t)wave * cap;
     const int qw = blockIdx.x * 2 + wave;
     if (qw >= Q) return;
     const int qi = qperm ? qperm[qw] : qw;
+    // second pass: only the queries whose candidates did not fit the first pass's buffer
+    if (only_status && status[qi] != only_status) return;
     // queries are float32 or float64 (the reference hands float64 shell points to KDTree.query, PMVO.py:671); distances
     // use the exact coordinates, the cell of the query only has to be near enough (see the reach margin below)
     double dqx, dqy, dqz;
@@ -85,14 +90,14 @@ __global__ __launch_bounds__(128) void mh_knn_kernel(MhGrid g, const float *__re
                     const bool keep = ok && d2 <= reach2 && (!valid || valid[id]);
                     const unsigned long long m = __ballot(keep);
                     const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
-                    if (keep && pos < MH_KNN_CAP) {
+                    if (keep && pos < cap) {
                         s_d[pos] = d2;
                         s_i[pos] = id;
                     }
                     cnt += __popcll(m);
                 }
             }
-        if (cnt > MH_KNN_CAP) overflow = true;
+        if (cnt > cap) overflow = true;
         if (overflow) {
             st = 2;
             break;
@@ -141,9 +146,15 @@ extern "C" int mh_launch_knn(float ox, float oy, float oz, float h, int dx, int 
                              int32_t *status, hipStream_t st) {
     if (k < 1 || k > MH_KNN_CAP) return -1;
     MhGrid g{ox, oy, oz, h, dx, dy, dz};
-    const size_t lds = 2 * (size_t)MH_KNN_CAP * (sizeof(double) + sizeof(int));
-    hipLaunchKernelGGL(mh_knn_kernel, dim3((Q + 1) / 2), dim3(128), lds, st, g, pts, order, cell_start, queries, q64, Q,
-                       k, ring0, qperm, valid, out_idx, status);
+    // two passes on the same grid: a small candidate buffer (high occupancy) for all queries, then the full buffer for
+    // the queries that overflowed it (status 2 after the first pass; the other waves of the second launch exit at once)
+    const int cap1 = k <= MH_KNN_CAP_FIRST / 2 ? MH_KNN_CAP_FIRST : MH_KNN_CAP;
+    const size_t per = sizeof(double) + sizeof(int);
+    hipLaunchKernelGGL(mh_knn_kernel, dim3((Q + 1) / 2), dim3(128), 2 * (size_t)cap1 * per, st, g, pts, order, cell_start,
+                       queries, q64, Q, k, ring0, qperm, valid, out_idx, status, cap1, 0);
+    if (cap1 < MH_KNN_CAP)
+        hipLaunchKernelGGL(mh_knn_kernel, dim3((Q + 1) / 2), dim3(128), 2 * (size_t)MH_KNN_CAP * per, st, g, pts, order,
+                           cell_start, queries, q64, Q, k, ring0, qperm, valid, out_idx, status, MH_KNN_CAP, 2);
     return (int)hipGetLastError();
 }
 

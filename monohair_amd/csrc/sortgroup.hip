@@ -192,6 +192,192 @@ extern "C" int mh_launch_voxel_group(const void *pts, int pts_f64, const float *
     return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Stable stream compaction on the device: the `points[index]`, `ori[index]`, `centres[keep]` and `np.concatenate` steps
+// between the stages of refine (PMVO.py:651-693) and the run boundaries of the sorted voxel keys (:705-715) without a
+// host round trip.  Three small launches: per-block counts, one-block exclusive scan (+ an optional base offset read
+// from device memory, so that a second selection appends to the first), scatter.  Order is preserved: an element's
+// output position is base + the number of selected elements before it.
+// ---------------------------------------------------------------------------------------------------------------
+#define MH_SEL_ROUNDS 4
+#define MH_SEL_ITEMS (256 * MH_SEL_ROUNDS)
+
+struct MhPredFlags {     // f[i] && !(g && g[i]), optionally inverted
+    const uint8_t *f, *g;
+    int invert;
+    __device__ __forceinline__ bool operator()(int i) const {
+        const bool v = f[i] != 0 && !(g && g[i] != 0);
+        return v != (invert != 0);
+    }
+};
+struct MhPredHeads {     // first element of a run of equal sorted keys
+    const unsigned long long *k;
+    __device__ __forceinline__ bool operator()(int i) const { return i == 0 || k[i] != k[i - 1]; }
+};
+
+template <class P>
+__global__ __launch_bounds__(256) void mh_sel_count_kernel(P pred, int n, int32_t *__restrict__ block_cnt) {
+    __shared__ int s_c[4];
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < MH_SEL_ROUNDS; ++r) {
+        const int i = blockIdx.x * MH_SEL_ITEMS + r * 256 + threadIdx.x;
+        c += __popcll(__ballot(i < n && pred(i)));
+    }
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = (s_c[0] + s_c[1]) + (s_c[2] + s_c[3]);
+}
+
+// block_cnt[b] <- base + (number selected in blocks before b); total[0] = base + number selected; optional: tail[total] =
+// tail_value (the closing entry of a segment table) and total[1] = 0 (the running maximum a later kernel fills)
+__global__ __launch_bounds__(256) void mh_sel_scan_kernel(int32_t *__restrict__ block_cnt, int nb,
+                                                          const int32_t *__restrict__ base, int32_t *__restrict__ total,
+                                                          int32_t *__restrict__ tail, int tail_value, int clear_second) {
+    __shared__ int s_w[4];
+    int carry = base ? base[0] : 0;
+    for (int b0 = 0; b0 < nb; b0 += 256) {
+        const int b = b0 + threadIdx.x;
+        const int v = b < nb ? block_cnt[b] : 0;
+        int x = v;      // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x, off);
+            if ((int)(threadIdx.x & 63) >= off) x += y;
+        }
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = x;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += s_w[w];
+        if (b < nb) block_cnt[b] = carry + before + x - v;
+        carry += (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        total[0] = carry;
+        if (clear_second) total[1] = 0;
+        if (tail) tail[carry] = tail_value;
+    }
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void mh_sel_scatter_kernel(P pred, int n, const int32_t *__restrict__ block_off,
+                                                             const float *__restrict__ a, const float *__restrict__ b,
+                                                             float *__restrict__ a_out, float *__restrict__ b_out,
+                                                             int32_t *__restrict__ idx_out,
+                                                             const unsigned long long *__restrict__ key_in,
+                                                             unsigned long long *__restrict__ key_out) {
+    __shared__ int s_c[4];
+    int off = block_off[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < MH_SEL_ROUNDS; ++r) {
+        const int i = blockIdx.x * MH_SEL_ITEMS + r * 256 + threadIdx.x;
+        const bool sel = i < n && pred(i);
+        const unsigned long long m = __ballot(sel);
+        if (lane == 0) s_c[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; ++w) before += s_c[w];
+        if (sel) {
+            const int pos = off + before + __popcll(m & ((1ull << lane) - 1ull));
+            if (a_out) {
+                a_out[3 * (size_t)pos] = a[3 * (size_t)i];
+                a_out[3 * (size_t)pos + 1] = a[3 * (size_t)i + 1];
+                a_out[3 * (size_t)pos + 2] = a[3 * (size_t)i + 2];
+            }
+            if (b_out) {
+                b_out[3 * (size_t)pos] = b[3 * (size_t)i];
+                b_out[3 * (size_t)pos + 1] = b[3 * (size_t)i + 1];
+                b_out[3 * (size_t)pos + 2] = b[3 * (size_t)i + 2];
+            }
+            if (idx_out) idx_out[pos] = i;
+            if (key_out) key_out[pos] = key_in[i];
+        }
+        off += (s_c[0] + s_c[1]) + (s_c[2] + s_c[3]);
+        __syncthreads();
+    }
+}
+
+// meta[1] = max over the G = meta[0] segments of seg[g+1] - seg[g]   (meta[1] cleared by the scan kernel)
+__global__ __launch_bounds__(256) void mh_seg_max_kernel(const int32_t *__restrict__ seg, int32_t *__restrict__ meta, int cap) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int G = meta[0];
+    int d = (g < G && g < cap) ? seg[g + 1] - seg[g] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d = max(d, __shfl_xor(d, off));
+    if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(meta + 1, d);
+}
+
+__global__ __launch_bounds__(256) void mh_flag_less_kernel(const float *__restrict__ x, float thr, int n,
+                                                           uint8_t *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = x[i] < thr ? 1 : 0;      // NaN: not selected, as `np.where(min_loss < threshold)` (PMVO.py:651)
+}
+
+// flag[0] = 1 when the two buffers differ in any 32-bit word (bitwise: NaN == NaN, -0 != +0)
+__global__ __launch_bounds__(256) void mh_words_differ_kernel(const uint32_t *__restrict__ a,
+                                                              const uint32_t *__restrict__ b, size_t nwords,
+                                                              int32_t *__restrict__ flag) {
+    bool diff = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256)
+        diff |= a[i] != b[i];
+    if (__ballot(diff) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+extern "C" int mh_launch_words_differ(const void *a, const void *b, size_t nwords, int32_t *flag, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
+    if (nwords) {
+        const unsigned nb = (unsigned)((nwords + 1023) / 1024 > 2048 ? 2048 : (nwords + 1023) / 1024);
+        hipLaunchKernelGGL(mh_words_differ_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t *)a, (const uint32_t *)b,
+                           nwords, flag);
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" size_t mh_select_scratch_bytes_impl(int n) {
+    const size_t nb = ((size_t)(n > 0 ? n : 1) + MH_SEL_ITEMS - 1) / MH_SEL_ITEMS;
+    return align256(nb * sizeof(int32_t)) + 256;
+}
+
+template <class P>
+static int mh_select_run(P pred, int n, const float *a, const float *b, float *a_out, float *b_out, int32_t *idx_out,
+                         const unsigned long long *key_in, unsigned long long *key_out, const int32_t *base,
+                         int32_t *total, int32_t *tail, int tail_value, int clear_second, void *scratch, hipStream_t st) {
+    int32_t *blk = (int32_t *)scratch;
+    const int nb = (n + MH_SEL_ITEMS - 1) / MH_SEL_ITEMS;
+    if (nb > 0) hipLaunchKernelGGL(mh_sel_count_kernel<P>, dim3(nb), dim3(256), 0, st, pred, n, blk);
+    hipLaunchKernelGGL(mh_sel_scan_kernel, dim3(1), dim3(256), 0, st, blk, nb, base, total, tail, tail_value, clear_second);
+    if (nb > 0)
+        hipLaunchKernelGGL(mh_sel_scatter_kernel<P>, dim3(nb), dim3(256), 0, st, pred, n, blk, a, b, a_out, b_out, idx_out,
+                           key_in, key_out);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mh_launch_select_rows(const uint8_t *flags, const uint8_t *veto, int invert, int n, const float *a,
+                                     const float *b, float *a_out, float *b_out, int32_t *idx_out, const int32_t *base,
+                                     int32_t *count, void *scratch, hipStream_t st) {
+    return mh_select_run(MhPredFlags{flags, veto, invert}, n, a, b, a_out, b_out, idx_out, nullptr, nullptr, base, count,
+                         nullptr, 0, 0, scratch, st);
+}
+
+// seg_start[0..G) = first positions of the runs of equal keys, seg_start[G] = n, head_keys[0..G) = their keys,
+// meta = {G, largest run}
+extern "C" int mh_launch_segment_heads(const unsigned long long *keys, int n, int32_t *seg_start,
+                                       unsigned long long *head_keys, int32_t *meta, void *scratch, hipStream_t st) {
+    const int rc = mh_select_run(MhPredHeads{keys}, n, nullptr, nullptr, nullptr, nullptr, seg_start, keys, head_keys,
+                                 nullptr, meta, seg_start, n, 1, scratch, st);
+    if (rc) return rc;
+    if (n > 0) hipLaunchKernelGGL(mh_seg_max_kernel, dim3((n + 255) / 256), dim3(256), 0, st, seg_start, meta, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int mh_launch_flag_less(const float *x, float thr, int n, uint8_t *out, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(mh_flag_less_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, thr, n, out);
+    return (int)hipGetLastError();
+}
+
 // forces this translation unit's code object onto the device (HIP loads a fat binary on the first use of one of its kernels:
 // 2-20 ms each, which a one-shot pass would pay in the middle of its stages); called from mh_ctx_create
 extern "C" int mh_preload_sortgroup() {

@@ -171,6 +171,8 @@ class PMVO:
             stg = getattr(self, "_stage_all", None)
             if stg is not None and stg[1] is not None:
                 stg[1].synchronize()
+            for ent in getattr(self, "_stage_named", {}).values():
+                ent[1].synchronize()
         except Exception:
             pass
         try:
@@ -449,6 +451,59 @@ class PMVO:
             self._side_streams = [torch.cuda.Stream(device=self.device) for _ in range(n)]
         return self._side_streams[:n]
 
+    def aux_stream(self, name, priority=None):
+        """A named HIP stream owned by this object, created on first use (the drivers' copy / side / prefetch streams)."""
+        d = self.__dict__.setdefault("_aux_streams", {})
+        if name not in d:
+            d[name] = (torch.cuda.Stream(device=self.device) if priority is None
+                       else torch.cuda.Stream(device=self.device, priority=int(priority)))
+        return d[name]
+
+    _TORCH_OF = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64, np.dtype(np.uint8): torch.uint8}
+
+    def stage_upload(self, key, arr, dtype=np.float32):
+        """Host array -> fresh device tensor of `dtype` through a pinned staging buffer kept per `key`: one conversion /
+        copy on the host (numpy's rounding for float64 -> float32 = the reference's `.type(torch.float)`, PMVO.py:40), one
+        asynchronous copy on the current stream.  `tensor.to(device)` from pageable memory blocks the host for the whole
+        transfer; the drivers upload a pass's arrays while the GPU works."""
+        a = np.asarray(arr)
+        dt = np.dtype(dtype)
+        dev = torch.empty(a.shape, dtype=self._TORCH_OF[dt], device=self.device)
+        nbytes = a.size * dt.itemsize
+        if nbytes == 0:
+            return dev
+        pool = self.__dict__.setdefault("_stage_named", {})
+        ent = pool.get(key)
+        if ent is not None:
+            ent[1].synchronize()          # the previous copy out of this buffer
+        if ent is None or ent[0].numel() < nbytes:
+            ent = pool[key] = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True), torch.cuda.Event()]
+        host = ent[0].numpy()[:nbytes].view(dt).reshape(a.shape)
+        np.copyto(host, a, casting="same_kind")
+        cs = torch.cuda.current_stream(self.device)
+        _lib.check(self._L.mh_upload_async(self._ctx, ent[0].data_ptr(), dev.data_ptr(), nbytes, cs.cuda_stream),
+                   "mh_upload_async")
+        ent[1].record(cs)
+        return dev
+
+    def start_refine_prefetch(self, pts_dev, sub_num=5000, k=100):
+        """What refine() needs of the POINTS alone (PMVO.py:605-612 the 100 nearest neighbours of every point; :96-137 the
+        head-filter votes and the scalp test) is prepared on a stream of its own while optimize()'s iterations run: see
+        RefinePrefetch.  Called by optimize() once its launches are queued; refine() adopts the result if it is handed
+        the same points (compared on the device, bit for bit)."""
+        if os.environ.get("MH_REFINE_PREFETCH", "1") == "0":
+            self._prefetch = None
+            return None
+        self._prefetch = RefinePrefetch(self, pts_dev, sub_num, k)
+        return self._prefetch
+
+    def take_refine_prefetch(self, pts_dev, sub_num, k):
+        """The prefetch of start_refine_prefetch if it was made for exactly these points and thresholds, else None."""
+        pf, self._prefetch = getattr(self, "_prefetch", None), None
+        if pf is None:
+            return None
+        return pf.adopt(pts_dev, sub_num, k)
+
     def _get_scratch(self, N, key=None):
         """Tap-list scratch of the search, one buffer per launch stream (chunks of `optimize` are independent and
         may be in flight on different streams)."""
@@ -648,11 +703,124 @@ class PMVO:
         return torch.logical_and(head, ~head_top.bool())
 
 
+class RefinePrefetch:
+    """The point-only inputs of refine()'s smoothing loop, prepared while optimize() runs (single rank).
+
+    refine's neighbour table `KDTree(points).query(points, 100)` (PMVO.py:605-612), the head-filter votes of every point
+    (:110-137, per 5000-point chunk) and the scalp test (:98-107) depend on the points alone, and the points exist before
+    optimize() starts.  A helper thread builds the grid, runs the self-query (with its host-side retries) and the two
+    vote kernels on a low-priority stream of its own; the search kernels of optimize() keep the GPU, these fill what they
+    leave.  refine() adopts the result only if the points it is handed equal these bit for bit (mh_buffers_differ on the
+    device) and the thresholds are the ones used here; otherwise it computes everything itself as before."""
+
+    def __init__(self, pmvo, pts_dev, sub_num, k):
+        import threading
+
+        self.pmvo, self.pts_dev, self.sub_num, self.k = pmvo, pts_dev, int(sub_num), int(k)
+        self.n = int(pts_dev.shape[0])
+        self.conf_threshold, self.visible_threshold = float(pmvo.conf_threshold), float(pmvo.visible_threshold)
+        self.scalp_tree = pmvo.scalp_tree
+        self.error = None
+        self.grid = self.index_all = self.head_all = self.head_top_all = None
+        prio = os.environ.get("MH_PREFETCH_PRIORITY", "low")
+        rng = (0, 0)
+        try:
+            rng = torch.cuda.Stream.priority_range()        # (least, greatest), e.g. (0, -1)
+        except Exception:
+            pass
+        self.stream = pmvo.aux_stream("prefetch_" + prio, priority=(rng[0] if prio == "low" else 0))
+        self.ready = torch.cuda.Event()
+        self.ready.record(torch.cuda.current_stream(pmvo.device))      # pts_dev's upload is queued on the caller's stream
+        self.done = torch.cuda.Event()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        from .pmvo_utils import GridKNN
+
+        pm = self.pmvo
+        try:
+            with torch.cuda.device(pm.device), torch.cuda.stream(self.stream):
+                self.stream.wait_event(self.ready)
+                if self.n:
+                    self.grid = GridKNN(self.pts_dev, k_hint=self.k, device=pm.device)
+                    self.index_all = self.grid.query(self.pts_dev, self.k, int32=True, self_query=True).contiguous()
+                    self.head_all = torch.empty((self.n,), dtype=torch.uint8, device=pm.device)
+                    _lib.check(pm._L.mh_filter_points(pm._ctx, _lib.ptr(self.pts_dev), self.n, pm._side,
+                                                      self.conf_threshold, self.visible_threshold, None, None, None,
+                                                      _lib.ptr(self.head_all), self.sub_num, 0, self.n,
+                                                      _lib.stream_ptr()), "mh_filter_points")
+                    if self.scalp_tree is not None:
+                        self.head_top_all = pm.head_top_mask_device(self.pts_dev)
+                self.done.record(self.stream)
+        except BaseException as e:          # refine() then prepares these itself
+            self.error = e
+
+    def adopt(self, pts_dev, sub_num, k):
+        """-> self (results valid on the CURRENT stream) or None.  Joins the helper thread."""
+        self.thread.join()
+        pm = self.pmvo
+        if (self.error is not None or self.n != int(pts_dev.shape[0]) or self.n == 0 or self.sub_num != int(sub_num)
+                or self.k != int(k) or self.conf_threshold != float(pm.conf_threshold)
+                or self.visible_threshold != float(pm.visible_threshold) or self.scalp_tree is not pm.scalp_tree
+                or self.head_top_all is None):
+            return None
+        cur = torch.cuda.current_stream(pm.device)
+        cur.wait_event(self.done)
+        flag = torch.empty(1, dtype=torch.int32, device=pm.device)
+        _lib.check(pm._L.mh_buffers_differ(pm._ctx, _lib.ptr(pts_dev), _lib.ptr(self.pts_dev), self.n * 12, _lib.ptr(flag),
+                                           _lib.stream_ptr()), "mh_buffers_differ")
+        if int(flag.cpu().numpy()[0]) != 0:
+            return None
+        for t in (self.index_all, self.head_all, self.head_top_all):
+            t.record_stream(cur)              # allocated on the prefetch stream, used on this one from now on
+        self.grid.record_stream(cur)
+        return self
+
+
 # =====================================================================================================
 # Drivers -- mirrors of the module-level functions of the reference's PMVO.py (:535-764).  Chunking, file
 # names and dtypes are the reference's (they are its checkpoint/resume mechanism); with torch.distributed
 # initialised the independent chunks are dealt round-robin to the ranks (monohair_amd.dist).
 # =====================================================================================================
+def _filter_single(points, pmvo, step, num_sub_p):
+    """filter_negative_points on one rank: the candidates go up in a few large blocks (the float64 -> float32 conversion of
+    block k+1 runs on the host while the GPU votes on block k), one vote launch per block -- the kernel is told where its
+    points sit in the reference's N//30-sized pieces (PMVO.py:540-552; include/mh_pmvo.h: batch / row0 / total) -- and the
+    surface points are compacted on the device (`covered[surface].astype(float32)` = the selected rows of the float32
+    copy the votes were computed on).  -> (flags [total,2] uint8 numpy, surface_points float32 [S,3] numpy, pinned)."""
+    dev = pmvo.device
+    L, ctx = pmvo._L, pmvo._ctx
+    total = min(int(points.shape[0]), step * num_sub_p)
+    per = max(1, -(-step // 4)) * num_sub_p                      # four blocks, cut at piece boundaries
+    bounds = [(lo, min(lo + per, total)) for lo in range(0, total, per)]
+    surf = torch.empty((total,), dtype=torch.uint8, device=dev)
+    filt = torch.empty((total,), dtype=torch.uint8, device=dev)
+    out = torch.empty((total, 3), dtype=torch.float32, device=dev)
+    cnt = torch.zeros((len(bounds) + 1,), dtype=torch.int32, device=dev)
+    scratch = torch.empty(int(L.mh_select_scratch_bytes(per)), dtype=torch.uint8, device=dev)
+    st = _lib.stream_ptr()
+    off = lambda t, row, width=1: ctypes.c_void_p(t.data_ptr() + row * width * t.element_size())   # noqa: E731
+    for k, (lo, hi) in enumerate(bounds):
+        blk = pmvo.stage_upload("filter%d" % k, points[lo:hi])
+        _lib.check(L.mh_filter_points(ctx, _lib.ptr(blk), hi - lo, pmvo._side, float(pmvo.conf_threshold),
+                                      float(pmvo.visible_threshold), off(surf, lo), off(filt, lo), None, None,
+                                      num_sub_p, lo, total, st), "mh_filter_points")
+        _lib.check(L.mh_select_rows(ctx, off(surf, lo), None, 0, hi - lo, _lib.ptr(blk), None, _lib.ptr(out), None, None,
+                                    off(cnt, k), off(cnt, k + 1), _lib.ptr(scratch), scratch.numel(), st), "mh_select_rows")
+    flags = torch.empty((2, total), dtype=torch.uint8, pin_memory=True)
+    hcnt = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+    flags[0].copy_(surf, non_blocking=True)
+    flags[1].copy_(filt, non_blocking=True)
+    hcnt.copy_(cnt[len(bounds):], non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()
+    S = int(hcnt[0])
+    pts = torch.empty((S, 3), dtype=torch.float32, pin_memory=True)
+    pts.copy_(out[:S], non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()
+    return flags.numpy(), pts.numpy()
+
+
 def filter_negative_points(points, pmvo, args, step=30):
     """PMVO.py:535-557: surface / shell classification of the raw candidates, in N//30-sized pieces."""
     from . import dist as mdist
@@ -660,6 +828,12 @@ def filter_negative_points(points, pmvo, args, step=30):
     if points.shape[0] % step != 0:
         step = step + 1
     num_sub_p = points.shape[0] // 30
+    if mdist.world() == 1 and num_sub_p > 0 and isinstance(points, np.ndarray) and os.environ.get("MH_FILTER_BLOCKS", "1") != "0":
+        flags, surface_points = _filter_single(points, pmvo, step, num_sub_p)
+        surface_indexs, filter_indexs = flags[0].astype(bool), flags[1].astype(bool)
+        print("surface_num:", surface_points.shape[:])
+        print("num filter_unvisible:", np.sum(filter_indexs))
+        return surface_indexs, surface_points, filter_indexs
     pieces = [points[i * num_sub_p:(i + 1) * num_sub_p] for i in range(step)]
 
     def work(sub):
@@ -679,38 +853,52 @@ def filter_negative_points(points, pmvo, args, step=30):
     return surface_indexs, surface_points, filter_indexs
 
 
-def optimize(points, pmvo, args):
-    """PMVO.py:565-595: forward() over chunks of 5000 points, results to optimize/*.npy."""
+def _start_mat_prefault(pmvo, args, points):
+    """Ori3D.mat / Occ3D.mat of refine() are created and their pages made resident by a background thread (SparseMatWriter:
+    26 ms of page faults at the headline size).  With refine's device-resident pass the whole of refine takes less than
+    that, so the thread starts HERE, while optimize()'s iterations run: every surface point is a candidate voxel.  refine()
+    adopts the writer when it is asked for the same directory and the default grid; a writer that is not adopted removes
+    its temporary files when it is dropped."""
     from . import dist as mdist
+    from . import pmvo_utils as U
 
-    num_sub_p = 5000
-    step = points.shape[0] // num_sub_p + 1
-    # the candidate points go to the device ONCE (3.4 MB at the headline size); a chunk is a slice of that tensor.  (One
-    # pageable `.to(device)` per chunk, as the reference does it, blocks the host for ~0.2 ms each.)
-    pts_np = points if isinstance(points, np.ndarray) else torch.as_tensor(points).detach().cpu().numpy()
-    # ONE float64 -> float32 conversion (numpy's rounding = the reference's `.type(torch.float)`, PMVO.py:40), in the pinned
-    # staging buffer: the result is both what is uploaded and select_p.npy (PMVO.py:575)
+    old = getattr(pmvo, "_mat_early", None)
+    pmvo._mat_early = None
+    if old is not None:
+        old[1].abort()
+    path = getattr(args, "save_path", "") or ""
+    if mdist.rank() != 0 or not os.path.isdir(path) or os.environ.get("MH_MAT_EARLY", "1") == "0" or not len(points):
+        return
+    pmvo._mat_early = (path, U.SparseMatWriter(path, U.GRID_RESOLUTION, points, U.VOXEL_MIN, U.VOXEL_SIZE))
+
+
+def _optimize_single(pts_np, pmvo, args):
+    """optimize() on one rank.  The chunks rotate over three HIP streams (consecutive chunks are independent: the tail of
+    one chunk's search kernel -- workgroups of points that see many views -- overlaps the front end and the head of the
+    next chunks); every chunk's search writes straight into its slice of three device buffers.  The result files are
+    STREAMED: a copy stream brings the rows of each group of eight finished chunks to pinned host arrays while later
+    chunks compute, and the host appends them to optimize/*.npy (np.save's bytes, NpyRowWriter) -- when the last search
+    ends, one group is left to copy and write.  While the GPU iterates, what refine() needs of the points alone is
+    prepared on a low-priority stream (PMVO.start_refine_prefetch)."""
     from concurrent.futures import ThreadPoolExecutor
 
-    pool = ThreadPoolExecutor(4)
+    from .pmvo_utils import NpyRowWriter
 
-    # consecutive chunks are independent: they rotate over three HIP streams so that the tail of one chunk's search
-    # kernel (workgroups of points that see many views) overlaps the front end and the head of the next chunks (two
-    # streams: -1 % on continuous maps, -5 % on 8-bit maps, where the front end is a third of an iteration)
-    streams = pmvo.side_streams(3)     # kept on the object: their tap-list scratch (1.2 GB each) is reused
-    counter = [0]
-    main = torch.cuda.current_stream()
+    num_sub_p = 5000
     M = int(pts_np.shape[0])
-    if mdist.world() == 1:
-        # one rank: every chunk's search writes straight into its slice of three result buffers; three copies to the
-        # host at the end
-        o_all = torch.empty((M, 3), dtype=torch.float32, device=pmvo.device)
-        l_all = torch.empty((M,), dtype=torch.float32, device=pmvo.device)
-        h_all = torch.empty((M,), dtype=torch.bool, device=pmvo.device)
-
-    def join():                        # results are read on the main stream: join the side streams first
-        for st in streams:
-            main.wait_stream(st)
+    step = M // num_sub_p + 1
+    dev = pmvo.device
+    streams = pmvo.side_streams(3)     # kept on the object: their tap-list scratch (1.2 GB each) is reused
+    main = torch.cuda.current_stream(dev)
+    cp = pmvo.aux_stream("copy")
+    o_all = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    l_all = torch.empty((M,), dtype=torch.float32, device=dev)
+    h_all = torch.empty((M,), dtype=torch.bool, device=dev)
+    # the arrays the caller gets: pinned, filled group by group (torch's host allocator recycles the blocks)
+    ho = torch.empty((M, 3), dtype=torch.float32, pin_memory=True)
+    hl = torch.empty((M,), dtype=torch.float32, pin_memory=True)
+    hh = torch.empty((M,), dtype=torch.bool, pin_memory=True)
+    done = {}                          # chunk -> event on its stream
 
     def launch(dev_all, lo_chunk, hi_chunk):
         for st in streams:
@@ -719,47 +907,109 @@ def optimize(points, pmvo, args):
             a, b = i * num_sub_p, min((i + 1) * num_sub_p, M)
             if b <= a:
                 continue
-            with torch.cuda.stream(streams[i % len(streams)]):
+            st = streams[i % len(streams)]
+            with torch.cuda.stream(st):
                 pmvo.forward(dev_all[a:b], out=(o_all[a:b], l_all[a:b], h_all[a:b]))
+                done[i] = torch.cuda.Event()
+                done[i].record(st)
 
     nhead = len(streams)               # chunks launched before the rest of the points is converted and copied
+    # the candidate points go to the device ONCE (3.4 MB at the headline size); a chunk is a slice of that tensor
+    dev_all, staged = pmvo.upload_all_points(pts_np, head=nhead * num_sub_p, after_head=lambda d: launch(d, 0, nhead))
+    launch(dev_all, nhead, step)
+    pmvo.start_refine_prefetch(dev_all, num_sub_p, 100)
+    _start_mat_prefault(pmvo, args, pts_np)
+    # select_p.npy is the float32 copy of the input (PMVO.py:40,575): written while the GPU works
+    select_points = pts_np if (pts_np.dtype == np.float32 and pts_np.flags.c_contiguous) else staged.copy()
+    os.makedirs(args.save_root, exist_ok=True)
+    pool = ThreadPoolExecutor(1)
+    early = pool.submit(np.save, args.save_root + "/select_p.npy", select_points)
+    # groups of finished chunks -> pinned host rows -> files
+    files = (NpyRowWriter(args.save_root + "/select_o.npy", (M, 3), np.float32),
+             NpyRowWriter(args.save_root + "/min_loss.npy", (M,), np.float32),
+             NpyRowWriter(args.save_root + "/high_conf_index.npy", (M,), np.bool_))
+    chunks = sorted(done)
+    GROUP = 8
+    groups = []
+    with torch.cuda.stream(cp):
+        for g0 in range(0, len(chunks), GROUP):
+            grp = chunks[g0:g0 + GROUP]
+            for i in grp[-len(streams):]:                 # the last chunk of the group on each stream
+                cp.wait_event(done[i])
+            a, b = grp[0] * num_sub_p, min((grp[-1] + 1) * num_sub_p, M)
+            ho[a:b].copy_(o_all[a:b], non_blocking=True)
+            hl[a:b].copy_(l_all[a:b], non_blocking=True)
+            hh[a:b].copy_(h_all[a:b], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(cp)
+            groups.append((a, b, ev))
+    select_ori, min_loss, high_conf_index = ho.numpy(), hl.numpy(), hh.numpy()
+    for a, b, ev in groups:
+        ev.synchronize()
+        files[0].write(select_ori[a:b])
+        files[1].write(min_loss[a:b])
+        files[2].write(high_conf_index[a:b])
+    for f in files:
+        f.close()
+    for st in streams:                 # (all their work is over: the last group's copy waited for it)
+        main.wait_stream(st)
+    main.wait_stream(cp)
+    early.result()
+    pool.shutdown()
+    return select_points, select_ori, min_loss, high_conf_index
+
+
+def optimize(points, pmvo, args):
+    """PMVO.py:565-595: forward() over chunks of 5000 points, results to optimize/*.npy.
+    Returns (select_points, select_ori, min_loss, high_conf_index) -- the arrays the reference loads back from the files
+    (PMVO.py:868-870); on one rank they live in pinned host memory."""
+    from . import dist as mdist
+
+    num_sub_p = 5000
+    step = points.shape[0] // num_sub_p + 1
+    pts_np = points if isinstance(points, np.ndarray) else torch.as_tensor(points).detach().cpu().numpy()
     if mdist.world() == 1:
-        dev_all, select_points = pmvo.upload_all_points(pts_np, head=nhead * num_sub_p,
-                                                        after_head=lambda d: launch(d, 0, nhead))
-    else:
-        dev_all, select_points = pmvo.upload_all_points(pts_np)
-    if mdist.world() == 1:
-        launch(dev_all, nhead, step)
-    # select_p.npy is the float32 copy of the input (PMVO.py:40,575): copied out of the staging buffer (which the next call
-    # reuses) and written while the GPU works
+        out = _optimize_single(pts_np, pmvo, args)
+        assert len(out[2]) == len(out[0])
+        return out
+    from concurrent.futures import ThreadPoolExecutor
+
+    pool = ThreadPoolExecutor(4)
+    streams = pmvo.side_streams(3)
+    counter = [0]
+    main = torch.cuda.current_stream()
+
+    def join():                        # results are read on the main stream: join the side streams first
+        for st in streams:
+            main.wait_stream(st)
+
+    # ONE float64 -> float32 conversion (numpy's rounding = the reference's `.type(torch.float)`, PMVO.py:40), in the pinned
+    # staging buffer: the result is both what is uploaded and select_p.npy (PMVO.py:575)
+    dev_all, select_points = pmvo.upload_all_points(pts_np)
     select_points = select_points.copy()
     early = None
     if mdist.rank() == 0:
         os.makedirs(args.save_root, exist_ok=True)
         early = pool.submit(np.save, args.save_root + "/select_p.npy", select_points)
-    if mdist.world() == 1:
-        join()
-        select_ori, min_loss, high_conf_index = o_all.cpu().numpy(), l_all.cpu().numpy(), h_all.cpu().numpy()
-    else:
-        for st in streams:
-            st.wait_stream(main)
-        chunks = [dev_all[i * num_sub_p:(i + 1) * num_sub_p] for i in range(step)]
+    for st in streams:
+        st.wait_stream(main)
+    chunks = [dev_all[i * num_sub_p:(i + 1) * num_sub_p] for i in range(step)]
 
-        def work(sub):
-            st = streams[counter[0] % len(streams)]
-            counter[0] += 1
-            with torch.cuda.stream(st):
-                _, o, l, h = pmvo.forward(sub)
-                # (the points forward() returns are the float32 copy of its input: they do not travel back)
-                out = torch.cat([o, l[:, None], h[:, None].to(torch.float32)], 1)
-            out.record_stream(main)
-            return out
+    def work(sub):
+        st = streams[counter[0] % len(streams)]
+        counter[0] += 1
+        with torch.cuda.stream(st):
+            _, o, l, h = pmvo.forward(sub)
+            # (the points forward() returns are the float32 copy of its input: they do not travel back)
+            out = torch.cat([o, l[:, None], h[:, None].to(torch.float32)], 1)
+        out.record_stream(main)
+        return out
 
-        res = mdist.map_chunks(chunks, work, pmvo.device,
-                               empty=lambda: torch.empty((0, 5), dtype=torch.float32, device=pmvo.device), after=join)
-        res = torch.cat(res, 0).cpu().numpy()
-        select_ori, min_loss = res[:, 0:3], res[:, 3]
-        high_conf_index = res[:, 4] > 0.5
+    res = mdist.map_chunks(chunks, work, pmvo.device,
+                           empty=lambda: torch.empty((0, 5), dtype=torch.float32, device=pmvo.device), after=join)
+    res = torch.cat(res, 0).cpu().numpy()
+    select_ori, min_loss = res[:, 0:3], res[:, 3]
+    high_conf_index = res[:, 4] > 0.5
     assert len(min_loss) == len(select_points)
     if mdist.rank() == 0:
         jobs = (("select_o", select_ori), ("min_loss", min_loss), ("high_conf_index", high_conf_index))
@@ -791,6 +1041,187 @@ def _knn(data_points, query_points, k, device, mode="device", int32=False, self_
     return torch.from_numpy(index.astype(np.int32) if int32 else index).to(device)
 
 
+def _refine_device(points, ori, loss, pmvo, filter_unvisible_points, args, threshold, voxel_min, voxel_size,
+                   grid_resolution):
+    """The smoothing loop, the loss threshold, the shell points and the voxel fit of refine() (PMVO.py:602-726) on one rank
+    with every array resident on the device from the first launch to the last: between the stages the host reads four
+    counters, nothing else -- the `np.where` / `ori[index]` / `np.concatenate` steps of the reference are stable
+    compactions on the device (mh_flag_less, mh_select_rows, mh_segment_heads), the neighbour table / head votes / scalp
+    test of the points come from optimize()'s prefetch when it was made for these points, and the refine/*.npy files are
+    written by a worker thread from pinned copies while the shell stage and the fit run.  Same kernels on the same values
+    in the same order as the host-driven form below (tests pin both to the reference's multi-chunk run).
+
+    -> dict(ori=..., loss=... host arrays of the smoothed result (also stored into the caller's arrays), grid, saver,
+    save_error, and -- unless the shell stage has to take the host path (fewer kept points than neighbours asked for, or
+    a query the grid could not finish at its first cell size) -- vox, vori, shell_points, shell_ori)."""
+    import threading
+
+    from . import pmvo_utils as U
+
+    device = pmvo.device
+    L, ctx = pmvo._L, pmvo._ctx
+    n_all, sub_num = int(points.shape[0]), 5000
+    step = n_all // sub_num + 1
+    main = torch.cuda.current_stream(device)
+    side = pmvo.aux_stream("refine_side")
+    cp = pmvo.aux_stream("copy")
+    off = lambda t, row, width=1: ctypes.c_void_p(t.data_ptr() + row * width * t.element_size())   # noqa: E731
+    fu = np.ascontiguousarray(filter_unvisible_points) if filter_unvisible_points is not None else np.zeros((0, 3), np.float32)
+    F = int(len(fu))
+    T_up = stage("refine: uploads + prefetch adoption", device).__enter__()
+    pts_dev = pmvo.stage_upload("refine_p", np.asarray(points).reshape(-1, 3))
+    ori_dev = pmvo.stage_upload("refine_o", np.asarray(ori).reshape(-1, 3))
+    loss_dev = pmvo.stage_upload("refine_l", np.asarray(loss).reshape(-1))
+    pf = pmvo.take_refine_prefetch(pts_dev, sub_num, 100)
+    T_up.__exit__()
+    # the shell points' votes and scalp test need the shell points only: first thing on the side stream
+    hd = ht = fb_dev = fq_dev = None
+    side.wait_stream(main)
+    if F:
+        with torch.cuda.stream(side):
+            fb_dev = pmvo.stage_upload("refine_fb", fu.reshape(-1, 3))                    # float32 (votes, scalp test, files)
+            fq_dev = pmvo.stage_upload("refine_fq", fu.reshape(-1, 3), np.float64) if fu.dtype == np.float64 else fb_dev
+            hd = torch.empty((F,), dtype=torch.uint8, device=device)
+            _lib.check(L.mh_filter_points(ctx, _lib.ptr(fb_dev), F, pmvo._side, float(pmvo.conf_threshold),
+                                          float(args.PMVO.visible_threshold), None, None, None, _lib.ptr(hd), 5000, 0, F,
+                                          _lib.stream_ptr()), "mh_filter_points")
+            ht = pmvo.head_top_mask_device(fb_dev)
+    if pf is not None:
+        grid, index_all, head_all, head_top_all = pf.grid, pf.index_all, pf.head_all, pf.head_top_all
+    else:
+        with stage("refine: knn (surface)", device):
+            grid = U.GridKNN(pts_dev, k_hint=100, device=device)
+            index_all = grid.query(pts_dev, min(100, n_all), int32=True, self_query=True).contiguous()
+        with stage("refine: head-top mask", device):
+            head_top_all = pmvo.head_top_mask_device(pts_dev)
+        head_all = torch.empty((n_all,), dtype=torch.uint8, device=device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            _lib.check(L.mh_filter_points(ctx, _lib.ptr(pts_dev), n_all, pmvo._side, float(pmvo.conf_threshold),
+                                          float(pmvo.visible_threshold), None, None, None, _lib.ptr(head_all), sub_num, 0,
+                                          n_all, _lib.stream_ptr()), "mh_filter_points")
+    T_loop = stage("refine: smoothing loop", device).__enter__()
+    K = int(index_all.shape[1])
+    st = _lib.stream_ptr()
+    centers = torch.empty((n_all, 3), dtype=torch.float32, device=device)
+    loss_all = torch.empty((n_all,), dtype=torch.float32, device=device)
+    # Only the ORIENTATIONS chain from chunk to chunk (chunk k+1's medoids read what chunk k replaced, PMVO.py:614,640):
+    # medoid -> replacement rule, two small launches per chunk on the main stream; the loss of a chunk's medoid directions
+    # (PMVO.py:619-623) feeds nothing in later chunks and runs beside the chain on the side stream, in groups of chunks as
+    # soon as their medoids exist (short groups first, so that the side stream starts early); one launch writes every loss.
+    g0, nxt, grp = 0, 2, 2
+    with torch.cuda.stream(side):
+        st2 = _lib.stream_ptr()
+    for i in range(step):
+        lo, hi = i * sub_num, min((i + 1) * sub_num, n_all)
+        if hi > lo:
+            _lib.check(L.mh_medoid_indexed(ctx, _lib.ptr(ori_dev), off(index_all, lo, K), hi - lo, K, off(centers, lo, 3),
+                                           None, st), "mh_medoid_indexed")
+            _lib.check(L.mh_replace_dissimilar(ctx, off(centers, lo, 3), off(ori_dev, lo, 3), 0.95, hi - lo, st),
+                       "mh_replace_dissimilar")
+        if (i + 1 == nxt or i == step - 1) and hi > g0:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            _lib.check(L.mh_refine_loss_maps(ctx, off(pts_dev, g0, 3), off(centers, g0, 3), 0.005, 4.0, hi - g0, pmvo._side,
+                                             float(pmvo.conf_threshold), off(loss_all, g0), None, sub_num, g0, n_all, st2),
+                       "mh_refine_loss_maps")
+            g0 = hi
+            grp = min(grp * 2, 8)
+            nxt = i + 1 + grp
+    main.wait_stream(side)
+    _lib.check(L.mh_refine_combine(ctx, _lib.ptr(centers), _lib.ptr(loss_all), _lib.ptr(head_all), _lib.ptr(head_top_all),
+                                   0.95, None, _lib.ptr(loss_dev), n_all, st), "mh_refine_combine")
+    # the smoothed arrays travel to pinned host memory on the copy stream while the shell stage runs; a worker writes the
+    # three files of PMVO.py:645-648 from them (the reference reads them back right away, :650-652 -- the arrays in memory
+    # are what np.load would return)
+    ev_loop = torch.cuda.Event()
+    ev_loop.record(main)
+    ho = torch.empty((n_all, 3), dtype=torch.float32, pin_memory=True)
+    hl = torch.empty((n_all,), dtype=torch.float32, pin_memory=True)
+    ev_res = torch.cuda.Event()
+    with torch.cuda.stream(cp):
+        cp.wait_event(ev_loop)
+        ho.copy_(ori_dev, non_blocking=True)
+        hl.copy_(loss_dev, non_blocking=True)
+        ev_res.record(cp)
+    new_ori, new_loss = ho.numpy(), hl.numpy()
+    save_error = []
+    os.makedirs(args.output_path + "/refine", exist_ok=True)
+
+    def _save():
+        try:
+            np.save(args.output_path + "/refine/select_p.npy", points)
+            ev_res.synchronize()
+            np.save(args.output_path + "/refine/select_o.npy", new_ori)
+            np.save(args.output_path + "/refine/min_loss.npy", new_loss)
+        except BaseException as e:      # re-raised on the calling thread after the join
+            save_error.append(e)
+
+    saver = threading.Thread(target=_save)
+    saver.start()
+    T_loop.__exit__()
+    out = dict(grid=grid, saver=saver, save_error=save_error, ori=new_ori, loss=new_loss, ev_res=ev_res)
+    # ---- loss threshold, shell points, concatenation: flags and compactions, no host in between (PMVO.py:651-693)
+    T_shell = stage("refine: shell points", device).__enter__()
+    valid = torch.empty((n_all,), dtype=torch.uint8, device=device)
+    _lib.check(L.mh_flag_less(ctx, _lib.ptr(loss_dev), float(threshold), n_all, _lib.ptr(valid), st), "mh_flag_less")
+    cap = n_all + F
+    sel_p = torch.empty((cap, 3), dtype=torch.float32, device=device)
+    sel_o = torch.empty((cap, 3), dtype=torch.float32, device=device)
+    cnt = torch.zeros((2,), dtype=torch.int32, device=device)
+    scratch = torch.empty(int(L.mh_select_scratch_bytes(max(n_all, F))), dtype=torch.uint8, device=device)
+    _lib.check(L.mh_select_rows(ctx, _lib.ptr(valid), None, 0, n_all, _lib.ptr(pts_dev), _lib.ptr(ori_dev), _lib.ptr(sel_p),
+                                _lib.ptr(sel_o), None, None, off(cnt, 0), _lib.ptr(scratch), scratch.numel(), st),
+               "mh_select_rows")
+    hcnt = torch.empty((2,), dtype=torch.int32, pin_memory=True)
+    hcnt[:1].copy_(cnt[:1], non_blocking=True)
+    main.synchronize()                   # (1) the number of points the threshold keeps
+    n_valid = int(hcnt[0])
+    n_sel = n_valid
+    if F and n_valid:
+        if n_valid < min(100, n_all):    # the reference then asks for n_valid neighbours: the host-driven stage below does
+            T_shell.__exit__()
+            return out
+        # KDTree(select_points).query(fu, 100) on the grid of ALL points with the kept ones flagged valid: the indices
+        # come back in terms of `points` (order-preserving compaction: same (distance, index) order), so the medoid reads
+        # the full orientation array (PMVO.py:660-672)
+        idx, status = grid.query_nosync(fq_dev, 100, valid_dev=valid)
+        cen = torch.empty((F, 3), dtype=torch.float32, device=device)
+        _lib.check(L.mh_medoid_indexed(ctx, _lib.ptr(ori_dev), _lib.ptr(idx), F, int(idx.shape[1]), _lib.ptr(cen), None, st),
+                   "mh_medoid_indexed")
+        main.wait_stream(side)
+        # kept = not filter_head_points = not (head votes and not under the scalp top) (PMVO.py:674-686)
+        _lib.check(L.mh_select_rows(ctx, _lib.ptr(hd), _lib.ptr(ht), 1, F, _lib.ptr(fb_dev), _lib.ptr(cen), _lib.ptr(sel_p),
+                                    _lib.ptr(sel_o), None, off(cnt, 0), off(cnt, 1), _lib.ptr(scratch), scratch.numel(), st),
+                   "mh_select_rows")
+        hst = torch.empty((F,), dtype=torch.int32, pin_memory=True)
+        hst.copy_(status, non_blocking=True)
+        hcnt[1:].copy_(cnt[1:], non_blocking=True)
+        main.synchronize()               # (2) kept shell rows; queries the grid could not finish at its first cell size
+        if bool(hst.numpy().any()):
+            T_shell.__exit__()
+            return out                   # the host-driven shell stage below retries them on other cell sizes
+        n_sel = int(hcnt[1])
+    else:
+        main.wait_stream(side)
+    T_shell.__exit__()
+    # (no shell stage without kept points or without shell points, PMVO.py:658)
+    hp = torch.empty((n_sel - n_valid, 3), dtype=torch.float32, pin_memory=True)
+    hq = torch.empty((n_sel - n_valid, 3), dtype=torch.float32, pin_memory=True)
+    ev_shell = torch.cuda.Event()
+    with torch.cuda.stream(cp):
+        cp.wait_stream(main)
+        hp.copy_(sel_p[n_valid:n_sel], non_blocking=True)
+        hq.copy_(sel_o[n_valid:n_sel], non_blocking=True)
+        ev_shell.record(cp)
+    with stage("refine: voxel fit + reduce", device):
+        vox, vori = U.voxel_fit_device(sel_p, sel_o, n_sel, device, voxel_min, voxel_size, grid_resolution)
+    ev_shell.synchronize()
+    out.update(vox=vox, vori=vori, shell_points=hp.numpy(), shell_ori=hq.numpy())
+    return out
+
+
 def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=True, threshold=0.001,
            genrate_ori_only=False, voxel_min=None, voxel_size=None, grid_resolution=None, return_dense=True):
     """PMVO.py:602-764: KNN-medoid smoothing (sequentially dependent 5000-point chunks, in place), threshold,
@@ -811,247 +1242,286 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     # Ori3D.mat / Occ3D.mat are created NOW and their pages made resident in the background (every point that can end up in the
     # volume is known: the surface points and the shell candidates); the occupied elements are stored at the end
     mat_writer = None
-    if is_root and os.path.isdir(getattr(args, "save_path", "") or ""):
+    early, pmvo._mat_early = getattr(pmvo, "_mat_early", None), None
+    if early is not None:           # optimize() started the files of this directory while its iterations ran
+        if (is_root and early[0] == (getattr(args, "save_path", "") or "") and voxel_size == U.VOXEL_SIZE
+                and np.array_equal(voxel_min, U.VOXEL_MIN) and np.array_equal(grid_resolution, U.GRID_RESOLUTION)):
+            mat_writer = early[1]
+        else:
+            early[1].abort()
+    if mat_writer is None and is_root and os.path.isdir(getattr(args, "save_path", "") or ""):
         cands = [np.asarray(p_)[:, :3] for p_ in (points, filter_unvisible_points) if p_ is not None and len(p_)]
         mat_writer = U.SparseMatWriter(args.save_path, grid_resolution, np.concatenate(cands, 0) if cands else None,
                                        voxel_min, voxel_size)
+    dev_out = None
     if not genrate_ori_only:
         print("filter nosiy points...")
-        # Neighbour indices and the head-top mask depend on the points only: ONE host query for all chunks (all
-        # cores), then the sequentially dependent smoothing loop (chunk k+1 reads the orientations chunk k wrote,
-        # PMVO.py:614,640) runs entirely on the device, stream-ordered, without a host round trip per chunk.
-        n_all = points.shape[0]
-        sub_num = 5000
-        step = n_all // sub_num + 1
-        # With several ranks (mdist.refine_sharded) every rank owns a fixed slice of EVERY chunk: slice k of a chunk of n
-        # points is rows [lo + k*s, lo + (k+1)*s) with s = ceil(n / ranks).  A point's new orientation depends on the
-        # orientations as they were when its chunk started (the medoid launch reads them before the chunk's write-back,
-        # PMVO.py:614,640), so the slices of a chunk are independent; after the chunk one in-place all_gather per array
-        # makes every rank's copy complete again -- the arrays a rank holds at the start of a chunk are the single-rank
-        # ones, bit for bit.  Neighbour queries are needed for the owned rows only.
-        R, rk = (mdist.world(), mdist.rank()) if mdist.refine_sharded() else (1, 0)
-        # MH_REFINE_CHAIN=0: one rank runs the four-launches-per-chunk form of the sharded path (tests pin BOTH forms to the
-        # reference's multi-chunk run, tests/test_multichunk_gpu.py)
-        chain = R == 1 and os.environ.get("MH_REFINE_CHAIN", "1") != "0"
+        # One rank, device k-NN: the whole of :602-726 runs device-resident (_refine_device).  MH_REFINE_DEVICE=0, several
+        # ranks, args.knn = "host" or MH_REFINE_CHAIN=0 take the host-driven form below (tests pin both to the reference).
+        if (mdist.world() == 1 and len(points) and getattr(args, "knn", "device") == "device"
+                and os.environ.get("MH_REFINE_DEVICE", "1") != "0" and os.environ.get("MH_REFINE_CHAIN", "1") != "0"):
+            dev_out = _refine_device(points, ori, loss, pmvo, filter_unvisible_points, args, threshold, voxel_min,
+                                     voxel_size, grid_resolution)
+            saver, save_error = dev_out["saver"], dev_out["save_error"]
+            grid_all.append(dev_out["grid"])
+            dev_out["ev_res"].synchronize()
+            ori[:] = dev_out["ori"]              # in place, like the reference's chunk write-backs (PMVO.py:640-642)
+            loss[:] = dev_out["loss"]
+        if dev_out is None:
+            # Neighbour indices and the head-top mask depend on the points only: ONE host query for all chunks (all
+            # cores), then the sequentially dependent smoothing loop (chunk k+1 reads the orientations chunk k wrote,
+            # PMVO.py:614,640) runs entirely on the device, stream-ordered, without a host round trip per chunk.
+            n_all = points.shape[0]
+            sub_num = 5000
+            step = n_all // sub_num + 1
+            # With several ranks (mdist.refine_sharded) every rank owns a fixed slice of EVERY chunk: slice k of a chunk of n
+            # points is rows [lo + k*s, lo + (k+1)*s) with s = ceil(n / ranks).  A point's new orientation depends on the
+            # orientations as they were when its chunk started (the medoid launch reads them before the chunk's write-back,
+            # PMVO.py:614,640), so the slices of a chunk are independent; after the chunk one in-place all_gather per array
+            # makes every rank's copy complete again -- the arrays a rank holds at the start of a chunk are the single-rank
+            # ones, bit for bit.  Neighbour queries are needed for the owned rows only.
+            R, rk = (mdist.world(), mdist.rank()) if mdist.refine_sharded() else (1, 0)
+            # MH_REFINE_CHAIN=0: one rank runs the four-launches-per-chunk form of the sharded path (tests pin BOTH forms to the
+            # reference's multi-chunk run, tests/test_multichunk_gpu.py)
+            chain = R == 1 and os.environ.get("MH_REFINE_CHAIN", "1") != "0"
 
-        def own(i):
-            lo, hi = i * sub_num, min((i + 1) * sub_num, n_all)
-            s_ = -(-(hi - lo) // R) if hi > lo else 0
-            return lo, hi, s_, min(lo + rk * s_, hi), min(lo + (rk + 1) * s_, hi)
-
-        with stage("refine: knn (surface)", device):
-            if R == 1:
-                index_all = _knn(points, points, 100, device, getattr(args, "knn", "device"), int32=True,
-                                 self_query=True, keep_grid=grid_all).contiguous()
-                row_of = [i * sub_num for i in range(step)]
-            else:
-                mine = [np.arange(own(i)[3], own(i)[4]) for i in range(step)]
-                row_of = np.concatenate([[0], np.cumsum([len(m) for m in mine])]).tolist()
-                qidx = np.concatenate(mine) if mine else np.zeros(0, np.int64)
-                index_all = _knn(points, points[qidx], 100, device, getattr(args, "knn", "device"), int32=True,
-                                 keep_grid=grid_all).contiguous()
-        T_loop = stage("refine: smoothing loop", device).__enter__()
-        pts_dev = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(device)
-        with stage("refine: head-top mask", device):      # scalp half of filter_head_points, once for all chunks
-            head_top_all = pmvo.head_top_mask_device(pts_dev)
-        slack = R * (-(-sub_num // R)) if R > 1 else 0     # rows the in-place exchange may touch past the last chunk
-        if slack:
-            ori_dev = torch.zeros((n_all + slack, 3), dtype=torch.float32, device=device)
-            loss_dev = torch.zeros((n_all + slack,), dtype=torch.float32, device=device)
-            ori_dev[:n_all] = torch.from_numpy(ori).to(device).type(torch.float)
-            loss_dev[:n_all] = torch.from_numpy(loss).to(device).type(torch.float)
-        else:       # (one rank: no tensor operation beyond the upload -- first uses of torch kernels cost a one-shot run ~40 ms)
-            ori_dev = torch.from_numpy(ori).to(device).type(torch.float).contiguous()
-            loss_dev = torch.from_numpy(loss).to(device).type(torch.float).contiguous()
-        # per chunk four launches and no tensor op: medoid over the neighbour rows, the loss of that direction straight
-        # from the maps, the head-filter votes, and the tail (-1 / replacement / 0.5) in place
-        K = index_all.shape[1]
-        center = torch.empty((sub_num, 3), dtype=torch.float32, device=device)
-        loss_u = torch.empty((sub_num,), dtype=torch.float32, device=device)
-        head = torch.empty((sub_num,), dtype=torch.uint8, device=device)
-        L, ctx, st = pmvo._L, pmvo._ctx, _lib.stream_ptr()
-        off = lambda t, row, width=1: ctypes.c_void_p(t.data_ptr() + row * width * t.element_size())   # noqa: E731
-        if chain:
-            # One rank.  Only the ORIENTATIONS chain from chunk to chunk (chunk k+1's medoids read what chunk k replaced,
-            # PMVO.py:614,640): medoid -> replacement rule, 2 small launches per chunk on the main stream.  The loss of a
-            # chunk's medoid directions (PMVO.py:619-623) and the head-filter votes feed nothing in later chunks, so they
-            # run beside the chain on a second stream -- the votes of all points in one launch, the losses in groups of
-            # eight chunks as soon as their medoids exist -- and one launch writes every loss at the end.  Same kernels on
-            # the same values as the four-launches-per-chunk form the sharded path keeps (tests compare the two bit for bit).
-            main = torch.cuda.current_stream(device)
-            side = pmvo.side_streams(1)[0]
-            centers = torch.empty((n_all, 3), dtype=torch.float32, device=device)
-            loss_all = torch.empty((n_all,), dtype=torch.float32, device=device)
-            head_all = torch.empty((n_all,), dtype=torch.uint8, device=device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                st2 = _lib.stream_ptr()
-                # (batch arguments: the reference votes and sums per 5000-point chunk, PMVO.py:604-621 -- the kernels place
-                # every point in its chunk, see include/mh_pmvo.h: mh_refine_loss_maps)
-                _lib.check(L.mh_filter_points(ctx, _lib.ptr(pts_dev), n_all, pmvo._side, float(pmvo.conf_threshold),
-                                              float(pmvo.visible_threshold), None, None, None, _lib.ptr(head_all),
-                                              sub_num, 0, n_all, st2),
-                           "mh_filter_points")
-            GROUP, g0 = 8, 0
-            for i in range(step):
+            def own(i):
                 lo, hi = i * sub_num, min((i + 1) * sub_num, n_all)
-                if hi > lo:
-                    _lib.check(L.mh_medoid_indexed(ctx, _lib.ptr(ori_dev), off(index_all, lo, K), hi - lo, K,
-                                                   off(centers, lo, 3), None, st), "mh_medoid_indexed")
-                    _lib.check(L.mh_replace_dissimilar(ctx, off(centers, lo, 3), off(ori_dev, lo, 3), 0.95, hi - lo, st),
-                               "mh_replace_dissimilar")
-                if ((i + 1) % GROUP == 0 or i == step - 1) and hi > g0:
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    side.wait_event(ev)
-                    _lib.check(L.mh_refine_loss_maps(ctx, off(pts_dev, g0, 3), off(centers, g0, 3), 0.005, 4.0, hi - g0,
-                                                     pmvo._side, float(pmvo.conf_threshold), off(loss_all, g0), None,
-                                                     sub_num, g0, n_all, st2),
-                               "mh_refine_loss_maps")
-                    g0 = hi
-            main.wait_stream(side)
-            _lib.check(L.mh_refine_combine(ctx, _lib.ptr(centers), _lib.ptr(loss_all), _lib.ptr(head_all),
-                                           _lib.ptr(head_top_all), 0.95, None, _lib.ptr(loss_dev), n_all, st),
-                       "mh_refine_combine")
-        for i in range(0 if chain else step):
-            lo, hi, s_, a, b = own(i)
-            if hi <= lo:
-                continue
-            n = b - a
-            if n > 0:
-                _lib.check(L.mh_medoid_indexed(ctx, _lib.ptr(ori_dev), off(index_all, row_of[i], K), n, K,
-                                               _lib.ptr(center), None, st), "mh_medoid_indexed")
-                _lib.check(L.mh_refine_loss_maps(ctx, off(pts_dev, a, 3), _lib.ptr(center), 0.005, 4.0, n,
-                                                 pmvo._side, float(pmvo.conf_threshold), _lib.ptr(loss_u), None,
-                                                 sub_num, a, n_all, st),
-                           "mh_refine_loss_maps")
-                _lib.check(L.mh_filter_points(ctx, off(pts_dev, a, 3), n, pmvo._side, float(pmvo.conf_threshold),
-                                              float(pmvo.visible_threshold), None, None, None, _lib.ptr(head),
-                                              sub_num, a, n_all, st),
-                           "mh_filter_points")
-                _lib.check(L.mh_refine_combine(ctx, _lib.ptr(center), _lib.ptr(loss_u), _lib.ptr(head),
-                                               off(head_top_all, a), 0.95, off(ori_dev, a, 3), off(loss_dev, a), n, st),
+                s_ = -(-(hi - lo) // R) if hi > lo else 0
+                return lo, hi, s_, min(lo + rk * s_, hi), min(lo + (rk + 1) * s_, hi)
+
+            with stage("refine: knn (surface)", device):
+                if R == 1:
+                    index_all = _knn(points, points, 100, device, getattr(args, "knn", "device"), int32=True,
+                                     self_query=True, keep_grid=grid_all).contiguous()
+                    row_of = [i * sub_num for i in range(step)]
+                else:
+                    mine = [np.arange(own(i)[3], own(i)[4]) for i in range(step)]
+                    row_of = np.concatenate([[0], np.cumsum([len(m) for m in mine])]).tolist()
+                    qidx = np.concatenate(mine) if mine else np.zeros(0, np.int64)
+                    index_all = _knn(points, points[qidx], 100, device, getattr(args, "knn", "device"), int32=True,
+                                     keep_grid=grid_all).contiguous()
+            T_loop = stage("refine: smoothing loop", device).__enter__()
+            pts_dev = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(device)
+            with stage("refine: head-top mask", device):      # scalp half of filter_head_points, once for all chunks
+                head_top_all = pmvo.head_top_mask_device(pts_dev)
+            slack = R * (-(-sub_num // R)) if R > 1 else 0     # rows the in-place exchange may touch past the last chunk
+            if slack:
+                ori_dev = torch.zeros((n_all + slack, 3), dtype=torch.float32, device=device)
+                loss_dev = torch.zeros((n_all + slack,), dtype=torch.float32, device=device)
+                ori_dev[:n_all] = torch.from_numpy(ori).to(device).type(torch.float)
+                loss_dev[:n_all] = torch.from_numpy(loss).to(device).type(torch.float)
+            else:       # (one rank: no tensor operation beyond the upload -- first uses of torch kernels cost a one-shot run ~40 ms)
+                ori_dev = torch.from_numpy(ori).to(device).type(torch.float).contiguous()
+                loss_dev = torch.from_numpy(loss).to(device).type(torch.float).contiguous()
+            # per chunk four launches and no tensor op: medoid over the neighbour rows, the loss of that direction straight
+            # from the maps, the head-filter votes, and the tail (-1 / replacement / 0.5) in place
+            K = index_all.shape[1]
+            center = torch.empty((sub_num, 3), dtype=torch.float32, device=device)
+            loss_u = torch.empty((sub_num,), dtype=torch.float32, device=device)
+            head = torch.empty((sub_num,), dtype=torch.uint8, device=device)
+            L, ctx, st = pmvo._L, pmvo._ctx, _lib.stream_ptr()
+            off = lambda t, row, width=1: ctypes.c_void_p(t.data_ptr() + row * width * t.element_size())   # noqa: E731
+            if chain:
+                # One rank.  Only the ORIENTATIONS chain from chunk to chunk (chunk k+1's medoids read what chunk k replaced,
+                # PMVO.py:614,640): medoid -> replacement rule, 2 small launches per chunk on the main stream.  The loss of a
+                # chunk's medoid directions (PMVO.py:619-623) and the head-filter votes feed nothing in later chunks, so they
+                # run beside the chain on a second stream -- the votes of all points in one launch, the losses in groups of
+                # eight chunks as soon as their medoids exist -- and one launch writes every loss at the end.  Same kernels on
+                # the same values as the four-launches-per-chunk form the sharded path keeps (tests compare the two bit for bit).
+                main = torch.cuda.current_stream(device)
+                side = pmvo.side_streams(1)[0]
+                centers = torch.empty((n_all, 3), dtype=torch.float32, device=device)
+                loss_all = torch.empty((n_all,), dtype=torch.float32, device=device)
+                head_all = torch.empty((n_all,), dtype=torch.uint8, device=device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    st2 = _lib.stream_ptr()
+                    # (batch arguments: the reference votes and sums per 5000-point chunk, PMVO.py:604-621 -- the kernels place
+                    # every point in its chunk, see include/mh_pmvo.h: mh_refine_loss_maps)
+                    _lib.check(L.mh_filter_points(ctx, _lib.ptr(pts_dev), n_all, pmvo._side, float(pmvo.conf_threshold),
+                                                  float(pmvo.visible_threshold), None, None, None, _lib.ptr(head_all),
+                                                  sub_num, 0, n_all, st2),
+                               "mh_filter_points")
+                GROUP, g0 = 8, 0
+                for i in range(step):
+                    lo, hi = i * sub_num, min((i + 1) * sub_num, n_all)
+                    if hi > lo:
+                        _lib.check(L.mh_medoid_indexed(ctx, _lib.ptr(ori_dev), off(index_all, lo, K), hi - lo, K,
+                                                       off(centers, lo, 3), None, st), "mh_medoid_indexed")
+                        _lib.check(L.mh_replace_dissimilar(ctx, off(centers, lo, 3), off(ori_dev, lo, 3), 0.95, hi - lo, st),
+                                   "mh_replace_dissimilar")
+                    if ((i + 1) % GROUP == 0 or i == step - 1) and hi > g0:
+                        ev = torch.cuda.Event()
+                        ev.record(main)
+                        side.wait_event(ev)
+                        _lib.check(L.mh_refine_loss_maps(ctx, off(pts_dev, g0, 3), off(centers, g0, 3), 0.005, 4.0, hi - g0,
+                                                         pmvo._side, float(pmvo.conf_threshold), off(loss_all, g0), None,
+                                                         sub_num, g0, n_all, st2),
+                                   "mh_refine_loss_maps")
+                        g0 = hi
+                main.wait_stream(side)
+                _lib.check(L.mh_refine_combine(ctx, _lib.ptr(centers), _lib.ptr(loss_all), _lib.ptr(head_all),
+                                               _lib.ptr(head_top_all), 0.95, None, _lib.ptr(loss_dev), n_all, st),
                            "mh_refine_combine")
-            if R > 1:
-                mdist.all_gather_rows_inplace(ori_dev, lo, s_)
-                mdist.all_gather_rows_inplace(loss_dev, lo, s_)
-        ori_dev, loss_dev = ori_dev[:n_all], loss_dev[:n_all]
-        ori[:] = ori_dev.cpu().numpy()
-        loss[:] = loss_dev.cpu().numpy()
-        T_loop.__exit__()
-        saver = None
-        if is_root:
-            # the three files of PMVO.py:645-648 are written by a worker thread while the shell stage runs; the reference
-            # reads them back right away (:650-652) -- the arrays in memory are what np.load would return
-            import threading
+            for i in range(0 if chain else step):
+                lo, hi, s_, a, b = own(i)
+                if hi <= lo:
+                    continue
+                n = b - a
+                if n > 0:
+                    _lib.check(L.mh_medoid_indexed(ctx, _lib.ptr(ori_dev), off(index_all, row_of[i], K), n, K,
+                                                   _lib.ptr(center), None, st), "mh_medoid_indexed")
+                    _lib.check(L.mh_refine_loss_maps(ctx, off(pts_dev, a, 3), _lib.ptr(center), 0.005, 4.0, n,
+                                                     pmvo._side, float(pmvo.conf_threshold), _lib.ptr(loss_u), None,
+                                                     sub_num, a, n_all, st),
+                               "mh_refine_loss_maps")
+                    _lib.check(L.mh_filter_points(ctx, off(pts_dev, a, 3), n, pmvo._side, float(pmvo.conf_threshold),
+                                                  float(pmvo.visible_threshold), None, None, None, _lib.ptr(head),
+                                                  sub_num, a, n_all, st),
+                               "mh_filter_points")
+                    _lib.check(L.mh_refine_combine(ctx, _lib.ptr(center), _lib.ptr(loss_u), _lib.ptr(head),
+                                                   off(head_top_all, a), 0.95, off(ori_dev, a, 3), off(loss_dev, a), n, st),
+                               "mh_refine_combine")
+                if R > 1:
+                    mdist.all_gather_rows_inplace(ori_dev, lo, s_)
+                    mdist.all_gather_rows_inplace(loss_dev, lo, s_)
+            ori_dev, loss_dev = ori_dev[:n_all], loss_dev[:n_all]
+            ori[:] = ori_dev.cpu().numpy()
+            loss[:] = loss_dev.cpu().numpy()
+            T_loop.__exit__()
+            saver = None
+            if is_root:
+                # the three files of PMVO.py:645-648 are written by a worker thread while the shell stage runs; the reference
+                # reads them back right away (:650-652) -- the arrays in memory are what np.load would return
+                import threading
 
-            os.makedirs(args.output_path + "/refine", exist_ok=True)
-            held = (points, ori, loss)          # not written again before the join below
+                os.makedirs(args.output_path + "/refine", exist_ok=True)
+                held = (points, ori, loss)          # not written again before the join below
 
-            save_error = []
+                save_error = []
 
-            def _save():
-                try:
-                    for name, arr in zip(("select_p", "select_o", "min_loss"), held):
-                        np.save(args.output_path + "/refine/%s.npy" % name, arr)
-                except BaseException as e:      # re-raised on the calling thread after the join
-                    save_error.append(e)
+                def _save():
+                    try:
+                        for name, arr in zip(("select_p", "select_o", "min_loss"), held):
+                            np.save(args.output_path + "/refine/%s.npy" % name, arr)
+                    except BaseException as e:      # re-raised on the calling thread after the join
+                        save_error.append(e)
 
-            saver = threading.Thread(target=_save)
-            saver.start()
+                saver = threading.Thread(target=_save)
+                saver.start()
         min_loss = loss
     else:
         saver = None
         points = np.load(args.output_path + "/refine/select_p.npy")
         ori = np.load(args.output_path + "/refine/select_o.npy")
         min_loss = np.load(args.output_path + "/refine/min_loss.npy")
-    index = np.where(min_loss < threshold)[0]
-    select_ori = ori[index]
-    select_points = points[index]
+    late = []               # worker threads that must be over before refine() returns
+    if dev_out is not None and "vox" in dev_out:
+        print("compute points orientation near the surface... ")
+        vox, vori = dev_out["vox"], dev_out["vori"]
+        if is_root:
+            import threading
 
-    # orientation of the occluded shell points from their 100 nearest kept neighbours (PMVO.py:662-686)
-    print("compute points orientation near the surface... ")
-    T_shell = stage("refine: shell points", device).__enter__()
-    filter_unvisible_ori = np.zeros((0, 3), np.float32)
-    select_filter_unvisible_points = np.zeros((0, 3), np.float32)
-    if len(select_points) and len(filter_unvisible_points):
-        fu = np.ascontiguousarray(filter_unvisible_points)
-        use_grid = bool(grid_all) and grid_all[0].M == len(points)
-        if use_grid:
-            # KDTree(select_points).query(fu) on the grid that already exists for all points: the points kept by the loss
-            # threshold are flagged valid, the indices come back in terms of `points` (order-preserving compaction: same
-            # (distance, index) order), so the medoid reads the full orientation array
-            valid = np.zeros(len(points), np.uint8)
-            valid[index] = 1
-            ori_rows = ori
-        else:
-            ori_rows = select_ori
-        sel_ori_dev = torch.from_numpy(np.ascontiguousarray(ori_rows, dtype=np.float32)).to(device)
+            def _save_shell():
+                try:
+                    np.save(args.output_path + "/refine/filter_unvisible.npy", dev_out["shell_points"])
+                    np.save(args.output_path + "/refine/filter_unvisible_ori.npy", dev_out["shell_ori"])
+                except BaseException as e:
+                    save_error.append(e)
 
-        def shell_block(fb, row0=0):
-            """rows row0.. of `fu` -> device tensors (medoid orientation of the 100 nearest kept points [n,3], head-filter votes [n],
-            head-top mask [n]).  The points are independent: one medoid launch and one vote launch for all of them (the
-            reference's 5000-point chunks bound its memory -- and place a point in a batch of its sums over views, which the
-            vote kernel is told: PMVO.py:662-672)."""
-            with stage("refine: knn (shell)", device):
-                if use_grid:
-                    idx = grid_all[0].query(fb, 100, int32=True, valid=valid).contiguous()
-                else:
-                    idx = _knn(select_points, fb, 100, device, getattr(args, "knn", "device"), int32=True).contiguous()
-            fb_dev = torch.from_numpy(fb.astype(np.float32)).to(device).contiguous()
-            F, K = idx.shape
-            cen = torch.empty((F, 3), dtype=torch.float32, device=device)
-            hd = torch.empty((F,), dtype=torch.uint8, device=device)
-            _lib.check(pmvo._L.mh_medoid_indexed(pmvo._ctx, _lib.ptr(sel_ori_dev), _lib.ptr(idx), F, K, _lib.ptr(cen), None,
-                                                 _lib.stream_ptr()), "mh_medoid_indexed")
-            _lib.check(pmvo._L.mh_filter_points(pmvo._ctx, _lib.ptr(fb_dev), F, pmvo._side, float(pmvo.conf_threshold),
-                                                float(args.PMVO.visible_threshold), None, None, None, _lib.ptr(hd),
-                                                5000, row0, len(fu), _lib.stream_ptr()), "mh_filter_points")
-            ht = pmvo.head_top_mask_device(fb_dev)
-            return cen, hd, ht
+            late.append(threading.Thread(target=_save_shell))
+            late[-1].start()
+        late.append(saver)
+        saver = None
+    else:
+        index = np.where(min_loss < threshold)[0]
+        select_ori = ori[index]
+        select_points = points[index]
 
-        if mdist.refine_sharded():           # block k of the shell points belongs to rank k; one all_gather of the results
-            W_ = mdist.world()
-            cuts = [(len(fu) * k) // W_ for k in range(W_ + 1)]
+        # orientation of the occluded shell points from their 100 nearest kept neighbours (PMVO.py:662-686)
+        print("compute points orientation near the surface... ")
+        T_shell = stage("refine: shell points", device).__enter__()
+        filter_unvisible_ori = np.zeros((0, 3), np.float32)
+        select_filter_unvisible_points = np.zeros((0, 3), np.float32)
+        if len(select_points) and len(filter_unvisible_points):
+            fu = np.ascontiguousarray(filter_unvisible_points)
+            use_grid = bool(grid_all) and grid_all[0].M == len(points)
+            if use_grid:
+                # KDTree(select_points).query(fu) on the grid that already exists for all points: the points kept by the loss
+                # threshold are flagged valid, the indices come back in terms of `points` (order-preserving compaction: same
+                # (distance, index) order), so the medoid reads the full orientation array
+                valid = np.zeros(len(points), np.uint8)
+                valid[index] = 1
+                ori_rows = ori
+            else:
+                ori_rows = select_ori
+            sel_ori_dev = torch.from_numpy(np.ascontiguousarray(ori_rows, dtype=np.float32)).to(device)
 
-            def packed(fb, k):
-                cen, hd, ht = shell_block(fb, cuts[k])
-                out = torch.empty((cen.shape[0], 4), dtype=torch.float32, device=device)
-                out[:, :3] = cen
-                out[:, 3] = (~(hd.bool() & ~ht.bool())).to(torch.float32)
-                return out
+            def shell_block(fb, row0=0):
+                """rows row0.. of `fu` -> device tensors (medoid orientation of the 100 nearest kept points [n,3], head-filter votes [n],
+                head-top mask [n]).  The points are independent: one medoid launch and one vote launch for all of them (the
+                reference's 5000-point chunks bound its memory -- and place a point in a batch of its sums over views, which the
+                vote kernel is told: PMVO.py:662-672)."""
+                with stage("refine: knn (shell)", device):
+                    if use_grid:
+                        idx = grid_all[0].query(fb, 100, int32=True, valid=valid).contiguous()
+                    else:
+                        idx = _knn(select_points, fb, 100, device, getattr(args, "knn", "device"), int32=True).contiguous()
+                fb_dev = torch.from_numpy(fb.astype(np.float32)).to(device).contiguous()
+                F, K = idx.shape
+                cen = torch.empty((F, 3), dtype=torch.float32, device=device)
+                hd = torch.empty((F,), dtype=torch.uint8, device=device)
+                _lib.check(pmvo._L.mh_medoid_indexed(pmvo._ctx, _lib.ptr(sel_ori_dev), _lib.ptr(idx), F, K, _lib.ptr(cen), None,
+                                                     _lib.stream_ptr()), "mh_medoid_indexed")
+                _lib.check(pmvo._L.mh_filter_points(pmvo._ctx, _lib.ptr(fb_dev), F, pmvo._side, float(pmvo.conf_threshold),
+                                                    float(args.PMVO.visible_threshold), None, None, None, _lib.ptr(hd),
+                                                    5000, row0, len(fu), _lib.stream_ptr()), "mh_filter_points")
+                ht = pmvo.head_top_mask_device(fb_dev)
+                return cen, hd, ht
 
-            res = torch.cat(mdist.map_chunks([fu[cuts[k]:cuts[k + 1]] for k in range(W_)], packed, device,
-                                             empty=lambda: torch.empty((0, 4), dtype=torch.float32, device=device),
-                                             with_index=True), 0)
-            res = res.cpu().numpy()
-            keep = res[:, 3] > 0.5
-            centres = res[:, :3]
-        else:
-            # one rank: the three results go to the host as they are (no tensor operation: in a one-shot process every
-            # first use of a torch kernel costs tens of milliseconds of code-object loading)
-            cen, hd, ht = shell_block(fu)
-            keep = ~np.logical_and(hd.cpu().numpy().astype(bool), ~ht.cpu().numpy().astype(bool))     # not filter_head_points
-            centres = cen.cpu().numpy()
-        filter_unvisible_ori = np.ascontiguousarray(centres[keep])
-        select_filter_unvisible_points = fu.astype(np.float32)[keep]
-    T_shell.__exit__()
-    if saver is not None:
-        saver.join()
-        if save_error:
-            raise save_error[0]
-    if is_root:
-        np.save(args.output_path + "/refine/filter_unvisible.npy", select_filter_unvisible_points)
-        np.save(args.output_path + "/refine/filter_unvisible_ori.npy", filter_unvisible_ori)
+            if mdist.refine_sharded():           # block k of the shell points belongs to rank k; one all_gather of the results
+                W_ = mdist.world()
+                cuts = [(len(fu) * k) // W_ for k in range(W_ + 1)]
 
-    select_ori = np.concatenate([select_ori, filter_unvisible_ori], 0)
-    select_points = np.concatenate([select_points, select_filter_unvisible_points], 0)
+                def packed(fb, k):
+                    cen, hd, ht = shell_block(fb, cuts[k])
+                    out = torch.empty((cen.shape[0], 4), dtype=torch.float32, device=device)
+                    out[:, :3] = cen
+                    out[:, 3] = (~(hd.bool() & ~ht.bool())).to(torch.float32)
+                    return out
 
-    # voxel fit (PMVO.py:695-726): every rank fits a disjoint slab of voxels; one reduce assembles the volume
-    # The volume stays a list of occupied voxels; the dense float64 arrays of the reference exist only on request.
-    with stage("refine: voxel fit + reduce", device):
-        vox, vori = mdist.voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size,
-                                            grid_resolution, sparse=True)
+                res = torch.cat(mdist.map_chunks([fu[cuts[k]:cuts[k + 1]] for k in range(W_)], packed, device,
+                                                 empty=lambda: torch.empty((0, 4), dtype=torch.float32, device=device),
+                                                 with_index=True), 0)
+                res = res.cpu().numpy()
+                keep = res[:, 3] > 0.5
+                centres = res[:, :3]
+            else:
+                # one rank: the three results go to the host as they are (no tensor operation: in a one-shot process every
+                # first use of a torch kernel costs tens of milliseconds of code-object loading)
+                cen, hd, ht = shell_block(fu)
+                keep = ~np.logical_and(hd.cpu().numpy().astype(bool), ~ht.cpu().numpy().astype(bool))     # not filter_head_points
+                centres = cen.cpu().numpy()
+            filter_unvisible_ori = np.ascontiguousarray(centres[keep])
+            select_filter_unvisible_points = fu.astype(np.float32)[keep]
+        T_shell.__exit__()
+        if saver is not None:
+            saver.join()
+            if save_error:
+                raise save_error[0]
+        if is_root:
+            np.save(args.output_path + "/refine/filter_unvisible.npy", select_filter_unvisible_points)
+            np.save(args.output_path + "/refine/filter_unvisible_ori.npy", filter_unvisible_ori)
+
+        select_ori = np.concatenate([select_ori, filter_unvisible_ori], 0)
+        select_points = np.concatenate([select_points, select_filter_unvisible_points], 0)
+
+        # voxel fit (PMVO.py:695-726): every rank fits a disjoint slab of voxels; one reduce assembles the volume
+        # The volume stays a list of occupied voxels; the dense float64 arrays of the reference exist only on request.
+        with stage("refine: voxel fit + reduce", device):
+            vox, vori = mdist.voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size,
+                                                grid_resolution, sparse=True)
 
     if is_root:
         if infer_inner:
@@ -1068,6 +1538,10 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
                 mat_writer.finish(vox, vori)
             else:
                 U.save_ori_occ_mat_sparse(args.save_path, grid_resolution, vox, vori)
+    for t in late:
+        t.join()
+    if late and save_error:
+        raise save_error[0]
     mdist.barrier()
     if not return_dense:
         return None

@@ -266,9 +266,12 @@ class GridKNN:
 
     def __init__(self, points, k_hint=100, device="cuda:0"):
         self.device = torch.device(device)
-        pts_np = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
-        self._raw = torch.from_numpy(pts_np).to(self.device)
-        self.M = pts_np.shape[0]
+        if isinstance(points, torch.Tensor):      # float32 [M,3] already on the device (the drivers' own copy)
+            self._raw = points.to(self.device).type(torch.float).contiguous().reshape(-1, 3)
+        else:
+            pts_np = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+            self._raw = torch.from_numpy(pts_np).to(self.device)
+        self.M = int(self._raw.shape[0])
         # bounding box: numpy's axis-0 reduction of an [M,3] array costs 2-5 ms per call at 3e5 points (inner loop of 3),
         # the device needs two tiny launches
         lo, hi = torch.aminmax(self._raw, dim=0) if self.M else (torch.zeros(3), torch.zeros(3))
@@ -326,12 +329,14 @@ class GridKNN:
             self._grids[h] = (grid, dims, pts, order, start)
         return self._grids[h]
 
-    def _run(self, h, q, k, perm=None, valid=None):
+    def _run(self, h, q, k, perm=None, valid=None, zero=False):
         import ctypes
 
         grid, dims, pts, order, start = self._grid(h)
         Q = q.shape[0]
-        out = torch.empty((Q, k), dtype=torch.int32, device=self.device)
+        # (zero: rows of queries the kernel does not finish stay valid indices -- a caller that reads the table before it has
+        # looked at the status must not gather through uninitialised memory)
+        out = (torch.zeros if zero else torch.empty)((Q, k), dtype=torch.int32, device=self.device)
         status = torch.empty((Q,), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().mh_knn_grid(_ctx_for(self.device), grid.ctypes.data_as(ctypes.c_void_p),
@@ -341,6 +346,35 @@ class GridKNN:
                                               _lib.stream_ptr()),
                        "mh_knn_grid")
         return out, status
+
+    def record_stream(self, stream):
+        """The grid was built on another stream than the one that will query it from now on (refine adopts the grid
+        optimize's prefetch built): tell the caching allocator."""
+        for t in (self._raw, self._scratch, self._nocc, self._order_tmp):
+            t.record_stream(stream)
+        for g in self._grids.values():
+            for t in g[2:]:
+                t.record_stream(stream)
+
+    def _queries(self, queries):
+        """[Q,3] queries on the device in the precision they were given in (float64 stays float64, see query)."""
+        if isinstance(queries, torch.Tensor):
+            q = queries.to(self.device)
+            return (q if q.dtype == torch.float64 else q.type(torch.float)).contiguous().reshape(-1, 3)
+        qn = np.ascontiguousarray(queries)
+        if qn.dtype != np.float64:
+            qn = qn.astype(np.float32, copy=False)
+        return torch.from_numpy(qn.reshape(-1, 3)).to(self.device).contiguous()
+
+    def query_nosync(self, queries, k, valid_dev=None, self_query=False):
+        """The first attempt of query() only, nothing read back: -> (index [Q,k] int32, status [Q] int32) on the device.
+        status != 0 marks queries that need query()'s retries on another cell size (their rows of the index are zeros).
+        With valid_dev (uint8 [M] on the device) the caller guarantees that at least k points are flagged (fewer: the kernel
+        pads with -1, which is not an index).  refine's device-resident pass checks the status once it has synchronised
+        anyway and falls back to query() if any is set."""
+        q = self._queries(queries)
+        perm = self._grid(self.h)[3] if (self_query and q.shape[0] == self.M) else None
+        return self._run(self.h, q, min(int(k), self.M), perm, valid_dev, zero=True)
 
     def query(self, queries, k, int32=False, self_query=False, valid=None):
         """-> index [Q,k] device tensor, int64 (or int32 as the kernel writes it); k clamped to the number of points,
@@ -355,10 +389,7 @@ class GridKNN:
             k = min(int(k), int(vh.sum()))
             valid = torch.from_numpy(vh).to(self.device)
         k = min(int(k), self.M)
-        qn = np.ascontiguousarray(queries)
-        if qn.dtype != np.float64:
-            qn = qn.astype(np.float32, copy=False)
-        q = torch.from_numpy(qn.reshape(-1, 3)).to(self.device).contiguous()
+        q = self._queries(queries)
         perm = self._grid(self.h)[3] if (self_query and q.shape[0] == self.M) else None
         out, status = self._run(self.h, q, k, perm, valid)
         self.last_retries = 0
@@ -463,6 +494,64 @@ def voxel_fit(select_points, select_ori, device, voxel_min=VOXEL_MIN, voxel_size
         ori[v[:, 0], v[:, 1], v[:, 2]] = med.cpu().numpy().astype(np.float64)
         out["occ"], out["ori_dense"] = occ, ori
     return out
+
+
+def voxel_fit_device(pts_dev, ori_dev, n, device, voxel_min=VOXEL_MIN, voxel_size=VOXEL_SIZE, grid_resolution=GRID_RESOLUTION):
+    """voxel_fit for rows [0, n) of float32 [*,3] tensors that are ALREADY on the device (refine's device-resident pass):
+    keys + stable sort + canonicalised gather (mh_voxel_group), run boundaries on the device (mh_segment_heads), one
+    segmented-medoid launch; the host reads two counters in between and the G voxel keys + orientations at the end.
+    -> (voxels [G,3] int64 (x,y,z) ascending, ori [G,3] float32) numpy arrays -- the same values as voxel_fit."""
+    import ctypes
+
+    g = np.asarray(grid_resolution).astype(np.int64)
+    dev = torch.device(device)
+    n = int(n)
+    if n == 0:
+        return np.zeros((0, 3), np.int64), np.zeros((0, 3), np.float32)
+    L = _lib.lib()
+    ctx = _ctx_for(dev)
+    ks_d = torch.empty(n, dtype=torch.int64, device=dev)
+    order_d = torch.empty(n, dtype=torch.int32, device=dev)
+    o = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    scratch = torch.empty(int(L.mh_voxel_group_scratch_bytes(n)), dtype=torch.uint8, device=dev)
+    seg = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    heads = torch.empty(n, dtype=torch.int64, device=dev)
+    meta = torch.empty(2, dtype=torch.int32, device=dev)
+    sel_scratch = torch.empty(int(L.mh_select_scratch_bytes(n)), dtype=torch.uint8, device=dev)
+    vmin = np.ascontiguousarray(voxel_min, dtype=np.float64)
+    dims = np.ascontiguousarray(g, dtype=np.int32)
+    with torch.cuda.device(dev):
+        st = _lib.stream_ptr()
+        _lib.check(L.mh_voxel_group(ctx, _lib.ptr(pts_dev), 0, _lib.ptr(ori_dev), n, vmin.ctypes.data_as(ctypes.c_void_p),
+                                    float(voxel_size), dims.ctypes.data_as(ctypes.c_void_p), _lib.ptr(scratch),
+                                    scratch.numel(), _lib.ptr(ks_d), _lib.ptr(order_d), _lib.ptr(o), st), "mh_voxel_group")
+        _lib.check(L.mh_segment_heads(ctx, _lib.ptr(ks_d), n, _lib.ptr(seg), _lib.ptr(heads), _lib.ptr(meta),
+                                      _lib.ptr(sel_scratch), sel_scratch.numel(), st), "mh_segment_heads")
+        G, max_group = (int(v) for v in meta.cpu().numpy())          # (the one synchronisation of the fit)
+        med = torch.empty((G, 3), dtype=torch.float32, device=dev)
+        _lib.check(L.mh_medoid_segmented(ctx, _lib.ptr(o), _lib.ptr(seg), G, max(max_group, 1), _lib.ptr(med), None, st),
+                   "mh_medoid_segmented")
+        kv = heads[:G].cpu().numpy()
+        vori = med.cpu().numpy()
+    vox = np.stack([kv // (int(g[1]) * int(g[2])), (kv // int(g[2])) % int(g[1]), kv % int(g[2])], 1).astype(np.int64)
+    return vox.reshape(-1, 3), vori
+
+
+class NpyRowWriter:
+    """The bytes of `np.save(path, a)` for a C-contiguous array of known shape, written a block of leading rows at a time
+    (version 1.0 header, then the raw rows): optimize() streams its result files out while later chunks still compute."""
+
+    def __init__(self, path, shape, dtype):
+        self._f = open(path, "wb")
+        np.lib.format.write_array_header_1_0(self._f, {"descr": np.lib.format.dtype_to_descr(np.dtype(dtype)),
+                                                       "fortran_order": False, "shape": tuple(int(v) for v in shape)})
+
+    def write(self, rows):
+        rows = np.ascontiguousarray(rows)
+        self._f.write(rows.view(np.uint8).reshape(-1).data if rows.size else b"")
+
+    def close(self):
+        self._f.close()
 
 
 def save_ori_occ_mat(path, occ, ori):
