@@ -79,6 +79,24 @@ def load_views(camera, args):
     return PMVO.from_u8(camera, depths, ori, conf, mask, **kw)
 
 
+def apply_reference_host(pmvo, spec):
+    """--PMVO.reference_host=<file.json | inline JSON>: the rounding facts of the host the reference's CPU run is compared on
+    (`python tools/probe_mkl_forms.py --emit-options` there): reproject_fma_min_cols -- the column count from which MKL's
+    sgemm in Camera.reprojection (Utils/Camera_utils.py:81-106) switches to its threaded fma-chain kernel, which moves with
+    the thread count (8 threads: 28 445, the default; 4: 14 223; 2: 21 334; 1: never) -- and sum_block.  Pinned end to end
+    at 1 / 2 / 4 / 8 threads by tests/golden/pmvo_threads.npz."""
+    if not spec:
+        return
+    import json
+
+    text = str(spec)
+    host = json.loads(open(text).read() if os.path.exists(text) else text)
+    for key in ("reproject_fma_min_cols", "sum_block", "reproject_rule"):
+        if key in host:
+            pmvo.set_option(key, int(host[key]))
+    print("reference host: %s" % {k: host[k] for k in host if k in ("threads", "reproject_fma_min_cols", "sum_block")})
+
+
 def main(argv=None):
     from scipy.spatial import KDTree
 
@@ -110,6 +128,7 @@ def main(argv=None):
     with stage("load maps -> device", args.device):
         pmvo = load_views(camera, args)
     pmvo.set_head(bust_tree, scalp_tree, scalp_max)
+    apply_reference_host(pmvo, args.PMVO.get("reference_host"))
 
     if args.PMVO.optimize:
         print("load raw mesh...")

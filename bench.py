@@ -30,7 +30,8 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 T
 VALU_PEAK_TF = 157.3         # same guide: peak fp32 vector (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
 FLOP_PER_PAIR = 8            # one (candidate, view, tap) evaluation
 CHUNK = 5000                 # PMVO.py:566
-PREWARM = 48                 # untimed set-up iterations before the --warmup ones (GPU clocks at their running state)
+PREWARM = 256                # untimed set-up iterations before the --warmup ones (GPU clocks at their running state;
+                             # round 6: 48 -> 256 = 0.16 s -- the first bench of a fresh box measured 1 442 it/s with 48, 1 633-1 646 after)
 XGMI_LINK_GBS = 153.0        # per-link xGMI bandwidth, 7 links per GPU
 
 

@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -37,6 +38,10 @@ struct mh_ctx {
     float4 *tapp = nullptr;
     bool tapp_failed = false;
     int use_tap_plane = 1;             // option "tap_plane": 0 = normalise per iteration (A/B, cross-check)
+    // the plane doubles the resident map memory for +1.2 % iterations/s: only below this size (option "tap_plane_max_mb",
+    // environment MH_TAP_PLANE_MAX_MB at context creation; 60 x 1080p = 1 991 MB fits, 120 x 4K = 15 925 MB does not) and
+    // only while it leaves a quarter of the device's free memory to the scratch buffers of the drivers
+    long long tap_plane_max_mb = 4096;
     std::vector<unsigned char> tap_view;   // per view: its slice of tapp is current
     const float4 *tap_ready() const {
         if (!tapp || !use_tap_plane || (int)tap_view.size() != V) return nullptr;
@@ -224,6 +229,7 @@ extern "C" int mh_ctx_create(int device_id, mh_ctx **out) {
     mh_ctx *c = new (std::nothrow) mh_ctx();
     if (!c) return fail(MH_ERR_NOMEM, "mh_ctx_create: out of host memory");
     c->device = device_id;
+    if (const char *e = getenv("MH_TAP_PLANE_MAX_MB")) c->tap_plane_max_mb = atoll(e);
     // the code objects of the library go onto the device now (HIP would load each translation unit's on the first launch
     // of one of its kernels -- in the middle of the first pass's stages); a failure here only means they load lazily
     if (hipSetDevice(device_id) == hipSuccess) {
@@ -304,19 +310,25 @@ extern "C" int mh_ctx_set_view(mh_ctx *ctx, int view, const float *cam_host, con
                           hipMemcpyHostToDevice, st));
     if ((int)ctx->code_view.size() == ctx->V) ctx->code_view[view] = 0;      // this view has no resident codes (any more)
     // the plane of ready-made taps (MhViews::tap): optional, like the code plane of the 8-bit views
-    if (!ctx->tapp && !ctx->tapp_failed) {
+    if (!ctx->tapp && !ctx->tapp_failed && ctx->use_tap_plane) {
         MH_HIP(hipSetDevice(ctx->device));
-        if (hipMalloc(&ctx->tapp, (size_t)ctx->V * npix * sizeof(float4)) != hipSuccess) {
+        const size_t bytes = (size_t)ctx->V * npix * sizeof(float4);
+        size_t free_b = 0, total_b = 0;
+        const bool fits = bytes <= (size_t)(ctx->tap_plane_max_mb > 0 ? ctx->tap_plane_max_mb : 0) * 1048576ull &&
+                          hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes <= free_b - free_b / 4;
+        if (!fits || hipMalloc(&ctx->tapp, bytes) != hipSuccess) {
             ctx->tapp = nullptr;
             ctx->tapp_failed = true;     // not retried per view: the front end normalises per iteration instead
             (void)hipGetLastError();
         }
     }
-    if (ctx->tapp && (int)ctx->tap_view.size() == ctx->V) ctx->tap_view[view] = 1;
-    return launched(mh_launch_pack_view(ctx->rec + (size_t)view * npix, ctx->mask + (size_t)view * npix, depth,
-                                        depth_stride, ori, conf, mask, mask_stride, npix,
-                                        ctx->tapp ? ctx->tapp + (size_t)view * npix : nullptr, st),
-                    "mh_ctx_set_view");
+    const int rc = launched(mh_launch_pack_view(ctx->rec + (size_t)view * npix, ctx->mask + (size_t)view * npix, depth,
+                                                depth_stride, ori, conf, mask, mask_stride, npix,
+                                                ctx->tapp ? ctx->tapp + (size_t)view * npix : nullptr, st),
+                            "mh_ctx_set_view");
+    // (the view's slice of the plane counts as current only once its pack launch has been accepted)
+    if (ctx->tapp && (int)ctx->tap_view.size() == ctx->V) ctx->tap_view[view] = rc == MH_OK ? 1 : 0;
+    return rc;
 }
 
 extern "C" int mh_ctx_set_view_u8(mh_ctx *ctx, int view, const float *cam_host, const float *depth, int depth_stride,
@@ -350,12 +362,14 @@ extern "C" int mh_ctx_set_view_u8(mh_ctx *ctx, int view, const float *cam_host, 
     MH_HIP(hipMemcpyAsync(ctx->cams + (size_t)view * MH_CAM_STRIDE, cam_host, MH_CAM_STRIDE * sizeof(float),
                           hipMemcpyHostToDevice, st));
     if ((int)ctx->code_view.size() == ctx->V) ctx->code_view[view] = ctx->oc ? 1 : 0;
-    if (ctx->tapp && (int)ctx->tap_view.size() == ctx->V) ctx->tap_view[view] = 1;   // (only when an fp32 view allocated it)
-    return launched(mh_launch_pack_view_u8(ctx->rec + (size_t)view * npix, ctx->mask + (size_t)view * npix, depth,
-                                           depth_stride, ori_u8, conf_u8, mask_u8, ctx->lut, npix,
-                                           ctx->oc ? ctx->oc + (size_t)view * npix : nullptr,
-                                           ctx->tapp ? ctx->tapp + (size_t)view * npix : nullptr, st),
-                    "mh_ctx_set_view_u8");
+    const int rc = launched(mh_launch_pack_view_u8(ctx->rec + (size_t)view * npix, ctx->mask + (size_t)view * npix, depth,
+                                                   depth_stride, ori_u8, conf_u8, mask_u8, ctx->lut, npix,
+                                                   ctx->oc ? ctx->oc + (size_t)view * npix : nullptr,
+                                                   ctx->tapp ? ctx->tapp + (size_t)view * npix : nullptr, st),
+                            "mh_ctx_set_view_u8");
+    // (only when an fp32 view allocated the plane; current only once the pack launch has been accepted)
+    if (ctx->tapp && (int)ctx->tap_view.size() == ctx->V) ctx->tap_view[view] = rc == MH_OK ? 1 : 0;
+    return rc;
 }
 
 static size_t render_vt_bytes(int Nv) { return (((size_t)(Nv > 0 ? Nv : 1) * 16) + 255) / 256 * 256; }
@@ -480,6 +494,11 @@ extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
     }
     if (!strcmp(key, "tap_plane")) {
         ctx->use_tap_plane = value ? 1 : 0;
+        return MH_OK;
+    }
+    if (!strcmp(key, "tap_plane_max_mb")) {      // takes effect for planes not yet allocated (before the first fp32 view)
+        if (value < 0) return fail(MH_ERR_ARG, "mh_ctx_set_option: tap_plane_max_mb must be >= 0");
+        ctx->tap_plane_max_mb = value;
         return MH_OK;
     }
     if (!strcmp(key, "tap_codes")) {

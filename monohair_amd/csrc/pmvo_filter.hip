@@ -25,7 +25,10 @@ __global__ __launch_bounds__(256) void mh_filter_kernel(MhViews vw, const float 
     if (n >= N) return;
     const int V = vw.V, H = vw.H, W = vw.W;
     const float X0 = pts[3 * n], X1 = pts[3 * n + 1], X2 = pts[3 * n + 2];
-    const bool single = bt.single_ok && mh_batch_single(bt, n);   // a batch of one point: single-column projections, [V,1] sums
+    // a batch of ONE point: its [V,1] sums over the views are ATen's inner sums whenever the outer-sum rule is on (sum_block > 0)
+    // and -- with the batch rule of the products (reproject_rule 0) -- its projections are single-column products
+    const bool one_point = mh_batch_single(bt, n);
+    const bool single = bt.single_ok && one_point;
     for (int v = lane; v < V; v += MH_WAVE) {
         const float *cam = vw.cams + v * MH_CAM_STRIDE;
         float u, w, z, rowf, colf;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void mh_filter_kernel(MhViews vw, const float 
         }
         float sum = mh_cascv_done(a);
         // the trailing (length mod 32) points of a batch of the reference: ATen's row_sum order (mh_device.h: MhBatch)
-        if (single && bt.block > 0) sum = mh_inner_sum_views(V, [&](int v) { return s_t(wave, lane, v); });
+        if (one_point && bt.block > 0) sum = mh_inner_sum_views(V, [&](int v) { return s_t(wave, lane, v); });
         else if (mh_tail_row(bt, n)) sum = mh_row_sum_views(V, [&](int v) { return s_t(wave, lane, v); });
         s_t(wave, lane, 0) = sum;
     }

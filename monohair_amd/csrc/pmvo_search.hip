@@ -221,7 +221,8 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
         int it = j * T + tid;
         it = it < nitems ? it : 0;
         const int r = it / S, s = it - r * S;
-        const int b = base_idx[(size_t)(r * rank_step) * N + n];
+        // (ranks with base_val <= 0 are unusable and their indices may be anything: clamped, as in mh_search3_kernel)
+        const int b = min(max(base_idx[(size_t)(r * rank_step) * N + n], 0), V - 1);
         const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
         mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[s], X0[j], X1[j], X2[j],
                        mh_group_forms(rule, r, V, b, S));
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(T) void mh_search_kernel(MhViews vw, const float *_
                 hc = s_rh[r];
             }
         }
-        const int b = base_idx[(size_t)(br * rank_step) * N + n];
+        const int b = min(max(base_idx[(size_t)(br * rank_step) * N + n], 0), V - 1);
         const float2 oc = reinterpret_cast<const float2 *>(ori_c)[(size_t)b * N + n];
         float B0, B1, B2;
         mh_sample_next(vw.cams + b * MH_CAM_STRIDE, P0, P1x, P2, oc.x, oc.y, Hf, Wf, offs[bs], B0, B1, B2,
@@ -1411,7 +1412,10 @@ __global__ __launch_bounds__(256) void mh_refine_loss_kernel(MhViews vw, const f
     const float P0 = pts[3 * n], P1 = pts[3 * n + 1], P2 = pts[3 * n + 2];
     const float Q0 = P0 + dir[3 * n] * mul / dv, Q1 = P1 + dir[3 * n + 1] * mul / dv,
                 Q2 = P2 + dir[3 * n + 2] * mul / dv;
-    const bool single = bt.single_ok && mh_batch_single(bt, n);   // a batch of one point: single-column projections, [V,1] sums
+    // a batch of ONE point: its [V,1] sums over the views are ATen's inner sums whenever the outer-sum rule is on (sum_block > 0)
+    // and -- with the batch rule of the products (reproject_rule 0) -- its projections are single-column products
+    const bool one_point = mh_batch_single(bt, n);
+    const bool single = bt.single_ok && one_point;
     for (int v = lane; v < V; v += MH_WAVE) {
         const float *cam = vw.cams + v * MH_CAM_STRIDE;
         float r0, c0, r1, c1, dx, dy;
@@ -1456,7 +1460,7 @@ __global__ __launch_bounds__(256) void mh_refine_loss_kernel(MhViews vw, const f
             cnt += (w > 0.0f) ? 1 : 0;
         }
         float d = mh_cascv_done(dn), m = mh_cascv_done(nm);
-        if (single && bt.block > 0) {   // [V, 1]: ATen's sum over a contiguous innermost dimension
+        if (one_point && bt.block > 0) {   // [V, 1]: ATen's sum over a contiguous innermost dimension
             m = mh_inner_sum_views(V, [&](int v) { return s_num[wave][v]; });
             d = mh_inner_sum_views(V, [&](int v) { return s_den[wave][v]; });
         } else if (mh_tail_row(bt, n)) {   // a trailing column of the batch's [V, N] sums (ATen's row_sum order)
@@ -1476,12 +1480,21 @@ __global__ __launch_bounds__(256) void mh_refine_loss_kernel(MhViews vw, const f
 // result is bit-identical to the two-kernel path; views that do not see the point have weight 0 (PMVO.py:212) and
 // are skipped, as in mh_search_kernel.
 // ---------------------------------------------------------------------------------------------
+// Round 6: lane = TAP for the patches.  A wave owns one point.  Phase 1 (lane = view, 64 views at a time): projection,
+// depth test, the projected direction of the candidate.  Phase 2: the views that see the point are walked on the ballot
+// mask; for each, the wave's lanes gather the P taps of the patch as PATCH contiguous runs (one coalesced request per view
+// instead of 2 P per-lane gathers with one address per view -- the round-1..5 form spent 5.1 ms per 288 k points, 4 % of
+// HBM), evaluate 1 - |cos| one tap per lane, and find (a) the patch maximum of the confidence and (b) the lexicographic
+// minimum of (loss, tap index) over tap 0 and the eligible taps with two shuffle reductions.  That IS the sequential rule
+// of compute_prj_loss (PMVO.py:160-190: tap 0 unconditionally, a later tap only if strictly smaller and eligible), NaN
+// cases included: a NaN loss never wins a `<`; a NaN at tap 0 stays.  The next view's taps are requested before the
+// current view is reduced.  Per-view terms go to LDS and lane 0 adds them in ATen's order, as before.
 template <int PATCH>
 __global__ __launch_bounds__(256) void mh_refine_loss_maps_kernel(MhViews vw, const float *__restrict__ pts,
                                                                   const float *__restrict__ dir, float mul, float dv,
                                                                   int N, float thr, float *__restrict__ loss,
                                                                   uint8_t *__restrict__ hcout, MhBatch bt) {
-    constexpr int P = PATCH * PATCH, HP = PATCH / 2;
+    constexpr int P = PATCH * PATCH, HP = PATCH / 2, ROUNDS = (P + MH_WAVE - 1) / MH_WAVE;
     __shared__ float s_num[4][MH_REFINE_VMAX], s_den[4][MH_REFINE_VMAX];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + wave;
@@ -1491,63 +1504,126 @@ __global__ __launch_bounds__(256) void mh_refine_loss_maps_kernel(MhViews vw, co
     const float P0 = pts[3 * n], P1 = pts[3 * n + 1], P2 = pts[3 * n + 2];
     const float Q0 = P0 + dir[3 * n] * mul / dv, Q1 = P1 + dir[3 * n + 1] * mul / dv,
                 Q2 = P2 + dir[3 * n + 2] * mul / dv;
-    const bool single = bt.single_ok && mh_batch_single(bt, n);   // a batch of one point: single-column projections, [V,1] sums
-    for (int v = lane; v < V; v += MH_WAVE) {
-        const float *cam = vw.cams + v * MH_CAM_STRIDE;
-        float u, w, z, r0, c0;
-        mh_cam_project_b(cam, P0, P1, P2, u, w, z, single);
-        mh_ndc_to_pixel(u, w, Hf, Wf, r0, c0);
-        float cr = __builtin_rintf(c0), rr = __builtin_rintf(r0);
-        const bool oob = !(cr <= (float)(W - 1)) || (cr < 0.0f) || !(rr <= (float)(H - 1)) || (rr < 0.0f);
-        cr = fminf(fmaxf(cr, 0.0f), (float)(W - 1));
-        rr = fminf(fmaxf(rr, 0.0f), (float)(H - 1));
-        const int r = (int)rr, c = (int)cr;
-        const float4 *__restrict__ rec = vw.rec + (size_t)v * H * W;
-        const float4 *__restrict__ tp = vw.tap ? vw.tap + (size_t)v * H * W : nullptr;
-        const float4 q = rec[(size_t)r * W + c];
-        const float visv = oob ? -1.0f : mh_soft_visible(q.w, (-z / 2.0f) * 255.0f);
-        float numv = 0.0f, denv = 0.0f;
-        if (visv != -1.0f) {
-            float r1, c1, dx, dy;
-            mh_pixel_of_b(cam, Q0, Q1, Q2, Hf, Wf, r1, c1, single);
-            mh_unit2(r1 - r0, c1 - c0, dx, dy);
-            // pass 1: the patch maximum of the clamped confidences (PMVO.py:162); pass 2: the masked minimum
-            float cmax = 0.0f;
-#pragma unroll 1
-            for (int p = 0; p < P; ++p) {
-                const int i = p / PATCH - HP, j = p - (p / PATCH) * PATCH - HP;
-                const int r2 = min(max(r + i, 0), H - 1), c2 = min(max(c + j, 0), W - 1);
-                const float cf = tp ? tp[(size_t)r2 * W + c2].z : mh_clampf(rec[(size_t)r2 * W + c2].z, 1e-6f, 1.0f);
-                cmax = (p == 0 || cf > cmax) ? cf : cmax;
+    // a batch of ONE point: its [V,1] sums over the views are ATen's inner sums whenever the outer-sum rule is on (sum_block > 0)
+    // and -- with the batch rule of the products (reproject_rule 0) -- its projections are single-column products
+    const bool one_point = mh_batch_single(bt, n);
+    const bool single = bt.single_ok && one_point;
+    int ti[ROUNDS], tj[ROUNDS];
+#pragma unroll
+    for (int t = 0; t < ROUNDS; ++t) {
+        const int p = min(lane + MH_WAVE * t, P - 1);
+        ti[t] = p / PATCH - HP;
+        tj[t] = p - (p / PATCH) * PATCH - HP;
+    }
+    auto rdf = [](float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); };
+    for (int v0 = 0; v0 < V; v0 += MH_WAVE) {
+        const int v = v0 + lane;
+        float visv = -1.0f, dx = 0.0f, dy = 0.0f;
+        int r = 0, c = 0;
+        if (v < V) {
+            const float *cam = vw.cams + v * MH_CAM_STRIDE;
+            float u, w, z, r0, c0;
+            mh_cam_project_b(cam, P0, P1, P2, u, w, z, single);
+            mh_ndc_to_pixel(u, w, Hf, Wf, r0, c0);
+            float cr = __builtin_rintf(c0), rr = __builtin_rintf(r0);
+            const bool oob = !(cr <= (float)(W - 1)) || (cr < 0.0f) || !(rr <= (float)(H - 1)) || (rr < 0.0f);
+            cr = fminf(fmaxf(cr, 0.0f), (float)(W - 1));
+            rr = fminf(fmaxf(rr, 0.0f), (float)(H - 1));
+            r = (int)rr;
+            c = (int)cr;
+            const float4 q = vw.rec[(size_t)v * H * W + (size_t)r * W + c];
+            visv = oob ? -1.0f : mh_soft_visible(q.w, (-z / 2.0f) * 255.0f);
+            if (visv != -1.0f) {
+                float r1, c1;
+                mh_pixel_of_b(cam, Q0, Q1, Q2, Hf, Wf, r1, c1, single);
+                mh_unit2(r1 - r0, c1 - c0, dx, dy);
+            } else {
+                s_num[wave][v] = 0.0f;
+                s_den[wave][v] = 0.0f;
             }
-            const bool hc = cmax > thr;
-            float ml = 0.f, bc = 0.f;
-#pragma unroll 1
-            for (int p = 0; p < P; ++p) {
-                const int i = p / PATCH - HP, j = p - (p / PATCH) * PATCH - HP;
-                const int r2 = min(max(r + i, 0), H - 1), c2 = min(max(c + j, 0), W - 1);
-                float o0, o1, cf;
-                if (tp) {   // (the plane of ready-made taps, MhViews::tap: the same values, made once at upload)
-                    const float4 t = tp[(size_t)r2 * W + c2];
-                    o0 = t.x;
-                    o1 = t.y;
-                    cf = t.z;
-                } else {
-                    const float4 t = rec[(size_t)r2 * W + c2];
-                    mh_unit2(t.x, t.y, o0, o1);
-                    cf = mh_clampf(t.z, 1e-6f, 1.0f);
-                }
-                const float cs = o0 * dx + o1 * dy;
-                const float l = 1.0f - __builtin_fabsf(cs);
-                const bool upd = (p == 0) || ((l < ml) && (hc ? (cf > thr) : true));
-                ml = upd ? l : ml;
-                bc = upd ? cf : bc;
-            }
-            numv = ml * bc;
-            denv = bc;
         }
-        s_num[wave][v] = numv;
-        s_den[wave][v] = denv;
+        unsigned long long m = __ballot(visv != -1.0f);
+        // taps of one view: {unit ori_row, unit ori_col, clamped conf} per lane and round
+        float o0[ROUNDS], o1[ROUNDS], cf[ROUNDS], no0[ROUNDS], no1[ROUNDS], ncf[ROUNDS];
+        auto gather = [&](int src, float *a0, float *a1, float *ac) {
+            const int rv = __builtin_amdgcn_readlane(r, src), cv = __builtin_amdgcn_readlane(c, src);
+            const size_t base = (size_t)(v0 + src) * H * W;
+#pragma unroll
+            for (int t = 0; t < ROUNDS; ++t) {
+                const int r2 = min(max(rv + ti[t], 0), H - 1), c2 = min(max(cv + tj[t], 0), W - 1);
+                if (vw.tap) {   // (the plane of ready-made taps, MhViews::tap: the same values, made once at upload)
+                    const float4 tq = vw.tap[base + (size_t)r2 * W + c2];
+                    a0[t] = tq.x;
+                    a1[t] = tq.y;
+                    ac[t] = tq.z;
+                } else {
+                    const float4 tq = vw.rec[base + (size_t)r2 * W + c2];
+                    mh_unit2(tq.x, tq.y, a0[t], a1[t]);
+                    ac[t] = mh_clampf(tq.z, 1e-6f, 1.0f);
+                }
+            }
+        };
+        int src = m ? __builtin_amdgcn_readfirstlane(__builtin_ctzll(m)) : 0;
+        if (m) gather(src, no0, no1, ncf);
+        while (m) {
+            const int cur = src;
+            m &= m - 1;
+#pragma unroll
+            for (int t = 0; t < ROUNDS; ++t) {
+                o0[t] = no0[t];
+                o1[t] = no1[t];
+                cf[t] = ncf[t];
+            }
+            if (m) {
+                src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+                gather(src, no0, no1, ncf);
+            }
+            const float dxv = rdf(dx, cur), dyv = rdf(dy, cur);
+            // (a) cmax as `cmax = (p == 0 || cf > cmax) ? cf : cmax` leaves it: the maximum, NaNs skipped -- unless tap 0 is NaN
+            const float cf0 = rdf(cf[0], 0);
+            float mx = -__builtin_inff();
+#pragma unroll
+            for (int t = 0; t < ROUNDS; ++t)
+                if (lane + MH_WAVE * t < P && cf[t] == cf[t]) mx = fmaxf(mx, cf[t]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            const float cmax = (cf0 != cf0) ? cf0 : mx;
+            const bool hc = cmax > thr;
+            // (b) lexicographic minimum of (loss, tap) over tap 0 and the eligible taps
+            float bl = __builtin_inff(), bcf = 0.0f;
+            int bp = 0x7fffffff;
+            float l0 = 0.0f;
+#pragma unroll
+            for (int t = 0; t < ROUNDS; ++t) {
+                const int p = lane + MH_WAVE * t;
+                const float cs = o0[t] * dxv + o1[t] * dyv;
+                const float l = 1.0f - __builtin_fabsf(cs);
+                if (t == 0) l0 = l;
+                const bool cand = p < P && (p == 0 || ((hc ? (cf[t] > thr) : true) && l == l));
+                if (cand && (bp == 0x7fffffff || l < bl)) {   // (rounds ascend in p: a tie keeps the earlier tap)
+                    bl = l;
+                    bp = p;
+                    bcf = cf[t];
+                }
+            }
+            l0 = rdf(l0, 0);
+            const float c0v = cf0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ol = __shfl_xor(bl, o), oc = __shfl_xor(bcf, o);
+                const int op = __shfl_xor(bp, o);
+                const bool take = op != 0x7fffffff && (bp == 0x7fffffff || ol < bl || (ol == bl && op < bp));
+                bl = take ? ol : bl;
+                bcf = take ? oc : bcf;
+                bp = take ? op : bp;
+            }
+            // a NaN at tap 0 is never replaced (`l < NaN` is false for every later tap)
+            const float ml = (l0 != l0) ? l0 : bl, bc = (l0 != l0) ? c0v : bcf;
+            if (lane == 0) {
+                s_num[wave][v0 + cur] = ml * bc;
+                s_den[wave][v0 + cur] = bc;
+            }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1565,7 +1641,7 @@ __global__ __launch_bounds__(256) void mh_refine_loss_maps_kernel(MhViews vw, co
             cnt += (w > 0.0f) ? 1 : 0;
         }
         float d = mh_cascv_done(dn), m = mh_cascv_done(nm);
-        if (single && bt.block > 0) {   // [V, 1]: ATen's sum over a contiguous innermost dimension
+        if (one_point && bt.block > 0) {   // [V, 1]: ATen's sum over a contiguous innermost dimension
             m = mh_inner_sum_views(V, [&](int v) { return s_num[wave][v]; });
             d = mh_inner_sum_views(V, [&](int v) { return s_den[wave][v]; });
         } else if (mh_tail_row(bt, n)) {   // a trailing column of the batch's [V, N] sums (ATen's row_sum order)

@@ -146,7 +146,7 @@ def all_gather_rows_inplace(buf, lo, s):
         out.copy_(torch.cat(parts, 0).to(buf.device))
 
 
-_INPLACE_GATHER_OK = {}     # (device index, backend, process-group identity) -> bool, decided ONCE per process group
+_INPLACE_GATHER_OK = {}     # (device index, backend) -> (process group object, bool): decided ONCE per process group
 
 
 def inplace_gather_supported(device):
@@ -155,13 +155,16 @@ def inplace_gather_supported(device):
     all_reduce(MIN): a rank that falls back on its own would issue a collective its peers never enter (deadlock).  An
     argument check that rejects the aliasing raises before any traffic (on every rank alike -- a probe that raised on some
     ranks only would leave the others inside the collective); the exception is logged, not swallowed.  The verdict is
-    cached per (device, backend, process group): a group that is destroyed and made again is probed again."""
+    cached per (device, backend) TOGETHER WITH the process group object it was probed on (held, so its identity cannot be
+    handed to a later group): a default group that was destroyed and made again is probed again; without a group object
+    to compare with (a torch build without `group.WORLD`) nothing is cached."""
     import warnings
 
     d = _dist()
-    pg = d.distributed_c10d._get_default_group() if hasattr(d, "distributed_c10d") else None
-    key = (torch.device(device).index or 0, d.get_backend(), id(pg))
-    if key not in _INPLACE_GATHER_OK:
+    pg = getattr(getattr(d, "group", None), "WORLD", None)
+    key = (torch.device(device).index or 0, d.get_backend())
+    hit = _INPLACE_GATHER_OK.get(key)
+    if hit is None or pg is None or hit[0] is not pg:
         R, r = world(), rank()
         ok = 1
         try:
@@ -178,8 +181,8 @@ def inplace_gather_supported(device):
                           "buffer" % (e,))
         t = torch.tensor([ok], dtype=torch.int32, device=device)
         d.all_reduce(t, op=d.ReduceOp.MIN)
-        _INPLACE_GATHER_OK[key] = bool(int(t.item()))
-    return _INPLACE_GATHER_OK[key]
+        hit = _INPLACE_GATHER_OK[key] = (pg, bool(int(t.item())))
+    return hit[1]
 
 
 _COMMS = {}

@@ -37,6 +37,12 @@ ap.add_argument("--ori-mode", default="", help="adversarial orientation fields f
                 "tests/test_key_reeval_gpu.py")
 ap.add_argument("--body", type=int, default=0, help="tap body of the shipped search: 0 by the maps, 1 keys, 2 select (option search_body)")
 a = ap.parse_args()
+# the oracle's rule state is process-global: whatever this sweep draws per scene is put back when it ends, however it ends
+import atexit  # noqa: E402
+
+_RULES0 = (oracle.get_reproject_rule(), oracle.set_sum_block(32))
+oracle.set_sum_block(_RULES0[1])
+atexit.register(lambda: (oracle.set_reproject_rule(*_RULES0[0]), oracle.set_sum_block(_RULES0[1])))
 rng = np.random.default_rng(a.seed)
 DEV = "cuda:0"
 offs = depth_offsets(90)
@@ -122,7 +128,7 @@ while time.time() < t_end:
     oracle.set_reproject_rule({0: "group", 1: "mid", 2: "chain"}[rule], fma_cols)
     oracle.set_sum_block(block)
     views = oracle.Views(rec, scene["depth"].numpy(), scene["ori"].numpy(), scene["conf"].numpy(), scene["mask"].numpy())
-    N = int(rng.integers(1, 400))
+    N = 1 if rng.random() < 0.04 else int(rng.integers(1, 400))     # (batches of ONE point: their own sum order)
     cand = synth.candidate_points(res=int(rng.choice([32, 64])), seed=seed % 1000)
     pts = cand[rng.choice(len(cand), N, replace=False)] * rng.uniform(0.9, 1.1)
     for fused in (True, False):

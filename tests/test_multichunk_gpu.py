@@ -5,7 +5,9 @@ and refine on exactly 10 000 points).
 SURVEY.md §8 row a14: refine's smoothing loop is Gauss-Seidel over the chunks -- `Neighbor_ori = ori[index]`
 (/root/reference/PMVO.py:612) reads what earlier chunks wrote back (:640).  Every form of the loop the product has is pinned
 here to the REFERENCE's files, not to another form of itself:
-  * one rank, split chain (medoid -> replacement on the main stream, losses in groups of eight chunks on a side stream);
+  * one rank, device-resident pass (round 6, the default: medoid -> replacement chain on the main stream, losses in groups of
+    chunks on a side stream, threshold / shell points / voxel fit without leaving the device);
+  * one rank, host-driven split chain (MH_REFINE_DEVICE=0: the default of rounds 4-5);
   * one rank, four launches per chunk (MH_REFINE_CHAIN=0: the form the sharded path runs);
   * 2 and 3 ranks (gloo ranks sharing the test GPU), every rank owning a slice of every chunk, one in-place all_gather per chunk.
 optimize over four chunks on three rotating streams is pinned the same way (row a10)."""
@@ -72,10 +74,15 @@ def run_helper(out, what, ranks=1, env_extra=None, port=29600):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("form", ["chain", "four_launch"])
+FORM_ENV = {"chain": {"MH_REFINE_CHAIN": "1", "MH_REFINE_DEVICE": "1"},
+            "host_chain": {"MH_REFINE_CHAIN": "1", "MH_REFINE_DEVICE": "0"},
+            "four_launch": {"MH_REFINE_CHAIN": "0"}}
+
+
+@pytest.mark.parametrize("form", ["chain", "host_chain", "four_launch"])
 def test_refine_four_chunks_equals_the_reference(tmp_path, form):
     z, meta = golden()
-    run_helper(tmp_path, "refine,refine_exact", env_extra={"MH_REFINE_CHAIN": "1" if form == "chain" else "0"})
+    run_helper(tmp_path, "refine,refine_exact", env_extra=FORM_ENV[form])
     check_refine_files(os.path.join(tmp_path, "run"), z, "ref_", 16901)
     # N = 10 000: `step = N // 5000 + 1` (PMVO.py:603) makes a third, empty chunk; the reference runs through it and so do we
     assert str(z["exact_raised"]) == ""
@@ -117,12 +124,12 @@ def test_optimize_four_chunks_equals_the_reference(tmp_path, ranks):
         assert len(ex[k]) == n and np.array_equal(ex[k], got[k][:n], equal_nan=(k != "high_conf_index")), k
 
 
-@pytest.mark.parametrize("form,ranks", [("chain", 1), ("four_launch", 1), ("sharded", 2)])
+@pytest.mark.parametrize("form,ranks", [("chain", 1), ("host_chain", 1), ("four_launch", 1), ("sharded", 2)])
 def test_refine_head_filtered_and_nan_rows_equal_the_reference(tmp_path, form, ranks):
     """tests/golden/e2e_headfilter.npz: 6000 points (two chunks), a third head-filtered (loss -1 -> 0.5, PMVO.py:91-92,639),
     40 rows of NaN orientation / loss among the inputs -- the reference's files, in every form of the loop."""
     z = np.load(os.path.join(GOLDEN, "e2e_headfilter.npz"), allow_pickle=False)
-    env = {"MH_REFINE_CHAIN": "0" if form == "four_launch" else "1"}
+    env = dict(FORM_ENV.get(form, {"MH_REFINE_CHAIN": "1"}))
     if ranks > 1:
         env["MH_REFINE_SHARD"] = "1"
     run_helper(tmp_path, "refine_headfilter", ranks=ranks, env_extra=env, port=29640)
@@ -136,3 +143,37 @@ def test_refine_head_filtered_and_nan_rows_equal_the_reference(tmp_path, form, r
     assert np.array_equal(np.isnan(got_l), np.isnan(ref_l)) and np.isnan(ref_l).sum() > 0
     assert np.array_equal(np.load(os.path.join(out, "filter_unvisible.npy")), z["ref_filter_unvisible"])
     assert np.array_equal(np.load(os.path.join(out, "filter_unvisible_ori.npy")), z["ref_filter_unvisible_ori"], equal_nan=True)
+
+
+@pytest.mark.parametrize("threads", [1, 2, 4])
+def test_forward_at_other_reference_thread_counts(threads):
+    """tests/golden/pmvo_threads.npz (tools/gen_golden_threads.py): the reference's forward() on the first chunk of the
+    four-chunk run under torch.set_num_threads(1 / 2 / 4).  The option reproject_fma_min_cols, set to the value the fixture
+    recorded for that thread count (tools/probe_mkl_forms.py --emit-options on the reference's host), makes the kernels
+    round as that host's MKL does: every row of (orientation, loss, flag), 70 / 494 / 1 780 of which differ from the
+    8-thread answer the default reproduces."""
+    import torch
+    from conftest import golden_records, golden_scene, rows_equal
+    from monohair_amd.pmvo import PMVO
+
+    z, meta = golden()
+    t = np.load(os.path.join(GOLDEN, "pmvo_threads.npz"), allow_pickle=False)
+    info = ast.literal_eval(str(t["meta"]))["by_threads"][threads]
+    dev = torch.device("cuda", 0)
+    scene = golden_scene(meta)
+    pm = PMVO.from_planes(golden_records(z), scene["depth"].to(dev), scene["ori"].to(dev), scene["conf"].to(dev),
+                          scene["mask"].to(dev), device=dev, patch_size=meta["patch"], visible_threshold=meta["vis_thr"],
+                          conf_threshold=meta["thr"])
+    pts = z["opt_select_p"][:5000]
+    ref = (t["t%d_ori" % threads], t["t%d_loss" % threads], t["t%d_hc" % threads])
+    eight = (z["opt_select_o"][:5000], z["opt_min_loss"][:5000], z["opt_high_conf_index"][:5000])
+
+    def fwd():
+        _, o, l, h = pm.forward(pts)
+        return o.cpu().numpy(), l.cpu().numpy(), h.cpu().numpy()
+
+    assert rows_equal(fwd(), eight).all()
+    pm.set_option("reproject_fma_min_cols", info["reproject_fma_min_cols"])
+    eq = rows_equal(fwd(), ref)
+    assert eq.all(), (threads, int((~eq).sum()))
+    assert int((~rows_equal(ref, eight)).sum()) == info["rows_differing_from_8_threads"]

@@ -303,6 +303,35 @@ def test_optimize_multichunk_vs_reference(multichunk):
     assert st["differ_from_original_batch"] == 135 and st["reference_self_disagreement_over_1e4"] == 2
 
 
+@pytest.mark.parametrize("threads", [1, 2, 4])
+def test_forward_at_other_reference_thread_counts(multichunk, threads):
+    """tests/golden/pmvo_threads.npz (tools/gen_golden_threads.py): the reference's forward() on the first 5000-point chunk of
+    the four-chunk run under torch.set_num_threads(1 / 2 / 4).  The column count from which MKL's sgemm takes the fma-chain
+    form in Camera.reprojection (Utils/Camera_utils.py:81-106) is the switch to its THREADED kernel and moves with the thread
+    count of the reference's host (1: never, 2: 21 334, 4: 14 223, 8: 28 445 columns); the fixture stores the value probed at
+    each count next to the reference's outputs.  With the rule set from the fixture the oracle equals the reference on every
+    row -- 70 / 494 / 1 780 of which differ from the 8-thread files -- and with the 8-thread default it does not."""
+    from conftest import GOLDEN, rows_equal
+
+    meta, z, views = multichunk
+    t = load_npz("pmvo_threads")
+    tm = ast.literal_eval(str(t["meta"]))
+    assert tm["case"] == meta and tm["rows"] == 5000
+    info = tm["by_threads"][threads]
+    pts = z["opt_select_p"][:5000]
+    offs = np.load(__import__("os").path.join(GOLDEN, "depth_offsets.npy"))
+    ref = (t["t%d_ori" % threads], t["t%d_loss" % threads], t["t%d_hc" % threads])
+    eight = (z["opt_select_o"][:5000], z["opt_min_loss"][:5000], z["opt_high_conf_index"][:5000])
+    assert int((~rows_equal(ref, eight)).sum()) == info["rows_differing_from_8_threads"] > 0
+    assert rows_equal(oracle.forward(views, pts, meta["patch"], meta["thr"], offs)[1:], eight).all()      # the default: 8 threads
+    prev = oracle.set_reproject_rule("group", info["reproject_fma_min_cols"])
+    try:
+        got = oracle.forward(views, pts, meta["patch"], meta["thr"], offs)[1:]
+    finally:
+        oracle.set_reproject_rule(*prev)
+    assert rows_equal(got, ref).all(), "%d rows differ at %d threads" % (int((~rows_equal(got, ref)).sum()), threads)
+
+
 def test_shell_points_and_volume_multichunk_vs_reference(multichunk):
     """SURVEY.md §8 rows a15-a18 on the four-chunk run: the 9 692 shell points (two of the reference's chunks, PMVO.py:655-691)
     and the voxel fit of surface + shell points (:695-764) -- every row, every voxel, bit for bit."""

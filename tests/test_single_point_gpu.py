@@ -58,3 +58,47 @@ def test_batches_of_one_point_equal_the_reference(name, depth_offsets):
     pm.set_option("reproject_rule", 0)
     pm.set_option("sum_block", 32)
     assert torch.equal(torch.nan_to_num(l1, nan=-7.0)[0], torch.nan_to_num(lN, nan=-7.0)[n])
+
+
+@pytest.mark.parametrize("rule", [1, 2])
+def test_one_point_batches_with_a_forced_product_form_keep_the_inner_sum_order(rule, depth_offsets):
+    """Non-default options (round-5 advisor finding): reproject_rule 1 / 2 force one sgemm form for every point, sum_block 32
+    keeps ATen's summation rule -- and a [V, 1] sum over the views is an INNER sum whatever the products do.  The kernels
+    used to tie the two (the inner-sum order only with reproject_rule 0); the oracle never did.  forward (fused, unfused,
+    portable), the method refine and the votes on lone points == oracle with the same options, every value."""
+    from test_hip_parity import make_pmvo
+
+    meta, z = load_golden("pmvo_small")
+    scene = golden_scene(meta)
+    rec = golden_records(z)
+    views = scene_views(scene, rec)
+    pm = make_pmvo(meta, scene, rec)
+    pm.set_option("reproject_rule", rule)
+    pm.set_option("sum_block", 32)
+    prev = oracle.set_reproject_rule({1: "mid", 2: "chain"}[rule]), oracle.set_sum_block(32)
+    try:
+        checked = finite = 0
+        for n in range(0, len(z["points"]), 3):
+            p = z["points"][n:n + 1]
+            _, o_o, o_l, o_h = oracle.forward(views, p, meta["patch"], meta["thr"], depth_offsets)
+            for variant, fused in ((0, True), (0, False), (1256, True)):
+                pm.set_option("search_variant", variant)
+                _, o, l, h = pm.forward(p, fused=fused)
+                assert np.array_equal(l.cpu().numpy(), o_l, equal_nan=True), (n, variant, fused)
+                assert np.array_equal(o.cpu().numpy(), o_o, equal_nan=True) and np.array_equal(h.cpu().numpy(), o_h)
+            pm.set_option("search_variant", 0)
+            d = z["refine_ori_in"][n:n + 1]
+            pm.Compute_Visible_and_Ori(p)
+            rl, _ = pm.prj_loss_of(pm._points, torch.from_numpy(d).to(DEV))
+            o_rl, _ = oracle.refine_loss(views, p, d, meta["patch"], meta["thr"])
+            assert np.array_equal(rl.cpu().numpy(), o_rl, equal_nan=True), n
+            q = z["filter_points_in"][n % len(z["filter_points_in"]):][:1]
+            got = [t.cpu().numpy() for t in pm._votes(q, (True, True, True, True), meta["vis_thr"])[1]]
+            want = oracle.filter_votes(views, q, meta["patch"], meta["thr"], meta["vis_thr"])
+            assert all(np.array_equal(a, b) for a, b in zip(got, want)), n
+            checked += 1
+            finite += int(np.isfinite(o_l).sum())
+        assert checked >= 40 and finite >= 10
+    finally:
+        oracle.set_reproject_rule(*prev[0])
+        oracle.set_sum_block(prev[1])

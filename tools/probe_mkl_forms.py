@@ -124,7 +124,49 @@ def row_sum(x):
     return parts[0]
 
 
+def chain_switch_columns(g, nt, hi=400000):
+    """The column count from which torch.matmul([3,3], [3,C]) takes the fma-chain form with `nt` threads (0: it never
+    does up to `hi` columns) -- the value of the option reproject_fma_min_cols for a reference host with that many threads.
+    Restores the thread count."""
+    nt0 = torch.get_num_threads()
+    torch.set_num_threads(nt)
+    try:
+        def chain(C):
+            A, B = mm3_inputs(g, C)
+            f = classify(A.numpy().copy(), B.numpy().copy(), torch.matmul(A, B).numpy())
+            return "f2[f1[p0]]" in f and "(p1+(p0+p2))" not in f
+
+        lo = 90
+        if not chain(hi):
+            return 0
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            lo, hi = (lo, mid) if chain(mid) else (mid, hi)
+        return hi
+    finally:
+        torch.set_num_threads(nt0)
+
+
+NEVER = 2 ** 31 - 1     # reproject_fma_min_cols for a host whose sgemm never switches (one thread)
+
+
+def emit_options(threads=None):
+    """`python tools/probe_mkl_forms.py --emit-options [--threads N]` on the host the REFERENCE runs on: prints the JSON the
+    drivers take as --PMVO.reference_host=<file> (PMVO.py) so that the kernels round as that host's MKL does."""
+    import json
+
+    nt = torch.get_num_threads() if threads is None else int(threads)
+    g = torch.Generator().manual_seed(1)
+    cols = chain_switch_columns(g, nt)
+    mkl = [l.strip() for l in torch.__config__.show().split("\n") if "Math Kernel" in l]
+    print(json.dumps({"reproject_fma_min_cols": cols if cols else NEVER, "sum_block": 32, "threads": nt,
+                      "torch": torch.__version__, "mkl": (mkl[0][:150] if mkl else "")}))
+
+
 def main():
+    if "--emit-options" in sys.argv:
+        emit_options(sys.argv[sys.argv.index("--threads") + 1] if "--threads" in sys.argv else None)
+        return
     quick = "--quick" in sys.argv
     g = torch.Generator().manual_seed(1)
     nt0 = torch.get_num_threads()
@@ -159,23 +201,11 @@ def main():
     print("\nswitch of the [3,3] x [3,C] product to the chain form, by thread count")
     switch = {}
     for nt in ([nt0] if quick else range(1, nt0 + 1)):
-        torch.set_num_threads(nt)
-
-        def chain(C):
-            A, B = mm3_inputs(g, C)
-            f = classify(A.numpy().copy(), B.numpy().copy(), torch.matmul(A, B).numpy())
-            return "f2[f1[p0]]" in f and "(p1+(p0+p2))" not in f
-
-        lo, hi = 90, 400000
-        if not chain(hi):
-            print("  %d thread(s): no switch up to %d columns" % (nt, hi))
-            switch[nt] = 0
-            continue
-        while hi - lo > 1:
-            mid = (lo + hi) // 2
-            lo, hi = (lo, mid) if chain(mid) else (mid, hi)
-        print("  %d thread(s): chain form from %d columns (= %d points of 90 samples)" % (nt, hi, -(-hi // 90)))
-        switch[nt] = hi
+        switch[nt] = chain_switch_columns(g, nt)
+        if switch[nt]:
+            print("  %d thread(s): chain form from %d columns (= %d points of 90 samples)" % (nt, switch[nt], -(-switch[nt] // 90)))
+        else:
+            print("  %d thread(s): no switch up to 400000 columns" % nt)
     torch.set_num_threads(nt0)
 
     print("\ntorch.sum(x [V, C], dim=0): columns that match ONLY the cascade / ONLY row_sum, before / in the last C mod 32")
