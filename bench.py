@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 T
 VALU_PEAK_TF = 157.3         # same guide: peak fp32 vector (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
 FLOP_PER_PAIR = 8            # one (candidate, view, tap) evaluation
 CHUNK = 5000                 # PMVO.py:566
-PREWARM = 256                # untimed set-up iterations before the --warmup ones (GPU clocks at their running state;
+PREWARM = int(os.environ.get("MH_BENCH_PREWARM", "256"))   # untimed set-up iterations before the --warmup ones (GPU clocks at their running state;
                              # round 6: 48 -> 256 = 0.16 s -- the first bench of a fresh box measured 1 442 it/s with 48, 1 633-1 646 after)
 XGMI_LINK_GBS = 153.0        # per-link xGMI bandwidth, 7 links per GPU
 
@@ -228,6 +228,7 @@ def main():
     last = None
     for i in range(a.steps):
         last = step(a.warmup + i)       # (the outputs of the LAST timed step stay alive: cpu_baseline checks them)
+    t_enq = time.perf_counter() - t0    # the host has ISSUED the K steps (it runs ahead of the GPU; the barrier waits for them)
     barrier()
     dt = time.perf_counter() - t0
     last_chunk = my[(a.warmup + a.steps - 1) % len(my)]
@@ -255,6 +256,7 @@ def main():
         "warmup": a.warmup,
         "ms_per_step": round(ms, 4),
         "timed_region_s": round(dt, 7),
+        "host_issue_ms_per_step": round(t_enq / a.steps * 1e3, 4),
         "per_rank_iterations_per_s": [round(v, 2) for v in per_rank],
         "higher_is_better": True,
         "scaling": "weak",
@@ -470,8 +472,8 @@ def kernel_rooflines(a, pm, my, dev, V, H, W, P, codes=False):
     taps_in = 12 * N + V * N * (16 + 4) + nvis * P * (2 if codes else 16)      # a tap is 2 B of codes or a 16-B record
     taps_out = V * N * (4 + 8 + 4 + 4) + V * N * 16 + taps_vis * 16 + V * N
     pg_bytes = 2 * V * N * (12 * P + 20) + 12 * N
-    prof = load_profile_facts(V, H, W)
     pre = "8bit:" if codes else ""          # profiles/traffic.json keeps the 8-bit regime's PMC figures under this prefix
+    prof = load_profile_facts(V, H, W, pre, dict(visible_pairs=nvis, taps_written=taps_vis, pair_evals_executed=pairs))
     return {
         "roofline": {
             "kernel": "mh_search3_kernel<256>", "bound": "valu",
@@ -521,13 +523,22 @@ PROFILE_SOURCE = ("profiles/traffic.json (the builder's rocprofv3 --pmc passes o
                   "this run)")
 
 
-def load_profile_facts(V, H, W):
+def load_profile_facts(V, H, W, pre="", counters=None):
     """Facts that cannot be measured from inside this process (rocprofv3 PMC passes of this same command), from the
-    committed profiles/traffic.json: HBM bytes per launch and the search kernel's VALU issue figures."""
+    committed profiles/traffic.json: HBM bytes per launch and the search kernel's VALU issue figures.  They are only
+    quoted when the work counters THIS run read back from its own launches (visible (view, point) pairs, taps written,
+    executed evaluations per launch) equal the ones the file was profiled at to 0.2 %: otherwise every copied field is
+    None and `source` says why."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         if not t.get("workload", "").startswith("%d views @ %dx%d" % (V, H, W)):
             return {}
+        at = t.get("profiled_at", {})
+        for k, v in (counters or {}).items():
+            ref = at.get(pre + k)
+            if ref is None or abs(float(v) - float(ref)) > 2e-3 * float(ref):
+                return {"source": "profiles/traffic.json NOT quoted: this run's %s = %s, the file was profiled at %s"
+                                  % (k, int(v), ref)}
         return {"source": PROFILE_SOURCE,
                 "traffic": {k: v.get("traffic_bytes") for k, v in t.items() if isinstance(v, dict) and "traffic_bytes" in v},
                 "search_valu_issue": t.get("search_valu_issue"), "8bit:search_valu_issue": t.get("8bit:search_valu_issue")}
@@ -772,9 +783,131 @@ def secondary_full_pass(dev, pm, cand, dist):
     T["optimize_ms_per_iteration"] = round(T["optimize_s"] * 1e3 / max(1, len(s_pts) // CHUNK + 1), 4)
     T.update(candidates=int(len(cand)), surface_points=int(s_idx.sum()), shell_points=int(f_idx.sum()),
              iterations=int(len(s_pts) // CHUNK + 1), unit="s", ranks=1 if dist is None else dist.get_world_size())
+    if dist is None:
+        # where the pass's time goes: one more pass with the drivers' stage timers on (device-synchronised at every stage
+        # boundary, so it is slower than the passes above and not one of them)
+        try:
+            import monohair_amd.timing as tm
+
+            tm.totals.clear()
+            was, tm.ENABLED = tm.ENABLED, True
+            try:
+                with contextlib.redirect_stderr(io.StringIO()):
+                    inst = one_pass(9)[0]
+            finally:
+                tm.ENABLED = was
+            T["instrumented_pass"] = {"total_s": inst["total_s"], "refine_and_volume_s": inst["refine_and_volume_s"],
+                                      "stage_ms": {k: round(v * 1e3, 2) for k, v in tm.totals.items()},
+                                      "note": "stage timers synchronise the device at every boundary: overlap between stages is "
+                                              "lost here, the sum exceeds the untimed passes"}
+        except Exception as e:
+            T["instrumented_pass"] = {"error": repr(e)[:300]}
+        try:
+            T["roofline_kernels"] = full_pass_kernel_rows(dev, pm, cand, s_pts, cand[:len(f_idx)][f_idx])
+        except Exception as e:          # (reported, never fatal for the line)
+            T["roofline_kernels"] = {"error": repr(e)[:300]}
     if dist is None or dist.get_rank() == 0:
         shutil.rmtree(tmp, ignore_errors=True)
     return T
+
+
+def full_pass_kernel_rows(dev, pm, cand, s_pts, shell_pts):
+    """Roofline rows of the kernels of the exterior pass OUTSIDE the iterations: each launched
+    alone on this scene's own arrays, HIP events on its stream, best of three.  Work models (stated per row):
+      mh_filter_kernel        one centre record (16 B) + one mask sample (4 B) per (candidate, view)
+      mh_knn_kernel           queries/s (latency of LDS sorts: no byte or FLOP model)
+      mh_medoid_kernel        K^2 (|cos| + accumulate) pairs per point, 7 FLOP per pair (3 mul, 2 add, abs, add)
+      mh_refine_loss_maps     one centre record per (point, view) + P taps of 16 B per visible (point, view)
+      voxel fit               points/s through keys + stable sort + run heads + segmented medoid"""
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    from monohair_amd import _lib
+    from monohair_amd import pmvo_utils as U
+
+    L, ctx = pm._L, pm._ctx
+    V, P = pm.num_view, pm._side ** 2
+    st = _lib.stream_ptr()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def timed(fn, reps=3):
+        best = None
+        for _ in range(reps + 1):
+            torch.cuda.synchronize()
+            ev[0].record()
+            fn()
+            ev[1].record()
+            torch.cuda.synchronize()
+            t = ev[0].elapsed_time(ev[1])
+            best = t if best is None else min(best, t)
+        return best
+
+    rows = []
+    cd = torch.from_numpy(np.ascontiguousarray(cand, dtype=np.float32)).to(dev)
+    pts = torch.from_numpy(np.ascontiguousarray(s_pts, dtype=np.float32)).to(dev)
+    M, N = int(cd.shape[0]), int(pts.shape[0])
+    surf = torch.empty((M,), dtype=torch.uint8, device=dev)
+    filt = torch.empty((M,), dtype=torch.uint8, device=dev)
+    t = timed(lambda: _lib.check(L.mh_filter_points(ctx, _lib.ptr(cd), M, pm._side, float(pm.conf_threshold),
+                                                    float(pm.visible_threshold), _lib.ptr(surf), _lib.ptr(filt), None, None,
+                                                    M // 30, 0, M, st)))
+    b = M * V * 20 + M * 12
+    rows.append({"kernel": "mh_filter_kernel<%d>" % pm._side, "bound": "hbm", "launch_ms": round(t, 4), "points": M,
+                 "algorithmic_bytes_per_launch": b, "achieved": round(b / t / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(b / t / 1e6 / HBM_PEAK_GBS, 4),
+                 "point_views_per_s": round(M * V / t / 1e6, 2), "point_views_unit": "G/s",
+                 "note": "isolated 20-byte gathers: every one moves a whole 64-B line or two"})
+    grid = U.GridKNN(pts, k_hint=100, device=dev)
+    grid.query_nosync(pts, 100, self_query=True)
+    t = timed(lambda: grid.query_nosync(pts, 100, self_query=True))
+    idx, _ = grid.query_nosync(pts, 100, self_query=True)
+    K = int(idx.shape[1])
+    rows.append({"kernel": "mh_knn_kernel (k = %d self-query, two passes)" % K, "bound": "lds-latency", "launch_ms": round(t, 4),
+                 "queries": N, "queries_per_s": round(N / t * 1e3, 0), "neighbours_per_s": round(N * K / t * 1e3, 0)})
+    ori = torch.nn.functional.normalize(torch.randn((N, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(0)), dim=1)
+    cen = torch.empty((N, 3), dtype=torch.float32, device=dev)
+    t_all = timed(lambda: _lib.check(L.mh_medoid_indexed(ctx, _lib.ptr(ori), _lib.ptr(idx), N, K, _lib.ptr(cen), None, st)))
+    n1 = min(N, CHUNK)
+    t_one = timed(lambda: _lib.check(L.mh_medoid_indexed(ctx, _lib.ptr(ori), _lib.ptr(idx), n1, K, _lib.ptr(cen), None, st)))
+    for name, n, tt in (("all points in one launch", N, t_all), ("one %d-point chunk of the Gauss-Seidel chain" % n1, n1, t_one)):
+        fl = n * K * K * 7
+        rows.append({"kernel": "mh_medoid_kernel (indexed, K = %d): %s" % (K, name), "bound": "valu", "launch_ms": round(tt, 4),
+                     "pairs": n * K * K, "gpairs_per_s": round(n * K * K / tt / 1e6, 1),
+                     "achieved": round(fl / tt / 1e9, 2), "peak": VALU_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": round(fl / tt / 1e9 / VALU_PEAK_TF, 4)})
+    # visible (point, view) pairs of the surface points (the loss kernel gathers a patch only for those)
+    nvis = 0
+    for a0 in range(0, N, 20000):
+        sub = pts[a0:a0 + 20000]
+        vis = torch.empty((V, sub.shape[0]), dtype=torch.float32, device=dev)
+        tmp = [torch.empty((V, sub.shape[0]) + sh, dtype=torch.float32, device=dev) for sh in ((2,), (), ())]
+        scratch, need = pm._get_scratch(sub.shape[0])
+        _lib.check(L.mh_forward_prepare(ctx, _lib.ptr(sub), sub.shape[0], pm._side, float(pm.conf_threshold), _lib.ptr(vis),
+                                        _lib.ptr(tmp[0]), _lib.ptr(tmp[1]), _lib.ptr(tmp[2]), _lib.ptr(scratch), need, st))
+        nvis += int((vis != -1).sum().item())
+    loss = torch.empty((N,), dtype=torch.float32, device=dev)
+    t = timed(lambda: _lib.check(L.mh_refine_loss_maps(ctx, _lib.ptr(pts), _lib.ptr(ori), 0.005, 4.0, N, pm._side,
+                                                       float(pm.conf_threshold), _lib.ptr(loss), None, CHUNK, 0, N, st)))
+    b = N * V * 16 + nvis * P * 16 + N * 28
+    rows.append({"kernel": "mh_refine_loss_maps_kernel<%d> (lane = tap)" % pm._side, "bound": "hbm", "launch_ms": round(t, 4),
+                 "points": N, "visible_pairs": nvis, "algorithmic_bytes_per_launch": b, "achieved": round(b / t / 1e6, 1),
+                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / t / 1e6 / HBM_PEAK_GBS, 4)})
+    nv = N + len(shell_pts)
+    vp = torch.cat([pts, torch.from_numpy(np.ascontiguousarray(shell_pts, dtype=np.float32)).to(dev)], 0)
+    vo = torch.nn.functional.normalize(torch.randn((nv, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(1)), dim=1)
+    import time as _t
+
+    U.voxel_fit_device(vp, vo, nv, dev)
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    vox, _ = U.voxel_fit_device(vp, vo, nv, dev)
+    tv = (_t.perf_counter() - t0) * 1e3
+    rows.append({"kernel": "voxel fit (mh_voxel_key + radix sort + mh_segment_heads + mh_medoid_kernel<segmented>)",
+                 "bound": "launch-latency", "wall_ms": round(tv, 4), "points": nv, "voxels": int(len(vox)),
+                 "points_per_s": round(nv / tv * 1e3, 0)})
+    return rows
 
 
 def secondary_gabor(a, dev):

@@ -401,46 +401,33 @@ int mh_mat_sparse_store_voxels(void *handle, const long long *vox, const void *o
                                int Z);
 int mh_mat_sparse_close(void *handle);
 
-/* Tuning knobs for A/B runs and cross-checks; every setting computes the same results (except "topk_order" 1, which
- * returns tied confidences in view order).
- *   "search_variant": 0 = default: mh_search3_kernel (tap lists staged in LDS), points in descending order of work;
- *       7: the same with the points in their natural order (A/B); 100 / 107: 0 / 7 with the compare-and-select tap body
- *       whatever "search_body" says; 1256: the portable mh_search_kernel, the cross-check of the shipped kernel (also
- *       what runs when the caller has no list lengths).  Same results.
- *   "search_body": which tap body mh_search3_kernel runs.  0 (default) = by the maps: contexts whose views were ALL
- *       uploaded with mh_ctx_set_view_u8 (tap lists of ~2 entries after the exact duplicate removal) take the
- *       compare-and-select body, all others (lists of ~45 entries) the key body -- the running minimum as one integer key
- *       per candidate, v_min3_u32 over two taps at a time; 1 = key body, 2 = select body.  Same results.
- *   "tap_codes": 1 (default) = contexts whose views were ALL uploaded with mh_ctx_set_view_u8 gather a patch tap as the
- *       two resident 8-bit codes of its pixel (mh_project_taps_codes_kernel); 0 = always the decoded records.
- *   "gabor_variant": 3 (default) mh_gabor_mfma2_kernel; 1 the first FP32-MFMA form; 0 / 2 the direct v_pk_fma forms.
+/* Supported options of a context (mh_ctx_set_option): how results are rounded and which shipped form computes them.
+ * Anything else is an argument error; the A/B forms and cross-check kernels the tests and bench.py switch between are NOT
+ * here but in include/mh_pmvo_lab.h (mh_ctx_set_lab_option).
  *   "reproject_rule": how the sgemms of PMVO.sample_next_3d_pos (Camera.projection / Camera.reprojection of the points that
  *       share a base view, PMVO.py:289,318 -> Utils/Camera_utils.py:50-53,103) round.  0 (default): by the number M of points
  *       of the batch that share the (rank, base view), as MKL does in the reference -- M == 1: single-column projection;
- *       S*M >= "reproject_fma_min_cols" (default 28445 = MKL 2024.2 / AVX-512 / 8 threads, where the goldens were generated;
- *       the switch is MKL's threaded kernel and moves with the thread count: 2 threads 21334, 4 threads 14223, 1 thread never)
- *       or S*M <= 3: k-ordered fma chain; otherwise separately rounded products.  1: the mid-size forms for every point
- *       (rounds 1-4; independent of the batch).  2: the chain forms for every point.
+ *       S*M >= "reproject_fma_min_cols" or S*M <= 3: k-ordered fma chain; otherwise separately rounded products.  1: the
+ *       mid-size forms for every point (rounds 1-4; independent of the batch).  2: the chain forms for every point.
+ *   "reproject_fma_min_cols": the column count from which MKL's sgemm switches to its threaded (fma chain) kernel ON THE
+ *       HOST THE REFERENCE RUNS ON -- it moves with that host's thread count: 8 threads 28445 (default: MKL 2024.2, AVX-512,
+ *       where the goldens were generated), 4 threads 14223, 2 threads 21334, 1 thread never (2147483647).
+ *       `python tools/probe_mkl_forms.py --emit-options` prints the value for a host; PMVO.py takes it as
+ *       --PMVO.reference_host=<json>; pinned end to end at 1 / 2 / 4 / 8 threads (tests/golden/pmvo_threads.npz).
  *   "sum_block": 32 (default) ATen's sum(dim=0) adds the trailing (columns mod 32) of a [V, N*S] / [V, N] sum in its
  *       row_sum order (forward: the last samples of the last point of a batch; refine / filter votes: the last points of a
- *       batch); 0: cascade order everywhere (rounds 1-4).
- *   "tap_plane": 1 (default) contexts with fp32 views keep every pixel once more as a ready-made patch tap (unit orientation,
- *       clamped confidence: 16 B per pixel, made at upload) and the fused front end gathers those; 0: it normalises per
- *       iteration (same results; A/B and cross-check).
- *   "topk_order": see mh_topk_views.   "taps_tile": points per wave of the fp32 front end (mh_project_taps2_kernel): 64
- *       (default; any other value) gives the fastest iteration, 32 / 16 the kernel's own best time (A/B; same results).
+ *       batch), and the [V, 1] sums of a batch of ONE point in its inner-sum order; 0: cascade order everywhere (rounds 1-4).
+ *   "topk_order": see mh_topk_views (0 = torch.topk's order among equal confidences, default; 1 = view order).
+ *   "gabor_variant": 3 (default) mh_gabor_mfma2_kernel (FP32 MFMA); 0 the direct v_pk_fma kernel.  Same results.
+ *   "tap_plane_max_mb" (default 4096; environment MH_TAP_PLANE_MAX_MB at context creation): contexts with fp32 views keep
+ *       every pixel once more as a ready-made patch tap (unit orientation, clamped confidence: 16 B per pixel, +1.2 %
+ *       iterations/s) only if that plane is at most this large and leaves a quarter of the free device memory: 60 x 1080p
+ *       (1 991 MB) gets it, 120 x 4K (15 925 MB) does not unless the budget is raised.  Takes effect before the first view.
  *   "line_rule" (mh_render_strands): 0 = OpenGL's diamond-exit rule (default), 1 = the pixel that holds a segment's end
  *       point is drawn too (what Google SwiftShader does; changes the image: used to compare with that GL).
  *   "raster_subpixel_bits" (mh_render_depth, mh_render_strands): window positions are snapped to 2^-bits pixel, 4..8,
  *       default 8; OpenGL requires at least 4, which is what SwiftShader uses (changes the image at silhouettes). */
 int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value);
-
-/* Debug counter of the search's key body (csrc/pmvo_search.hip: mh_tap_key): out[2] = how many (wave, view) visits were
- * evaluated a second time with the compare-and-select body because a key could not state the winner (a best tap with
- * |cos| <= 2^-14, a NaN).  Process-wide, all contexts; reset != 0 clears it after the read.  out[0], out[1], out[3] are
- * only counted in the -DMH_KEY_STATS build (tools/exp_key_stats.py).  The reference has no counterpart: it exists so that
- * a test can prove it entered that branch (tests/test_key_reeval_gpu.py).  Synchronises the device. */
-int mh_debug_key_stats(unsigned long long *out /* 4 */, int reset);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,7 @@ _SIGS = {
     "mh_ctx_set_depth_offsets": (ci, [vp, vp, ci]),
     "mh_upload_async": (ci, [vp, vp, vp, ctypes.c_size_t, vp]),
     "mh_ctx_set_option": (ci, [vp, ctypes.c_char_p, ci]),
+    "mh_ctx_set_lab_option": (ci, [vp, ctypes.c_char_p, ci]),
     "mh_debug_key_stats": (ci, [vp, ci]),
     "mh_project_gather": (ci, [vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mh_topk_views": (ci, [vp, vp, vp, ci, vp, vp, vp]),

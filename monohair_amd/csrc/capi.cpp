@@ -462,15 +462,6 @@ extern "C" int mh_upload_async(mh_ctx *ctx, const void *host, void *device, size
 
 extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return fail(MH_ERR_ARG, "mh_ctx_set_option: bad arguments");
-    if (!strcmp(key, "search_variant")) {
-        ctx->search_variant = value;
-        return MH_OK;
-    }
-    if (!strcmp(key, "search_body")) {
-        if (value < 0 || value > 2) return fail(MH_ERR_ARG, "mh_ctx_set_option: search_body must be 0 (by the maps), 1 (keys) or 2 (select)");
-        ctx->search_body = value;
-        return MH_OK;
-    }
     if (!strcmp(key, "topk_order")) {
         if ((value & 255) > 1) return fail(MH_ERR_ARG, "mh_ctx_set_option: topk_order must be 0 (torch.topk's order) or 1");
         ctx->topk_order = value;
@@ -492,21 +483,9 @@ extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
         ctx->sum_block = value;
         return MH_OK;
     }
-    if (!strcmp(key, "tap_plane")) {
-        ctx->use_tap_plane = value ? 1 : 0;
-        return MH_OK;
-    }
     if (!strcmp(key, "tap_plane_max_mb")) {      // takes effect for planes not yet allocated (before the first fp32 view)
         if (value < 0) return fail(MH_ERR_ARG, "mh_ctx_set_option: tap_plane_max_mb must be >= 0");
         ctx->tap_plane_max_mb = value;
-        return MH_OK;
-    }
-    if (!strcmp(key, "tap_codes")) {
-        ctx->use_codes = value ? 1 : 0;
-        return MH_OK;
-    }
-    if (!strcmp(key, "taps_tile")) {
-        ctx->taps_tile = value;
         return MH_OK;
     }
     if (!strcmp(key, "gabor_variant")) {
@@ -523,7 +502,38 @@ extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
         ctx->raster_subpixel_bits = value;
         return MH_OK;
     }
+    for (const char *lab : {"search_variant", "search_body", "tap_plane", "tap_codes", "taps_tile"})
+        if (!strcmp(key, lab))
+            return fail(MH_ERR_ARG, "mh_ctx_set_option: %s is a lab switch, not a supported option: mh_ctx_set_lab_option "
+                                    "(include/mh_pmvo_lab.h)", key);
     return fail(MH_ERR_ARG, "mh_ctx_set_option: unknown key %s", key);
+}
+
+// ---- lab switches (include/mh_pmvo_lab.h): A/B forms and cross-check kernels; same results, not part of the supported surface
+extern "C" int mh_ctx_set_lab_option(mh_ctx *ctx, const char *key, int value) {
+    if (!ctx || !key) return fail(MH_ERR_ARG, "mh_ctx_set_lab_option: bad arguments");
+    if (!strcmp(key, "search_variant")) {
+        ctx->search_variant = value;
+        return MH_OK;
+    }
+    if (!strcmp(key, "search_body")) {
+        if (value < 0 || value > 2) return fail(MH_ERR_ARG, "mh_ctx_set_lab_option: search_body must be 0 (by the maps), 1 (keys) or 2 (select)");
+        ctx->search_body = value;
+        return MH_OK;
+    }
+    if (!strcmp(key, "tap_plane")) {
+        ctx->use_tap_plane = value ? 1 : 0;
+        return MH_OK;
+    }
+    if (!strcmp(key, "tap_codes")) {
+        ctx->use_codes = value ? 1 : 0;
+        return MH_OK;
+    }
+    if (!strcmp(key, "taps_tile")) {
+        ctx->taps_tile = value;
+        return MH_OK;
+    }
+    return fail(MH_ERR_ARG, "mh_ctx_set_lab_option: unknown key %s", key);
 }
 
 extern "C" int mh_project_gather(mh_ctx *ctx, const float *points, int N, int patch, float *vis, float *ori,

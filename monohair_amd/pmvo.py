@@ -182,8 +182,18 @@ class PMVO:
         except Exception:
             pass
 
+    LAB_OPTIONS = ("search_variant", "search_body", "tap_plane", "tap_codes", "taps_tile")
+
     def set_option(self, key, value):
+        """A supported option of the context (include/mh_pmvo.h: reproject_rule, reproject_fma_min_cols, sum_block, topk_order,
+        gabor_variant, tap_plane_max_mb, line_rule, raster_subpixel_bits).  The lab switches of include/mh_pmvo_lab.h (A/B
+        forms and cross-check kernels: LAB_OPTIONS) are routed to mh_ctx_set_lab_option so that tests and bench.py keep one call."""
+        if key in self.LAB_OPTIONS:
+            return self.set_lab_option(key, value)
         _lib.check(self._L.mh_ctx_set_option(self._ctx, key.encode(), int(value)), "mh_ctx_set_option")
+
+    def set_lab_option(self, key, value):
+        _lib.check(self._L.mh_ctx_set_lab_option(self._ctx, key.encode(), int(value)), "mh_ctx_set_lab_option")
 
     def set_head(self, bust_tree, scalp_tree, scalp_max):
         """The reference reads these from module globals (PMVO.py:99-106, 814-820)."""

@@ -6,10 +6,22 @@ import re
 from conftest import ROOT
 
 
-def declared_symbols():
-    hdr = open(os.path.join(ROOT, "include", "mh_pmvo.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(mh_[a-z_0-9]+)\s*\(", hdr)))
+def declared_symbols(headers=("mh_pmvo.h", "mh_pmvo_lab.h")):
+    out = set()
+    for h in headers:
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        out |= set(re.findall(r"\b(mh_[a-z_0-9]+)\s*\(", hdr))
+    return sorted(out)
+
+
+def test_lab_switches_are_not_in_the_supported_header():
+    """include/mh_pmvo.h is what an integrator binds; the A/B forms and cross-check kernels live in mh_pmvo_lab.h"""
+    main, lab = set(declared_symbols(("mh_pmvo.h",))), set(declared_symbols(("mh_pmvo_lab.h",)))
+    assert lab == {"mh_ctx_set_lab_option", "mh_debug_key_stats"} and not (main & lab)
+    doc = open(os.path.join(ROOT, "include", "mh_pmvo.h")).read()
+    for key in ("search_variant", "search_body", "taps_tile", "tap_codes"):
+        assert '"%s"' % key not in doc, key
 
 
 def test_header_declares_the_bound_entry_points():
