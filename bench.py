@@ -32,6 +32,7 @@ FLOP_PER_PAIR = 8            # one (candidate, view, tap) evalua
 CHUNK = 5000                 # PMVO.py:566
 PREWARM = int(os.environ.get("MH_BENCH_PREWARM", "256"))   # untimed set-up iterations before the --warmup ones (GPU clocks at their running state;
                              # round 6: 48 -> 256 = 0.16 s -- the first bench of a fresh box measured 1 442 it/s with 48, 1 633-1 646 after)
+SETTLE = int(os.environ.get("MH_BENCH_SETTLE", "16"))   # iterations between two drains after the pre-warm (see main)
 XGMI_LINK_GBS = 153.0        # per-link xGMI bandwidth, 7 links per GPU
 
 
@@ -214,6 +215,15 @@ def main():
     gc.freeze()          # no full collection of the set-up's objects (scene, chunks) in the middle of the timed region
     for i in range(PREWARM):
         step(i)
+    # settle: drain, then a few more iterations and another drain.  (Round 6: after a long run-ahead of the host, ONE
+    # hipMemcpyAsync among the first steps after a device-wide drain blocks for ~7 ms -- the runtime reclaims the
+    # command objects that piled up while the host was ahead -- which with the GPU queue still shallow is 7 ms of idle GPU
+    # inside a 60 ms timed region: 1 470 instead of 1 640 it/s, measured on every box with 256 / 320 pre-warm steps, never
+    # with 16 / 48 / 1000 / 2000; docs/HISTORY.md.  The hiccup is taken here, not in the timed region.)
+    torch.cuda.synchronize()
+    for i in range(SETTLE):
+        step(i)
+    torch.cuda.synchronize()
     for i in range(a.warmup):
         step(i)
 
@@ -223,14 +233,32 @@ def main():
         torch.cuda.synchronize()
 
     # --- timed region: exactly K steps
+    trace = [] if os.environ.get("MH_BENCH_TRACE_STEPS") else None
+    if trace is not None:               # (diagnostic: when did the host issue each step, which collections ran in between)
+        gc.callbacks.append(lambda phase, info: trace.append((time.perf_counter(), "gc-" + phase, info.get("generation"))))
     barrier()
     t0 = time.perf_counter()
     last = None
     for i in range(a.steps):
+        if trace is not None:
+            import faulthandler
+
+            faulthandler.dump_traceback_later(0.002, exit=False)      # a step that stalls for 2 ms shows where
         last = step(a.warmup + i)       # (the outputs of the LAST timed step stay alive: cpu_baseline checks them)
+        if trace is not None:
+            faulthandler.cancel_dump_traceback_later()
+            trace.append((time.perf_counter(), "step", i))
     t_enq = time.perf_counter() - t0    # the host has ISSUED the K steps (it runs ahead of the GPU; the barrier waits for them)
     barrier()
     dt = time.perf_counter() - t0
+    if trace is not None:
+        del gc.callbacks[-1]
+        prev = t0
+        for t, what, k in trace:
+            if what != "step" or t - prev > 3e-4:
+                print("[trace] +%.3f ms  %s %s  (%.3f ms since the previous mark)" % ((t - t0) * 1e3, what, k, (t - prev) * 1e3),
+                      file=sys.stderr)
+            prev = t
     last_chunk = my[(a.warmup + a.steps - 1) % len(my)]
     timed_region_s = dt
     per_rank = [a.steps / dt]
@@ -278,7 +306,7 @@ def main():
             "options": dict(kv.split("=") for kv in a.option),
             "maps": "8-bit file codes (PMVO.from_u8)" if a.codes else ("quantized-8bit" if a.quantize else "continuous"),
             "streams": len(streams),
-            "prewarm_steps": PREWARM,
+            "prewarm_steps": PREWARM, "settle_steps": SETTLE,
             "step_input": "host numpy chunk [5000,3] float64, uploaded inside the step (PMVO.py:40); maps resident in HBM",
         },
     }
@@ -791,11 +819,14 @@ def secondary_full_pass(dev, pm, cand, dist):
 
             tm.totals.clear()
             was, tm.ENABLED = tm.ENABLED, True
+            keep = dict(T)               # (one_pass refills the shared dict)
             try:
                 with contextlib.redirect_stderr(io.StringIO()):
                     inst = one_pass(9)[0]
             finally:
                 tm.ENABLED = was
+                T.clear()
+                T.update(keep)
             T["instrumented_pass"] = {"total_s": inst["total_s"], "refine_and_volume_s": inst["refine_and_volume_s"],
                                       "stage_ms": {k: round(v * 1e3, 2) for k, v in tm.totals.items()},
                                       "note": "stage timers synchronise the device at every boundary: overlap between stages is "
