@@ -216,10 +216,10 @@ def main():
     for i in range(PREWARM):
         step(i)
     # settle: drain, then a few more iterations and another drain.  (Round 6: after a long run-ahead of the host, ONE
-    # hipMemcpyAsync among the first steps after a device-wide drain blocks for ~7 ms -- the runtime reclaims the
-    # command objects that piled up while the host was ahead -- which with the GPU queue still shallow is 7 ms of idle GPU
-    # inside a 60 ms timed region: 1 470 instead of 1 640 it/s, measured on every box with 256 / 320 pre-warm steps, never
-    # with 16 / 48 / 1000 / 2000; docs/HISTORY.md.  The hiccup is taken here, not in the timed region.)
+    # hipMemcpyAsync among the first steps after a device-wide drain blocked for ~7 ms -- the runtime reclaiming the copy
+    # commands that piled up while the host was ahead -- which with the GPU queue still shallow is 7 ms of idle GPU inside a
+    # 60 ms timed region: 1 470 instead of 1 640 it/s, on every box with 256 / 320 pre-warm steps, never with 16 / 48 / 1000 /
+    # 2000; docs/HISTORY.md.  The chunk upload is a kernel now (mh_upload_pinned) and has no such call; the drain stays.)
     torch.cuda.synchronize()
     for i in range(SETTLE):
         step(i)

@@ -71,6 +71,14 @@ int mh_ctx_set_depth_offsets(mh_ctx *ctx, const float *offsets_host, int S);
  * also records an allocator-tracking event per call: 70 -> 55 us of host time per forward() on the 8-bit loop, where the host
  * has 0.24 ms per iteration to enqueue the next one. */
 int mh_upload_async(mh_ctx *ctx, const void *host, void *device, size_t bytes, void *stream);
+/* The same copy when `pinned_host` IS page-locked, device-visible memory (hipHostMalloc / a pin_memory tensor): up to 1 MiB
+ * (4-byte aligned) it is issued as a KERNEL on `stream` that reads the host buffer over the link, larger copies as
+ * hipMemcpyAsync.  Round 6: the 60 KB chunk of an iteration through hipMemcpyAsync stalls ONE call for 6-7 ms every so often
+ * (the runtime reclaiming the copy commands that piled up while the host ran ahead: 7 ms of idle GPU when its queue is
+ * shallow -- the "one timed round in ten is 20 % slower" of rounds 3-5); the kernel form has no such call, and the iteration
+ * is 0.8 % (fp32 maps) / 4 % (8-bit maps) faster with it because the copy no longer waits for a copy engine.  MH_UPLOAD_KERNEL=0
+ * in the environment selects hipMemcpyAsync for every size (A/B). */
+int mh_upload_pinned(mh_ctx *ctx, const void *pinned_host, void *device, size_t bytes, void *stream);
 
 /* ---- K3+K4+K5: PMVO.Compute_Visible_and_Ori (PMVO.py:346-376) with project_points (:378-397),
  * the gathers (:482-523) and compute_visible (:525-529).  Any output may be NULL.

@@ -24,6 +24,7 @@ _SIGS = {
     "mh_ctx_set_view_u8": (ci, [vp, ci, vp, vp, ci, vp, vp, vp, vp, vp]),
     "mh_ctx_set_depth_offsets": (ci, [vp, vp, ci]),
     "mh_upload_async": (ci, [vp, vp, vp, ctypes.c_size_t, vp]),
+    "mh_upload_pinned": (ci, [vp, vp, vp, ctypes.c_size_t, vp]),
     "mh_ctx_set_option": (ci, [vp, ctypes.c_char_p, ci]),
     "mh_ctx_set_lab_option": (ci, [vp, ctypes.c_char_p, ci]),
     "mh_debug_key_stats": (ci, [vp, ci]),

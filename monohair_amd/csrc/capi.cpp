@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -139,6 +140,7 @@ int mh_launch_segment_heads(const unsigned long long *, int, int32_t *, unsigned
                             hipStream_t);
 int mh_launch_flag_less(const float *, float, int, uint8_t *, hipStream_t);
 int mh_launch_words_differ(const void *, const void *, size_t, int32_t *, hipStream_t);
+int mh_launch_copy_words(const void *, void *, size_t, hipStream_t);
 int mh_launch_voxel_group(const void *, int, const float *, int, const double *, double, const int32_t *, void *, size_t,
                           unsigned long long *, int32_t *, float *, hipStream_t);
 int mh_launch_render_strands(const float *, const float *, int, const int32_t *, int, const float *, const float *, int,
@@ -457,6 +459,19 @@ extern "C" int mh_upload_async(mh_ctx *ctx, const void *host, void *device, size
     if (!ctx || (bytes && (!host || !device))) return fail(MH_ERR_ARG, "mh_upload_async: bad arguments");
     if (!bytes) return MH_OK;
     MH_HIP(hipMemcpyAsync(device, host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return MH_OK;
+}
+
+// the same copy for a PAGE-LOCKED source: up to 1 MiB as a kernel that reads the host buffer over the link (see the header)
+extern "C" int mh_upload_pinned(mh_ctx *ctx, const void *pinned_host, void *device, size_t bytes, void *stream) {
+    if (!ctx || (bytes && (!pinned_host || !device))) return fail(MH_ERR_ARG, "mh_upload_pinned: bad arguments");
+    if (!bytes) return MH_OK;
+    static const bool by_copy_engine = getenv("MH_UPLOAD_KERNEL") && atoi(getenv("MH_UPLOAD_KERNEL")) == 0;
+    if (!by_copy_engine && !(bytes & 3) && !((uintptr_t)pinned_host & 3) && !((uintptr_t)device & 3) && bytes <= (1u << 20)) {
+        MH_HIP(hipSetDevice(ctx->device));
+        return launched(mh_launch_copy_words(pinned_host, device, bytes / 4, (hipStream_t)stream), "mh_upload_pinned");
+    }
+    MH_HIP(hipMemcpyAsync(device, pinned_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     return MH_OK;
 }
 

@@ -336,6 +336,17 @@ extern "C" int mh_launch_words_differ(const void *a, const void *b, size_t nword
     return (int)hipGetLastError();
 }
 
+// a small host -> device upload as a KERNEL that reads the page-locked host buffer over the link (mh_upload_pinned)
+__global__ __launch_bounds__(256) void mh_copy_words_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
+                                                            size_t nwords) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+extern "C" int mh_launch_copy_words(const void *src, void *dst, size_t nwords, hipStream_t st) {
+    const unsigned nb = (unsigned)((nwords + 255) / 256 > 1024 ? 1024 : (nwords + 255) / 256);
+    hipLaunchKernelGGL(mh_copy_words_kernel, dim3(nb), dim3(256), 0, st, (const uint32_t *)src, (uint32_t *)dst, nwords);
+    return (int)hipGetLastError();
+}
+
 extern "C" size_t mh_select_scratch_bytes_impl(int n) {
     const size_t nb = ((size_t)(n > 0 ? n : 1) + MH_SEL_ITEMS - 1) / MH_SEL_ITEMS;
     return align256(nb * sizeof(int32_t)) + 256;

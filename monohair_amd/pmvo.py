@@ -251,7 +251,7 @@ class PMVO:
             # ONE pinned slab of 32 slots per launch stream (3 MB), allocated on the stream's first call (a ring that grew
             # slot by slot paid a pinned allocation -- milliseconds, and it drains the device -- up to 32 times per stream
             # during the first few hundred iterations of a loop)
-            # The copies go through mh_upload_async, which torch's host caching allocator does not track: before the old slab
+            # The copies go through mh_upload_pinned, which torch's host caching allocator does not track: before the old slab
             # is dropped (its pinned block could be handed out again at once), every copy still queued out of it must be over.
             self._drain_ring(ring)
             cap = max(n, 8192)
@@ -271,8 +271,8 @@ class PMVO:
         dev = torch.empty((n, 3), dtype=torch.float32, device=self.device)
         # (not `dev.copy_(pinned, non_blocking=True)`: that also records an allocator-tracking event per call -- 70 -> 55 us of
         # host time per forward())
-        _lib.check(self._L.mh_upload_async(self._ctx, ring["ptr"] + k * ring["cap"] * 12, dev.data_ptr(), n * 12,
-                                           cs.cuda_stream), "mh_upload_async")
+        _lib.check(self._L.mh_upload_pinned(self._ctx, ring["ptr"] + k * ring["cap"] * 12, dev.data_ptr(), n * 12,
+                                            cs.cuda_stream), "mh_upload_pinned")
         ev.record(cs)
         return dev
 
@@ -491,8 +491,8 @@ class PMVO:
         host = ent[0].numpy()[:nbytes].view(dt).reshape(a.shape)
         np.copyto(host, a, casting="same_kind")
         cs = torch.cuda.current_stream(self.device)
-        _lib.check(self._L.mh_upload_async(self._ctx, ent[0].data_ptr(), dev.data_ptr(), nbytes, cs.cuda_stream),
-                   "mh_upload_async")
+        _lib.check(self._L.mh_upload_pinned(self._ctx, ent[0].data_ptr(), dev.data_ptr(), nbytes, cs.cuda_stream),
+                   "mh_upload_pinned")
         ent[1].record(cs)
         return dev
 
