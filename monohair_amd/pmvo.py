@@ -1083,6 +1083,7 @@ def _refine_device(points, ori, loss, pmvo, filter_unvisible_points, args, thres
     ori_dev = pmvo.stage_upload("refine_o", np.asarray(ori).reshape(-1, 3))
     loss_dev = pmvo.stage_upload("refine_l", np.asarray(loss).reshape(-1))
     pf = pmvo.take_refine_prefetch(pts_dev, sub_num, 100)
+    pmvo.last_refine = {"device_pass": True, "prefetch_adopted": pf is not None, "shell_stage": "device"}   # (what ran: tests, bench)
     T_up.__exit__()
     # the shell points' votes and scalp test need the shell points only: first thing on the side stream
     hd = ht = fb_dev = fq_dev = None
@@ -1196,6 +1197,7 @@ def _refine_device(points, ori, loss, pmvo, filter_unvisible_points, args, thres
     n_sel = n_valid
     if F and n_valid:
         if n_valid < min(100, n_all):    # the reference then asks for n_valid neighbours: the host-driven stage below does
+            pmvo.last_refine["shell_stage"] = "host (fewer kept points than neighbours)"
             T_shell.__exit__()
             return out
         # KDTree(select_points).query(fu, 100) on the grid of ALL points with the kept ones flagged valid: the indices
@@ -1215,6 +1217,7 @@ def _refine_device(points, ori, loss, pmvo, filter_unvisible_points, args, thres
         hcnt[1:].copy_(cnt[1:], non_blocking=True)
         main.synchronize()               # (2) kept shell rows; queries the grid could not finish at its first cell size
         if bool(hst.numpy().any()):
+            pmvo.last_refine["shell_stage"] = "host (queries to retry on another cell size)"
             T_shell.__exit__()
             return out                   # the host-driven shell stage below retries them on other cell sizes
         n_sel = int(hcnt[1])
@@ -1269,6 +1272,7 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         mat_writer = U.SparseMatWriter(args.save_path, grid_resolution, np.concatenate(cands, 0) if cands else None,
                                        voxel_min, voxel_size)
     dev_out = None
+    pmvo.last_refine = {"device_pass": False, "prefetch_adopted": False, "shell_stage": "host"}
     if not genrate_ori_only:
         print("filter nosiy points...")
         # One rank, device k-NN: the whole of :602-726 runs device-resident (_refine_device).  MH_REFINE_DEVICE=0, several

@@ -3,7 +3,7 @@ reference's own chunked run (tests/golden/e2e_multichunk.npz) and leave the outp
 them with the reference's files -- in this process, or as N ranks under torch.distributed.run (gloo ranks sharing the test GPU,
 as tests/test_cli_gpu.py does; MH_REFINE_SHARD=1 shards the smoothing loop).
 
-    python tests/golden_drivers.py --out DIR [--what optimize,optimize_exact,refine,refine_exact,refine_headfilter]
+    python tests/golden_drivers.py --out DIR [--what pass,optimize,optimize_exact,refine,refine_exact,refine_headfilter]
 """
 import argparse
 import ast
@@ -44,6 +44,21 @@ def run(out_dir, what=("optimize", "refine", "refine_exact"), device="cuda:0"):
         os.makedirs(a.save_path, exist_ok=True)
         return a
 
+    if "pass" in what:
+        # the three drivers in sequence on the reference's candidates, arrays handed from one to the next as PMVO.py's caller
+        # would: refine() then finds the neighbour table / head votes / .mat pages that optimize() prepared for these points
+        import json
+
+        from monohair_amd.pmvo import filter_negative_points
+
+        a = args_for("pass")
+        s_idx, s_pts, f_idx = filter_negative_points(z["candidates"].copy(), pm, a)
+        sp, so, ml, hc = optimize(s_pts, pm, a)
+        np.save(os.path.join(a.save_root, "surface_index.npy"), s_idx)
+        np.save(os.path.join(a.save_root, "filter_index.npy"), f_idx)
+        refine(sp, so, ml, pm, z["candidates"][:len(f_idx)][f_idx], a, infer_inner=False, threshold=meta["threshold"],
+               genrate_ori_only=False, return_dense=False)
+        json.dump(pm.last_refine, open(os.path.join(a.output_path, "last_refine.json"), "w"))
     if "optimize" in what:
         # the surface points exactly as the reference's optimize received them (float32 rows of filter_negative_points)
         optimize(z["opt_select_p"].copy(), pm, args_for("run"))

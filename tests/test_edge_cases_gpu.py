@@ -271,7 +271,7 @@ def test_topk_tie_order_is_torchs_on_adversarial_columns():
 
 
 def test_upload_ring_wraps_and_changes_size_with_many_calls_in_flight():
-    """forward() uploads its host chunk through a ring of 32 pinned slots per launch stream and mh_upload_async: more calls
+    """forward() uploads its host chunk through a ring of 32 pinned slots per launch stream and mh_upload_pinned: more calls
     than slots without a synchronisation in between (the ring wraps while copies are in flight), chunk sizes that change from
     call to call and one that exceeds the slab (re-allocation) must all read the right points: every result is compared with
     the same call made on a device tensor."""
@@ -297,6 +297,66 @@ def test_upload_ring_wraps_and_changes_size_with_many_calls_in_flight():
     L = _lib.lib()
     assert L.mh_upload_async(pm._ctx, None, None, 16, None) != 0 and b"mh_upload_async" in L.mh_last_error()
     assert L.mh_upload_async(pm._ctx, None, None, 0, None) == 0
+    assert L.mh_upload_pinned(pm._ctx, None, None, 16, None) != 0 and b"mh_upload_pinned" in L.mh_last_error()
+    assert L.mh_upload_pinned(pm._ctx, None, None, 0, None) == 0
+
+
+def test_upload_pinned_kernel_and_copy_engine_forms_move_the_same_bytes():
+    """mh_upload_pinned: up to 1 MiB (4-byte multiples) as a kernel that reads the page-locked buffer, anything else as
+    hipMemcpyAsync -- sizes on both sides of the switch, odd sizes, unaligned offsets; mh_buffers_differ agrees with torch."""
+    import ctypes
+
+    from monohair_amd import _lib
+
+    scene, pm, views = build(20, 48, 40, 3)
+    L = _lib.lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    host = torch.empty(3 << 20, dtype=torch.uint8, pin_memory=True)
+    host.numpy()[:] = np.random.default_rng(1).integers(0, 256, host.numel(), dtype=np.uint8)
+    for nbytes, off in ((4, 0), (60000, 0), (1 << 20, 0), ((1 << 20) + 4, 0), (3 << 20, 0), (1023, 0), (4096, 1), (4096, 8)):
+        nbytes = min(nbytes, host.numel() - off)
+        dev = torch.zeros(nbytes + 8, dtype=torch.uint8, device=DEV)
+        _lib.check(L.mh_upload_pinned(pm._ctx, host.data_ptr() + off, dev.data_ptr(), nbytes, st), "mh_upload_pinned")
+        torch.cuda.synchronize()
+        got = dev.cpu().numpy()
+        assert np.array_equal(got[:nbytes], host.numpy()[off:off + nbytes]) and not got[nbytes:].any(), (nbytes, off)
+    a = torch.randn(70001, 3, device=DEV)
+    flag = torch.empty(1, dtype=torch.int32, device=DEV)
+    for change in (False, True):
+        b = a.clone()
+        if change:
+            b[70000, 2] = b[70000, 2] + 1
+        _lib.check(L.mh_buffers_differ(pm._ctx, _lib.ptr(a), _lib.ptr(b), a.numel() * 4, _lib.ptr(flag), st))
+        assert bool(flag.item()) == change
+
+
+def test_tap_plane_respects_its_budget(monkeypatch):
+    """The plane of ready-made taps doubles the resident map memory: contexts only keep it below tap_plane_max_mb (environment
+    MH_TAP_PLANE_MAX_MB at creation); with or without it forward() returns the same bits."""
+    from monohair_amd import synth
+
+    cand = synth.candidate_points(res=32, seed=1)[:257]
+    scene, pm, views = build(24, 96, 80, 5)
+    ref = [t.cpu().numpy() for t in pm.forward(cand)[1:]]
+    monkeypatch.setenv("MH_TAP_PLANE_MAX_MB", "0")
+    scene2, pm2, _ = build(24, 96, 80, 5)
+    got = [t.cpu().numpy() for t in pm2.forward(cand)[1:]]
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(ref, got))
+    with pytest.raises(_lib_error()):
+        pm2.set_option("tap_plane_max_mb", -1)
+    from monohair_amd import _lib as _l
+
+    with pytest.raises(_lib_error()):         # a lab key through the supported entry point is refused, and says where it lives
+        _l.check(pm2._L.mh_ctx_set_option(pm2._ctx, b"search_variant", 7), "mh_ctx_set_option")
+    assert b"mh_pmvo_lab.h" in pm2._L.mh_last_error()
+    pm2.set_option("search_variant", 7)           # ... but PMVO.set_option routes lab keys to mh_ctx_set_lab_option
+    pm2.set_option("search_variant", 0)
+
+
+def _lib_error():
+    from monohair_amd._lib import MhError
+
+    return MhError
 
 
 @pytest.mark.parametrize("N", [0, 29, 59, 3000, 3001])

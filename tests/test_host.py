@@ -483,3 +483,56 @@ def test_unseeded_options_before_process_group_init_agree_across_ranks(tmp_path,
     assert names[0] == names[1] and names[0].startswith("run_") and len(names[0]) == 8 and draws[0] == draws[1]
     monkeypatch.setenv("MASTER_PORT", "30000")               # another launch: another suffix
     assert options.set(options.parse_arguments(["--yaml=%s" % (tmp_path / "c")])).name != names[0]
+
+
+def test_npy_row_writer_writes_np_save_bytes(tmp_path):
+    """optimize() streams optimize/*.npy out a group of chunks at a time (monohair_amd.pmvo_utils.NpyRowWriter): the file must
+    be byte for byte what np.save writes for the whole array (the reference's np.save, PMVO.py:575-579)."""
+    from monohair_amd.pmvo_utils import NpyRowWriter
+
+    rng = np.random.default_rng(0)
+    for arr in (rng.normal(size=(12001, 3)).astype(np.float32), rng.normal(size=(12001,)).astype(np.float32),
+                rng.random(12001) > 0.5, np.zeros((0, 3), np.float32), np.zeros((1,), np.bool_)):
+        np.save(tmp_path / "a.npy", arr)
+        w = NpyRowWriter(str(tmp_path / "b.npy"), arr.shape, arr.dtype)
+        for lo in range(0, len(arr), 5000):
+            w.write(arr[lo:lo + 5000])
+        w.close()
+        assert (tmp_path / "a.npy").read_bytes() == (tmp_path / "b.npy").read_bytes(), (arr.shape, arr.dtype)
+        assert np.array_equal(np.load(tmp_path / "b.npy"), arr)
+
+
+def test_reference_host_option_is_applied_from_file_and_inline(tmp_path):
+    """PMVO.py --PMVO.reference_host=<file | JSON>: the rounding facts of the host the reference runs on become context options
+    (INTEGRATION.md 3.1); the probe prints exactly that JSON."""
+    import json
+    import subprocess
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import importlib
+
+    drv = importlib.import_module("PMVO")
+
+    class Rec:
+        def __init__(self):
+            self.calls = []
+
+        def set_option(self, k, v):
+            self.calls.append((k, v))
+
+    r = Rec()
+    drv.apply_reference_host(r, None)
+    assert r.calls == []
+    drv.apply_reference_host(r, '{"reproject_fma_min_cols": 14223, "sum_block": 32, "threads": 4}')
+    assert r.calls == [("reproject_fma_min_cols", 14223), ("sum_block", 32)]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "probe_mkl_forms.py"), "--emit-options", "--threads", "1"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    host = json.loads(out.stdout.strip().splitlines()[-1])
+    assert host["threads"] == 1 and host["reproject_fma_min_cols"] == 2 ** 31 - 1 and host["sum_block"] == 32
+    f = tmp_path / "host.json"
+    f.write_text(json.dumps(host))
+    r2 = Rec()
+    drv.apply_reference_host(r2, str(f))
+    assert ("reproject_fma_min_cols", 2 ** 31 - 1) in r2.calls

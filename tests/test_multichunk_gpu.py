@@ -177,3 +177,29 @@ def test_forward_at_other_reference_thread_counts(threads):
     eq = rows_equal(fwd(), ref)
     assert eq.all(), (threads, int((~eq).sum()))
     assert int((~rows_equal(ref, eight)).sum()) == info["rows_differing_from_8_threads"]
+
+
+@pytest.mark.parametrize("prefetch", ["1", "0"])
+def test_whole_pass_through_the_three_drivers_equals_the_reference(tmp_path, prefetch):
+    """filter_negative_points -> optimize -> refine on the reference's candidates, the arrays handed from one driver to the next
+    (PMVO.py:847-873).  With the prefetch on, refine adopts the neighbour table, the head votes and the .mat writer that
+    optimize prepared while it iterated (asserted: that path ran); off, it prepares them itself.  Either way: the reference's
+    masks, its four optimize files on all 16 901 rows, its five refine files and every voxel."""
+    import json
+
+    from conftest import rows_equal
+
+    z, meta = golden()
+    run_helper(tmp_path, "pass", env_extra={"MH_REFINE_PREFETCH": prefetch, "MH_MAT_EARLY": prefetch})
+    out = os.path.join(tmp_path, "pass")
+    info = json.load(open(os.path.join(out, "last_refine.json")))
+    assert info["device_pass"] and info["prefetch_adopted"] == (prefetch == "1") and info["shell_stage"] == "device", info
+    assert np.array_equal(np.load(os.path.join(out, "optimize", "surface_index.npy")), z["surface_index"])
+    assert np.array_equal(np.load(os.path.join(out, "optimize", "filter_index.npy")), z["filter_index"])
+    got = {k: np.load(os.path.join(out, "optimize", k + ".npy")) for k in ("select_p", "select_o", "min_loss", "high_conf_index")}
+    assert np.array_equal(got["select_p"], z["opt_select_p"])
+    eq = rows_equal((got["select_o"], got["min_loss"], got["high_conf_index"]),
+                    (z["opt_select_o"], z["opt_min_loss"], z["opt_high_conf_index"]))
+    assert len(eq) == 16901 and eq.all()
+    check_refine_files(out, z, "ref_", 16901)
+    assert not [f for f in os.listdir(os.path.join(out, "refine")) if f.endswith(".writing")]

@@ -18,6 +18,25 @@ MH_TIMING=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d 
     python $R/tools/time_full_pass.py 3 > $OUT/${TAG}_trace.log 2>&1
 echo "trace rc=$?"
 python $R/tools/summarize_fullpass.py $OUT/${TAG}_trace $OUT/${TAG}_stages.txt > $OUT/${TAG}_summary.txt 2>&1
+# HBM traffic of the pass's own kernels (separate --pmc passes, counters only; one pass of the driver each)
+RX="mh_refine_loss_maps|mh_filter_kernel|mh_knn_kernel|mh_medoid_kernel"
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $OUT/${TAG}_pmc_$C
+  MH_TIMING=0 timeout 600 rocprofv3 --pmc $C --kernel-include-regex "$RX" --output-format csv -d $OUT/${TAG}_pmc_$C -o pmc -- \
+      python $R/tools/time_full_pass.py 1 > $OUT/${TAG}_pmc_$C.log 2>&1
+  echo "pmc $C rc=$?"
+done
+python - <<PY >> $OUT/${TAG}_summary.txt
+import csv, glob, collections
+print("## PMC of the pass's kernels (one pass, --pmc only; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; totals over the pass)")
+for f in sorted(glob.glob("$OUT/${TAG}_pmc_*/**/*counter_collection.csv", recursive=True)):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        acc[(r["Kernel_Name"].split("(")[0].replace("void ", "")[:48], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for k, v in sorted(acc.items()):
+        print("%s,%s,sum=%.6g,launches=%d" % (k[0], k[1], sum(v), len(v)))
+PY
+rm -rf $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE
 # the raw trace is large: keep the compact last-pass timeline only
 python - <<PY
 import csv, glob, gzip

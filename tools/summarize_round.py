@@ -105,5 +105,19 @@ if path is not None:
         notes.append("gabor: MFMA pipe busy %.1f %% of the kernel's %.2f M cycles" % (100 * g["mfma_busy"], cyc / 1e6))
     facts["gabor_stage"] = g
     notes.append("gabor stage: %.1f MB HBM traffic per view (%s)" % (tot / 1e6, {k: round(v / 1e6, 1) for k, v in per.items()}))
+# the work counters of the profiled launches (bench.py quotes this file only when its own launches report the same ones)
+at = {"_comment": "the launch's own work counters when these PMC passes were made (bench.py reads the same counters back from "
+                  "its launches and drops every field copied from this file when they differ: a stale file cannot decorate "
+                  "another workload)"}
+for tag, pre in ((RND + "_main", ""), (RND + "_8bit", "8bit:")):
+    b = os.path.join(SRC, "%s_bench.json" % tag)
+    if os.path.exists(b) and os.path.getsize(b):
+        d = json.load(open(b))
+        d = d.get("secondary_8bit_maps", d) if (pre and "roofline" not in d) else d
+        front = next((k for k in d.get("roofline_kernels", []) if "visible_pairs" in k), {})
+        at.update({pre + "visible_pairs": front.get("visible_pairs"), pre + "taps_written": front.get("taps_written"),
+                   pre + "pair_evals_executed": d.get("roofline", {}).get("pair_evals_executed")})
+if len(at) > 1:
+    facts["profiled_at"] = at
 json.dump(facts, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
 print("\n".join(notes))
