@@ -808,6 +808,7 @@ def secondary_full_pass(dev, pm, cand, dist):
     T["value"] = first["total_s"]
     T["value_is"] = "first_pass.total_s"
     T["steady_total_s"] = T["total_s"]
+    T["refine_path"] = dict(getattr(pm, "last_refine", {}))      # which form of refine ran (device-resident pass, prefetch adopted)
     T["optimize_ms_per_iteration"] = round(T["optimize_s"] * 1e3 / max(1, len(s_pts) // CHUNK + 1), 4)
     T.update(candidates=int(len(cand)), surface_points=int(s_idx.sum()), shell_points=int(f_idx.sum()),
              iterations=int(len(s_pts) // CHUNK + 1), unit="s", ranks=1 if dist is None else dist.get_world_size())

@@ -106,3 +106,42 @@ def test_refine_loop_58_chunks_vs_oracle(headline, form, monkeypatch):
           % (form, len(want_l), len(trace), sum(r for _, _, r in trace), int((want_l == 0.5).sum())))
     # Gauss-Seidel, not Jacobi: the result differs from medoids taken from the INPUT orientations
     assert not eq(got_o, opt["select_o"])
+
+
+def test_device_resident_refine_writes_the_files_of_the_host_driven_form(headline, monkeypatch, tmp_path):
+    """Round 6: refine()'s default on one rank keeps threshold / kept rows / shell neighbours / concatenation / voxel fit on the
+    device (pmvo.py::_refine_device).  At the headline size, with a threshold that keeps most points (0.025, bench.py's), the
+    whole of it runs there -- asserted -- and every file it writes (the three smoothed arrays, the kept shell points and their
+    orientations, Ori3D.mat / Occ3D.mat) is byte for byte the file of the host-driven form of rounds 4-5 (MH_REFINE_DEVICE=0),
+    whose shell stage, voxel fit and files are pinned to the reference's (tests/test_multichunk_gpu.py)."""
+    import hashlib
+
+    from monohair_amd.pmvo import refine
+
+    h = headline
+    opt = h["opt"]
+    digests, info = {}, {}
+    for form in ("device", "host"):
+        monkeypatch.setenv("MH_REFINE_DEVICE", "1" if form == "device" else "0")
+        root = tmp_path / form
+        args = types.SimpleNamespace(device=DEV, output_path=str(root), save_root=str(root / "optimize"),
+                                     save_path=str(root / "refine"), PMVO=types.SimpleNamespace(visible_threshold=1.0),
+                                     data=types.SimpleNamespace(root=str(root)))
+        os.makedirs(args.save_path, exist_ok=True)
+        refine(opt["select_p"].copy(), opt["select_o"].copy(), opt["min_loss"].copy(), h["pm"], h["shell"].copy(), args,
+               infer_inner=False, threshold=0.025, genrate_ori_only=False, return_dense=False)
+        info[form] = dict(h["pm"].last_refine)
+        names = sorted(os.listdir(root / "refine"))
+        digests[form] = {n: hashlib.sha256(open(root / "refine" / n, "rb").read()).hexdigest() for n in names}
+    assert info["device"] == {"device_pass": True, "prefetch_adopted": False, "shell_stage": "device"}, info
+    assert not info["host"]["device_pass"]
+    assert sorted(digests["device"]) == ["Occ3D.mat", "Ori3D.mat", "filter_unvisible.npy", "filter_unvisible_ori.npy",
+                                         "min_loss.npy", "select_o.npy", "select_p.npy"]
+    # (the .mat header carries a creation time: compare the payloads)
+    for n in digests["device"]:
+        a, b = (open(tmp_path / f / "refine" / n, "rb").read() for f in ("device", "host"))
+        if n.endswith(".mat"):
+            a, b = a[128:], b[128:]
+        assert a == b, n
+    kept = np.load(tmp_path / "device" / "refine" / "filter_unvisible.npy")
+    assert 1000 < len(kept) <= len(h["shell"])
