@@ -555,7 +555,8 @@ def load_profile_facts(V, H, W, pre="", counters=None):
     """Facts that cannot be measured from inside this process (rocprofv3 PMC passes of this same command), from the
     committed profiles/traffic.json: HBM bytes per launch and the search kernel's VALU issue figures.  They are only
     quoted when the work counters THIS run read back from its own launches (visible (view, point) pairs, taps written,
-    executed evaluations per launch) equal the ones the file was profiled at to 0.2 %: otherwise every copied field is
+    executed evaluations per launch) equal the ones the file was profiled at to 1 % (the 8-bit PMC passes are made with
+    `--codes` as the main regime, whose chunks differ by 0.5 % from the secondary leg's): otherwise every copied field is
     None and `source` says why."""
     try:
         t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
@@ -564,7 +565,7 @@ def load_profile_facts(V, H, W, pre="", counters=None):
         at = t.get("profiled_at", {})
         for k, v in (counters or {}).items():
             ref = at.get(pre + k)
-            if ref is None or abs(float(v) - float(ref)) > 2e-3 * float(ref):
+            if ref is None or abs(float(v) - float(ref)) > 1e-2 * float(ref):
                 return {"source": "profiles/traffic.json NOT quoted: this run's %s = %s, the file was profiled at %s"
                                   % (k, int(v), ref)}
         return {"source": PROFILE_SOURCE,

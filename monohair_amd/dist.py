@@ -108,18 +108,19 @@ def all_gather_views(local, n_views, shape, dtype, device):
 
 
 def refine_sharded():
-    """Does `refine` shard its per-point stages over the ranks?  Default: yes under the nccl backend (one small in-place
-    all_gather per 5000-point chunk of the smoothing loop is cheap on RCCL), no under gloo (every exchange would be a device
-    -> host -> device round trip); MH_REFINE_SHARD=1 / 0 forces it either way (the tests force it under gloo)."""
+    """Does `refine` shard its per-point stages over the ranks?  Default since round 6: NO -- every rank runs the
+    device-resident pass on all points (pmvo.py::_refine_device: ~10 ms at the headline size, no communication at all) and
+    rank 0 writes the files.  The sharded smoothing loop pays two small all_gathers per 5000-point chunk -- 116 collectives of
+    >= 20 us each at 58 chunks, i.e. at least what the WHOLE single-rank loop takes (3.6 ms) -- and hands its shell stage and
+    voxel fit to the host-driven path.  MH_REFINE_SHARD=1 selects it (kept, and pinned to the reference's four-chunk run with 2
+    and 3 ranks: tests/test_multichunk_gpu.py; tools/scale_first_run.sh measures both on the first multi-GPU node)."""
     import os
 
     d = _dist()
     if not d or world() == 1:
         return False
     env = os.environ.get("MH_REFINE_SHARD")
-    if env is not None:
-        return env == "1"
-    return d.get_backend() == "nccl"
+    return env == "1"
 
 
 def all_gather_rows_inplace(buf, lo, s):

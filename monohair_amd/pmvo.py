@@ -1163,14 +1163,20 @@ def _refine_device(points, ori, loss, pmvo, filter_unvisible_points, args, thres
         ev_res.record(cp)
     new_ori, new_loss = ho.numpy(), hl.numpy()
     save_error = []
-    os.makedirs(args.output_path + "/refine", exist_ok=True)
+    from . import dist as mdist
+
+    is_root = mdist.rank() == 0          # (several ranks, refine not sharded: all compute, rank 0 writes)
+    if is_root:
+        os.makedirs(args.output_path + "/refine", exist_ok=True)
 
     def _save():
         try:
-            np.save(args.output_path + "/refine/select_p.npy", points)
+            if is_root:
+                np.save(args.output_path + "/refine/select_p.npy", points)
             ev_res.synchronize()
-            np.save(args.output_path + "/refine/select_o.npy", new_ori)
-            np.save(args.output_path + "/refine/min_loss.npy", new_loss)
+            if is_root:
+                np.save(args.output_path + "/refine/select_o.npy", new_ori)
+                np.save(args.output_path + "/refine/min_loss.npy", new_loss)
         except BaseException as e:      # re-raised on the calling thread after the join
             save_error.append(e)
 
@@ -1275,9 +1281,11 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
     pmvo.last_refine = {"device_pass": False, "prefetch_adopted": False, "shell_stage": "host"}
     if not genrate_ori_only:
         print("filter nosiy points...")
-        # One rank, device k-NN: the whole of :602-726 runs device-resident (_refine_device).  MH_REFINE_DEVICE=0, several
-        # ranks, args.knn = "host" or MH_REFINE_CHAIN=0 take the host-driven form below (tests pin both to the reference).
-        if (mdist.world() == 1 and len(points) and getattr(args, "knn", "device") == "device"
+        # Device k-NN: the whole of :602-726 runs device-resident (_refine_device) -- on one rank, and on EVERY rank of a
+        # multi-rank run that does not shard refine (the default: no communication, rank 0 writes the files).
+        # MH_REFINE_DEVICE=0, MH_REFINE_SHARD=1, args.knn = "host" or MH_REFINE_CHAIN=0 take the host-driven forms below
+        # (tests pin all of them to the reference).
+        if ((mdist.world() == 1 or not mdist.refine_sharded()) and len(points) and getattr(args, "knn", "device") == "device"
                 and os.environ.get("MH_REFINE_DEVICE", "1") != "0" and os.environ.get("MH_REFINE_CHAIN", "1") != "0"):
             dev_out = _refine_device(points, ori, loss, pmvo, filter_unvisible_points, args, threshold, voxel_min,
                                      voxel_size, grid_resolution)

@@ -15,7 +15,7 @@ CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu --no-secondary --streams 
 rm -rf $OUT/${TAG}_trace
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -- $CMD > $OUT/${TAG}_trace.log 2>&1
 echo "trace rc=$?"
-tail -1 $OUT/${TAG}_trace.log | grep '^{' > $OUT/${TAG}_bench.json
+grep "^{\"metric\"" $OUT/${TAG}_trace.log | tail -1 > $OUT/${TAG}_bench.json
 i=0
 for SET in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE" \
            "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" \

@@ -84,7 +84,7 @@ print("   codes on every rank and all files equal the 1-rank stage byte for byte
 PY
 
 echo "== 4. refine over four chunks, sharded over $NR ranks with RCCL's in-place all_gather, vs the REFERENCE's files"
-$TR --nproc-per-node $NR --master-port 29821 tests/golden_drivers.py --out "$OUT/golden" --what refine,refine_exact > "$OUT/4_refine.log" 2>&1
+MH_REFINE_SHARD=1 $TR --nproc-per-node $NR --master-port 29821 tests/golden_drivers.py --out "$OUT/golden" --what refine,refine_exact > "$OUT/4_refine.log" 2>&1
 python - <<PY
 import sys; sys.path.insert(0, "tests")
 import test_multichunk_gpu as T

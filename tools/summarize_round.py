@@ -80,6 +80,14 @@ for tag, pre, kernels in ((RND + "_main", "", (("mh_project_gather_kernel<7>", "
             "note": "the tap body's own rate, all SIMDs busy, is 1.02 ns per instruction (tools/ubench/valu3.hip); the ratio "
                     "is the kernel's VALU issue utilisation", "valu_issue_utilisation": round(1.02 / per, 3)}
 path, dur, pmc = parse(RND + "_gabor")
+if path is None:
+    # no Gabor profile this round (the kernels did not change): the facts of the last round that made one are carried over, tagged
+    try:
+        prev = json.load(open(os.path.join(DST, "traffic.json")))
+        if "gabor_stage" in prev:
+            facts["gabor_stage"] = dict(prev["gabor_stage"], profiled_in_round=prev["gabor_stage"].get("profiled_in_round", prev.get("round")))
+    except Exception:
+        pass
 if path is not None:
     shutil.copy(path, os.path.join(DST, RND + "_gabor_summary.txt"))
     tot = 0.0
