@@ -813,7 +813,7 @@ def secondary_full_pass(dev, pm, cand, dist):
     T["optimize_ms_per_iteration"] = round(T["optimize_s"] * 1e3 / max(1, len(s_pts) // CHUNK + 1), 4)
     T.update(candidates=int(len(cand)), surface_points=int(s_idx.sum()), shell_points=int(f_idx.sum()),
              iterations=int(len(s_pts) // CHUNK + 1), unit="s", ranks=1 if dist is None else dist.get_world_size())
-    if dist is None:
+    if dist is None and not os.environ.get("MH_FULLPASS_PLAIN"):     # (tools/profile_fullpass.sh traces the plain passes only)
         # where the pass's time goes: one more pass with the drivers' stage timers on (device-synchronised at every stage
         # boundary, so it is slower than the passes above and not one of them)
         try:

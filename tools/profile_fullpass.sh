@@ -11,10 +11,10 @@ OUT=$R/gpurun_out
 TAG=${1:-r06_fullpass}
 mkdir -p $OUT
 cd /tmp
-MH_TIMING=1 timeout 600 python $R/tools/time_full_pass.py 4 > $OUT/${TAG}_stages.txt 2>&1
+MH_FULLPASS_PLAIN=1 MH_TIMING=1 timeout 600 python $R/tools/time_full_pass.py 4 > $OUT/${TAG}_stages.txt 2>&1
 echo "stages rc=$?"
 rm -rf $OUT/${TAG}_trace
-MH_TIMING=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -- \
+MH_FULLPASS_PLAIN=1 MH_TIMING=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -o t -- \
     python $R/tools/time_full_pass.py 3 > $OUT/${TAG}_trace.log 2>&1
 echo "trace rc=$?"
 python $R/tools/summarize_fullpass.py $OUT/${TAG}_trace $OUT/${TAG}_stages.txt > $OUT/${TAG}_summary.txt 2>&1
@@ -22,13 +22,13 @@ python $R/tools/summarize_fullpass.py $OUT/${TAG}_trace $OUT/${TAG}_stages.txt >
 RX="mh_refine_loss_maps|mh_filter_kernel|mh_knn_kernel|mh_medoid_kernel"
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/${TAG}_pmc_$C
-  MH_TIMING=0 timeout 600 rocprofv3 --pmc $C --kernel-include-regex "$RX" --output-format csv -d $OUT/${TAG}_pmc_$C -o pmc -- \
+  MH_FULLPASS_PLAIN=1 MH_TIMING=0 timeout 600 rocprofv3 --pmc $C --kernel-include-regex "$RX" --output-format csv -d $OUT/${TAG}_pmc_$C -o pmc -- \
       python $R/tools/time_full_pass.py 1 > $OUT/${TAG}_pmc_$C.log 2>&1
   echo "pmc $C rc=$?"
 done
 python - <<PY >> $OUT/${TAG}_summary.txt
 import csv, glob, collections
-print("## PMC of the pass's kernels (one pass, --pmc only; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; totals over the pass)")
+print("## PMC of the pass's kernels (--pmc only; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; SUMS over the 4 passes of one call of the driver: divide by 4 for a pass)")
 for f in sorted(glob.glob("$OUT/${TAG}_pmc_*/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
