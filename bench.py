@@ -768,7 +768,7 @@ def secondary_full_pass(dev, pm, cand, dist):
             t = torch.tensor([dt], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        T[name] = round(dt, 3)
+        T[name] = round(dt, 4)
         return r
 
     def one_pass(k):
@@ -784,7 +784,7 @@ def secondary_full_pass(dev, pm, cand, dist):
             sp, so, ml, _ = timed("optimize_s", lambda: optimize(s_pts, pm, args))
             timed("refine_and_volume_s", lambda: refine(sp, so, ml, pm, cand[:len(f_idx)][f_idx].astype(np.float32), args,
                                                        infer_inner=False, threshold=0.025, return_dense=False))
-        T["total_s"] = round(sum(T.values()), 3)
+        T["total_s"] = round(sum(T.values()), 4)
         if dist is None or dist.get_rank() == 0:
             shutil.rmtree(args.output_path, ignore_errors=True)
         return dict(T), s_idx, s_pts, f_idx

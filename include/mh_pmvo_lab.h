@@ -23,7 +23,9 @@ extern "C" {
  *   "tap_plane": 1 (default) = use the plane of ready-made taps when the context has one (mh_pmvo.h: "tap_plane_max_mb");
  *       0 = normalise per iteration (A/B and cross-check).
  *   "taps_tile": points per wave of the fp32 front end (mh_project_taps2_kernel): 64 (default; any other value) gives the
- *       fastest iteration, 32 / 16 the kernel's own best time. */
+ *       fastest iteration, 32 / 16 the kernel's own best time.
+ *   "filter_rows": 1 (default) = mh_filter_points launches of >= 4096 points vote with lane = point (mh_filter_rows_kernel;
+ *       the rows whose sums take another order stay with the wave-per-point kernel), 0 = wave per point for every row. */
 int mh_ctx_set_lab_option(mh_ctx *ctx, const char *key, int value);
 
 /* Debug counter of the search's key body (csrc/pmvo_search.hip: mh_tap_key): out[2] = how many (wave, view) visits were

@@ -39,6 +39,7 @@ _SIGS = {
     "mh_forward": (ci, [vp, vp, ci, ci, cf, ci, ci, vp, vp, vp, vp, vp, csz, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mh_refine_loss": (ci, [vp, vp, vp, cf, cf, ci, ci, cf, vp, vp, vp, vp, vp, vp]),
     "mh_filter_points": (ci, [vp, vp, ci, ci, cf, cf, vp, vp, vp, vp, ci, cll, cll, vp]),
+    "mh_filter_points_ordered": (ci, [vp, vp, ci, ci, cf, cf, vp, vp, vp, vp, ci, cll, cll, vp, vp]),
     "mh_project_points": (ci, [vp, ci, vp, ci, vp, vp, vp, vp, vp]),
     "mh_gather_pixels": (ci, [vp, ci, vp, ci, ci, vp, vp, vp]),
     "mh_compute_visible": (ci, [vp, vp, vp, csz, vp, vp]),

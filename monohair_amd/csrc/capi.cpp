@@ -96,6 +96,7 @@ struct mh_ctx {
     int reproject_fma_min_cols = 28445;   // columns (S x group) from which MKL's threaded sgemm (fma chain) takes over
     int sum_block = 32;       // ATen's outer sum adds the trailing (columns mod 32) of a batch in row_sum order; 0: never
     int topk_order = 0;       // 0: torch.topk's CPU tie order (mh_topk_wave.h); 1: value desc, view asc (round 1's rule)
+    int filter_rows = 1;      // lab "filter_rows": 1 = votes of large launches with lane = point (mh_filter_rows_kernel), 0 = wave per point
     int taps_tile = 1;        // points per wave of mh_project_taps2_kernel: 16 / 32 (A/B), anything else = 64 (default)
     int line_rule = 0;        // strand renderer: 0 GL's diamond-exit, 1 every touched diamond (SwiftShader)
     int raster_subpixel_bits = 8;   // both rasterisers: window positions snapped to 2^-bits pixel (SwiftShader: 4)
@@ -171,7 +172,7 @@ int mh_launch_search(MhViews, const float *, int, int, int, const float *, int, 
 int mh_launch_refine_loss(MhViews, const float *, const float *, float, float, int, int, float, const float *,
                           const float *, const float *, float *, uint8_t *, int, hipStream_t);
 int mh_launch_filter_points(MhViews, const float *, int, int, float, float, uint8_t *, uint8_t *, uint8_t *,
-                            uint8_t *, int, long long, long long, int, hipStream_t);
+                            uint8_t *, int, long long, long long, int, int, const int32_t *, hipStream_t);
 int mh_launch_medoid_dense(const float *, const int32_t *, int, int, float *, int32_t *, hipStream_t);
 int mh_launch_refine_loss_maps(MhViews, const float *, const float *, float, float, int, int, float, float *, uint8_t *,
                                int, long long, long long, int, hipStream_t);
@@ -517,7 +518,7 @@ extern "C" int mh_ctx_set_option(mh_ctx *ctx, const char *key, int value) {
         ctx->raster_subpixel_bits = value;
         return MH_OK;
     }
-    for (const char *lab : {"search_variant", "search_body", "tap_plane", "tap_codes", "taps_tile"})
+    for (const char *lab : {"search_variant", "search_body", "tap_plane", "tap_codes", "taps_tile", "filter_rows"})
         if (!strcmp(key, lab))
             return fail(MH_ERR_ARG, "mh_ctx_set_option: %s is a lab switch, not a supported option: mh_ctx_set_lab_option "
                                     "(include/mh_pmvo_lab.h)", key);
@@ -546,6 +547,10 @@ extern "C" int mh_ctx_set_lab_option(mh_ctx *ctx, const char *key, int value) {
     }
     if (!strcmp(key, "taps_tile")) {
         ctx->taps_tile = value;
+        return MH_OK;
+    }
+    if (!strcmp(key, "filter_rows")) {
+        ctx->filter_rows = value ? 1 : 0;
         return MH_OK;
     }
     return fail(MH_ERR_ARG, "mh_ctx_set_lab_option: unknown key %s", key);
@@ -744,19 +749,35 @@ extern "C" int mh_refine_loss(mh_ctx *ctx, const float *points, const float *dir
                     "mh_refine_loss");
 }
 
+static int filter_points_impl(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold,
+                              float visible_threshold, uint8_t *surface_index, uint8_t *filter_index,
+                              uint8_t *unvisible_index, uint8_t *head_filter, int batch, long long row0, long long total,
+                              const int32_t *order, void *stream, const char *what) {
+    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "%s: views not set", what);
+    if (N == 0) return MH_OK;
+    if (!points || N < 0 || patch < 1 || !(patch & 1) || batch < 0 || row0 < 0 || (batch > 0 && total < row0 + N))
+        return fail(MH_ERR_ARG, "%s: bad arguments", what);
+    if (batch == 0) row0 = 0, total = N;
+    return launched(mh_launch_filter_points(ctx->views(), points, N, patch, conf_threshold, visible_threshold,
+                                            surface_index, filter_index, unvisible_index, head_filter, batch, row0, total,
+                                            ctx->sum_block, ctx->filter_rows, order, (hipStream_t)stream),
+                    what);
+}
+
 extern "C" int mh_filter_points(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold,
                                 float visible_threshold, uint8_t *surface_index, uint8_t *filter_index,
                                 uint8_t *unvisible_index, uint8_t *head_filter, int batch, long long row0,
                                 long long total, void *stream) {
-    if (!ctx || !ctx->rec) return fail(MH_ERR_STATE, "mh_filter_points: views not set");
-    if (N == 0) return MH_OK;
-    if (!points || N < 0 || patch < 1 || !(patch & 1) || batch < 0 || row0 < 0 || (batch > 0 && total < row0 + N))
-        return fail(MH_ERR_ARG, "mh_filter_points: bad arguments");
-    if (batch == 0) row0 = 0, total = N;
-    return launched(mh_launch_filter_points(ctx->views(), points, N, patch, conf_threshold, visible_threshold,
-                                            surface_index, filter_index, unvisible_index, head_filter, batch, row0, total,
-                                            ctx->sum_block, (hipStream_t)stream),
-                    "mh_filter_points");
+    return filter_points_impl(ctx, points, N, patch, conf_threshold, visible_threshold, surface_index, filter_index,
+                              unvisible_index, head_filter, batch, row0, total, nullptr, stream, "mh_filter_points");
+}
+
+extern "C" int mh_filter_points_ordered(mh_ctx *ctx, const float *points, int N, int patch, float conf_threshold,
+                                        float visible_threshold, uint8_t *surface_index, uint8_t *filter_index,
+                                        uint8_t *unvisible_index, uint8_t *head_filter, int batch, long long row0,
+                                        long long total, const int32_t *order, void *stream) {
+    return filter_points_impl(ctx, points, N, patch, conf_threshold, visible_threshold, surface_index, filter_index,
+                              unvisible_index, head_filter, batch, row0, total, order, stream, "mh_filter_points_ordered");
 }
 
 extern "C" int mh_medoid_dense(mh_ctx *ctx, const float *ori, int G, int K, float *out, int32_t *out_index,

@@ -182,7 +182,7 @@ class PMVO:
         except Exception:
             pass
 
-    LAB_OPTIONS = ("search_variant", "search_body", "tap_plane", "tap_codes", "taps_tile")
+    LAB_OPTIONS = ("search_variant", "search_body", "tap_plane", "tap_codes", "taps_tile", "filter_rows")
 
     def set_option(self, key, value):
         """A supported option of the context (include/mh_pmvo.h: reproject_rule, reproject_fma_min_cols, sum_block, topk_order,
@@ -471,17 +471,14 @@ class PMVO:
 
     _TORCH_OF = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64, np.dtype(np.uint8): torch.uint8}
 
-    def stage_upload(self, key, arr, dtype=np.float32):
-        """Host array -> fresh device tensor of `dtype` through a pinned staging buffer kept per `key`: one conversion /
-        copy on the host (numpy's rounding for float64 -> float32 = the reference's `.type(torch.float)`, PMVO.py:40), one
-        asynchronous copy on the current stream.  `tensor.to(device)` from pageable memory blocks the host for the whole
-        transfer; the drivers upload a pass's arrays while the GPU works."""
+    def stage_fill(self, key, arr, dtype=np.float32):
+        """First half of stage_upload, safe to run on a worker thread (one key per thread): convert / copy `arr` into the
+        pinned staging buffer of `key` (waiting for the previous copy out of it).  -> handle for stage_issue."""
         a = np.asarray(arr)
         dt = np.dtype(dtype)
-        dev = torch.empty(a.shape, dtype=self._TORCH_OF[dt], device=self.device)
         nbytes = a.size * dt.itemsize
         if nbytes == 0:
-            return dev
+            return (None, a.shape, dt, 0)
         pool = self.__dict__.setdefault("_stage_named", {})
         ent = pool.get(key)
         if ent is not None:
@@ -490,11 +487,26 @@ class PMVO:
             ent = pool[key] = [torch.empty(nbytes, dtype=torch.uint8, pin_memory=True), torch.cuda.Event()]
         host = ent[0].numpy()[:nbytes].view(dt).reshape(a.shape)
         np.copyto(host, a, casting="same_kind")
+        return (ent, a.shape, dt, nbytes)
+
+    def stage_issue(self, handle):
+        """Second half: the asynchronous copy of a filled staging buffer on the current stream -> fresh device tensor."""
+        ent, shape, dt, nbytes = handle
+        dev = torch.empty(shape, dtype=self._TORCH_OF[dt], device=self.device)
+        if nbytes == 0:
+            return dev
         cs = torch.cuda.current_stream(self.device)
         _lib.check(self._L.mh_upload_pinned(self._ctx, ent[0].data_ptr(), dev.data_ptr(), nbytes, cs.cuda_stream),
                    "mh_upload_pinned")
         ent[1].record(cs)
         return dev
+
+    def stage_upload(self, key, arr, dtype=np.float32):
+        """Host array -> fresh device tensor of `dtype` through a pinned staging buffer kept per `key`: one conversion /
+        copy on the host (numpy's rounding for float64 -> float32 = the reference's `.type(torch.float)`, PMVO.py:40), one
+        asynchronous copy on the current stream.  `tensor.to(device)` from pageable memory blocks the host for the whole
+        transfer; the drivers upload a pass's arrays while the GPU works."""
+        return self.stage_issue(self.stage_fill(key, arr, dtype))
 
     def start_refine_prefetch(self, pts_dev, sub_num=5000, k=100):
         """What refine() needs of the POINTS alone (PMVO.py:605-612 the 100 nearest neighbours of every point; :96-137 the
@@ -756,10 +768,12 @@ class RefinePrefetch:
                     self.grid = GridKNN(self.pts_dev, k_hint=self.k, device=pm.device)
                     self.index_all = self.grid.query(self.pts_dev, self.k, int32=True, self_query=True).contiguous()
                     self.head_all = torch.empty((self.n,), dtype=torch.uint8, device=pm.device)
-                    _lib.check(pm._L.mh_filter_points(pm._ctx, _lib.ptr(self.pts_dev), self.n, pm._side,
-                                                      self.conf_threshold, self.visible_threshold, None, None, None,
-                                                      _lib.ptr(self.head_all), self.sub_num, 0, self.n,
-                                                      _lib.stream_ptr()), "mh_filter_points")
+                    # (rows in the cell order of the grid the neighbour search just built: 64 spatial neighbours per wave)
+                    _lib.check(pm._L.mh_filter_points_ordered(pm._ctx, _lib.ptr(self.pts_dev), self.n, pm._side,
+                                                              self.conf_threshold, self.visible_threshold, None, None, None,
+                                                              _lib.ptr(self.head_all), self.sub_num, 0, self.n,
+                                                              _lib.ptr(self.grid.cell_order()), _lib.stream_ptr()),
+                               "mh_filter_points_ordered")
                     if self.scalp_tree is not None:
                         self.head_top_all = pm.head_top_mask_device(self.pts_dev)
                 self.done.record(self.stream)
@@ -799,6 +813,8 @@ def _filter_single(points, pmvo, step, num_sub_p):
     points sit in the reference's N//30-sized pieces (PMVO.py:540-552; include/mh_pmvo.h: batch / row0 / total) -- and the
     surface points are compacted on the device (`covered[surface].astype(float32)` = the selected rows of the float32
     copy the votes were computed on).  -> (flags [total,2] uint8 numpy, surface_points float32 [S,3] numpy, pinned)."""
+    from .pmvo_utils import spatial_order
+
     dev = pmvo.device
     L, ctx = pmvo._L, pmvo._ctx
     total = min(int(points.shape[0]), step * num_sub_p)
@@ -812,10 +828,14 @@ def _filter_single(points, pmvo, step, num_sub_p):
     st = _lib.stream_ptr()
     off = lambda t, row, width=1: ctypes.c_void_p(t.data_ptr() + row * width * t.element_size())   # noqa: E731
     for k, (lo, hi) in enumerate(bounds):
+        # (the conversions of the four blocks on four worker threads side by side: 3.9-4.1 ms for the stage instead of 3.2 --
+        # thread wake-ups and the GIL cost more than the 0.25 ms conversions they overlap; measured, dropped)
         blk = pmvo.stage_upload("filter%d" % k, points[lo:hi])
-        _lib.check(L.mh_filter_points(ctx, _lib.ptr(blk), hi - lo, pmvo._side, float(pmvo.conf_threshold),
-                                      float(pmvo.visible_threshold), off(surf, lo), off(filt, lo), None, None,
-                                      num_sub_p, lo, total, st), "mh_filter_points")
+        # (the rows of a block are taken cell by cell -- 64 spatial neighbours per wave -- not in the candidates' raster order)
+        order = spatial_order(blk)
+        _lib.check(L.mh_filter_points_ordered(ctx, _lib.ptr(blk), hi - lo, pmvo._side, float(pmvo.conf_threshold),
+                                              float(pmvo.visible_threshold), off(surf, lo), off(filt, lo), None, None,
+                                              num_sub_p, lo, total, _lib.ptr(order), st), "mh_filter_points_ordered")
         _lib.check(L.mh_select_rows(ctx, off(surf, lo), None, 0, hi - lo, _lib.ptr(blk), None, _lib.ptr(out), None, None,
                                     off(cnt, k), off(cnt, k + 1), _lib.ptr(scratch), scratch.numel(), st), "mh_select_rows")
     flags = torch.empty((2, total), dtype=torch.uint8, pin_memory=True)
@@ -1108,9 +1128,10 @@ def _refine_device(points, ori, loss, pmvo, filter_unvisible_points, args, thres
         head_all = torch.empty((n_all,), dtype=torch.uint8, device=device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            _lib.check(L.mh_filter_points(ctx, _lib.ptr(pts_dev), n_all, pmvo._side, float(pmvo.conf_threshold),
-                                          float(pmvo.visible_threshold), None, None, None, _lib.ptr(head_all), sub_num, 0,
-                                          n_all, _lib.stream_ptr()), "mh_filter_points")
+            _lib.check(L.mh_filter_points_ordered(ctx, _lib.ptr(pts_dev), n_all, pmvo._side, float(pmvo.conf_threshold),
+                                                  float(pmvo.visible_threshold), None, None, None, _lib.ptr(head_all),
+                                                  sub_num, 0, n_all, _lib.ptr(grid.cell_order()), _lib.stream_ptr()),
+                       "mh_filter_points_ordered")
     T_loop = stage("refine: smoothing loop", device).__enter__()
     K = int(index_all.shape[1])
     st = _lib.stream_ptr()

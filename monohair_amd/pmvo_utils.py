@@ -347,6 +347,10 @@ class GridKNN:
                        "mh_knn_grid")
         return out, status
 
+    def cell_order(self):
+        """int32 [M] on the device: the data points' indices sorted by cell of the search grid (spatial neighbours adjacent)."""
+        return self._grid(self.h)[3]
+
     def record_stream(self, stream):
         """The grid was built on another stream than the one that will query it from now on (refine adopts the grid
         optimize's prefetch built): tell the caching allocator."""
@@ -420,6 +424,30 @@ class GridKNN:
                     d2 = torch.where(valid.bool(), d2, torch.full_like(d2, float("inf")))
                 out[i] = torch.sort(d2, stable=True).indices[:k].to(torch.int32)
         return out if int32 else out.long()
+
+
+def spatial_order(points_dev, cell=0.005, half_extent=2.56):
+    """Rows of float32 [M,3] device points sorted by the cell of a FIXED uniform grid (cells of `cell` metres over
+    +-`half_extent`: 1024^3 cells at the defaults; points outside are clamped into the border cells) -> int32 [M] permutation on
+    the device (mh_grid_build: cell keys + one radix sort; nothing is read back).  Only the ORDER in which a kernel takes the
+    rows depends on it (mh_filter_points_ordered): 64 consecutive entries are spatial neighbours."""
+    import ctypes
+
+    dev = points_dev.device
+    M = int(points_dev.shape[0])
+    order = torch.empty(M, dtype=torch.int32, device=dev)
+    if M == 0:
+        return order
+    L = _lib.lib()
+    n = int(round(2 * half_extent / cell))
+    grid = np.array([-half_extent, -half_extent, -half_extent, cell], dtype=np.float32)
+    dims = np.array([n, n, n], dtype=np.int32)
+    scratch = torch.empty(int(L.mh_grid_scratch_bytes(M)), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(L.mh_grid_build(_ctx_for(dev), grid.ctypes.data_as(ctypes.c_void_p), dims.ctypes.data_as(ctypes.c_void_p),
+                                   _lib.ptr(points_dev), M, _lib.ptr(scratch), scratch.numel(), None, _lib.ptr(order), None,
+                                   None, _lib.stream_ptr()), "mh_grid_build")
+    return order
 
 
 def p2v(points, voxel_min, voxel_size, grid_resolution):

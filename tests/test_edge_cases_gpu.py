@@ -385,3 +385,66 @@ def test_filter_negative_points_chunking_quirks(N, tmp_path):
         assert np.array_equal(surf, o_s) and np.array_equal(filt, o_f)
         assert np.array_equal(spts, pts[:covered][o_s].astype(np.float32))
         assert 0 < o_s.sum() < covered or covered < 40
+
+
+@pytest.mark.parametrize("patch,quantize", [(5, False), (3, True), (9, False)])
+def test_votes_lane_per_point_kernel_equals_wave_per_point_and_oracle(patch, quantize):
+    """Round 6: mh_filter_points launches of >= 4096 points vote with lane = point (mh_filter_rows_kernel); the trailing
+    (len mod 32) rows of every batch and one-point batches stay with the wave-per-point kernel.  Same bits as the wave-per-point
+    kernel for every row (lab switch filter_rows 0) in one batch, in batches that do not divide the launch, in a slice of a
+    longer run, with a one-point last batch -- and equal to the oracle batch by batch."""
+    import ctypes
+
+    from monohair_amd import _lib, synth
+
+    scene, pm, views = build(24, 96, 80, patch, quantize=quantize)
+    cand = synth.candidate_points(res=48, seed=3)
+    rng = np.random.default_rng(patch)
+    pts = (cand[rng.choice(len(cand), 12001, replace=len(cand) < 12001)] * rng.uniform(0.95, 1.05, (12001, 1))).astype(np.float32)
+    d = torch.from_numpy(pts).to(DEV)
+    L = _lib.lib()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def votes(lo, n, batch, row0, total, rows):
+        pm.set_option("filter_rows", rows)
+        outs = [torch.full((n,), 7, dtype=torch.uint8, device=DEV) for _ in range(4)]
+        _lib.check(L.mh_filter_points(pm._ctx, ctypes.c_void_p(d.data_ptr() + lo * 12), n, pm._side, 0.15, 1.0,
+                                      *[_lib.ptr(o) for o in outs], batch, row0, total, st), "mh_filter_points")
+        return [o.cpu().numpy() for o in outs]
+
+    cases = [(0, 12001, 0, 0, 0),            # one batch of 12001 = 375 * 32 + 1
+             (0, 12001, 1777, 0, 12001),     # batches that do not divide the launch, last one of 1339 rows
+             (3000, 6000, 1000, 3000, 12001),  # a slice of a longer run (one-point LAST batch outside the slice)
+             (5000, 7001, 1000, 5000, 12001),  # ... and the slice that holds that one-point batch
+             (0, 4096, 4096, 0, 4096)]        # tails of length 0: only the lane-per-point kernel runs
+    for lo, n, batch, row0, total in cases:
+        a, b = votes(lo, n, batch, row0, total, 1), votes(lo, n, batch, row0, total, 0)
+        for k in range(4):
+            assert np.array_equal(a[k], b[k]) and a[k].max() <= 1, (lo, n, batch, k, int((a[k] != b[k]).sum()))
+        # the oracle, batch by batch
+        bsz = batch if batch else n
+        tot = total if batch else n
+        want = [np.zeros(n, bool) for _ in range(4)]
+        for s0 in range(row0 // bsz * bsz, row0 + n, bsz):
+            e0 = min(s0 + bsz, tot)
+            got = oracle.filter_votes(views, pts[lo + (s0 - row0):lo + (e0 - row0)] if s0 >= row0 else
+                                      pts[lo - (row0 - s0):lo + (e0 - row0)], patch, 0.15, 1.0)
+            a0, a1 = max(s0, row0) - row0, min(e0, row0 + n) - row0
+            off = max(s0, row0) - s0
+            for k in range(4):
+                want[k][a0:a1] = got[k][off:off + (a1 - a0)]
+        for k in range(4):
+            assert np.array_equal(a[k].astype(bool), want[k]), (lo, n, batch, k)
+    pm.set_option("filter_rows", 1)
+    # rows taken in another order (mh_filter_points_ordered: a random permutation, and the cell order the drivers use): the same
+    # votes row for row
+    from monohair_amd.pmvo_utils import spatial_order
+
+    lo, n, batch, row0, total = cases[1]
+    ref = votes(lo, n, batch, row0, total, 1)
+    for order in (torch.from_numpy(rng.permutation(n).astype(np.int32)).to(DEV), spatial_order(d[lo:lo + n].contiguous())):
+        assert sorted(order.cpu().numpy().tolist()) == list(range(n))
+        outs = [torch.full((n,), 7, dtype=torch.uint8, device=DEV) for _ in range(4)]
+        _lib.check(L.mh_filter_points_ordered(pm._ctx, ctypes.c_void_p(d.data_ptr() + lo * 12), n, pm._side, 0.15, 1.0,
+                                              *[_lib.ptr(o) for o in outs], batch, row0, total, _lib.ptr(order), st))
+        assert all(np.array_equal(o.cpu().numpy(), r) for o, r in zip(outs, ref))
