@@ -847,7 +847,8 @@ def secondary_full_pass(dev, pm, cand, dist):
 def full_pass_kernel_rows(dev, pm, cand, s_pts, shell_pts):
     """Roofline rows of the kernels of the exterior pass OUTSIDE the iterations: each launched
     alone on this scene's own arrays, HIP events on its stream, best of three.  Work models (stated per row):
-      mh_filter_kernel        one centre record (16 B) + one mask sample (4 B) per (candidate, view)
+      votes (mh_filter_rows_kernel + mh_filter_kernel for the rows with another summation order)
+                              one centre record (16 B) + one mask sample (4 B) per (candidate, view)
       mh_knn_kernel           queries/s (latency of LDS sorts: no byte or FLOP model)
       mh_medoid_kernel        K^2 (|cos| + accumulate) pairs per point, 7 FLOP per pair (3 mul, 2 add, abs, add)
       mh_refine_loss_maps     one centre record per (point, view) + P taps of 16 B per visible (point, view)
@@ -887,11 +888,21 @@ def full_pass_kernel_rows(dev, pm, cand, s_pts, shell_pts):
                                                     float(pm.visible_threshold), _lib.ptr(surf), _lib.ptr(filt), None, None,
                                                     M // 30, 0, M, st)))
     b = M * V * 20 + M * 12
-    rows.append({"kernel": "mh_filter_kernel<%d>" % pm._side, "bound": "hbm", "launch_ms": round(t, 4), "points": M,
-                 "algorithmic_bytes_per_launch": b, "achieved": round(b / t / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                 "frac": round(b / t / 1e6 / HBM_PEAK_GBS, 4),
-                 "point_views_per_s": round(M * V / t / 1e6, 2), "point_views_unit": "G/s",
-                 "note": "isolated 20-byte gathers: every one moves a whole 64-B line or two"})
+    order = U.spatial_order(cd)
+    t_sort = timed(lambda: U.spatial_order(cd))
+    t_ord = timed(lambda: _lib.check(L.mh_filter_points_ordered(ctx, _lib.ptr(cd), M, pm._side, float(pm.conf_threshold),
+                                                                float(pm.visible_threshold), _lib.ptr(surf), _lib.ptr(filt),
+                                                                None, None, M // 30, 0, M, _lib.ptr(order), st)))
+    for name, tt, note in (("mh_filter_rows_kernel<%d>, rows in the candidates' own (raster) order" % pm._side, t,
+                            "every isolated 20-byte gather of a (point, view) pair moves its own line: the raster sweeps each "
+                            "image once per slab of the volume"),
+                           ("mh_filter_rows_kernel<%d>, rows in grid-cell order (mh_filter_points_ordered: what the drivers "
+                            "launch)" % pm._side, t_ord, "a wave = one small cube; the ordering itself (mh_grid_build on a "
+                            "5 mm grid) takes %.3f ms" % t_sort)):
+        rows.append({"kernel": name, "bound": "hbm", "launch_ms": round(tt, 4), "points": M,
+                     "algorithmic_bytes_per_launch": b, "achieved": round(b / tt / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(b / tt / 1e6 / HBM_PEAK_GBS, 4),
+                     "point_views_per_s": round(M * V / tt / 1e6, 2), "point_views_unit": "G/s", "note": note})
     grid = U.GridKNN(pts, k_hint=100, device=dev)
     grid.query_nosync(pts, 100, self_query=True)
     t = timed(lambda: grid.query_nosync(pts, 100, self_query=True))

@@ -1544,7 +1544,7 @@ __global__ __launch_bounds__(256) void mh_refine_loss_maps_kernel(MhViews vw, co
         }
         unsigned long long m = __ballot(visv != -1.0f);
         // taps of one view: {unit ori_row, unit ori_col, clamped conf} per lane and round
-        float o0[ROUNDS], o1[ROUNDS], cf[ROUNDS];
+        float o0[ROUNDS], o1[ROUNDS], cf[ROUNDS], no0[ROUNDS], no1[ROUNDS], ncf[ROUNDS];
         auto gather = [&](int src, float *a0, float *a1, float *ac) {
             const int rv = __builtin_amdgcn_readlane(r, src), cv = __builtin_amdgcn_readlane(c, src);
             const size_t base = (size_t)(v0 + src) * H * W;
@@ -1563,27 +1563,20 @@ __global__ __launch_bounds__(256) void mh_refine_loss_maps_kernel(MhViews vw, co
                 }
             }
         };
-        // NQ views in flight: the taps of the next NQ views that see the point are requested back to back, then reduced in turn
-        // (one view ahead -- the first form of this kernel -- left a wave with one request outstanding: 2.39 ms per 288 k points)
-        constexpr int NQ = ROUNDS == 1 ? 4 : 2;
+        int src = m ? __builtin_amdgcn_readfirstlane(__builtin_ctzll(m)) : 0;
+        if (m) gather(src, no0, no1, ncf);
         while (m) {
-            int srcs[NQ];
-            float q0[NQ][ROUNDS], q1[NQ][ROUNDS], qc[NQ][ROUNDS];
-#pragma unroll
-            for (int k = 0; k < NQ; ++k) {
-                srcs[k] = m ? __builtin_amdgcn_readfirstlane(__builtin_ctzll(m)) : -1;
-                m &= m - 1;
-                if (srcs[k] >= 0) gather(srcs[k], q0[k], q1[k], qc[k]);
-            }
-#pragma unroll
-            for (int k = 0; k < NQ; ++k) {
-            if (srcs[k] < 0) continue;
-            const int cur = srcs[k];
+            const int cur = src;
+            m &= m - 1;
 #pragma unroll
             for (int t = 0; t < ROUNDS; ++t) {
-                o0[t] = q0[k][t];
-                o1[t] = q1[k][t];
-                cf[t] = qc[k][t];
+                o0[t] = no0[t];
+                o1[t] = no1[t];
+                cf[t] = ncf[t];
+            }
+            if (m) {
+                src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+                gather(src, no0, no1, ncf);
             }
             const float dxv = rdf(dx, cur), dyv = rdf(dy, cur);
             // (a) cmax as `cmax = (p == 0 || cf > cmax) ? cf : cmax` leaves it: the maximum, NaNs skipped -- unless tap 0 is NaN
@@ -1629,7 +1622,6 @@ __global__ __launch_bounds__(256) void mh_refine_loss_maps_kernel(MhViews vw, co
             if (lane == 0) {
                 s_num[wave][v0 + cur] = ml * bc;
                 s_den[wave][v0 + cur] = bc;
-            }
             }
         }
     }
