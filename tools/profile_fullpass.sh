@@ -19,7 +19,7 @@ MH_FULLPASS_PLAIN=1 MH_TIMING=0 timeout 900 rocprofv3 --kernel-trace --stats --o
 echo "trace rc=$?"
 python $R/tools/summarize_fullpass.py $OUT/${TAG}_trace $OUT/${TAG}_stages.txt > $OUT/${TAG}_summary.txt 2>&1
 # HBM traffic of the pass's own kernels (separate --pmc passes, counters only; one pass of the driver each)
-RX="mh_refine_loss_maps|mh_filter_kernel|mh_knn_kernel|mh_medoid_kernel"
+RX="mh_refine_loss_maps|mh_filter_|mh_knn_kernel|mh_medoid_kernel"
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $OUT/${TAG}_pmc_$C
   MH_FULLPASS_PLAIN=1 MH_TIMING=0 timeout 600 rocprofv3 --pmc $C --kernel-include-regex "$RX" --output-format csv -d $OUT/${TAG}_pmc_$C -o pmc -- \
