@@ -30,7 +30,7 @@ a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 DEV = "cuda:0"
 t_end = time.time() + a.minutes * 60
-count = {"knn": 0, "raster": 0, "strands": 0, "gabor": 0, "medoid": 0, "voxel_fit": 0, "trace": 0}
+count = {"knn": 0, "raster": 0, "strands": 0, "gabor": 0, "medoid": 0, "voxel_fit": 0, "trace": 0, "votes": 0}
 bad = []
 gabs = {v: calOrientationGabor(device=DEV, variant=v) for v in ("mfma2", "valu")}
 bank = gabor_bank()
@@ -164,5 +164,53 @@ while time.time() < t_end:
         if not ok:
             bad.append(("trace", Z, Hh, Ww, thr))
     count["trace"] += 1
+    # ---- the votes of LARGE launches (round 6: mh_filter_rows_kernel, lane = point, rows taken in grid-cell order, the trailing
+    # rows of every batch by the wave-per-point kernel) against the oracle batch by batch: random views / patch / batch length /
+    # slice of a longer run, continuous and 8-bit maps
+    if count["trace"] % 3 == 0:
+        import ctypes
+
+        from monohair_amd.pmvo import PMVO
+        from monohair_amd.pmvo_utils import spatial_order
+
+        Vv, Hv, Wv = int(rng.integers(20, 70)), int(rng.integers(48, 200)), int(rng.integers(40, 160))
+        patch = int(rng.choice([1, 3, 5, 7, 9]))
+        thr = float(rng.choice([0.05, 0.15, 0.4]))
+        scene = synth.make_scene(Vv, Hv, Wv, seed=int(rng.integers(0, 1 << 30)), quantize=bool(rng.integers(0, 2)),
+                                 rings=int(rng.integers(1, 3)), scale=float(rng.uniform(0.9, 2.4)))
+        recs = camera_records(cameras_from_list(scene["cams"]))
+        pmv = PMVO.from_planes(recs, scene["depth"].to(DEV), scene["ori"].to(DEV), scene["conf"].to(DEV), scene["mask"].to(DEV),
+                               device=DEV, patch_size=patch, visible_threshold=1, conf_threshold=thr)
+        views = oracle.Views(recs, scene["depth"].numpy(), scene["ori"].numpy(), scene["conf"].numpy(), scene["mask"].numpy())
+        total = int(rng.integers(4200, 15000))
+        cand = synth.candidate_points(res=48, seed=int(rng.integers(0, 1000)))
+        P = (cand[rng.choice(len(cand), total, replace=total > len(cand))] * rng.uniform(0.9, 1.1, (total, 1))).astype(np.float32)
+        batch = int(rng.choice([0, int(rng.integers(1, total + 10)), int(rng.integers(100, 3000))]))
+        row0 = 0 if batch == 0 else int(rng.integers(0, total - 4096))
+        nrow = total if batch == 0 else int(rng.integers(4096, total - row0 + 1))
+        dP = torch.from_numpy(P).to(DEV)
+        sub = dP[row0:row0 + nrow].contiguous()
+        order = spatial_order(sub) if rng.integers(0, 2) else None
+        outs = [torch.full((nrow,), 9, dtype=torch.uint8, device=DEV) for _ in range(4)]
+        vt = float(rng.choice([1.0, 0.5]))
+        _lib.check(_lib.lib().mh_filter_points_ordered(pmv._ctx, _lib.ptr(sub), nrow, pmv._side, thr, vt,
+                                                       *[_lib.ptr(o) for o in outs], batch, row0, total if batch else 0,
+                                                       _lib.ptr(order), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                   "mh_filter_points_ordered")
+        got = [o.cpu().numpy().astype(bool) for o in outs]
+        bsz, tot = (batch, total) if batch else (nrow, nrow)
+        base = row0 if batch else 0
+        want = [np.zeros(nrow, bool) for _ in range(4)]
+        for s0 in range(base // bsz * bsz, base + nrow, bsz):
+            e0 = min(s0 + bsz, tot)
+            src = P if batch else P[row0:row0 + nrow]
+            w = oracle.filter_votes(views, src[s0:e0], patch, thr, vt)
+            a0, a1 = max(s0, base), min(e0, base + nrow)
+            for kq in range(4):
+                want[kq][a0 - base:a1 - base] = w[kq][a0 - s0:a1 - s0]
+        if not all(np.array_equal(g_, w_) for g_, w_ in zip(got, want)):
+            bad.append(("votes", Vv, Hv, Wv, patch, thr, total, batch, row0, nrow, order is not None))
+        count["votes"] += 1
+        del pmv
 print({"rounds": count, "mismatching_cases": len(bad), "first": bad[:6]})
 sys.exit(1 if bad else 0)
