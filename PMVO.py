@@ -142,15 +142,34 @@ def main(argv=None):
             with stage("filter_negative_points", args.device):
                 surface_index, surface_points, filter_index = filter_negative_points(points, pmvo, args)
             points = surface_points
+            writer = None
             if mdist.rank() == 0:
+                # surface.npy / filter_unvisible.npy (PMVO.py:853-854: float64 rows of the raw candidates, 7 + 1.5 MB at the
+                # headline size) are selected and written by a worker while optimize() iterates; joined before they are read
+                import threading
+
                 os.makedirs(args.save_root, exist_ok=True)
-                np.save(os.path.join(args.save_root, "surface.npy"), raw_points[:len(surface_index)][surface_index])
-                np.save(os.path.join(args.save_root, "filter_unvisible.npy"),
-                        raw_points[:len(filter_index)][filter_index])
-            mdist.barrier()
+                failed = []
+
+                def _save_masks():
+                    try:
+                        np.save(os.path.join(args.save_root, "surface.npy"), raw_points[:len(surface_index)][surface_index])
+                        np.save(os.path.join(args.save_root, "filter_unvisible.npy"),
+                                raw_points[:len(filter_index)][filter_index])
+                    except BaseException as e:
+                        failed.append(e)
+
+                writer = threading.Thread(target=_save_masks)
+                writer.start()
         print("process points:", points.shape[0])
         with stage("optimize", args.device):
             optimize(points, pmvo, args)
+        if args.PMVO.filter_point:
+            if writer is not None:
+                writer.join()
+                if failed:
+                    raise failed[0]
+            mdist.barrier()
         select_points = np.load(args.save_root + "/select_p.npy")
         select_ori = np.load(args.save_root + "/select_o.npy")
         min_loss = np.load(args.save_root + "/min_loss.npy")
