@@ -256,6 +256,9 @@ int mh_nearest_distance(mh_ctx *ctx, const float *points, int N, const double *r
  * position of every cell.  grid_origin_h (host): {ox, oy, oz, cell size}, grid_dims (host): {dx, dy, dz}.  Any of
  * pts_sorted / cell_start [dx*dy*dz + 1] / n_occupied (device int32: number of non-empty cells) may be NULL; order[M]
  * is always written.  (Replaces the torch sort / searchsorted / unique pipeline of the first implementation.) */
+/* Bounding box of M float32 points: out6 (device) = {min x, min y, min z, max x, max y, max z} (M == 0: +inf / -inf).  What
+ * the grid is laid over (scipy's KDTree needs no such thing: PMVO.py:605). */
+int mh_points_bbox(mh_ctx *ctx, const float *points, int M, float *out6, void *stream);
 size_t mh_grid_scratch_bytes(int M);
 int mh_grid_build(mh_ctx *ctx, const float *grid_origin_h, const int32_t *grid_dims, const float *points, int M,
                   void *scratch, size_t scratch_bytes, float *pts_sorted, int32_t *order, int32_t *cell_start,

@@ -59,6 +59,7 @@ _SIGS = {
     "mh_strands_compact": (ci, [vp, vp, vp, vp, vp, ci, ci, vp, vp]),
     "mh_knn_grid": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp]),
     "mh_nearest_distance": (ci, [vp, vp, ci, vp, ci, vp, ctypes.c_double, ctypes.c_double, vp, vp]),
+    "mh_points_bbox": (ci, [vp, vp, ci, vp, vp]),
     "mh_grid_scratch_bytes": (csz, [ci]),
     "mh_grid_build": (ci, [vp, vp, vp, vp, ci, vp, csz, vp, vp, vp, vp, vp]),
     "mh_sort_scratch_bytes": (csz, [ci]),

@@ -142,6 +142,7 @@ int mh_launch_segment_heads(const unsigned long long *, int, int32_t *, unsigned
 int mh_launch_flag_less(const float *, float, int, uint8_t *, hipStream_t);
 int mh_launch_words_differ(const void *, const void *, size_t, int32_t *, hipStream_t);
 int mh_launch_copy_words(const void *, void *, size_t, hipStream_t);
+int mh_launch_points_bbox(const float *, int, float *, hipStream_t);
 int mh_launch_voxel_group(const void *, int, const float *, int, const double *, double, const int32_t *, void *, size_t,
                           unsigned long long *, int32_t *, float *, hipStream_t);
 int mh_launch_render_strands(const float *, const float *, int, const int32_t *, int, const float *, const float *, int,
@@ -944,6 +945,12 @@ extern "C" int mh_flag_less(mh_ctx *ctx, const float *x, float threshold, int n,
     if (!ctx || !x || !out || n < 0) return fail(MH_ERR_ARG, "mh_flag_less: bad arguments");
     MH_HIP(hipSetDevice(ctx->device));
     return launched(mh_launch_flag_less(x, threshold, n, out, (hipStream_t)stream), "mh_flag_less");
+}
+
+extern "C" int mh_points_bbox(mh_ctx *ctx, const float *points, int M, float *out6, void *stream) {
+    if (!ctx || !out6 || M < 0 || (M > 0 && !points)) return fail(MH_ERR_ARG, "mh_points_bbox: bad arguments");
+    MH_HIP(hipSetDevice(ctx->device));
+    return launched(mh_launch_points_bbox(points, M, out6, (hipStream_t)stream), "mh_points_bbox");
 }
 
 extern "C" int mh_buffers_differ(mh_ctx *ctx, const void *a, const void *b, size_t bytes, int32_t *flag, void *stream) {

@@ -274,8 +274,15 @@ class GridKNN:
         self.M = int(self._raw.shape[0])
         # bounding box: numpy's axis-0 reduction of an [M,3] array costs 2-5 ms per call at 3e5 points (inner loop of 3),
         # the device needs two tiny launches
-        lo, hi = torch.aminmax(self._raw, dim=0) if self.M else (torch.zeros(3), torch.zeros(3))
-        self._lo, self._hi = lo.cpu().numpy(), hi.cpu().numpy()
+        if self.M:
+            box = torch.empty(6, dtype=torch.float32, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().mh_points_bbox(_ctx_for(self.device), _lib.ptr(self._raw), self.M, _lib.ptr(box),
+                                                     _lib.stream_ptr()), "mh_points_bbox")
+            box = box.cpu().numpy()
+            self._lo, self._hi = box[:3].copy(), box[3:].copy()
+        else:
+            self._lo, self._hi = np.zeros(3, np.float32), np.zeros(3, np.float32)
         ext = float((self._hi - self._lo).max()) + 1e-6
         self._ext = ext
         self._grids = {}

@@ -118,3 +118,21 @@ def test_voxel_fit_device_equals_voxel_fit():
     vox, vori = U.voxel_fit_device(torch.from_numpy(pts).to(dev), torch.from_numpy(ori).to(dev), n, dev)
     assert np.array_equal(vox, ref["voxels"].cpu().numpy())
     assert np.array_equal(vori, ref["ori"].cpu().numpy())
+
+
+@pytest.mark.parametrize("n", [1, 63, 4097, 300001])
+def test_points_bbox_equals_numpy(n):
+    import torch
+
+    from monohair_amd import _lib
+
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(n)
+    pts = (rng.normal(size=(n, 3)) * np.array([1.0, 1e-3, 50.0]) + np.array([-3.0, 0.0, 7.0])).astype(np.float32)
+    pts[rng.integers(0, n)] = [-0.0, 0.0, -1e-30]
+    box = torch.empty(6, dtype=torch.float32, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(L.mh_points_bbox(_ctx(dev), _lib.ptr(torch.from_numpy(pts).to(dev)), n, _lib.ptr(box), st))
+    got = box.cpu().numpy()
+    assert np.array_equal(got[:3], pts.min(0)) and np.array_equal(got[3:], pts.max(0))
