@@ -119,6 +119,6 @@ for n, d in rows.items():
     pc = d.get("parity_check", {})
     assert pc.get("bit_exact") is True, ("bench line of N=%d did not verify its outputs" % n, pc)
 print("   expectations (DESIGN.md §8): iterations/s >= 7.8x at 8 GPUs (no collective inside an iteration); the full pass "
-      "~3.8x (Amdahl: k-NN build, .npy/.mat writes on rank 0); Gabor stage ~N x minus one 249 MB all_gather")
+      "~3.2x of a 0.054 s pass (Amdahl: refine runs un-sharded on every rank, ~11 ms; MH_REFINE_SHARD=1 for the sharded loop); Gabor stage ~N x minus one 249 MB all_gather")
 PY
 echo "== done; logs and lines under $OUT"
