@@ -12,6 +12,7 @@
 #   3. the view-sharded Gabor stage, N ranks (nccl), against the 1-rank codes and files -- byte for byte
 #   4. refine's four-chunk golden under real RCCL (in-place all_gather per chunk) -- the reference's files
 #   5. bench.py --gpus 1/2/4/8 and the curve next to docs' expectations
+#   6. the full pass with refine sharded / un-sharded (the round-6 default), to settle that default on real RCCL
 set -euo pipefail
 cd "$(dirname "$0")/.."
 ROOT=$PWD
@@ -121,4 +122,20 @@ for n, d in rows.items():
 print("   expectations (DESIGN.md §8): iterations/s >= 7.8x at 8 GPUs (no collective inside an iteration); the full pass "
       "~3.2x of a 0.054 s pass (Amdahl: refine runs un-sharded on every rank, ~11 ms; MH_REFINE_SHARD=1 for the sharded loop); Gabor stage ~N x minus one 249 MB all_gather")
 PY
+echo "== 6. the full pass with refine sharded (MH_REFINE_SHARD=1) against the default (every rank runs the device-resident pass)"
+if [ "$DRY" = "1" ]; then N6=2; else N6=$NR; fi
+for SH in 0 1; do
+  MH_REFINE_SHARD=$SH python bench.py --gpus $N6 $BENCH_ARGS --no-cpu 2> "$OUT/6_bench_shard$SH.err" | grep '^{' > "$OUT/6_bench_shard$SH.json" || true
+  python - <<PY
+import json, os
+p = "$OUT/6_bench_shard$SH.json"
+if os.path.exists(p) and os.path.getsize(p):
+    fp = json.loads(open(p).read()).get("secondary_full_pass", {})
+    print("   MH_REFINE_SHARD=$SH, $N6 ranks: full pass %s s (filter %s, optimize %s, refine + volume %s)" % (
+        fp.get("steady_total_s", fp.get("total_s")), fp.get("filter_s"), fp.get("optimize_s"), fp.get("refine_and_volume_s")))
+else:
+    print("   MH_REFINE_SHARD=$SH: no line (see $OUT/6_bench_shard$SH.err)")
+PY
+done
+echo "   (choose the default of monohair_amd/dist.py::refine_sharded from these two lines)"
 echo "== done; logs and lines under $OUT"
