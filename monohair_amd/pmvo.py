@@ -1571,8 +1571,14 @@ def refine(points, ori, loss, pmvo, filter_unvisible_points, args, infer_inner=T
         # voxel fit (PMVO.py:695-726): every rank fits a disjoint slab of voxels; one reduce assembles the volume
         # The volume stays a list of occupied voxels; the dense float64 arrays of the reference exist only on request.
         with stage("refine: voxel fit + reduce", device):
-            vox, vori = mdist.voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size,
-                                                grid_resolution, sparse=True)
+            if mdist.world() > 1 and not mdist.refine_sharded():
+                # several ranks, refine not sharded: every rank holds every point -- each fits the whole volume itself, no
+                # exchange (rank 0 writes); the slab exchange belongs to the sharded form
+                res = U.voxel_fit(select_points, select_ori, device, voxel_min, voxel_size, grid_resolution, dense=False)
+                vox, vori = res["voxels"].cpu().numpy(), res["ori"].cpu().numpy()
+            else:
+                vox, vori = mdist.voxel_fit_reduced(select_points, select_ori, device, voxel_min, voxel_size,
+                                                    grid_resolution, sparse=True)
 
     if is_root:
         if infer_inner:
