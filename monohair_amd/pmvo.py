@@ -1247,9 +1247,17 @@ def _refine_device(points, ori, loss, pmvo, filter_unvisible_points, args, thres
         hcnt[1:].copy_(cnt[1:], non_blocking=True)
         main.synchronize()               # (2) kept shell rows; queries the grid could not finish at its first cell size
         if bool(hst.numpy().any()):
-            pmvo.last_refine["shell_stage"] = "host (queries to retry on another cell size)"
-            T_shell.__exit__()
-            return out                   # the host-driven shell stage below retries them on other cell sizes
+            # some shell points need another cell size (kept points sparser than the grid was laid out for): GridKNN's own
+            # retries fix those rows of the table in place, then the medoids and the selection of the shell rows once more
+            pmvo.last_refine["shell_stage"] = "device (%d queries retried on another cell size)" % int((hst.numpy() != 0).sum())
+            grid.finish_nosync(fq_dev, 100, idx, hst.numpy(), valid_dev=valid)
+            _lib.check(L.mh_medoid_indexed(ctx, _lib.ptr(ori_dev), _lib.ptr(idx), F, int(idx.shape[1]), _lib.ptr(cen), None, st),
+                       "mh_medoid_indexed")
+            _lib.check(L.mh_select_rows(ctx, _lib.ptr(hd), _lib.ptr(ht), 1, F, _lib.ptr(fb_dev), _lib.ptr(cen), _lib.ptr(sel_p),
+                                        _lib.ptr(sel_o), None, off(cnt, 0), off(cnt, 1), _lib.ptr(scratch), scratch.numel(), st),
+                       "mh_select_rows")
+            hcnt[1:].copy_(cnt[1:], non_blocking=True)
+            main.synchronize()
         n_sel = int(hcnt[1])
     else:
         main.wait_stream(side)

@@ -387,24 +387,11 @@ class GridKNN:
         perm = self._grid(self.h)[3] if (self_query and q.shape[0] == self.M) else None
         return self._run(self.h, q, min(int(k), self.M), perm, valid_dev, zero=True)
 
-    def query(self, queries, k, int32=False, self_query=False, valid=None):
-        """-> index [Q,k] device tensor, int64 (or int32 as the kernel writes it); k clamped to the number of points,
-        like the drivers do.  Queries keep their precision: float64 arrays (the shell points of refine, PMVO.py:671) are
-        searched with their exact coordinates, as scipy does.  self_query=True (queries are the data points, in the same
-        order): the waves take the queries in cell order, so neighbouring waves read the same cells.
-        valid (bool [M]): only these data points count as neighbours -- the answer equals
-        KDTree(points[valid]).query(...) with the indices mapped back to `points` (order-preserving, so the
-        (distance, index) order is the same); k is clamped to the number of valid points."""
-        if valid is not None:
-            vh = np.ascontiguousarray(valid, dtype=np.uint8)
-            k = min(int(k), int(vh.sum()))
-            valid = torch.from_numpy(vh).to(self.device)
-        k = min(int(k), self.M)
-        q = self._queries(queries)
-        perm = self._grid(self.h)[3] if (self_query and q.shape[0] == self.M) else None
-        out, status = self._run(self.h, q, k, perm, valid)
+    def _finish(self, q, k, out, st, valid):
+        """The retries of a query: rows of `out` whose status `st` (host array, updated in place) is not 0 are searched again
+        on finer (candidate buffer overflow) or coarser (ring limit) cells, what is left after that exhaustively -- all on
+        the GPU, the loop on the host."""
         self.last_retries = 0
-        st = status.cpu().numpy()                        # (host side: no torch kernels on this path)
         for code, factor in ((2, 0.5), (1, 2.0)):        # overflow -> finer cells, ring limit -> coarser cells
             h = self.h
             for _ in range(6):
@@ -430,6 +417,28 @@ class GridKNN:
                 if valid is not None:
                     d2 = torch.where(valid.bool(), d2, torch.full_like(d2, float("inf")))
                 out[i] = torch.sort(d2, stable=True).indices[:k].to(torch.int32)
+
+    def finish_nosync(self, queries, k, out, status_host, valid_dev=None):
+        """query()'s retries for the rows a query_nosync left unfinished (status_host != 0), in place in `out`."""
+        self._finish(self._queries(queries), min(int(k), self.M), out, np.array(status_host, copy=True), valid_dev)
+
+    def query(self, queries, k, int32=False, self_query=False, valid=None):
+        """-> index [Q,k] device tensor, int64 (or int32 as the kernel writes it); k clamped to the number of points,
+        like the drivers do.  Queries keep their precision: float64 arrays (the shell points of refine, PMVO.py:671) are
+        searched with their exact coordinates, as scipy does.  self_query=True (queries are the data points, in the same
+        order): the waves take the queries in cell order, so neighbouring waves read the same cells.
+        valid (bool [M]): only these data points count as neighbours -- the answer equals
+        KDTree(points[valid]).query(...) with the indices mapped back to `points` (order-preserving, so the
+        (distance, index) order is the same); k is clamped to the number of valid points."""
+        if valid is not None:
+            vh = np.ascontiguousarray(valid, dtype=np.uint8)
+            k = min(int(k), int(vh.sum()))
+            valid = torch.from_numpy(vh).to(self.device)
+        k = min(int(k), self.M)
+        q = self._queries(queries)
+        perm = self._grid(self.h)[3] if (self_query and q.shape[0] == self.M) else None
+        out, status = self._run(self.h, q, k, perm, valid)
+        self._finish(q, k, out, status.cpu().numpy(), valid)        # (host side: no torch kernels on this path)
         return out if int32 else out.long()
 
 
